@@ -1,0 +1,261 @@
+// oracle/oracle_capi.cpp — plain-C entry points over ear_oracle.hpp so that the
+// pytest suite (ctypes) and bench.py's cpu_baseline leg can drive the CPU
+// restatement.  TEST INFRASTRUCTURE ONLY; never linked into libearhip.so.
+#include <cstring>
+#include <sstream>
+
+#include "ear_oracle.hpp"
+
+using namespace ear_oracle;
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int guarded(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const invalid_argument &e) {
+    g_err = e.what();
+    return 1;
+  } catch (const internal_error &e) {
+    g_err = e.what();
+    return 2;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 3;
+  }
+}
+std::vector<const float *> planar_c(const float *base, size_t nch, size_t stride,
+                                    size_t ofs) {
+  std::vector<const float *> p(nch);
+  for (size_t c = 0; c < nch; c++) p[c] = base + c * stride + ofs;
+  return p;
+}
+std::vector<float *> planar(float *base, size_t nch, size_t stride, size_t ofs) {
+  std::vector<float *> p(nch);
+  for (size_t c = 0; c < nch; c++) p[c] = base + c * stride + ofs;
+  return p;
+}
+}  // namespace
+
+extern "C" {
+
+const char *oracle_last_error() { return g_err.c_str(); }
+
+// ---- GainInterpolator ------------------------------------------------------
+// kind: 0 single (1->1), 1 vector (1->n_out), 2 matrix (n_in->n_out).
+// values: [npoints][n_in][n_out].  in: [n_in][total], out: [n_out][total],
+// processed as consecutive calls of call_sizes[0..ncalls) samples starting at
+// sample index t0 (so block_start of call k = t0 + sum(call_sizes[:k])).
+int oracle_gain_interp(int kind, int n_in, int n_out, int npoints,
+                       const int64_t *times, const float *values, int64_t t0,
+                       const size_t *call_sizes, int ncalls, const float *in,
+                       float *out) {
+  return guarded([&] {
+    size_t total = 0;
+    for (int k = 0; k < ncalls; k++) total += call_sizes[k];
+    auto run = [&](auto &gi) {
+      size_t ofs = 0;
+      for (int k = 0; k < ncalls; k++) {
+        auto ip = planar_c(in, n_in, total, ofs);
+        auto op = planar(out, n_out, total, ofs);
+        gi.process((SampleIndex)(t0 + (int64_t)ofs), call_sizes[k], ip.data(),
+                   op.data());
+        ofs += call_sizes[k];
+      }
+    };
+    const size_t pstride = (size_t)n_in * n_out;
+    if (kind == 0) {
+      GainInterpolator<LinearInterpSingle> gi;
+      for (int p = 0; p < npoints; p++)
+        gi.interp_points.emplace_back((SampleIndex)times[p], values[p * pstride]);
+      run(gi);
+    } else if (kind == 1) {
+      GainInterpolator<LinearInterpVector> gi;
+      for (int p = 0; p < npoints; p++)
+        gi.interp_points.emplace_back(
+            (SampleIndex)times[p],
+            std::vector<float>(values + p * pstride, values + (p + 1) * pstride));
+      run(gi);
+    } else {
+      GainInterpolator<LinearInterpMatrix> gi;
+      for (int p = 0; p < npoints; p++) {
+        std::vector<std::vector<float>> mat(n_in);
+        for (int m = 0; m < n_in; m++)
+          mat[m].assign(values + p * pstride + (size_t)m * n_out,
+                        values + p * pstride + (size_t)(m + 1) * n_out);
+        gi.interp_points.emplace_back((SampleIndex)times[p], std::move(mat));
+      }
+      run(gi);
+    }
+  });
+}
+
+// ---- FFT -------------------------------------------------------------------
+int oracle_cfft_f32(size_t n, int inverse, const float *in, float *out) {
+  return guarded([&] {
+    KissLikeFFT<float> f(n, inverse != 0);
+    f.transform(reinterpret_cast<const std::complex<float> *>(in),
+                reinterpret_cast<std::complex<float> *>(out));
+  });
+}
+int oracle_cfft_f64(size_t n, int inverse, const double *in, double *out) {
+  return guarded([&] {
+    KissLikeFFT<double> f(n, inverse != 0);
+    f.transform(reinterpret_cast<const std::complex<double> *>(in),
+                reinterpret_cast<std::complex<double> *>(out));
+  });
+}
+// out: n_fft/2+1 complex
+int oracle_rfft_forward(size_t n_fft, const float *in, float *out) {
+  return guarded([&] {
+    RealFFT f(n_fft);
+    f.forward(in, reinterpret_cast<std::complex<float> *>(out));
+  });
+}
+int oracle_rfft_reverse(size_t n_fft, const float *in, float *out) {
+  return guarded([&] {
+    RealFFT f(n_fft);
+    f.reverse(reinterpret_cast<const std::complex<float> *>(in), out);
+  });
+}
+
+// ---- BlockConvolver ----------------------------------------------------------
+struct OCtx { std::shared_ptr<block_convolver::Context> p; };
+struct OFilter { std::shared_ptr<const block_convolver::Filter> p; };
+struct OConv { std::unique_ptr<block_convolver::BlockConvolver> p; };
+
+OCtx *oracle_conv_ctx_create(size_t block_size) {
+  return new OCtx{std::make_shared<block_convolver::Context>(block_size)};
+}
+void oracle_conv_ctx_destroy(OCtx *c) { delete c; }
+OFilter *oracle_conv_filter_create(OCtx *c, size_t n, const float *taps) {
+  return new OFilter{std::make_shared<block_convolver::Filter>(c->p, n, taps)};
+}
+size_t oracle_conv_filter_num_blocks(OFilter *f) { return f->p->num_blocks(); }
+// spectrum of partition `block`, fd_size complex values
+void oracle_conv_filter_spectrum(OFilter *f, size_t block, float *out) {
+  auto &b = f->p->blocks[block];
+  std::memcpy(out, b.data(), b.size() * sizeof(std::complex<float>));
+}
+void oracle_conv_filter_destroy(OFilter *f) { delete f; }
+// filter may be null; num_blocks 0 = take from filter
+int oracle_conv_create(OCtx *c, OFilter *f, size_t num_blocks, OConv **out) {
+  return guarded([&] {
+    if (f)
+      *out = new OConv{std::unique_ptr<block_convolver::BlockConvolver>(
+          new block_convolver::BlockConvolver(c->p, f->p, num_blocks))};
+    else
+      *out = new OConv{std::unique_ptr<block_convolver::BlockConvolver>(
+          new block_convolver::BlockConvolver(c->p, num_blocks))};
+  });
+}
+void oracle_conv_destroy(OConv *c) { delete c; }
+int oracle_conv_set_filter(OConv *c, OFilter *f) {
+  return guarded([&] { c->p->set_filter(f ? f->p : nullptr); });
+}
+int oracle_conv_crossfade_filter(OConv *c, OFilter *f) {
+  return guarded([&] { c->p->crossfade_filter(f ? f->p : nullptr); });
+}
+int oracle_conv_process(OConv *c, const float *in, float *out) {
+  return guarded([&] { c->p->process(in, out); });
+}
+
+// ---- DelayBuffer -----------------------------------------------------------
+DelayBuffer *oracle_delay_create(size_t nch, size_t delay) {
+  return new DelayBuffer(nch, delay);
+}
+void oracle_delay_destroy(DelayBuffer *d) { delete d; }
+// in/out: [nch][stride], processes nsamples from offset ofs
+int oracle_delay_process(DelayBuffer *d, size_t nch, size_t nsamples,
+                         const float *in, float *out, size_t stride, size_t ofs) {
+  return guarded([&] {
+    auto ip = planar_c(in, nch, stride, ofs);
+    auto op = planar(out, nch, stride, ofs);
+    d->process(nsamples, ip.data(), op.data());
+  });
+}
+
+// ---- VariableBlockSizeAdapter ------------------------------------------------
+typedef void (*oracle_process_cb)(const float *const *in, float *const *out,
+                                  void *user);
+struct OVbs { std::unique_ptr<VariableBlockSizeAdapter> p; };
+OVbs *oracle_vbs_create(size_t block_size, size_t n_in, size_t n_out,
+                        oracle_process_cb cb, void *user) {
+  return new OVbs{std::unique_ptr<VariableBlockSizeAdapter>(
+      new VariableBlockSizeAdapter(
+          block_size, n_in, n_out,
+          [cb, user](const float *const *i, float *const *o) { cb(i, o, user); }))};
+}
+void oracle_vbs_destroy(OVbs *v) { delete v; }
+int oracle_vbs_get_delay(OVbs *v) { return v->p->get_delay(); }
+int oracle_vbs_process(OVbs *v, size_t n_in, size_t n_out, size_t nsamples,
+                       const float *in, float *out, size_t stride, size_t ofs) {
+  return guarded([&] {
+    auto ip = planar_c(in, n_in, stride, ofs);
+    auto op = planar(out, n_out, stride, ofs);
+    v->p->process(nsamples, ip.data(), op.data());
+  });
+}
+
+// ---- decorrelator design -----------------------------------------------------
+int oracle_design_decorrelator_basic(int id, int size, double *out) {
+  return guarded([&] {
+    auto h = design_decorrelator_basic(id, size);
+    std::copy(h.begin(), h.end(), out);
+  });
+}
+// names: '\n'-separated channel names; out: [nch][512] float
+int oracle_design_decorrelators(const char *names, float *out) {
+  return guarded([&] {
+    std::vector<std::string> v;
+    std::stringstream ss(names);
+    for (std::string s; std::getline(ss, s, '\n');) v.push_back(s);
+    auto f = design_decorrelators(v);
+    for (size_t c = 0; c < f.size(); c++)
+      std::copy(f[c].begin(), f[c].end(), out + c * kDecorrelatorSize);
+  });
+}
+int oracle_decorrelator_compensation_delay() {
+  return decorrelator_compensation_delay();
+}
+
+// ---- composed Objects render -------------------------------------------------
+ObjectsRenderer *oracle_render_create(size_t n_obj, size_t n_out, size_t block,
+                                      const float *filters, size_t ntaps,
+                                      size_t delay) {
+  std::vector<std::vector<float>> f(n_out);
+  for (size_t c = 0; c < n_out; c++)
+    f[c].assign(filters + c * ntaps, filters + (c + 1) * ntaps);
+  return new ObjectsRenderer(n_obj, n_out, block, f, delay);
+}
+void oracle_render_destroy(ObjectsRenderer *r) { delete r; }
+// bus: 0 direct, 1 diffuse; gains: [npoints][n_out]
+int oracle_render_set_points(ObjectsRenderer *r, size_t obj, int bus, int npoints,
+                             const int64_t *times, const float *gains,
+                             size_t n_out) {
+  return guarded([&] {
+    auto &gi = bus == 0 ? r->direct.at(obj) : r->diffuse.at(obj);
+    gi.interp_points.clear();
+    for (int p = 0; p < npoints; p++)
+      gi.interp_points.emplace_back(
+          (SampleIndex)times[p],
+          std::vector<float>(gains + (size_t)p * n_out, gains + (size_t)(p + 1) * n_out));
+  });
+}
+// in: [n_obj][nblocks*block], out: [n_out][nblocks*block]
+int oracle_render_process(ObjectsRenderer *r, size_t n_obj, size_t n_out,
+                          size_t block, size_t nblocks, const float *in,
+                          float *out) {
+  return guarded([&] {
+    const size_t stride = nblocks * block;
+    for (size_t t = 0; t < nblocks; t++) {
+      auto ip = planar_c(in, n_obj, stride, t * block);
+      auto op = planar(out, n_out, stride, t * block);
+      r->process(ip.data(), op.data());
+    }
+  });
+}
+
+}  // extern "C"
