@@ -1,0 +1,235 @@
+/* earhip.h — C ABI of the MI355X-native ADM render DSP path.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libearhip.so) whose
+ * entry points are what a binding for libear's DSP hot path would call.  Each
+ * group below names the libear interface it replaces (paths relative to the
+ * libear tree).  The C++14 classes in libear_amd/host/ear/dsp/ wrap these entry
+ * points behind libear's own class names and signatures and map the status
+ * codes back to libear's exception types.
+ *
+ * Conventions (libear's, include/ear/dsp/ptr_adapter.hpp:10-40):
+ *   - audio is planar float32: `const float *const *in` is an array of channel
+ *     pointers, each to contiguous samples;
+ *   - the caller owns every buffer; the library reads/writes host pointers only
+ *     during the call and never retains them;
+ *   - `*_device` entry points take device pointers in the same planar layout
+ *     (channel c at base + c * stride) and enqueue on the context's stream
+ *     without synchronising;
+ *   - no entry point allocates host or device memory in a `process` call.
+ *
+ * Errors: every function returns an int status.  Nothing throws across this
+ * boundary.  earhip_last_error() returns the message of the calling thread's
+ * last failure.
+ */
+#ifndef EARHIP_H
+#define EARHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EARHIP_VERSION 100 /* 0.1.0 */
+
+/* status codes; the C++ shim maps 1 -> ear::invalid_argument and 2,3 ->
+ * ear::internal_error (include/ear/exceptions.hpp:8-43) */
+#define EARHIP_OK 0
+#define EARHIP_INVALID_ARGUMENT 1
+#define EARHIP_INTERNAL_ERROR 2
+#define EARHIP_DEVICE_ERROR 3
+
+int earhip_version(void);
+const char *earhip_last_error(void);
+int earhip_device_count(int *count);
+
+/* ------------------------------------------------------------------------
+ * Context: one HIP device + one stream.  Not thread-safe (libear's stateful
+ * DSP objects are single-owner as well).
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_ctx earhip_ctx;
+
+/* hip_stream: a hipStream_t to enqueue on (e.g. the caller's current stream),
+ * or NULL to let the context create its own. */
+int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out);
+int earhip_ctx_destroy(earhip_ctx *ctx);
+int earhip_ctx_synchronize(earhip_ctx *ctx);
+/* strict != 0: gain kernels reproduce libear's float arithmetic exactly
+ * (un-contracted `in * ((1-p)*s + p*e)`, inputs accumulated in channel order),
+ * so M->N results are bit-identical to the CPU path.  Default 0: fused
+ * multiply-adds and tree accumulation (faster, within 1e-6 relative RMS). */
+int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
+
+/* ------------------------------------------------------------------------
+ * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector
+ * / LinearInterpMatrix ::apply_interp and ::apply_constant
+ * (include/ear/dsp/gain_interpolator.hpp:187-208, 214-241, 250-299).
+ * n_in x n_out = 1x1 (Single), 1xN (Vector), MxN (Matrix).  Points are dense
+ * row-major [n_in][n_out] (libear's Matrix point is vector<vector<float>>
+ * indexed [in][out], gain_interpolator.hpp:247).  Writes out[o][range_start ..
+ * range_end) for every output o; in and out must not alias.
+ * ---------------------------------------------------------------------- */
+int earhip_interp_apply_interp(earhip_ctx *ctx, int n_in, int n_out,
+                               const float *const *in, float *const *out,
+                               int64_t range_start, int64_t range_end,
+                               int64_t block_start, int64_t start, int64_t end,
+                               const float *start_point, const float *end_point);
+int earhip_interp_apply_constant(earhip_ctx *ctx, int n_in, int n_out,
+                                 const float *const *in, float *const *out,
+                                 int64_t range_start, int64_t range_end,
+                                 const float *point);
+
+/* ------------------------------------------------------------------------
+ * (A') Whole-curve GainInterpolator with device-resident points — replaces
+ * GainInterpolator<InterpType>::process (gain_interpolator.hpp:53-87) for
+ * callers that keep the curve fixed across calls.  values: [npoints][n_in]
+ * [n_out]; times must be sorted (duplicates = step).
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_gain_interp earhip_gain_interp;
+int earhip_gain_interp_create(earhip_ctx *ctx, int n_in, int n_out,
+                              earhip_gain_interp **out);
+int earhip_gain_interp_destroy(earhip_gain_interp *gi);
+int earhip_gain_interp_set_points(earhip_gain_interp *gi, int npoints,
+                                  const int64_t *times, const float *values);
+int earhip_gain_interp_process(earhip_gain_interp *gi, int64_t block_start,
+                               size_t nsamples, const float *const *in,
+                               float *const *out);
+/* in_dev: [n_in][in_stride], out_dev: [n_out][out_stride], device memory */
+int earhip_gain_interp_process_device(earhip_gain_interp *gi, int64_t block_start,
+                                      size_t nsamples, const float *in_dev,
+                                      size_t in_stride, float *out_dev,
+                                      size_t out_stride);
+
+/* ------------------------------------------------------------------------
+ * (B) FFT plugin — an r2c/c2r transform with libear's FFTPlan contract
+ * (include/ear/fft.hpp:27-50): forward n_fft reals -> n_fft/2+1 unpacked
+ * complex bins; reverse the inverse; both un-normalised.  n_fft must be a
+ * power of two in [64, 8192].  Host pointers.
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_fft_plan earhip_fft_plan;
+int earhip_fft_plan_create(earhip_ctx *ctx, size_t n_fft, earhip_fft_plan **out);
+int earhip_fft_plan_destroy(earhip_fft_plan *plan);
+int earhip_fft_forward(earhip_fft_plan *plan, const float *in, float *out_complex);
+int earhip_fft_reverse(earhip_fft_plan *plan, const float *in_complex, float *out);
+
+/* ------------------------------------------------------------------------
+ * (C) BlockConvolver — replaces ear::dsp::block_convolver::{Context, Filter,
+ * BlockConvolver} (include/ear/dsp/block_convolver.hpp:28-112; behaviour of
+ * src/dsp/block_convolver_impl.cpp:10-243).  block_size must be a power of two
+ * in [32, 4096].
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_conv_ctx earhip_conv_ctx;
+typedef struct earhip_conv_filter earhip_conv_filter;
+typedef struct earhip_conv earhip_conv;
+
+int earhip_conv_ctx_create(earhip_ctx *ctx, size_t block_size,
+                           earhip_conv_ctx **out);
+int earhip_conv_ctx_destroy(earhip_conv_ctx *cctx);
+int earhip_conv_filter_create(earhip_conv_ctx *cctx, size_t n, const float *taps,
+                              earhip_conv_filter **out);
+int earhip_conv_filter_destroy(earhip_conv_filter *filter);
+size_t earhip_conv_filter_num_blocks(const earhip_conv_filter *filter);
+/* filter may be NULL (then num_blocks must be > 0); num_blocks 0 = take the
+ * partition count from the filter (block_convolver.hpp:67-77) */
+int earhip_conv_create(earhip_conv_ctx *cctx, const earhip_conv_filter *filter,
+                       size_t num_blocks, earhip_conv **out);
+int earhip_conv_destroy(earhip_conv *conv);
+/* in may be NULL = a block of silence (block_convolver_impl.cpp:145-147,156) */
+int earhip_conv_process(earhip_conv *conv, const float *in, float *out);
+/* filter NULL = fade_down() / unset_filter() (src/dsp/block_convolver.cpp:27-37) */
+int earhip_conv_crossfade_filter(earhip_conv *conv, const earhip_conv_filter *filter);
+int earhip_conv_set_filter(earhip_conv *conv, const earhip_conv_filter *filter);
+
+/* ------------------------------------------------------------------------
+ * (D) DelayBuffer — replaces ear::dsp::DelayBuffer
+ * (include/ear/dsp/delay_buffer.hpp:12-30, src/dsp/delay_buffer_impl.cpp:19-43)
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_delay earhip_delay;
+int earhip_delay_create(earhip_ctx *ctx, size_t nchannels, size_t nsamples,
+                        earhip_delay **out);
+int earhip_delay_destroy(earhip_delay *d);
+int earhip_delay_process(earhip_delay *d, size_t nsamples, const float *const *in,
+                         float *const *out);
+int earhip_delay_get_delay(const earhip_delay *d);
+
+/* ------------------------------------------------------------------------
+ * (E) VariableBlockSizeAdapter — replaces ear::dsp::VariableBlockSizeAdapter
+ * (include/ear/dsp/variable_block_size.hpp:17-40,
+ * src/dsp/variable_block_size_impl.cpp:27-85).  Host-side FIFO re-blocking
+ * around a user callback; adds block_size samples of delay.
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_vbs earhip_vbs;
+typedef int (*earhip_process_func)(const float *const *in, float *const *out,
+                                   void *user); /* returns an earhip status */
+int earhip_vbs_create(size_t block_size, size_t num_channels_in,
+                      size_t num_channels_out, earhip_process_func process_func,
+                      void *user, earhip_vbs **out);
+int earhip_vbs_destroy(earhip_vbs *v);
+int earhip_vbs_process(earhip_vbs *v, size_t nsamples, const float *const *in,
+                       float *const *out);
+int earhip_vbs_get_delay(const earhip_vbs *v);
+
+/* ------------------------------------------------------------------------
+ * (F) Composed Objects render block — the chain libear documents but does not
+ * implement (docs/dsp.rst:40-71, include/ear/gain_calculators.hpp:45-56):
+ *   per object: interpolated direct and diffuse gain vectors (a
+ *   GainInterpolator<LinearInterpVector> each) summed into a direct and a
+ *   diffuse loudspeaker bus; diffuse bus -> one BlockConvolver per loudspeaker
+ *   (decorrelator FIRs); direct bus -> DelayBuffer(delay); out = sum.
+ * It has the shape of VariableBlockSizeAdapter::ProcessFunc
+ * (variable_block_size.hpp:19) and processes `nblocks` consecutive blocks per
+ * call ("stream mode"), which is what lets the device path approach its
+ * roofline.
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_render earhip_render;
+
+typedef struct earhip_render_config {
+  int n_objects;  /* M: input channels handled by this instance (this GPU's shard) */
+  int n_out;      /* N: loudspeakers */
+  int block_size; /* B: power of two in [64, 4096] */
+  int n_buses;    /* 1: direct bus only, written straight to the output
+                     2: direct + diffuse with decorrelation, delay and mix */
+  /* n_buses == 2: decorrelator FIRs [n_out][n_taps] (designDecorrelators,
+   * include/ear/decorrelate.hpp:26-28); n_taps <= block_size */
+  const float *decorrelators;
+  int n_taps;
+  int delay;      /* compensation delay on the direct bus in samples
+                     (decorrelatorCompensationDelay() = 255); 0 = none */
+  int max_blocks; /* capacity T: largest nblocks of one process call */
+} earhip_render_config;
+
+int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg,
+                         earhip_render **out);
+int earhip_render_destroy(earhip_render *r);
+/* Replace one object's gain curve: times[npoints] sorted; direct and diffuse
+ * [npoints][n_out] (diffuse ignored / may be NULL when n_buses == 1).  Same
+ * semantics as GainInterpolator::interp_points (gain_interpolator.hpp:27-43). */
+int earhip_render_set_object_points(earhip_render *r, int object, int npoints,
+                                    const int64_t *times, const float *direct,
+                                    const float *diffuse);
+/* Upload pending curve changes now (otherwise done at the next process). */
+int earhip_render_commit(earhip_render *r);
+/* Zero the DSP state (convolver tails, delay line) and set the sample clock. */
+int earhip_render_reset(earhip_render *r, int64_t sample_time);
+/* Process nblocks blocks from device memory: in_dev [n_objects][in_stride],
+ * out_dev [n_out][out_stride], nblocks*block_size samples per channel.
+ * Enqueues on the context's stream; does not synchronise. */
+int earhip_render_process_device(earhip_render *r, size_t nblocks,
+                                 const float *in_dev, size_t in_stride,
+                                 float *out_dev, size_t out_stride);
+/* Same from host channel pointers (H2D, kernels, D2H, synchronise). */
+int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *in,
+                          float *const *out);
+/* Kernel timing (HIP events on the context's stream around each launch).
+ * enable != 0 starts collecting and zeroes the counters. */
+int earhip_render_enable_timing(earhip_render *r, int enable);
+/* Sums since enable: [0] gain_mix kernel ms, [1] its launches, [2] decorrelate/
+ * delay/mix kernel ms, [3] its launches, [4] segment-prep kernel ms, [5] its
+ * launches.  Synchronises the stream. */
+int earhip_render_get_timing(earhip_render *r, double out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EARHIP_H */

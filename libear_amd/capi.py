@@ -1,0 +1,348 @@
+"""ctypes bindings of the libearhip C ABI (include/earhip.h).
+
+Thin and explicit on purpose: every call goes through the C ABI exactly as a foreign-language
+binding would, so the GPU parity tests exercise the drop-in boundary itself.  Arrays are numpy
+float32, planar ``[channels][samples]``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+f32p = C.POINTER(C.c_float)
+i64p = C.POINTER(C.c_int64)
+pp_f32 = C.POINTER(f32p)
+
+OK, INVALID_ARGUMENT, INTERNAL_ERROR, DEVICE_ERROR = 0, 1, 2, 3
+
+
+class EarHipError(Exception):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class InvalidArgument(EarHipError, ValueError):
+    """maps to ear::invalid_argument"""
+
+
+class InternalError(EarHipError, RuntimeError):
+    """maps to ear::internal_error"""
+
+
+class RenderConfig(C.Structure):
+    _fields_ = [("n_objects", C.c_int), ("n_out", C.c_int), ("block_size", C.c_int),
+                ("n_buses", C.c_int), ("decorrelators", f32p), ("n_taps", C.c_int),
+                ("delay", C.c_int), ("max_blocks", C.c_int)]
+
+
+PROCESS_FUNC = C.CFUNCTYPE(C.c_int, pp_f32, pp_f32, C.c_void_p)
+
+_lib = None
+
+
+def load():
+    """Loads libearhip.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(libear_amd has no CPU fallback)")
+    lib = C.CDLL(path)
+    lib.earhip_last_error.restype = C.c_char_p
+    lib.earhip_conv_filter_num_blocks.restype = C.c_size_t
+    lib.earhip_conv_filter_num_blocks.argtypes = [C.c_void_p]
+    lib.earhip_delay_get_delay.argtypes = [C.c_void_p]
+    lib.earhip_vbs_get_delay.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = load().earhip_last_error().decode()
+    if rc == INVALID_ARGUMENT:
+        raise InvalidArgument(rc, msg)
+    raise InternalError(rc, msg)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, t=f32p):
+    return a.ctypes.data_as(t)
+
+
+def _chan_ptrs(a, offset=0):
+    """float*[] over the rows of a C-contiguous [channels][samples] float32 array."""
+    n = a.shape[0]
+    arr = (f32p * max(n, 1))()
+    base = a.ctypes.data
+    for c in range(n):
+        arr[c] = C.cast(base + (c * a.shape[1] + offset) * 4, f32p)
+    return arr
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().earhip_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        check(load().earhip_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+
+    def set_strict(self, strict):
+        check(load().earhip_ctx_set_strict(self.h, int(bool(strict))))
+
+    def synchronize(self):
+        check(load().earhip_ctx_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            load().earhip_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    # --- (A) interpolation policies -------------------------------------------------
+    def apply_interp(self, x, out, range_start, range_end, block_start, start, end, start_point, end_point):
+        """x [n_in][n], out [n_out][n] (written in place on [range_start, range_end))."""
+        sp, ep = _f32(start_point), _f32(end_point)
+        n_in, n_out = x.shape[0], out.shape[0]
+        assert sp.size == n_in * n_out and ep.size == n_in * n_out
+        check(load().earhip_interp_apply_interp(
+            self.h, n_in, n_out, _chan_ptrs(x), _chan_ptrs(out), C.c_int64(range_start), C.c_int64(range_end),
+            C.c_int64(block_start), C.c_int64(start), C.c_int64(end), _ptr(sp), _ptr(ep)))
+
+    def apply_constant(self, x, out, range_start, range_end, point):
+        pt = _f32(point)
+        n_in, n_out = x.shape[0], out.shape[0]
+        assert pt.size == n_in * n_out
+        check(load().earhip_interp_apply_constant(
+            self.h, n_in, n_out, _chan_ptrs(x), _chan_ptrs(out), C.c_int64(range_start), C.c_int64(range_end),
+            _ptr(pt)))
+
+
+class GainInterp:
+    """(A') whole-curve GainInterpolator with device-resident points."""
+
+    def __init__(self, ctx, n_in, n_out):
+        self.ctx, self.n_in, self.n_out = ctx, n_in, n_out
+        self.h = C.c_void_p()
+        check(load().earhip_gain_interp_create(ctx.h, n_in, n_out, C.byref(self.h)))
+
+    def set_points(self, times, values):
+        t = np.ascontiguousarray(times, dtype=np.int64)
+        v = _f32(values).reshape(len(t), self.n_in, self.n_out) if len(t) else _f32(values)
+        check(load().earhip_gain_interp_set_points(self.h, len(t), _ptr(t, i64p), _ptr(v)))
+
+    def process(self, block_start, x):
+        x = _f32(x).reshape(self.n_in, -1)
+        out = np.zeros((self.n_out, x.shape[1]), np.float32)
+        check(load().earhip_gain_interp_process(self.h, C.c_int64(block_start), C.c_size_t(x.shape[1]),
+                                                _chan_ptrs(x), _chan_ptrs(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            load().earhip_gain_interp_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class FFTPlan:
+    def __init__(self, ctx, n_fft):
+        self.n = n_fft
+        self.h = C.c_void_p()
+        check(load().earhip_fft_plan_create(ctx.h, C.c_size_t(n_fft), C.byref(self.h)))
+
+    def forward(self, x):
+        x = _f32(x)
+        assert x.size == self.n
+        out = np.empty(self.n // 2 + 1, np.complex64)
+        check(load().earhip_fft_forward(self.h, _ptr(x), _ptr(out)))
+        return out
+
+    def reverse(self, X):
+        X = np.ascontiguousarray(X, dtype=np.complex64)
+        assert X.size == self.n // 2 + 1
+        out = np.empty(self.n, np.float32)
+        check(load().earhip_fft_reverse(self.h, _ptr(X), _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            load().earhip_fft_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class ConvCtx:
+    def __init__(self, ctx, block_size):
+        self.block_size = block_size
+        self.h = C.c_void_p()
+        check(load().earhip_conv_ctx_create(ctx.h, C.c_size_t(block_size), C.byref(self.h)))
+
+
+class ConvFilter:
+    def __init__(self, cctx, taps):
+        taps = _f32(taps)
+        self.h = C.c_void_p()
+        check(load().earhip_conv_filter_create(cctx.h, C.c_size_t(taps.size), _ptr(taps), C.byref(self.h)))
+
+    def num_blocks(self):
+        return load().earhip_conv_filter_num_blocks(self.h)
+
+
+class BlockConvolver:
+    def __init__(self, cctx, filt=None, num_blocks=0):
+        self.B = cctx.block_size
+        self.h = C.c_void_p()
+        check(load().earhip_conv_create(cctx.h, filt.h if filt else None, C.c_size_t(num_blocks),
+                                        C.byref(self.h)))
+
+    def set_filter(self, f):
+        check(load().earhip_conv_set_filter(self.h, f.h if f else None))
+
+    def crossfade_filter(self, f):
+        check(load().earhip_conv_crossfade_filter(self.h, f.h if f else None))
+
+    def fade_down(self):
+        self.crossfade_filter(None)
+
+    def unset_filter(self):
+        self.set_filter(None)
+
+    def process(self, x):
+        out = np.empty(self.B, np.float32)
+        if x is None:
+            check(load().earhip_conv_process(self.h, None, _ptr(out)))
+        else:
+            x = _f32(x)
+            assert x.size == self.B
+            check(load().earhip_conv_process(self.h, _ptr(x), _ptr(out)))
+        return out
+
+
+class DelayBuffer:
+    def __init__(self, ctx, nch, delay):
+        self.nch = nch
+        self.h = C.c_void_p()
+        check(load().earhip_delay_create(ctx.h, C.c_size_t(nch), C.c_size_t(delay), C.byref(self.h)))
+
+    def get_delay(self):
+        return load().earhip_delay_get_delay(self.h)
+
+    def process(self, x):
+        x = _f32(x).reshape(self.nch, -1)
+        out = np.empty_like(x)
+        check(load().earhip_delay_process(self.h, C.c_size_t(x.shape[1]), _chan_ptrs(x), _chan_ptrs(out)))
+        return out
+
+
+class VariableBlockSizeAdapter:
+    """Host-side adapter; fn(in [n_in][B]) -> out [n_out][B]."""
+
+    def __init__(self, block_size, n_in, n_out, fn):
+        self.B, self.n_in, self.n_out = block_size, n_in, n_out
+        self.error = None
+
+        def cb(inp, outp, _user):
+            try:
+                x = np.stack([np.ctypeslib.as_array(inp[c], (block_size,)) for c in range(n_in)])
+                y = _f32(fn(x))
+                for c in range(n_out):
+                    np.ctypeslib.as_array(outp[c], (block_size,))[:] = y[c]
+                return OK
+            except Exception as e:  # surfaced by process()
+                self.error = e
+                return INTERNAL_ERROR
+
+        self._cb = PROCESS_FUNC(cb)
+        self.h = C.c_void_p()
+        check(load().earhip_vbs_create(C.c_size_t(block_size), C.c_size_t(n_in), C.c_size_t(n_out), self._cb,
+                                       None, C.byref(self.h)))
+
+    def get_delay(self):
+        return load().earhip_vbs_get_delay(self.h)
+
+    def process(self, x):
+        x = _f32(x).reshape(self.n_in, -1)
+        n = x.shape[1]
+        out = np.empty((self.n_out, n), np.float32)
+        xs = x if n else np.zeros((self.n_in, 1), np.float32)
+        os_ = out if n else np.zeros((self.n_out, 1), np.float32)
+        rc = load().earhip_vbs_process(self.h, C.c_size_t(n), _chan_ptrs(xs), _chan_ptrs(os_))
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+        check(rc)
+        return out
+
+
+class Renderer:
+    """(F) composed Objects render block."""
+
+    def __init__(self, ctx, n_objects, n_out, block_size, decorrelators=None, delay=0, max_blocks=1):
+        self.ctx = ctx
+        self.M, self.N, self.B = n_objects, n_out, block_size
+        self.K = 2 if decorrelators is not None else 1
+        cfg = RenderConfig()
+        cfg.n_objects, cfg.n_out, cfg.block_size, cfg.n_buses = n_objects, n_out, block_size, self.K
+        if decorrelators is not None:
+            self._dec = _f32(decorrelators).reshape(n_out, -1)
+            cfg.decorrelators = _ptr(self._dec)
+            cfg.n_taps = self._dec.shape[1]
+        else:
+            cfg.decorrelators = None
+            cfg.n_taps = 0
+        cfg.delay = delay
+        cfg.max_blocks = max_blocks
+        self.h = C.c_void_p()
+        check(load().earhip_render_create(ctx.h, C.byref(cfg), C.byref(self.h)))
+
+    def set_object_points(self, obj, times, direct, diffuse=None):
+        t = np.ascontiguousarray(times, dtype=np.int64)
+        d = _f32(direct).reshape(len(t), self.N)
+        f = _f32(diffuse).reshape(len(t), self.N) if diffuse is not None else None
+        check(load().earhip_render_set_object_points(self.h, obj, len(t), _ptr(t, i64p), _ptr(d),
+                                                     _ptr(f) if f is not None else None))
+
+    def commit(self):
+        check(load().earhip_render_commit(self.h))
+
+    def reset(self, sample_time=0):
+        check(load().earhip_render_reset(self.h, C.c_int64(sample_time)))
+
+    def process(self, x):
+        """x [M][nblocks*B] host array -> [N][nblocks*B]."""
+        x = _f32(x).reshape(self.M, -1)
+        nblocks = x.shape[1] // self.B
+        assert nblocks * self.B == x.shape[1]
+        out = np.empty((self.N, x.shape[1]), np.float32)
+        check(load().earhip_render_process(self.h, C.c_size_t(nblocks), _chan_ptrs(x), _chan_ptrs(out)))
+        return out
+
+    def process_device(self, nblocks, in_ptr, in_stride, out_ptr, out_stride):
+        check(load().earhip_render_process_device(self.h, C.c_size_t(nblocks), C.c_void_p(in_ptr),
+                                                  C.c_size_t(in_stride), C.c_void_p(out_ptr),
+                                                  C.c_size_t(out_stride)))
+
+    def enable_timing(self, on=True):
+        check(load().earhip_render_enable_timing(self.h, int(on)))
+
+    def get_timing(self):
+        out = (C.c_double * 6)()
+        check(load().earhip_render_get_timing(self.h, out))
+        return {"gain_mix_ms": out[0], "gain_mix_launches": out[1], "decor_ms": out[2],
+                "decor_launches": out[3], "prep_ms": out[4], "prep_launches": out[5]}
+
+    def close(self):
+        if self.h:
+            load().earhip_render_destroy(self.h)
+            self.h = C.c_void_p()

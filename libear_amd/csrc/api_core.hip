@@ -1,0 +1,357 @@
+// api_core.hip — context, error reporting, the interpolation-policy entry
+// points (A) and the whole-curve GainInterpolator (A') of include/earhip.h.
+#include <cmath>
+#include <memory>
+
+#include "common.h"
+#include "curves.h"
+#include "gain_kernels.h"
+
+namespace earhip {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml) {
+  return ml.wsplit > 1 ? (size_t)cp.ngroups * cp.nout * kTileSamples * sizeof(float) : 0;
+}
+
+template <int NOUT, bool STRICT>
+static void launch_mix_t(const GainMixParams &P, dim3 grid, dim3 block, size_t lds,
+                         hipStream_t s) {
+  hipLaunchKernelGGL((k_gain_mix<NOUT, STRICT>), grid, block, lds, s, P);
+}
+
+void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, bool strict,
+                     int64_t t_call, int nsamples, const float *in_dev, size_t in_stride,
+                     float *out_dev, size_t out_stride, size_t part_stride, SegDesc *desc,
+                     hipEvent_t *ev) {
+  const ColumnPlan &cp = cs.plan();
+  const PointStore ps = cs.device();
+  const int M = cs.M();
+  {
+    const int total = M * ml.ntiles;
+    if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_seg_prep, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ps, M,
+                       ml.ntiles, t_call, t_call + nsamples, desc);
+    if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
+  }
+  GainMixParams P;
+  P.in = in_dev;
+  P.in_stride = in_stride;
+  P.out = out_dev;
+  P.out_stride = out_stride;
+  P.part_stride = part_stride;
+  P.desc = desc;
+  P.ps = ps;
+  P.t_call = t_call;
+  P.nsamples = nsamples;
+  P.ntiles = ml.ntiles;
+  P.M = M;
+  P.ncols = cs.ncols();
+  P.ngroups = cp.ngroups;
+  P.wsplit = ml.wsplit;
+  P.vec_ok = (in_stride % 4 == 0 && out_stride % 4 == 0 && part_stride % 4 == 0 &&
+              ((uintptr_t)in_dev & 15) == 0 && ((uintptr_t)out_dev & 15) == 0)
+                 ? 1
+                 : 0;
+  const dim3 grid(ml.ntiles, ml.gsplit, cp.nz);
+  const dim3 block(64 * cp.ngroups * ml.wsplit);
+  const size_t lds = mix_lds_bytes(cp, ml);
+  if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
+  switch (cp.nout * 2 + (strict ? 1 : 0)) {
+    case 16: launch_mix_t<8, false>(P, grid, block, lds, ctx->stream); break;
+    case 17: launch_mix_t<8, true>(P, grid, block, lds, ctx->stream); break;
+    case 32: launch_mix_t<16, false>(P, grid, block, lds, ctx->stream); break;
+    case 33: launch_mix_t<16, true>(P, grid, block, lds, ctx->stream); break;
+    case 48: launch_mix_t<24, false>(P, grid, block, lds, ctx->stream); break;
+    case 49: launch_mix_t<24, true>(P, grid, block, lds, ctx->stream); break;
+    default: fail_internal("no gain_mix instantiation for this column plan");
+  }
+  if (ev) EARHIP_HIP(hipEventRecord(ev[3], ctx->stream));
+  EARHIP_HIP(hipGetLastError());
+}
+
+// Device-resident M -> N gain stage with host staging; shared by the policy
+// entry points and by earhip_gain_interp.
+struct GainStage {
+  earhip_ctx *ctx;
+  int n_in, n_out;
+  CurveSet curves;
+  DevBuf<SegDesc> desc;
+  DevBuf<float> parts;  // grid-level partial slabs
+  bool force_ramp;
+  GainStage(earhip_ctx *c, int ni, int no, bool ramp = false)
+      : ctx(c), n_in(ni), n_out(no), curves(ni, no, 1, ramp), force_ramp(ramp) {}
+
+  // in_dev [n_in][in_stride] -> out_dev [n_out][out_stride]
+  void run_device(int64_t t_call, int nsamples, const float *in_dev, size_t in_stride,
+                  float *out_dev, size_t out_stride) {
+    curves.commit(ctx);
+    // 1 -> N policies have no accumulation: always use libear's exact arithmetic
+    const bool strict = ctx->strict || n_in == 1;
+    MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32);
+    desc.reserve((size_t)n_in * ml.ntiles);
+    if (ml.gsplit == 1) {
+      launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,
+                      out_stride, 0, desc.p, nullptr);
+    } else {
+      const size_t row_stride = ((size_t)nsamples + 3) & ~(size_t)3;
+      const size_t part_stride = row_stride * n_out;
+      parts.reserve(part_stride * ml.gsplit);
+      launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, parts.p,
+                      row_stride, part_stride, desc.p, nullptr);
+      hipLaunchKernelGGL(k_sum_parts, dim3((nsamples + 255) / 256, n_out), dim3(256), 0,
+                         ctx->stream, parts.p, part_stride, ml.gsplit, row_stride, n_out,
+                         nsamples, out_dev, out_stride);
+      EARHIP_HIP(hipGetLastError());
+    }
+  }
+
+  // host planar pointers, samples [r0, r1) of each channel
+  void run_host(int64_t t_call, const float *const *in, float *const *out, int64_t r0,
+                int64_t r1) {
+    const int n = (int)(r1 - r0);
+    if (n <= 0) return;
+    const size_t stride = ((size_t)n + 3) & ~(size_t)3;
+    ctx->pin_in.reserve(stride * n_in);
+    ctx->pin_out.reserve(stride * n_out);
+    ctx->dev_in.reserve(stride * n_in);
+    ctx->dev_out.reserve(stride * n_out);
+    for (int c = 0; c < n_in; c++)
+      std::memcpy(ctx->pin_in.p + c * stride, in[c] + r0, sizeof(float) * n);
+    EARHIP_HIP(hipMemcpyAsync(ctx->dev_in.p, ctx->pin_in.p, sizeof(float) * stride * n_in,
+                              hipMemcpyHostToDevice, ctx->stream));
+    run_device(t_call, n, ctx->dev_in.p, stride, ctx->dev_out.p, stride);
+    EARHIP_HIP(hipMemcpyAsync(ctx->pin_out.p, ctx->dev_out.p, sizeof(float) * stride * n_out,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < n_out; c++)
+      std::memcpy(out[c] + r0, ctx->pin_out.p + c * stride, sizeof(float) * n);
+  }
+};
+
+}  // namespace earhip
+
+using namespace earhip;
+
+struct earhip_gain_interp {
+  std::unique_ptr<GainStage> stage;
+};
+
+// policy scratch: one GainStage per (n_in, n_out) shape seen on this context
+struct PolicyCache {
+  std::vector<std::unique_ptr<GainStage>> stages;
+  GainStage *get(earhip_ctx *ctx, int n_in, int n_out, bool ramp) {
+    for (auto &s : stages)
+      if (s->n_in == n_in && s->n_out == n_out && s->force_ramp == ramp) return s.get();
+    stages.emplace_back(new GainStage(ctx, n_in, n_out, ramp));
+    return stages.back().get();
+  }
+};
+static std::vector<std::pair<earhip_ctx *, std::unique_ptr<PolicyCache>>> g_policy;
+static PolicyCache *policy_cache(earhip_ctx *ctx) {
+  for (auto &p : g_policy)
+    if (p.first == ctx) return p.second.get();
+  g_policy.emplace_back(ctx, std::unique_ptr<PolicyCache>(new PolicyCache));
+  return g_policy.back().second.get();
+}
+
+extern "C" {
+
+int earhip_version(void) { return EARHIP_VERSION; }
+const char *earhip_last_error(void) { return g_last_error.c_str(); }
+
+int earhip_device_count(int *count) {
+  return guarded([&] {
+    require(count != nullptr, "count must not be NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *count = n;
+  });
+}
+
+int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
+  return guarded([&] {
+    require(out != nullptr, "out must not be NULL");
+    int n = 0;
+    EARHIP_HIP(hipGetDeviceCount(&n));
+    if (n <= 0)
+      throw Error{EARHIP_DEVICE_ERROR,
+                  "internal error: no HIP device available (libearhip has no CPU fallback)"};
+    require(device >= 0 && device < n, "device index out of range");
+    std::unique_ptr<earhip_ctx> c(new earhip_ctx);
+    c->device = device;
+    EARHIP_HIP(hipSetDevice(device));
+    if (hip_stream) {
+      c->stream = (hipStream_t)hip_stream;
+    } else {
+      EARHIP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    EARHIP_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c.release();
+  });
+}
+
+int earhip_ctx_destroy(earhip_ctx *ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (size_t i = 0; i < g_policy.size(); i++)
+      if (g_policy[i].first == ctx) {
+        g_policy.erase(g_policy.begin() + i);
+        break;
+      }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+
+int earhip_ctx_synchronize(earhip_ctx *ctx) {
+  return guarded([&] {
+    require(ctx != nullptr, "ctx must not be NULL");
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int earhip_ctx_set_strict(earhip_ctx *ctx, int strict) {
+  return guarded([&] {
+    require(ctx != nullptr, "ctx must not be NULL");
+    ctx->strict = strict != 0;
+  });
+}
+
+static void check_policy_args(earhip_ctx *ctx, int n_in, int n_out, const float *const *in,
+                              float *const *out, int64_t r0, int64_t r1) {
+  require(ctx != nullptr, "ctx must not be NULL");
+  require(n_in >= 1 && n_out >= 1, "n_in and n_out must be >= 1");
+  require(in != nullptr && out != nullptr, "in and out must not be NULL");
+  require(r0 >= 0 && r1 >= r0, "invalid sample range");
+  require(r1 - r0 < (int64_t)1 << 30, "sample range too long");
+}
+
+int earhip_interp_apply_interp(earhip_ctx *ctx, int n_in, int n_out, const float *const *in,
+                               float *const *out, int64_t range_start, int64_t range_end,
+                               int64_t block_start, int64_t start, int64_t end,
+                               const float *start_point, const float *end_point) {
+  return guarded([&] {
+    check_policy_args(ctx, n_in, n_out, in, out, range_start, range_end);
+    require(start_point && end_point, "points must not be NULL");
+    require(end > start, "interpolation curve must have end > start");
+    const int64_t first = block_start + range_start - start;
+    require(first > -((int64_t)1 << 30) && first + (range_end - range_start) < ((int64_t)1 << 30),
+            "sample range too far from the interpolation curve");
+    ctx->use();
+    GainStage *st = policy_cache(ctx)->get(ctx, n_in, n_out, true);
+    // a two-point curve per input channel, evaluated as ONE ramp (also outside
+    // [start, end) and between equal points, like a direct call of apply_interp,
+    // gain_interpolator.hpp:147-169)
+    const int64_t t[2] = {start, end};
+    std::vector<float> rows(2 * (size_t)n_out);
+    for (int m = 0; m < n_in; m++) {
+      std::memcpy(rows.data(), start_point + (size_t)m * n_out, sizeof(float) * n_out);
+      std::memcpy(rows.data() + n_out, end_point + (size_t)m * n_out, sizeof(float) * n_out);
+      st->curves.set_object(m, 2, t, rows.data());
+    }
+    st->curves.commit(ctx);
+    st->run_host(block_start + range_start, in, out, range_start, range_end);
+  });
+}
+
+int earhip_interp_apply_constant(earhip_ctx *ctx, int n_in, int n_out, const float *const *in,
+                                 float *const *out, int64_t range_start, int64_t range_end,
+                                 const float *point) {
+  return guarded([&] {
+    check_policy_args(ctx, n_in, n_out, in, out, range_start, range_end);
+    require(point != nullptr, "point must not be NULL");
+    ctx->use();
+    GainStage *st = policy_cache(ctx)->get(ctx, n_in, n_out, false);
+    const int64_t t[1] = {0};
+    for (int m = 0; m < n_in; m++) st->curves.set_object(m, 1, t, point + (size_t)m * n_out);
+    st->curves.commit(ctx);
+    st->run_host(range_start, in, out, range_start, range_end);
+  });
+}
+
+int earhip_gain_interp_create(earhip_ctx *ctx, int n_in, int n_out, earhip_gain_interp **out) {
+  return guarded([&] {
+    require(ctx != nullptr && out != nullptr, "ctx/out must not be NULL");
+    require(n_in >= 1 && n_out >= 1, "n_in and n_out must be >= 1");
+    ctx->use();
+    std::unique_ptr<earhip_gain_interp> g(new earhip_gain_interp);
+    g->stage.reset(new GainStage(ctx, n_in, n_out));
+    *out = g.release();
+  });
+}
+
+int earhip_gain_interp_destroy(earhip_gain_interp *gi) {
+  return guarded([&] {
+    if (!gi) return;
+    (void)hipStreamSynchronize(gi->stage->ctx->stream);
+    delete gi;
+  });
+}
+
+int earhip_gain_interp_set_points(earhip_gain_interp *gi, int npoints, const int64_t *times,
+                                  const float *values) {
+  return guarded([&] {
+    require(gi != nullptr, "gi must not be NULL");
+    require(npoints >= 1, "interp_points must not be empty");
+    require(times != nullptr && values != nullptr, "times/values must not be NULL");
+    GainStage *st = gi->stage.get();
+    st->ctx->use();
+    // libear compares whole points (all inputs x outputs) to choose the constant
+    // path (gain_interpolator.hpp:68-70,141-143)
+    const size_t psz = (size_t)st->n_in * st->n_out;
+    std::vector<uint8_t> flat(npoints, 0);
+    for (int k = 1; k < npoints; k++) {
+      bool same = true;
+      for (size_t i = 0; same && i < psz; i++)
+        same = values[(size_t)(k - 1) * psz + i] == values[(size_t)k * psz + i];
+      flat[k] = same ? 1 : 0;
+    }
+    // values [npoints][n_in][n_out] -> per input channel [npoints][n_out]
+    std::vector<float> rows((size_t)npoints * st->n_out);
+    for (int m = 0; m < st->n_in; m++) {
+      for (int k = 0; k < npoints; k++)
+        std::memcpy(&rows[(size_t)k * st->n_out],
+                    values + ((size_t)k * st->n_in + m) * st->n_out, sizeof(float) * st->n_out);
+      st->curves.set_object(m, npoints, times, rows.data(), flat.data());
+    }
+    st->curves.commit(st->ctx);
+  });
+}
+
+int earhip_gain_interp_process(earhip_gain_interp *gi, int64_t block_start, size_t nsamples,
+                               const float *const *in, float *const *out) {
+  return guarded([&] {
+    require(gi != nullptr, "gi must not be NULL");
+    require(in != nullptr && out != nullptr, "in and out must not be NULL");
+    require(nsamples < ((size_t)1 << 30), "nsamples too large");
+    gi->stage->ctx->use();
+    gi->stage->run_host(block_start, in, out, 0, (int64_t)nsamples);
+  });
+}
+
+int earhip_gain_interp_process_device(earhip_gain_interp *gi, int64_t block_start,
+                                      size_t nsamples, const float *in_dev, size_t in_stride,
+                                      float *out_dev, size_t out_stride) {
+  return guarded([&] {
+    require(gi != nullptr, "gi must not be NULL");
+    require(in_dev != nullptr && out_dev != nullptr, "device pointers must not be NULL");
+    require(nsamples < ((size_t)1 << 30), "nsamples too large");
+    require(in_stride % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0 &&
+                ((uintptr_t)out_dev & 15) == 0,
+            "device buffers must be 16-byte aligned with strides that are multiples of 4");
+    if (nsamples == 0) return;
+    gi->stage->ctx->use();
+    gi->stage->run_device(block_start, (int)nsamples, in_dev, in_stride, out_dev, out_stride);
+  });
+}
+
+}  // extern "C"

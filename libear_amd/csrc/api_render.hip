@@ -1,0 +1,372 @@
+// api_render.hip — (F) the composed Objects render block of include/earhip.h:
+// K0 segment prep -> K1 gain_mix (direct + diffuse buses) -> K2
+// decorrelate_delay_mix, `nblocks` blocks per call, state resident in HBM.
+#include <cmath>
+#include <memory>
+
+#include "common.h"
+#include "curves.h"
+#include "fft_kernels.h"
+#include "render_kernels.h"
+
+using namespace earhip;
+
+namespace earhip {
+// twiddle table exp(-2*pi*i*t/L), computed in double
+std::vector<cf> make_twiddles(int L) {
+  std::vector<cf> tw(L);
+  const double pi = 3.14159265358979323846264338327950288;
+  for (int t = 0; t < L; t++) {
+    const double a = -2.0 * pi * (double)t / (double)L;
+    tw[t] = cf_make((float)std::cos(a), (float)std::sin(a));
+  }
+  return tw;
+}
+
+template <int L>
+static void launch_spectrum_t(const float *in, size_t stride, int n_valid, const cf *tw, cf *out,
+                              int rows, hipStream_t s) {
+  hipLaunchKernelGGL((k_spectrum_real<L>), dim3(rows), dim3(kFftThreads), 0, s, in, stride,
+                     n_valid, tw, out);
+}
+void launch_spectrum(int L, const float *in, size_t stride, int n_valid, const cf *tw, cf *out,
+                     int rows, hipStream_t s) {
+  switch (L) {
+    case 64: launch_spectrum_t<64>(in, stride, n_valid, tw, out, rows, s); break;
+    case 128: launch_spectrum_t<128>(in, stride, n_valid, tw, out, rows, s); break;
+    case 256: launch_spectrum_t<256>(in, stride, n_valid, tw, out, rows, s); break;
+    case 512: launch_spectrum_t<512>(in, stride, n_valid, tw, out, rows, s); break;
+    case 1024: launch_spectrum_t<1024>(in, stride, n_valid, tw, out, rows, s); break;
+    case 2048: launch_spectrum_t<2048>(in, stride, n_valid, tw, out, rows, s); break;
+    case 4096: launch_spectrum_t<4096>(in, stride, n_valid, tw, out, rows, s); break;
+    case 8192: launch_spectrum_t<8192>(in, stride, n_valid, tw, out, rows, s); break;
+    default: fail_invalid("FFT size must be a power of two in [64, 8192]");
+  }
+  EARHIP_HIP(hipGetLastError());
+}
+}  // namespace earhip
+
+template <int L>
+static void launch_decor_t(const DecorParams &P, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((k_decorrelate_delay_mix<L>), grid, dim3(256), 0, s, P);
+}
+static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s) {
+  switch (L) {
+    case 128: launch_decor_t<128>(P, grid, s); break;
+    case 256: launch_decor_t<256>(P, grid, s); break;
+    case 512: launch_decor_t<512>(P, grid, s); break;
+    case 1024: launch_decor_t<1024>(P, grid, s); break;
+    case 2048: launch_decor_t<2048>(P, grid, s); break;
+    case 4096: launch_decor_t<4096>(P, grid, s); break;
+    case 8192: launch_decor_t<8192>(P, grid, s); break;
+    default: fail_invalid("block_size must be a power of two in [64, 4096]");
+  }
+  EARHIP_HIP(hipGetLastError());
+}
+
+struct earhip_render {
+  earhip_ctx *ctx = nullptr;
+  int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
+  std::unique_ptr<CurveSet> curves;
+  int64_t t = 0;  // sample clock: absolute time of the next block
+  int run_len = 15;
+
+  DevBuf<SegDesc> desc;
+  DevBuf<float> bus;  // [gsplit][K*N][bus_stride], strides chosen per call
+  int max_gsplit = 1;
+  DevBuf<cf> H, tw;
+  DevBuf<float> tail[2], dly[2];
+  int cur = 0;  // which state buffer holds the current state
+  // host-pointer staging
+  DevBuf<float> d_in, d_out;
+  PinBuf<float> p_in, p_out;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  struct Pending { hipEvent_t e[6]; bool has_k2; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  double acc_ms[3] = {0, 0, 0};
+  double acc_n[3] = {0, 0, 0};
+
+  ~earhip_render() {
+    for (auto &p : pending)
+      for (auto e : p.e)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : pool) (void)hipEventDestroy(e);
+  }
+
+  hipEvent_t get_event() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    EARHIP_HIP(hipEventCreate(&e));
+    return e;
+  }
+
+  void drain_timing() {
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &p : pending) {
+      float ms = 0;
+      EARHIP_HIP(hipEventElapsedTime(&ms, p.e[0], p.e[1]));
+      acc_ms[2] += ms; acc_n[2] += 1;
+      EARHIP_HIP(hipEventElapsedTime(&ms, p.e[2], p.e[3]));
+      acc_ms[0] += ms; acc_n[0] += 1;
+      if (p.has_k2) {
+        EARHIP_HIP(hipEventElapsedTime(&ms, p.e[4], p.e[5]));
+        acc_ms[1] += ms; acc_n[1] += 1;
+      }
+      for (auto e : p.e)
+        if (e) pool.push_back(e);
+    }
+    pending.clear();
+  }
+
+  void process_device(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev,
+                      size_t out_stride) {
+    const int nsamples = (int)(nblocks * (size_t)B);
+    curves->commit(ctx);
+    const bool strict = ctx->strict;
+    MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit);
+    const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
+    const size_t part_stride = bus_stride * K * N;
+    if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");
+    Pending pd;
+    hipEvent_t *evp = nullptr;
+    if (timing) {
+      for (int i = 0; i < 6; i++) pd.e[i] = get_event();
+      pd.has_k2 = K == 2;
+      evp = pd.e;
+    }
+    if (K == 1) {
+      // direct bus only: K1 writes the output rows itself
+      if (ml.gsplit == 1) {
+        launch_gain_mix(ctx, *curves, ml, strict, t, nsamples, in_dev, in_stride, out_dev,
+                        out_stride, 0, desc.p, evp);
+      } else {
+        launch_gain_mix(ctx, *curves, ml, strict, t, nsamples, in_dev, in_stride, bus.p,
+                        bus_stride, part_stride, desc.p, evp);
+        hipLaunchKernelGGL(k_sum_parts, dim3((nsamples + 255) / 256, N), dim3(256), 0,
+                           ctx->stream, bus.p, part_stride, ml.gsplit, bus_stride, N, nsamples,
+                           out_dev, out_stride);
+        EARHIP_HIP(hipGetLastError());
+      }
+    } else {
+      launch_gain_mix(ctx, *curves, ml, strict, t, nsamples, in_dev, in_stride, bus.p,
+                      bus_stride, part_stride, desc.p, evp);
+      DecorParams P;
+      P.bus = bus.p;
+      P.bus_stride = bus_stride;
+      P.part_stride = part_stride;
+      P.nparts = ml.gsplit;
+      P.out = out_dev;
+      P.out_stride = out_stride;
+      P.H = H.p;
+      P.tw = tw.p;
+      P.tail_in = tail[cur].p;
+      P.tail_out = tail[cur ^ 1].p;
+      P.dly_in = dly[cur].p;
+      P.dly_out = dly[cur ^ 1].p;
+      P.N = N;
+      P.T = (int)nblocks;
+      P.R = run_len;
+      P.D = D;
+      const dim3 grid((unsigned)((nblocks + run_len - 1) / run_len), N);
+      if (evp) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
+      launch_decor(L, P, grid, ctx->stream);
+      if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
+      cur ^= 1;
+    }
+    if (timing) pending.push_back(pd);
+    t += nsamples;
+  }
+};
+
+extern "C" {
+
+int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhip_render **out) {
+  return guarded([&] {
+    require(ctx != nullptr && cfg != nullptr && out != nullptr, "NULL argument");
+    require(cfg->n_objects >= 1 && cfg->n_out >= 1, "n_objects and n_out must be >= 1");
+    require(cfg->n_buses == 1 || cfg->n_buses == 2, "n_buses must be 1 or 2");
+    require(is_pow2((size_t)cfg->block_size) && cfg->block_size >= 64 && cfg->block_size <= 4096,
+            "block_size must be a power of two in [64, 4096]");
+    require(cfg->max_blocks >= 1, "max_blocks must be >= 1");
+    require((int64_t)cfg->max_blocks * cfg->block_size < ((int64_t)1 << 30),
+            "max_blocks * block_size too large");
+    require(cfg->delay >= 0, "delay must be >= 0");
+    if (cfg->n_buses == 2) {
+      require(cfg->decorrelators != nullptr && cfg->n_taps >= 1,
+              "n_buses == 2 needs decorrelator filters");
+      require(cfg->n_taps <= cfg->block_size,
+              "decorrelator filters longer than block_size are not supported by the fused "
+              "render (use BlockConvolver)");
+    } else {
+      require(cfg->delay == 0, "delay needs n_buses == 2");
+    }
+    ctx->use();
+    std::unique_ptr<earhip_render> r(new earhip_render);
+    r->ctx = ctx;
+    r->M = cfg->n_objects;
+    r->N = cfg->n_out;
+    r->B = cfg->block_size;
+    r->K = cfg->n_buses;
+    r->D = cfg->delay;
+    r->T = cfg->max_blocks;
+    r->L = 2 * r->B;
+    r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
+    const size_t max_samples = (size_t)r->T * r->B;
+    const size_t max_tiles = (max_samples + kTileSamples - 1) / kTileSamples;
+    r->desc.alloc((size_t)r->M * max_tiles);
+    // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits
+    // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps
+    // gsplit * ntiles < 4 * num_cus, so gsplit * nsamples < 4 * num_cus * 256.
+    r->max_gsplit = 32;
+    const size_t pad_samples = (max_samples + 3) & ~(size_t)3;
+    const size_t split_samples = (size_t)4 * ctx->num_cus * kTileSamples + 4 * r->max_gsplit;
+    r->bus.alloc_zero((size_t)r->K * r->N * std::max(pad_samples, split_samples), ctx->stream);
+    if (r->K == 2) {
+      const auto tw = make_twiddles(r->L);
+      r->tw.alloc(r->L);
+      EARHIP_HIP(hipMemcpy(r->tw.p, tw.data(), sizeof(cf) * r->L, hipMemcpyHostToDevice));
+      // H = DFT_L(zero-padded FIR), computed with the device transform, then made
+      // exactly Hermitian so that two real blocks separate cleanly
+      DevBuf<float> taps;
+      taps.alloc((size_t)r->N * cfg->n_taps);
+      EARHIP_HIP(hipMemcpy(taps.p, cfg->decorrelators, sizeof(float) * r->N * cfg->n_taps,
+                           hipMemcpyHostToDevice));
+      r->H.alloc((size_t)r->N * r->L);
+      launch_spectrum(r->L, taps.p, cfg->n_taps, cfg->n_taps, r->tw.p, r->H.p, r->N, ctx->stream);
+      EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+      std::vector<cf> h((size_t)r->N * r->L);
+      EARHIP_HIP(hipMemcpy(h.data(), r->H.p, sizeof(cf) * h.size(), hipMemcpyDeviceToHost));
+      for (int n = 0; n < r->N; n++) {
+        cf *hn = h.data() + (size_t)n * r->L;
+        hn[0].y = 0.0f;
+        hn[r->B].y = 0.0f;
+        for (int k = 1; k < r->B; k++) hn[r->L - k] = cf_conj(hn[k]);
+      }
+      EARHIP_HIP(hipMemcpy(r->H.p, h.data(), sizeof(cf) * h.size(), hipMemcpyHostToDevice));
+      for (int i = 0; i < 2; i++) {
+        r->tail[i].alloc_zero((size_t)r->N * r->B, ctx->stream);
+        r->dly[i].alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
+      }
+    }
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    *out = r.release();
+  });
+}
+
+int earhip_render_destroy(earhip_render *r) {
+  return guarded([&] {
+    if (!r) return;
+    (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    delete r;
+  });
+}
+
+int earhip_render_set_object_points(earhip_render *r, int object, int npoints,
+                                    const int64_t *times, const float *direct,
+                                    const float *diffuse) {
+  return guarded([&] {
+    require(r != nullptr, "render must not be NULL");
+    require(npoints >= 1, "interp_points must not be empty");
+    require(times != nullptr && direct != nullptr, "times/direct must not be NULL");
+    require(r->K == 1 || diffuse != nullptr, "diffuse gains must not be NULL when n_buses == 2");
+    const int N = r->N, cols = r->K * N;
+    std::vector<float> rows((size_t)npoints * cols);
+    for (int k = 0; k < npoints; k++) {
+      std::memcpy(&rows[(size_t)k * cols], direct + (size_t)k * N, sizeof(float) * N);
+      if (r->K == 2)
+        std::memcpy(&rows[(size_t)k * cols + N], diffuse + (size_t)k * N, sizeof(float) * N);
+    }
+    r->curves->set_object(object, npoints, times, rows.data());
+  });
+}
+
+int earhip_render_commit(earhip_render *r) {
+  return guarded([&] {
+    require(r != nullptr, "render must not be NULL");
+    r->ctx->use();
+    r->curves->commit(r->ctx);
+  });
+}
+
+int earhip_render_reset(earhip_render *r, int64_t sample_time) {
+  return guarded([&] {
+    require(r != nullptr, "render must not be NULL");
+    r->ctx->use();
+    r->t = sample_time;
+    if (r->K == 2)
+      for (int i = 0; i < 2; i++) {
+        EARHIP_HIP(hipMemsetAsync(r->tail[i].p, 0, r->tail[i].n * sizeof(float), r->ctx->stream));
+        EARHIP_HIP(hipMemsetAsync(r->dly[i].p, 0, r->dly[i].n * sizeof(float), r->ctx->stream));
+      }
+  });
+}
+
+int earhip_render_process_device(earhip_render *r, size_t nblocks, const float *in_dev,
+                                 size_t in_stride, float *out_dev, size_t out_stride) {
+  return guarded([&] {
+    require(r != nullptr, "render must not be NULL");
+    require(in_dev != nullptr && out_dev != nullptr, "device pointers must not be NULL");
+    require(nblocks <= (size_t)r->T, "nblocks exceeds max_blocks");
+    require(in_stride >= nblocks * r->B && out_stride >= nblocks * r->B, "stride too small");
+    if (nblocks == 0) return;
+    r->ctx->use();
+    r->process_device(nblocks, in_dev, in_stride, out_dev, out_stride);
+  });
+}
+
+int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *in,
+                          float *const *out) {
+  return guarded([&] {
+    require(r != nullptr, "render must not be NULL");
+    require(in != nullptr && out != nullptr, "in and out must not be NULL");
+    require(nblocks <= (size_t)r->T, "nblocks exceeds max_blocks");
+    if (nblocks == 0) return;
+    earhip_ctx *ctx = r->ctx;
+    ctx->use();
+    const size_t n = nblocks * r->B;
+    const size_t cap = (size_t)r->T * r->B;
+    r->p_in.reserve(cap * r->M);
+    r->p_out.reserve(cap * r->N);
+    r->d_in.reserve(cap * r->M);
+    r->d_out.reserve(cap * r->N);
+    for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + m * n, in[m], sizeof(float) * n);
+    EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, sizeof(float) * n * r->M,
+                              hipMemcpyHostToDevice, ctx->stream));
+    r->process_device(nblocks, r->d_in.p, n, r->d_out.p, n);
+    EARHIP_HIP(hipMemcpyAsync(r->p_out.p, r->d_out.p, sizeof(float) * n * r->N,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < r->N; c++) std::memcpy(out[c], r->p_out.p + c * n, sizeof(float) * n);
+  });
+}
+
+int earhip_render_enable_timing(earhip_render *r, int enable) {
+  return guarded([&] {
+    require(r != nullptr, "render must not be NULL");
+    r->ctx->use();
+    if (r->timing) r->drain_timing();
+    r->timing = enable != 0;
+    for (int i = 0; i < 3; i++) r->acc_ms[i] = r->acc_n[i] = 0;
+  });
+}
+
+int earhip_render_get_timing(earhip_render *r, double out[6]) {
+  return guarded([&] {
+    require(r != nullptr && out != nullptr, "NULL argument");
+    r->ctx->use();
+    r->drain_timing();
+    out[0] = r->acc_ms[0]; out[1] = r->acc_n[0];
+    out[2] = r->acc_ms[1]; out[3] = r->acc_n[1];
+    out[4] = r->acc_ms[2]; out[5] = r->acc_n[2];
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// api_vbs.cpp — (E) VariableBlockSizeAdapter of include/earhip.h: host-side FIFO
+// re-blocking around a fixed-block-size callback, behaviour of libear's
+// src/dsp/variable_block_size_impl.cpp:27-85 (first block_size output samples
+// are zeros; the callback runs in place on the internal buffers each time a
+// block has been collected).  No device work here: the callback is where the
+// device chain (e.g. earhip_render_process) is invoked.
+#include <algorithm>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+using namespace earhip;
+
+struct earhip_vbs {
+  size_t B, nin, nout, fill = 0;
+  earhip_process_func fn;
+  void *user;
+  std::vector<float> ibuf, obuf;  // channel-major [nch][B]
+  std::vector<const float *> iptr;
+  std::vector<float *> optr;
+};
+
+extern "C" {
+
+int earhip_vbs_create(size_t block_size, size_t num_channels_in, size_t num_channels_out,
+                      earhip_process_func process_func, void *user, earhip_vbs **out) {
+  return guarded([&] {
+    require(out != nullptr && process_func != nullptr, "NULL argument");
+    require(block_size >= 1, "block_size must be >= 1");
+    std::unique_ptr<earhip_vbs> v(new earhip_vbs);
+    v->B = block_size;
+    v->nin = num_channels_in;
+    v->nout = num_channels_out;
+    v->fn = process_func;
+    v->user = user;
+    v->ibuf.assign(block_size * num_channels_in, 0.0f);
+    v->obuf.assign(block_size * num_channels_out, 0.0f);
+    v->iptr.resize(num_channels_in);
+    v->optr.resize(num_channels_out);
+    for (size_t c = 0; c < num_channels_in; c++) v->iptr[c] = v->ibuf.data() + c * block_size;
+    for (size_t c = 0; c < num_channels_out; c++) v->optr[c] = v->obuf.data() + c * block_size;
+    *out = v.release();
+  });
+}
+
+int earhip_vbs_destroy(earhip_vbs *v) {
+  delete v;
+  return EARHIP_OK;
+}
+
+int earhip_vbs_get_delay(const earhip_vbs *v) { return v ? (int)v->B : 0; }
+
+int earhip_vbs_process(earhip_vbs *v, size_t nsamples, const float *const *in, float *const *out) {
+  int cb_status = EARHIP_OK;
+  const int rc = guarded([&] {
+    require(v != nullptr, "adapter must not be NULL");
+    require(nsamples == 0 || (in != nullptr && out != nullptr), "in and out must not be NULL");
+    size_t done = 0;
+    while (done < nsamples) {
+      const size_t n = std::min(nsamples - done, v->B - v->fill);
+      for (size_t c = 0; c < v->nin; c++)
+        std::copy(in[c] + done, in[c] + done + n, v->ibuf.data() + c * v->B + v->fill);
+      for (size_t c = 0; c < v->nout; c++)
+        std::copy(v->obuf.data() + c * v->B + v->fill, v->obuf.data() + c * v->B + v->fill + n,
+                  out[c] + done);
+      done += n;
+      v->fill += n;
+      const bool run = v->fill == v->B;
+      if (run) {
+        cb_status = v->fn(v->iptr.data(), v->optr.data(), v->user);
+        v->fill = 0;
+        if (cb_status != EARHIP_OK) return;  // message already set by the callee
+      }
+      if (!run && n == 0) fail_internal("no progress made");
+    }
+    if (done != nsamples) fail_internal("processed more samples than expected");
+  });
+  return rc != EARHIP_OK ? rc : cb_status;
+}
+
+}  // extern "C"

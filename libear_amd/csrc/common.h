@@ -1,0 +1,125 @@
+// common.h — shared host-side plumbing of libearhip: status codes, the
+// thread-local error string, the context object and HIP error checks.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/earhip.h"
+
+namespace earhip {
+
+struct Error {
+  int code;
+  std::string msg;
+};
+
+void set_last_error(const std::string &msg);
+
+// Runs f, translating earhip::Error / std::exception into a status code.
+template <typename F>
+int guarded(F &&f) {
+  try {
+    f();
+    return EARHIP_OK;
+  } catch (const Error &e) {
+    set_last_error(e.msg);
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    set_last_error("out of host memory");
+    return EARHIP_INTERNAL_ERROR;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return EARHIP_INTERNAL_ERROR;
+  }
+}
+
+[[noreturn]] inline void fail_invalid(const std::string &m) {
+  throw Error{EARHIP_INVALID_ARGUMENT, m};
+}
+[[noreturn]] inline void fail_internal(const std::string &m) {
+  throw Error{EARHIP_INTERNAL_ERROR, "internal error: " + m};
+}
+inline void require(bool ok, const char *m) {
+  if (!ok) fail_invalid(m);
+}
+
+#define EARHIP_HIP(expr)                                                        \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess)                                                       \
+      throw ::earhip::Error{EARHIP_DEVICE_ERROR,                                \
+                            std::string("internal error: HIP: ") +              \
+                                hipGetErrorString(e_) + " in " #expr};          \
+  } while (0)
+
+inline bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
+
+// Owning device buffer (setup-time allocation only).
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    EARHIP_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+  void alloc_zero(size_t count, hipStream_t s) {
+    alloc(count);
+    EARHIP_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+  // grows (never shrinks); contents are lost on growth
+  void reserve(size_t count) {
+    if (count > n) alloc(count);
+  }
+};
+
+// Pinned host staging buffer.
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf &) = delete;
+  PinBuf &operator=(const PinBuf &) = delete;
+  ~PinBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void reserve(size_t count) {
+    if (count <= n) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+    EARHIP_HIP(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault));
+    n = count;
+  }
+};
+
+}  // namespace earhip
+
+struct earhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool strict = false;
+  int num_cus = 256;
+  // staging for the host-pointer entry points (grown at first use / create)
+  earhip::PinBuf<float> pin_in, pin_out;
+  earhip::DevBuf<float> dev_in, dev_out, dev_pts;
+  void use() const { EARHIP_HIP(hipSetDevice(device)); }
+};

@@ -1,0 +1,183 @@
+// curves.h — host mirror + device image of the gain curves of M input channels
+// (libear's GainInterpolator::interp_points, gain_interpolator.hpp:27-43), and
+// the launcher of K0/K1 over them.
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "gain_kernels.h"
+
+namespace earhip {
+
+// column tiling of the K*N output columns over waves
+struct ColumnPlan {
+  int nout = 24;     // columns per wave (8, 16 or 24)
+  int ngroups = 1;   // column groups per workgroup
+  int nz = 1;        // column super-groups (grid.z)
+  int row = 24;      // padded row length = nz * ngroups * nout
+  static ColumnPlan make(int ncols) {
+    ColumnPlan p;
+    int groups = (ncols + 23) / 24;
+    const int per = (ncols + groups - 1) / groups;
+    p.nout = per <= 8 ? 8 : per <= 16 ? 16 : 24;
+    groups = (ncols + p.nout - 1) / p.nout;
+    p.ngroups = std::min(groups, 8);
+    p.nz = (groups + p.ngroups - 1) / p.ngroups;
+    p.row = p.nz * p.ngroups * p.nout;
+    return p;
+  }
+};
+
+class CurveSet {
+ public:
+  // ncols = nbus * bus_cols; each bus is one libear GainInterpolator per object
+  CurveSet(int M, int ncols, int nbus = 1, bool force_ramp = false)
+      : M_(M), ncols_(ncols), nbus_(nbus), force_ramp_(force_ramp),
+        plan_(ColumnPlan::make(ncols)) {
+    times_.resize(M);
+    gains_.resize(M);
+    flat_.resize(M);
+    // an object without a curve is silent: one all-zero point
+    for (int m = 0; m < M; m++) {
+      times_[m].assign(1, 0);
+      gains_[m].assign(plan_.row, 0.0f);
+      flat_[m].assign(1, 0);
+    }
+    dirty_ = true;
+  }
+  int M() const { return M_; }
+  int ncols() const { return ncols_; }
+  const ColumnPlan &plan() const { return plan_; }
+
+  // rows: [npoints][ncols] for this object.  flat_override (optional, [npoints]):
+  // caller-decided "point k equals point k-1" bits, used when libear compares a
+  // larger point than this object's row (LinearInterpMatrix: the whole matrix).
+  void set_object(int m, int npoints, const int64_t *times, const float *rows,
+                  const uint8_t *flat_override = nullptr) {
+    if (m < 0 || m >= M_) fail_invalid("object index out of range");
+    if (npoints < 1) fail_invalid("interp_points must not be empty");
+    for (int k = 1; k < npoints; k++) {
+      if (times[k] < times[k - 1]) fail_invalid("interpolation points are not sorted");
+      if (times[k] - times[k - 1] > (int64_t)0x7fffffff)
+        fail_invalid("interpolation ramp longer than 2^31-1 samples is not supported");
+    }
+    times_[m].assign(times, times + npoints);
+    gains_[m].assign((size_t)npoints * plan_.row, 0.0f);
+    for (int k = 0; k < npoints; k++)
+      std::memcpy(&gains_[m][(size_t)k * plan_.row], rows + (size_t)k * ncols_,
+                  sizeof(float) * ncols_);
+    flat_[m].assign(npoints, 0);
+    const int bc = ncols_ / nbus_;
+    for (int k = 1; k < npoints; k++) {
+      if (flat_override) {
+        flat_[m][k] = flat_override[k];
+        continue;
+      }
+      // InterpType::constant_interp: a == b on every component
+      // (gain_interpolator.hpp:141-143); float ==, so -0 == +0 and NaN != NaN
+      for (int b = 0; b < nbus_; b++) {
+        bool same = true;
+        for (int c = b * bc; same && c < (b + 1) * bc; c++)
+          same = rows[(size_t)(k - 1) * ncols_ + c] == rows[(size_t)k * ncols_ + c];
+        if (same) flat_[m][k] |= (uint8_t)(1 << b);
+      }
+    }
+    dirty_ = true;
+  }
+
+  // flatten and upload (setup-time; synchronous)
+  void commit(earhip_ctx *ctx) {
+    if (!dirty_) return;
+    size_t P = 0;
+    for (int m = 0; m < M_; m++) P += times_[m].size();
+    std::vector<int32_t> off(M_ + 1);
+    std::vector<int64_t> time(P);
+    std::vector<uint8_t> flat(P);
+    std::vector<float> gain(P * plan_.row);
+    size_t at = 0;
+    for (int m = 0; m < M_; m++) {
+      off[m] = (int32_t)at;
+      const size_t n = times_[m].size();
+      std::memcpy(&time[at], times_[m].data(), n * sizeof(int64_t));
+      std::memcpy(&gain[at * plan_.row], gains_[m].data(), n * plan_.row * sizeof(float));
+      std::memcpy(&flat[at], flat_[m].data(), n);
+      at += n;
+    }
+    off[M_] = (int32_t)at;
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // old image may still be in use
+    d_off_.reserve(off.size());
+    d_time_.reserve(P);
+    d_flat_.reserve(P);
+    d_gain_.reserve(gain.size());
+    EARHIP_HIP(hipMemcpy(d_off_.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    EARHIP_HIP(hipMemcpy(d_time_.p, time.data(), P * sizeof(int64_t), hipMemcpyHostToDevice));
+    EARHIP_HIP(hipMemcpy(d_flat_.p, flat.data(), P, hipMemcpyHostToDevice));
+    EARHIP_HIP(hipMemcpy(d_gain_.p, gain.data(), gain.size() * sizeof(float), hipMemcpyHostToDevice));
+    dirty_ = false;
+  }
+
+  PointStore device() const {
+    PointStore ps;
+    ps.off = d_off_.p;
+    ps.time = d_time_.p;
+    ps.flat = d_flat_.p;
+    ps.gain = d_gain_.p;
+    ps.row = plan_.row;
+    ps.bus_cols = ncols_ / nbus_;
+    ps.nbus = nbus_;
+    ps.force_ramp = force_ramp_ ? 1 : 0;
+    return ps;
+  }
+
+ private:
+  int M_, ncols_, nbus_;
+  bool force_ramp_;
+  ColumnPlan plan_;
+  std::vector<std::vector<int64_t>> times_;
+  std::vector<std::vector<float>> gains_;
+  std::vector<std::vector<uint8_t>> flat_;
+  bool dirty_ = true;
+  DevBuf<int32_t> d_off_;
+  DevBuf<int64_t> d_time_;
+  DevBuf<uint8_t> d_flat_;
+  DevBuf<float> d_gain_;
+};
+
+// How K1 is spread over the chip for one call.
+struct MixLaunch {
+  int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
+};
+
+inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
+                          bool strict, int max_gsplit) {
+  MixLaunch L;
+  L.ntiles = (nsamples + kTileSamples - 1) / kTileSamples;
+  if (strict) {
+    L.wsplit = 1;
+    L.gsplit = 1;
+    return L;
+  }
+  // 8 waves per workgroup: what the column groups leave goes to object splits
+  L.wsplit = std::max(1, std::min(8 / cp.ngroups, std::max(1, M / 8)));
+  // few tiles (block mode): split the objects across workgroups as well until
+  // the grid covers the chip about twice over
+  const int per_wg = std::max(1, M / L.wsplit);
+  int g = 1;
+  const int want = 2 * ctx->num_cus;
+  while (g < max_gsplit && L.ntiles * cp.nz * g < want && per_wg / (g * 2) >= 8) g *= 2;
+  L.gsplit = g;
+  return L;
+}
+
+size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml);
+
+// Enqueue K0 + K1.  out: [gsplit][ncols][out_stride] (part_stride floats apart)
+void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, bool strict,
+                     int64_t t_call, int nsamples, const float *in_dev, size_t in_stride,
+                     float *out_dev, size_t out_stride, size_t part_stride, SegDesc *desc,
+                     hipEvent_t *ev /* optional [4]: prep begin/end, mix begin/end */);
+
+}  // namespace earhip

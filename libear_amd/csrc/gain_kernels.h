@@ -1,0 +1,308 @@
+// gain_kernels.h — K0 (segment prep) and K1 (gain_mix): piecewise-linear gain
+// curves applied to M planar input channels and mixed down into loudspeaker
+// buses.  Device restatement of libear's LinearInterp{Single,Vector,Matrix}
+// (include/ear/dsp/gain_interpolator.hpp:187-299) and of the segment walk of
+// GainInterpolator::process (:53-87), re-shaped for CDNA4:
+//
+//   * lane = 4 consecutive samples (one 16-byte coalesced load per object),
+//     wave = one 256-sample tile x one group of <= 24 output columns,
+//     workgroup = 8 waves = column groups x in-workgroup object splits;
+//   * per object the two gain rows are wave-uniform, so they are fetched with
+//     scalar loads and enter the FMAs as SGPR operands; the 96 accumulators
+//     (24 columns x 4 samples) never leave VGPRs until the tile is finished;
+//   * the ramp is folded into the input once per object and sample:
+//         a = x*(1-p), b = x*p          (shared by all columns)
+//         acc[col] += a*S[col] + b*E[col]   -> 2 FMAs per (object,column,sample)
+//     instead of the reference's 5 un-fused flops;
+//   * object splits are combined through LDS in a fixed order (deterministic).
+//
+// STRICT instantiations keep libear's arithmetic verbatim (un-contracted
+// `x * ((1-p)*s + p*e)`, objects accumulated in order by a single wave): they
+// are bit-identical to the CPU path and are used for parity pinning and for
+// the 1->N policies, which are store-bound anyway.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace earhip {
+
+// Flattened gain curves of all objects (device pointers).
+struct PointStore {
+  const int32_t *off;    // [M+1] first point of each object
+  const int64_t *time;   // [P]   point times, sorted per object
+  const uint8_t *flat;   // [P]   bit b: bus b's gain vector at point k equals point k-1
+  const float *gain;     // [P][row] gain rows (bus-major columns, zero padded)
+  int row;               // floats per row (multiple of 4)
+  int bus_cols;          // columns per bus (columns [b*bus_cols, (b+1)*bus_cols) = bus b)
+  int nbus;              // 1 or 2; each bus is one libear GainInterpolator
+  int force_ramp;        // policy mode: every object is ONE ramp through its 2 points,
+                         // extrapolated outside (LinearInterp*::apply_interp as called directly)
+};
+
+// What one (object, 256-sample tile) pair has to do; written by K0.
+struct SegDesc {
+  int32_t row;    // first gain row to load (ramp: start point; constant: the point)
+  int32_t d0;     // ramp: tile_start - curve_start (>= 0, < 2^31)
+  float scale;    // ramp: 1.0f / (float)(end - start)
+  int32_t info;   // bit0 ramp, bit1 the segment ends inside this tile, bits 2-3 per-bus
+                  // "constant" flags, bits 4..: segment index
+};
+static_assert(sizeof(SegDesc) == 16, "SegDesc is loaded as one dwordx4");
+
+constexpr int kTileSamples = 256;  // samples per tile = 64 lanes x 4
+constexpr int kSegRamp = 1;
+constexpr int kSegMulti = 2;
+
+// number of points of object m with time <= t  (= libear's find_block result)
+__device__ __forceinline__ int upper_bound_time(const int64_t *t, int n, int64_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (t[mid] <= v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// Describe segment k of an object for samples starting at absolute time t0.
+__device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int base,
+                                                    int n, int k, int64_t t0,
+                                                    int64_t t_end) {
+  // (k, t_end are adjusted below in policy mode)
+  SegDesc d;
+  if (ps.force_ramp) {
+    k = 1;
+    t_end = t0;  // never "multi"
+  }
+  const int allflat = (1 << ps.nbus) - 1;
+  const int fb = (k > 0 && k < n) ? (ps.flat[base + k] & allflat) : allflat;
+  // constant before the first / after the last point or between equal points
+  // (gain_interpolator.hpp:68-75)
+  const bool ramp = ps.force_ramp || fb != allflat;
+  const bool multi = k < n && ps.time[base + k] < t_end;
+  d.info = (k << 4) | (fb << 2) | (multi ? kSegMulti : 0) | (ramp ? kSegRamp : 0);
+  if (ramp) {
+    const int64_t start = ps.time[base + k - 1], end = ps.time[base + k];
+    d.row = base + k - 1;
+    d.d0 = (int32_t)(t0 - start);
+    d.scale = 1.0f / (float)(end - start);  // gain_interpolator.hpp:191,221,255
+  } else {
+    d.row = base + (k == n ? k - 1 : k);  // gain_interpolator.hpp:71-72
+    d.d0 = 0;
+    d.scale = 0.0f;
+  }
+  return d;
+}
+
+// K0: one thread per (object, tile).
+static __global__ void k_seg_prep(PointStore ps, int M, int ntiles, int64_t t_call,
+                           int64_t t_call_end, SegDesc *desc) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * ntiles) return;
+  const int m = idx / ntiles, tile = idx - m * ntiles;
+  const int base = ps.off[m], n = ps.off[m + 1] - base;
+  const int64_t t0 = t_call + (int64_t)tile * kTileSamples;
+  int64_t t_end = t0 + kTileSamples;
+  if (t_end > t_call_end) t_end = t_call_end;
+  const int k = upper_bound_time(ps.time + base, n, t0);
+  desc[idx] = describe_segment(ps, base, n, k, t0, t_end);
+}
+
+struct GainMixParams {
+  const float *in;      // [M][in_stride] planar input, sample 0 = call start
+  size_t in_stride;
+  float *out;           // [part][col][out_stride]
+  size_t out_stride;
+  size_t part_stride;   // floats between the slabs of two grid-level splits
+  const SegDesc *desc;  // [M][ntiles]
+  PointStore ps;
+  int64_t t_call;       // absolute sample time of sample 0
+  int nsamples;         // samples in this call
+  int ntiles;
+  int M;
+  int ncols;            // valid output columns (<= row)
+  int ngroups;          // column groups per workgroup (waves: group-major)
+  int wsplit;           // object splits inside a workgroup
+  int vec_ok;           // in/out rows are 16-byte aligned: float4 accesses allowed
+};
+
+// accumulate one segment piece of one object into acc
+template <int NOUT, bool STRICT>
+__device__ __forceinline__ void accumulate_piece(float (&acc)[NOUT][4], const float4 x,
+                                                 const SegDesc d, const float *__restrict__ rows,
+                                                 int rowlen, int lane, int col0, int bus_cols) {
+  const float xs[4] = {x.x, x.y, x.z, x.w};
+  const bool ramp = d.info & kSegRamp;
+  const float *__restrict__ S = rows;
+  const float *__restrict__ E = rows + (ramp ? rowlen : 0);
+  float p[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    p[i] = (float)(d.d0 + lane * 4 + i) * d.scale;  // gain_interpolator.hpp:193,224,272
+    q[i] = 1.0f - p[i];
+  }
+  if (STRICT) {
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) {
+      const float s = S[j], e = E[j];
+      // constant segment, or a bus whose two points compare equal: libear's
+      // apply_constant with the segment's end point (gain_interpolator.hpp:68-75)
+      const bool cflat = !ramp || ((d.info >> (2 + (col0 + j >= bus_cols ? 1 : 0))) & 1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float g = cflat ? e : q[i] * s + p[i] * e;  // un-contracted (-ffp-contract=off)
+        acc[j][i] = acc[j][i] + xs[i] * g;
+      }
+    }
+  } else {
+    float a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      a[i] = ramp ? xs[i] * q[i] : xs[i];
+      b[i] = xs[i] * p[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) {
+      const float s = S[j];
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[j][i] = __builtin_fmaf(a[i], s, acc[j][i]);
+    }
+    if (ramp) {
+#pragma unroll
+      for (int j = 0; j < NOUT; j++) {
+        const float e = E[j];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[j][i] = __builtin_fmaf(b[i], e, acc[j][i]);
+      }
+    }
+  }
+}
+
+// K1.  grid = (ntiles, grid-level object splits, column super-groups)
+// block = 64 * ngroups * wsplit threads.
+template <int NOUT, bool STRICT>
+__global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [ngroups][NOUT][256]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = wave % P.ngroups;           // column group inside the workgroup
+  const int ws = wave / P.ngroups;          // object split inside the workgroup
+  const int tile = blockIdx.x;
+  const int nparts = P.wsplit * gridDim.y;
+  const int part = blockIdx.y * P.wsplit + ws;
+  const int m_lo = (int)(((int64_t)P.M * part) / nparts);
+  const int m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
+  const int col0 = (blockIdx.z * P.ngroups + g) * NOUT;
+
+  const int s0 = tile * kTileSamples + lane * 4;  // first sample of this lane
+  const int64_t tile_t0 = P.t_call + (int64_t)tile * kTileSamples;
+  int64_t tile_t1 = tile_t0 + kTileSamples;
+  if (tile_t1 > P.t_call + P.nsamples) tile_t1 = P.t_call + P.nsamples;
+  const bool full = P.vec_ok && s0 + 3 < P.nsamples;
+
+  float acc[NOUT][4];
+#pragma unroll
+  for (int j = 0; j < NOUT; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[j][i] = 0.0f;
+
+  for (int m = m_lo; m < m_hi; m++) {
+    SegDesc d = P.desc[(size_t)m * P.ntiles + tile];
+    const float *xp = P.in + (size_t)m * P.in_stride + s0;
+    float4 x;
+    if (full) {
+      x = *reinterpret_cast<const float4 *>(xp);
+    } else {
+      x.x = s0 + 0 < P.nsamples ? xp[0] : 0.0f;
+      x.y = s0 + 1 < P.nsamples ? xp[1] : 0.0f;
+      x.z = s0 + 2 < P.nsamples ? xp[2] : 0.0f;
+      x.w = s0 + 3 < P.nsamples ? xp[3] : 0.0f;
+    }
+    // Usually the whole tile lies inside one curve segment and the loop body
+    // runs once.  If a curve point falls inside the tile, walk the segments
+    // like GainInterpolator::process (gain_interpolator.hpp:58-86), masking the
+    // lanes outside each piece.
+    int64_t cur = tile_t0;
+    for (;;) {
+      float4 xm = x;
+      int64_t seg_end = tile_t1;
+      if (d.info & kSegMulti) {
+        const int base = P.ps.off[m], k = d.info >> 4;
+        seg_end = P.ps.time[base + k];
+        const int r0 = (int)(cur - tile_t0), r1 = (int)(seg_end - tile_t0);
+        xm.x = (lane * 4 + 0 >= r0 && lane * 4 + 0 < r1) ? x.x : 0.0f;
+        xm.y = (lane * 4 + 1 >= r0 && lane * 4 + 1 < r1) ? x.y : 0.0f;
+        xm.z = (lane * 4 + 2 >= r0 && lane * 4 + 2 < r1) ? x.z : 0.0f;
+        xm.w = (lane * 4 + 3 >= r0 && lane * 4 + 3 < r1) ? x.w : 0.0f;
+      } else if (cur != tile_t0) {
+        const int r0 = (int)(cur - tile_t0);
+        xm.x = lane * 4 + 0 >= r0 ? x.x : 0.0f;
+        xm.y = lane * 4 + 1 >= r0 ? x.y : 0.0f;
+        xm.z = lane * 4 + 2 >= r0 ? x.z : 0.0f;
+        xm.w = lane * 4 + 3 >= r0 ? x.w : 0.0f;
+      }
+      if (seg_end > cur)  // duplicate times make empty segments (steps)
+        accumulate_piece<NOUT, STRICT>(acc, xm, d, P.ps.gain + (size_t)d.row * P.ps.row + col0,
+                                       P.ps.row, lane, col0, P.ps.bus_cols);
+      if (!(d.info & kSegMulti)) break;
+      cur = seg_end;
+      const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+      d = describe_segment(P.ps, base, n, (d.info >> 4) + 1, tile_t0, tile_t1);
+    }
+  }
+
+  // combine the in-workgroup object splits through LDS, highest split first
+  float *slab = lds + (size_t)g * NOUT * kTileSamples + lane * 4;
+  for (int r = P.wsplit - 1; r >= 1; r--) {
+    if (ws == r) {
+#pragma unroll
+      for (int j = 0; j < NOUT; j++) {
+        float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        if (r != P.wsplit - 1) {
+          const float4 o = *reinterpret_cast<const float4 *>(slab + j * kTileSamples);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4 *>(slab + j * kTileSamples) = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (ws != 0) return;
+
+  float *op = P.out + (size_t)blockIdx.y * P.part_stride + s0;
+#pragma unroll
+  for (int j = 0; j < NOUT; j++) {
+    if (col0 + j >= P.ncols) break;
+    float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    if (P.wsplit > 1) {
+      const float4 o = *reinterpret_cast<const float4 *>(slab + j * kTileSamples);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    float *o = op + (size_t)(col0 + j) * P.out_stride;
+    if (full) {
+      *reinterpret_cast<float4 *>(o) = v;
+    } else {
+      if (s0 + 0 < P.nsamples) o[0] = v.x;
+      if (s0 + 1 < P.nsamples) o[1] = v.y;
+      if (s0 + 2 < P.nsamples) o[2] = v.z;
+      if (s0 + 3 < P.nsamples) o[3] = v.w;
+    }
+  }
+}
+
+// sum grid-level partial slabs: out[c][s] = sum_p part[p][c][s]  (only used
+// when the buses go straight to the caller, i.e. no decorrelate/mix kernel)
+static __global__ void k_sum_parts(const float *parts, size_t part_stride, int nparts,
+                            size_t row_stride, int ncols, int nsamples, float *out,
+                            size_t out_stride) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (s >= nsamples || c >= ncols) return;
+  float v = 0.0f;
+  for (int p = 0; p < nparts; p++) v += parts[(size_t)p * part_stride + (size_t)c * row_stride + s];
+  out[(size_t)c * out_stride + s] = v;
+}
+
+}  // namespace earhip

@@ -1,0 +1,126 @@
+// render_kernels.h — K2 `decorrelate_delay_mix`: everything of the composed
+// Objects render block (libear docs/dsp.rst:40-71) that follows the bus-forming
+// gain stage, fused into one kernel:
+//
+//   diffuse bus --> BlockConvolver (P = 1 partition, static decorrelator FIR;
+//                   overlap-add exactly as block_convolver_impl.cpp:143-237)
+//   direct bus  --> DelayBuffer(D)            (delay_buffer_impl.cpp:19-40)
+//   out = decorrelated + delayed              (docs/figures/objects.png)
+//
+// One 256-thread workgroup owns one loudspeaker and a run of R consecutive
+// blocks.  Two real blocks t, t+1 ride through ONE complex FFT of length
+// L = 2B as z = pad(x_t) + i*pad(x_{t+1}); because the FIR is real its spectrum
+// H is Hermitian and  IDFT(H (.) DFT(z)) = y_t + i*y_{t+1}, so no untangling is
+// needed.  The overlap-add tail of the block before the run is recomputed (one
+// extra block per run) instead of being exchanged between workgroups, so the
+// time axis is embarrassingly parallel; the tail of the block before the call
+// and the delay line come from the persistent state, which the workgroup that
+// owns the last block of the call rewrites (double-buffered).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fft_lds.h"
+
+namespace earhip {
+
+struct DecorParams {
+  const float *bus;    // [part][2N][bus_stride]; rows 0..N-1 direct, N..2N-1 diffuse
+  size_t bus_stride;
+  size_t part_stride;
+  int nparts;
+  float *out;          // [N][out_stride]
+  size_t out_stride;
+  const cf *H;         // [N][L] decorrelator spectra (full, Hermitian)
+  const cf *tw;        // [L]
+  const float *tail_in;  // [N][B] un-normalised OLA tail of the block before the call
+  float *tail_out;
+  const float *dly_in;   // [N][D] last D direct-bus samples before the call
+  float *dly_out;
+  int N, T, R, D;
+};
+
+template <int L>
+__global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
+  constexpr int B = L / 2;
+  constexpr int NT = 256;
+  __shared__ __attribute__((aligned(16))) cf lds[2 * L];
+  __shared__ float tail[B];
+  cf *a = lds, *b = lds + L;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int first = blockIdx.x * P.R;
+  const int last = min(first + P.R, P.T);
+  const float norm = 1.0f / (float)(2 * B);  // block_convolver_impl.cpp:212
+  const cf *H = P.H + (size_t)n * L;
+  const float *direct = P.bus + (size_t)n * P.bus_stride;
+  const float *diffuse = P.bus + (size_t)(P.N + n) * P.bus_stride;
+  float *out = P.out + (size_t)n * P.out_stride;
+
+  auto bus_at = [&](const float *row, int s) {
+    float v = row[s];
+    for (int p = 1; p < P.nparts; p++) v += row[(size_t)p * P.part_stride + s];
+    return v;
+  };
+  // direct bus delayed by D: sample s of the call (s may reach back into state)
+  auto delayed = [&](int s) {
+    const int sd = s - P.D;
+    return sd >= 0 ? bus_at(direct, sd) : P.dly_in[(size_t)n * P.D + (sd + P.D)];
+  };
+
+  if (first == 0)
+    for (int i = tid; i < B; i += NT) tail[i] = P.tail_in[(size_t)n * B + i];
+
+  for (int tb = first - 1; tb < last; tb += 2) {
+    const bool have_re = tb >= 0, have_im = tb + 1 < last;
+    __syncthreads();  // previous pair's reads of a/b are finished
+    for (int i = tid; i < L; i += NT) {
+      cf v = cf_make(0.0f, 0.0f);
+      if (i < B) {
+        if (have_re) v.x = bus_at(diffuse, tb * B + i);
+        if (have_im) v.y = bus_at(diffuse, (tb + 1) * B + i);
+      }
+      a[i] = v;
+    }
+    cf *Z = fft_run_passes<L, -1, NT>(a, b, P.tw, 0, tid);
+    cf *W = Z == a ? b : a;
+    __syncthreads();
+    // first inverse pass with the spectral multiply folded into its loads
+    if (fft_r4_passes(L) > 0) {
+      for (int j = tid; j < L / 4; j += NT)
+        r4_core<L, +1>(cf_mul(Z[j], H[j]), cf_mul(Z[j + L / 4], H[j + L / 4]),
+                       cf_mul(Z[j + L / 2], H[j + L / 2]),
+                       cf_mul(Z[j + 3 * L / 4], H[j + 3 * L / 4]), W, P.tw, 1, j);
+    }
+    cf *y = fft_run_passes<L, +1, NT>(W, Z, P.tw, 1, tid);
+    __syncthreads();
+    // real part = block tb, imaginary part = block tb+1
+    for (int i = tid; i < B; i += NT) {
+      float tl = tail[i];
+      if (have_re) {
+        if (tb >= first) {
+          const float dec = (y[i].x + tl) * norm;  // :223-226
+          out[tb * B + i] = dec + delayed(tb * B + i);
+        }
+        tl = y[B + i].x;  // :224
+      }
+      if (have_im) {
+        const float dec = (y[i].y + tl) * norm;
+        out[(tb + 1) * B + i] = dec + delayed((tb + 1) * B + i);
+        tl = y[B + i].y;
+      }
+      tail[i] = tl;
+    }
+  }
+
+  if (last == P.T) {  // this workgroup owns the end of the call: publish the state
+    for (int i = tid; i < B; i += NT) P.tail_out[(size_t)n * B + i] = tail[i];
+    const int total = P.T * B;
+    for (int j = tid; j < P.D; j += NT) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+  }
+}
+
+// n_buses == 2 without decorrelators is not a libear configuration; n_buses == 1
+// (direct bus only) never reaches this kernel: K1 writes the output directly.
+
+}  // namespace earhip

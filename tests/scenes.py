@@ -1,0 +1,126 @@
+"""Synthetic ADM-render scenes shared by the GPU parity tests, the smoke check and bench.py.
+
+All inputs are seeded (numpy PCG64).  A scene = per-object gain curves (times + direct/diffuse
+gain vectors) + input audio.  `dense` is the worst case SURVEY §8(d) asks for (every block a
+full-length ramp between uniform(0,1) gain vectors on every loudspeaker); `sparse` is the
+realistic case (3 non-zero loudspeakers per object, power-normalised, sqrt(1-d)/sqrt(d)
+direct/diffuse split, zero LFE columns); `ragged` stresses the segment walk (points inside
+blocks, steps from duplicate times, objects with a single point, constant stretches).
+"""
+import numpy as np
+
+
+def audio(n_obj, n_samples, seed=1234):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1.0, 1.0, (n_obj, n_samples)).astype(np.float32)
+
+
+def dense_curves(n_obj, n_out, block, n_blocks, seed=7, t0=0):
+    """points at every block boundary: each block is one full-length ramp."""
+    rng = np.random.default_rng(seed)
+    times = t0 + block * np.arange(n_blocks + 1, dtype=np.int64)
+    curves = []
+    for _ in range(n_obj):
+        d = rng.uniform(0.0, 1.0, (n_blocks + 1, n_out)).astype(np.float32)
+        f = rng.uniform(0.0, 1.0, (n_blocks + 1, n_out)).astype(np.float32)
+        curves.append((times, d, f))
+    return curves
+
+
+def constant_curves(n_obj, n_out, seed=8):
+    rng = np.random.default_rng(seed)
+    curves = []
+    for _ in range(n_obj):
+        d = rng.uniform(0.0, 1.0, (1, n_out)).astype(np.float32)
+        f = rng.uniform(0.0, 1.0, (1, n_out)).astype(np.float32)
+        curves.append((np.zeros(1, np.int64), d, f))
+    return curves
+
+
+def sparse_curves(n_obj, n_out, block, n_blocks, lfe=(), seed=9):
+    """VBAP-like: 3 active loudspeakers per point, unit power, diffuseness d in {0, .5, 1}."""
+    rng = np.random.default_rng(seed)
+    times = block * np.arange(n_blocks + 1, dtype=np.int64)
+    speakers = [c for c in range(n_out) if c not in lfe]
+    curves = []
+    for _ in range(n_obj):
+        d = np.zeros((n_blocks + 1, n_out), np.float32)
+        f = np.zeros((n_blocks + 1, n_out), np.float32)
+        for k in range(n_blocks + 1):
+            idx = rng.choice(speakers, 3, replace=False)
+            g = rng.uniform(0.1, 1.0, 3)
+            g /= np.sqrt(np.sum(g * g))
+            diff = rng.choice([0.0, 0.5, 1.0])
+            d[k, idx] = (g * np.sqrt(1.0 - diff)).astype(np.float32)
+            f[k, idx] = (g * np.sqrt(diff)).astype(np.float32)
+        curves.append((times, d, f))
+    return curves
+
+
+def ragged_curves(n_obj, n_out, total, seed=10):
+    """irregular point times incl. duplicates (steps), equal neighbours (constant), single points."""
+    rng = np.random.default_rng(seed)
+    curves = []
+    for m in range(n_obj):
+        kind = m % 5
+        if kind == 0:  # one point
+            t = np.array([rng.integers(0, total)], np.int64)
+        elif kind == 1:  # a few random points, may fall anywhere (incl. inside tiles)
+            t = np.sort(rng.integers(-50, total + 50, rng.integers(2, 9))).astype(np.int64)
+        elif kind == 2:  # steps: duplicated times
+            base = np.sort(rng.integers(0, total, 3)).astype(np.int64)
+            t = np.sort(np.concatenate([base, base[:2]]))
+        elif kind == 3:  # dense points, closer than a tile
+            t = np.sort(rng.integers(0, total, 40)).astype(np.int64)
+        else:  # long ramp that starts before 0 and ends after the end
+            t = np.array([-1000, total + 777], np.int64)
+        n = len(t)
+        d = rng.uniform(0.0, 1.0, (n, n_out)).astype(np.float32)
+        f = rng.uniform(0.0, 1.0, (n, n_out)).astype(np.float32)
+        if kind == 3:  # some equal neighbours -> constant segments, per bus
+            d[5] = d[4]
+            f[9] = f[8]
+            d[20] = d[19]
+            f[20] = f[19]
+        curves.append((t, d, f))
+    return curves
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def render_f64(curves, x, n_out, decorrelators=None, delay=0):
+    """float64 evaluation of the composed render (truth for error budgets; small sizes only)."""
+    n_obj, total = x.shape
+    t = np.arange(total)
+    direct = np.zeros((n_out, total))
+    diffuse = np.zeros((n_out, total))
+    for m, (times, d, f) in enumerate(curves):
+        for bus, (g, acc) in enumerate(((d, direct), (f, diffuse))):
+            if g is None:
+                continue
+            k = np.searchsorted(times, t, side="right")  # segment index per sample
+            n = len(times)
+            km1 = np.clip(k - 1, 0, n - 1)
+            kk = np.clip(k, 0, n - 1)
+            inside = (k > 0) & (k < n)
+            span = np.where(inside, (times[kk] - times[km1]).astype(np.float64), 1.0)
+            span[span == 0] = 1.0
+            p = np.where(inside, (t - times[km1]) / span, 0.0)
+            gs = g[np.where(k == 0, 0, km1)].astype(np.float64)
+            ge = g[kk].astype(np.float64)
+            gain = gs * (1 - p)[:, None] + ge * p[:, None]
+            gain[k == 0] = g[0]
+            gain[k == n] = g[n - 1]
+            acc += (gain * x[m].astype(np.float64)[:, None]).T
+    if decorrelators is None:
+        return direct
+    out = np.zeros((n_out, total))
+    for c in range(n_out):
+        dec = np.convolve(diffuse[c], decorrelators[c].astype(np.float64))[:total]
+        dl = np.concatenate([np.zeros(delay), direct[c]])[:total]
+        out[c] = dec + dl
+    return out

@@ -1,0 +1,73 @@
+"""HIP BlockConvolver through the reference's scenarios (reference
+tests/block_convolver_tests.cpp:197-356): every sample within abs 1e-6 of the brute-force
+time-domain convolution (:77,191-193), and close to the CPU oracle."""
+import numpy as np
+import pytest
+
+import _oracle
+from _hip import ctx
+from refcases import conv_scenarios, generate_random
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_classes():
+    from libear_amd import capi
+    return capi.ConvCtx, capi.ConvFilter, capi.BlockConvolver
+
+
+def test_filter_correct_num_blocks():
+    ConvCtx, ConvFilter, _ = _hip_classes()
+    c = ConvCtx(ctx(), 512)
+    coeff = generate_random(2000, 100, 0)
+    for n, want in ((1, 1), (511, 1), (512, 1), (513, 2)):
+        assert ConvFilter(c, coeff[:n]).num_blocks() == want
+
+
+@pytest.mark.parametrize("sc", conv_scenarios(), ids=lambda s: s.name)
+def test_scenario(sc):
+    ConvCtx, ConvFilter, BlockConvolver = _hip_classes()
+    c = ConvCtx(ctx(), sc.block_size)
+    got = sc.run(c, ConvFilter, BlockConvolver)
+    want = sc.expected()
+    assert np.max(np.abs(got - want)) < 1e-6
+    ref = sc.run(_oracle.ConvCtx(sc.block_size), _oracle.ConvFilter, _oracle.BlockConvolver)
+    assert np.max(np.abs(got - ref)) < 1e-6
+
+
+@pytest.mark.parametrize("block", [32, 64, 256, 1024, 2048])
+def test_other_block_sizes_dense_input(block):
+    """full-scale dense input (not sparse impulses), 3 partitions, one crossfade"""
+    ConvCtx, ConvFilter, BlockConvolver = _hip_classes()
+    rng = np.random.default_rng(block)
+    nblk = 6
+    x = rng.uniform(-1, 1, nblk * block).astype(np.float32)
+    irs = [rng.uniform(-1, 1, 3 * block).astype(np.float32) / 8, rng.uniform(-1, 1, 2 * block).astype(np.float32) / 8]
+
+    def run(c, F, BC):
+        f = [F(c, ir) for ir in irs]
+        conv = BC(c, f[0], 3)
+        out = np.zeros_like(x)
+        for b in range(nblk):
+            if b == 3:
+                conv.crossfade_filter(f[1])
+            out[b * block:(b + 1) * block] = conv.process(x[b * block:(b + 1) * block])
+        return out
+
+    got = run(ConvCtx(ctx(), block), ConvFilter, BlockConvolver)
+    ref = run(_oracle.ConvCtx(block), _oracle.ConvFilter, _oracle.BlockConvolver)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-6
+
+
+def test_errors():
+    from libear_amd import capi
+    ConvCtx, ConvFilter, BlockConvolver = _hip_classes()
+    c512, c256 = ConvCtx(ctx(), 512), ConvCtx(ctx(), 256)
+    conv = BlockConvolver(c512, None, 1)
+    with pytest.raises(capi.InvalidArgument):
+        conv.set_filter(ConvFilter(c256, np.ones(10, np.float32)))
+    with pytest.raises(capi.InvalidArgument) as e:
+        conv.crossfade_filter(ConvFilter(c512, np.ones(513, np.float32)))
+    assert "too many blocks" in str(e.value)
+    with pytest.raises(capi.InvalidArgument):
+        ConvCtx(ctx(), 500)

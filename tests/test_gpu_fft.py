@@ -1,0 +1,52 @@
+"""HIP FFT plugin (include/earhip.h group B; libear include/ear/fft.hpp:27-50) vs the CPU oracle's
+kissfft restatement.  Float FFTs of different factorizations differ in rounding; tolerance:
+relative L2 <= 5e-7 against the oracle and against numpy's float64 transform."""
+import numpy as np
+import pytest
+
+import _oracle
+from _hip import ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_fft", [64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_forward_and_reverse(n_fft):
+    from libear_amd import capi
+    plan = capi.FFTPlan(ctx(), n_fft)
+    rng = np.random.default_rng(n_fft)
+    x = rng.uniform(-1, 1, n_fft).astype(np.float32)
+    X = plan.forward(x)
+    want = _oracle.rfft(x)
+    ref = np.fft.rfft(x.astype(np.float64))
+    assert np.linalg.norm(X - want) / np.linalg.norm(want) < 5e-7
+    assert np.linalg.norm(X - ref) / np.linalg.norm(ref) < 5e-7
+    y = plan.reverse(want)
+    want_y = _oracle.irfft_unnorm(want, n_fft)
+    assert np.linalg.norm(y - want_y) / np.linalg.norm(want_y) < 5e-7
+    assert np.max(np.abs(y / n_fft - x)) < 3e-6  # un-normalised both ways
+    plan.close()
+
+
+def test_golden_vectors():
+    """the committed kissfft vectors (tests/golden) through the device transform"""
+    import os
+    from libear_amd import capi
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "kiss_fft_vectors.npz"))
+    for nhalf in (256, 512, 1024):
+        x = gold[f"rfft32_packed_nhalf{nhalf}_in"]
+        packed = gold[f"rfft32_packed_nhalf{nhalf}_out"]
+        want = np.empty(nhalf + 1, np.complex64)
+        want[:nhalf] = packed
+        want[nhalf] = packed[0].imag
+        want[0] = packed[0].real
+        plan = capi.FFTPlan(ctx(), 2 * nhalf)
+        got = plan.forward(x)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-7
+        plan.close()
+
+
+def test_bad_size_is_invalid_argument():
+    from libear_amd import capi
+    with pytest.raises(capi.InvalidArgument):
+        capi.FFTPlan(ctx(), 1000)

@@ -1,0 +1,187 @@
+"""The composed Objects render block on the GPU (K0 segment prep -> K1 gain_mix -> K2
+decorrelate/delay/mix) vs the CPU oracle's composition of the restated libear components
+(docs/dsp.rst:40-71).
+
+Bars:
+  * gain stage alone (n_buses = 1), strict mode: bit-exact vs the oracle;
+  * full chain, default mode: relative RMS <= 1e-6 vs the oracle over all outputs (north_star's
+    tolerance; relative as BASELINE.md §2 argues), and both close to a float64 evaluation;
+  * streamed (T blocks per call) == block-at-a-time within 1e-6 relative RMS; state carries over;
+  * full BASELINE sizes: size-independent properties (shard linearity, silence, impulse -> FIR).
+"""
+import numpy as np
+import pytest
+
+import _oracle
+import scenes
+from _hip import ctx, set_oracle_curves, set_renderer_curves
+from layouts import LAYOUTS
+
+pytestmark = pytest.mark.gpu
+
+
+def decorrelators(layout):
+    return _oracle.design_decorrelators(LAYOUTS[layout])
+
+
+def run_hip(curves, x, n_out, block, dec, delay, calls, strict=False):
+    from libear_amd import capi
+    two = dec is not None
+    ctx().set_strict(strict)
+    try:
+        r = capi.Renderer(ctx(), x.shape[0], n_out, block, dec, delay, max_blocks=max(calls))
+        set_renderer_curves(r, curves, two)
+        out = np.zeros((n_out, x.shape[1]), np.float32)
+        ofs = 0
+        for nb in calls:
+            n = nb * block
+            out[:, ofs:ofs + n] = r.process(x[:, ofs:ofs + n])
+            ofs += n
+        r.close()
+    finally:
+        ctx().set_strict(False)
+    return out
+
+
+def run_oracle(curves, x, n_out, block, dec, delay):
+    if dec is None:  # direct bus only: zero decorrelators, no delay => out == direct bus exactly
+        o = _oracle.ObjectsRenderer(x.shape[0], n_out, block, np.zeros((n_out, 1), np.float32), 0)
+        set_oracle_curves(o, curves, two_bus=False)
+    else:
+        o = _oracle.ObjectsRenderer(x.shape[0], n_out, block, dec, delay)
+        set_oracle_curves(o, curves)
+    return o.process(x)
+
+
+@pytest.mark.parametrize("m,n,block,nblocks", [(1, 6, 512, 3), (64, 10, 512, 4), (5, 3, 64, 9), (33, 24, 256, 5)])
+def test_gain_stage_strict_bit_exact(m, n, block, nblocks):
+    """C1/C2-shaped: ramped gains only; strict mode reproduces the CPU path bit for bit."""
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks)
+    want = run_oracle(curves, x, n, block, None, 0)
+    got = run_hip(curves, x, n, block, None, 0, [nblocks], strict=True)
+    assert np.array_equal(got, want)
+    got2 = run_hip(curves, x, n, block, None, 0, [1] * nblocks, strict=True)
+    assert np.array_equal(got2, want)
+
+
+def test_gain_stage_ragged_curves_strict_bit_exact():
+    """points inside tiles, steps, equal neighbours, single points, ramps crossing the call"""
+    m, n, block, nblocks = 40, 7, 128, 11
+    total = block * nblocks
+    curves = scenes.ragged_curves(m, n, total)
+    x = scenes.audio(m, total)
+    want = run_oracle(curves, x, n, block, None, 0)
+    got = run_hip(curves, x, n, block, None, 0, [3, 1, 7], strict=True)
+    assert np.array_equal(got, want)
+    fast = run_hip(curves, x, n, block, None, 0, [nblocks])
+    assert scenes.rel_rms(fast, want) <= 1e-6
+
+
+@pytest.mark.parametrize("m,layout,block,nblocks,kind",
+                         [(64, "4+5+0", 512, 4, "dense"), (256, "9+10+3", 512, 3, "dense"),
+                          (16, "0+5+0", 1024, 3, "dense"), (48, "9+10+3", 512, 4, "sparse"),
+                          (20, "4+5+0", 128, 9, "ragged"), (12, "0+5+0", 2048, 2, "constant")])
+def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    if block < 512:
+        dec = dec[:, :block].copy()  # fused render supports FIRs up to one block
+    total = block * nblocks
+    if kind == "dense":
+        curves = scenes.dense_curves(m, n, block, nblocks)
+    elif kind == "sparse":
+        lfe = [i for i, nm in enumerate(LAYOUTS[layout]) if nm.startswith("LFE")]
+        curves = scenes.sparse_curves(m, n, block, nblocks, lfe)
+    elif kind == "ragged":
+        curves = scenes.ragged_curves(m, n, total)
+    else:
+        curves = scenes.constant_curves(m, n)
+    x = scenes.audio(m, total)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(got, want) <= 1e-6
+    step = run_hip(curves, x, n, block, dec, 255, [1] * nblocks)
+    assert scenes.rel_rms(step, want) <= 1e-6
+    assert scenes.rel_rms(step, got) <= 1e-6
+    if m * total * n <= 64 * 2048 * 24:
+        truth = scenes.render_f64(curves, x, n, dec, 255)
+        assert scenes.rel_rms(got, truth) <= 1e-6
+        assert scenes.rel_rms(want, truth) <= 1e-6
+
+
+def test_strict_full_chain_matches_oracle_closely():
+    """strict gain stage + device FFT: only the FFT rounding differs from the CPU path"""
+    m, layout, block, nblocks = 32, "9+10+3", 512, 3
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks], strict=True)
+    assert scenes.rel_rms(got, want) <= 3e-7
+
+
+def test_c4_size_vs_oracle_and_shard_linearity():
+    """1024 objects -> 9+10+3, block 512 (BASELINE config 4), two blocks against the oracle, and
+    the multi-GPU decomposition: rendering two object shards separately and summing the outputs
+    equals rendering all objects (the chain after the buses is linear)."""
+    m, layout, block, nblocks = 1024, "9+10+3", 512, 2
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(got, want) <= 1e-6
+    half = m // 2
+    a = run_hip(curves[:half], x[:half], n, block, dec, 255, [nblocks])
+    b = run_hip(curves[half:], x[half:], n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(a + b, got) <= 1e-6
+    assert scenes.rel_rms(a + b, want) <= 1e-6
+
+
+def test_long_stream_properties():
+    """64 blocks per call at 256 objects: silence in -> exact silence out; a unit impulse on one
+    object with a constant diffuse-only gain reproduces the decorrelator FIR; direct-only gain
+    reproduces the 255-sample delay."""
+    from libear_amd import capi
+    m, layout, block, nblocks = 256, "9+10+3", 512, 64
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+    set_renderer_curves(r, scenes.dense_curves(m, n, block, nblocks))
+    assert not np.any(r.process(np.zeros((m, total), np.float32)))
+    r.close()
+
+    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+    one = np.zeros((1, n), np.float32)
+    sel = np.zeros((1, n), np.float32)
+    sel[0, 5] = 1.0
+    r.set_object_points(3, [0], one, sel)       # object 3: diffuse only, loudspeaker 5
+    r.set_object_points(7, [0], sel * 0.5, one)  # object 7: direct only, gain 0.5
+    x = np.zeros((m, total), np.float32)
+    x[3, 1000] = 1.0
+    x[7, 20000] = 1.0
+    out = r.process(x)
+    want = np.zeros((n, total), np.float32)
+    want[5, 1000:1512] += dec[5]
+    want[5, 20255] += 0.5
+    assert np.max(np.abs(out - want)) < 1e-6
+    r.close()
+
+
+def test_render_errors():
+    from libear_amd import capi
+    dec = decorrelators("0+5+0")
+    with pytest.raises(capi.InvalidArgument):
+        capi.Renderer(ctx(), 4, 6, 500, dec, 255)  # block size not a power of two
+    r = capi.Renderer(ctx(), 4, 6, 512, dec, 255, max_blocks=2)
+    with pytest.raises(capi.InvalidArgument):
+        r.process(np.zeros((4, 512 * 3), np.float32))  # more blocks than max_blocks
+    with pytest.raises(capi.InvalidArgument):
+        r.set_object_points(9, [0], np.zeros((1, 6)), np.zeros((1, 6)))
+    with pytest.raises(capi.InvalidArgument):
+        r.set_object_points(0, [5, 1], np.zeros((2, 6)), np.zeros((2, 6)))
+    r.close()
