@@ -115,7 +115,7 @@ def test_matrix_dense_ramps(m, n, length, strict):
     rng = np.random.default_rng(m * 1000 + n)
     times = list(range(100, length, 100))
     vals = rng.uniform(0, 1, (len(times), m, n)).astype(np.float32)
-    vals[3] = vals[2]  # one constant segment
+    vals[2] = vals[1]  # one constant segment
     x = rng.uniform(-1, 1, (m, length)).astype(np.float32)
     want = _oracle.gain_interp("matrix", times, vals, x, [length])
     ctx().set_strict(strict)
