@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X:
+
+    N objects -> 9+10+3 (22.2, 24 ch), block 512, 48 kHz: ramped direct+diffuse gain matrices,
+    24 decorrelators (512-tap FIR, FFT 1024), 255-sample compensation delay, mix-down.
+
+One "step" = one stream-mode pass of the hot path over T consecutive blocks (default 1024, i.e.
+10.9 s of audio) for 1024 objects per GPU, inputs and gain curves already resident in HBM.  Every
+block is a full-length ramp between dense uniform(0,1) gain vectors (worst case).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Rank 0 prints ONE JSON line.  `value` = object-samples consumed per second over all GPUs
+(Msamples/s = M*B*T / t_step / 1e6); `rtf` = real-time factor (B*T/48000) / t_step.
+Multi-GPU: objects are sharded (1024 per rank, weak scaling), each rank renders its shard and the
+partial loudspeaker buses are summed by one RCCL reduce-scatter over the channel axis, overlapped
+with the next step's render.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3  # vector / f32-MFMA peak, same guide
+SAMPLE_RATE = 48000.0
+
+
+def algorithmic_bytes(m, n, b, k, ramp=True):
+    """bytes_gain, bytes_dec, bytes_delay_mix per block"""
+    e = 2 if ramp else 1
+    gain = 4 * (m * b + e * k * m * n + k * n * b)
+    p, d = 1, 255
+    dec = n * (4 * b + 8 * p * (b + 1) + 2 * 8 * p * (b + 1) + 2 * 4 * b + 4 * b) if k == 2 else 0
+    dm = n * (4 * b + 2 * 4 * d + 4 * b + 4 * b) if k == 2 else 0
+    return gain, dec, dm
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
+    ap.add_argument("--blocks", type=int, default=1024, help="blocks per step (stream length T)")
+    ap.add_argument("--block-size", type=int, default=512)
+    ap.add_argument("--layout", default="9+10+3")
+    ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import scenes
+    from layouts import LAYOUTS
+    from libear_amd import capi
+    from libear_amd.distributed import exchange
+
+    names = LAYOUTS[args.layout]
+    M, N, B, T, K = args.objects, len(names), args.block_size, args.blocks, 2
+    total = B * T
+
+    # decorrelator FIRs: designed natively (libearhip group G, setup path)
+    dec = capi.design_decorrelators(names)
+
+    # ---- scene: resident in HBM before the timed region --------------------------------------
+    curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    x = torch.rand((M, total), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    outs = [torch.zeros((N, total), device=dev, dtype=torch.float32) for _ in range(2)]
+    owned = [torch.zeros((N // world, total), device=dev, dtype=torch.float32) for _ in range(2)] \
+        if world > 1 else None
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = capi.Context(local_rank, stream.cuda_stream)
+    ctx.set_strict(args.strict)
+    r = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=T)
+    for m, (t, d, f) in enumerate(curves):
+        r.set_object_points(m, t, d, f)
+    r.commit()
+
+    pending = [None, None]
+
+    def step(i):
+        buf = i % 2
+        if pending[buf] is not None:  # the exchange that last read this buffer must be done
+            pending[buf].wait()
+            pending[buf] = None
+        r.reset(0)
+        r.process_device(T, x.data_ptr(), total, outs[buf].data_ptr(), total)
+        if world > 1:
+            _, work = exchange(outs[buf], owned[buf], async_op=True)
+            pending[buf] = work
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    r.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = r.get_timing()
+    r.enable_timing(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    t_step = dt / args.steps
+    value = world * M * total / t_step / 1e6
+    rtf = (total / SAMPLE_RATE) / t_step
+
+    result = None
+    if rank == 0:
+        gain_b, dec_b, dm_b = algorithmic_bytes(M, N, B, K)
+        k1_ms = timing["gain_mix_ms"] / max(timing["gain_mix_launches"], 1)
+        k2_ms = timing["decor_ms"] / max(timing["decor_launches"], 1)
+        k0_ms = timing["prep_ms"] / max(timing["prep_launches"], 1)
+        achieved = gain_b * T / (k1_ms * 1e-3) / 1e9
+        whole = (gain_b + dec_b + dm_b) * T / t_step / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("objects") == M and tj.get("blocks") == T and tj.get("block_size") == B:
+                    traffic = tj.get("gain_mix_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Msamples/s", "value": round(value, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": round(rtf, 1),
+            "config": {
+                "workload": f"{M} objects/GPU -> {args.layout} ({N} ch), block {B}, 48 kHz: ramped direct+diffuse "
+                            f"gains, {N} decorrelators (512 taps), delay 255, mix; stream of {T} blocks per step",
+                "objects_per_gpu": M, "objects_total": M * world, "channels": N, "block": B,
+                "blocks_per_step": T, "buses": K, "gains": "dense uniform(0,1), full-length ramp every block",
+                "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels",
+                "strict": bool(args.strict)},
+            "roofline": {"bound": "hbm", "kernel": "k_gain_mix", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": gain_b * T,
+                         "avg_launch_ms": round(k1_ms, 4)},
+            "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
+                           "decorrelate_delay_mix": round(k2_ms, 4)},
+            "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
+                           "gain_fp32_tflops_executed": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2),
+                           "fp32_peak_tflops": FP32_PEAK_TFLOPS},
+        }
+
+        # ---- parity gate in the same run: first two blocks against the CPU oracle -------------
+        import _oracle  # the checker; used only below (parity gate and cpu_baseline)
+        nb = 2
+        xs = x[:, :nb * B].cpu().numpy()
+        rr = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=nb)
+        for m, (t, d, f) in enumerate(curves):
+            rr.set_object_points(m, t[:nb + 1], d[:nb + 1], f[:nb + 1])
+        got = rr.process(xs)
+        rr.close()
+        o = _oracle.ObjectsRenderer(M, N, B, dec, 255)
+        for m, (t, d, f) in enumerate(curves):
+            o.set_points(m, 0, t[:nb + 1], d[:nb + 1])
+            o.set_points(m, 1, t[:nb + 1], f[:nb + 1])
+        want = o.process(xs)
+        result["parity"] = {"rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
+                            "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
+                            "tolerance": 1e-6}
+
+        # ---- CPU baseline: the scalar restatement on this host, bounded sample -----------------
+        if world == 1 and args.cpu_blocks > 0:
+            cb = min(args.cpu_blocks, T)
+            xc = x[:, :cb * B].cpu().numpy()
+            res = {}
+            for native in (False, True):
+                oc = _oracle.ObjectsRenderer(M, N, B, dec, 255, native=native)
+                for m, (t, d, f) in enumerate(curves):
+                    oc.set_points(m, 0, t[:cb + 1], d[:cb + 1])
+                    oc.set_points(m, 1, t[:cb + 1], f[:cb + 1])
+                c0 = time.perf_counter()
+                oc.process(xc)
+                cdt = time.perf_counter() - c0
+                res[native] = M * cb * B / cdt / 1e6
+                del oc
+            result["cpu_baseline"] = {
+                "value": round(res[False], 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": f"first {cb} blocks of the same scene ({M} objects -> {N} ch), scalar C++14 restatement "
+                          "of libear's per-object GainInterpolator<LinearInterpVector> + bus sum, BlockConvolver, "
+                          "DelayBuffer; -O3 -DNDEBUG (libear Release flags), 1 thread",
+                "rtf": round((B / SAMPLE_RATE) / (M * B / (res[False] * 1e6)), 3),
+                "value_march_native": round(res[True], 2),
+                "host_cpus": os.cpu_count()}
+        print(json.dumps(result), flush=True)
+
+    r.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

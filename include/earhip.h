@@ -171,6 +171,18 @@ int earhip_vbs_process(earhip_vbs *v, size_t nsamples, const float *const *in,
 int earhip_vbs_get_delay(const earhip_vbs *v);
 
 /* ------------------------------------------------------------------------
+ * (G) Decorrelator design (setup path, host code) — replaces designDecorrelators
+ * <float> and decorrelatorCompensationDelay (include/ear/decorrelate.hpp:16-34,
+ * src/decorrelate.cpp:31-97).  channel_names: the layout's channel names in
+ * layout order (the filter id of a channel is the rank of its name);
+ * out: [n_channels][512].
+ * ---------------------------------------------------------------------- */
+int earhip_decorrelator_size(void);               /* 512 */
+int earhip_decorrelator_compensation_delay(void); /* 255 */
+int earhip_design_decorrelator_basic(int decorrelator_id, int size, double *out);
+int earhip_design_decorrelators(int n_channels, const char *const *channel_names, float *out);
+
+/* ------------------------------------------------------------------------
  * (F) Composed Objects render block — the chain libear documents but does not
  * implement (docs/dsp.rst:40-71, include/ear/gain_calculators.hpp:45-56):
  *   per object: interpolated direct and diffuse gain vectors (a

@@ -285,6 +285,24 @@ class VariableBlockSizeAdapter:
         return out
 
 
+def design_decorrelators(names):
+    """(G) 512-tap decorrelator FIR per channel, [n][512] float32."""
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    out = np.empty((len(names), load().earhip_decorrelator_size()), np.float32)
+    check(load().earhip_design_decorrelators(len(names), arr, _ptr(out)))
+    return out
+
+
+def design_decorrelator_basic(dec_id, size=512):
+    out = np.empty(size, np.float64)
+    check(load().earhip_design_decorrelator_basic(dec_id, size, _ptr(out, C.POINTER(C.c_double))))
+    return out
+
+
+def compensation_delay():
+    return load().earhip_decorrelator_compensation_delay()
+
+
 class Renderer:
     """(F) composed Objects render block."""
 
