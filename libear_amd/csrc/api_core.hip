@@ -1,11 +1,13 @@
 // api_core.hip — context, error reporting, the interpolation-policy entry
 // points (A) and the whole-curve GainInterpolator (A') of include/earhip.h.
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "common.h"
 #include "curves.h"
 #include "gain_kernels.h"
+#include "gain_mfma.h"
 
 namespace earhip {
 
@@ -13,13 +15,21 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml) {
-  return ml.wsplit > 1 ? (size_t)cp.ngroups * cp.nout * kTileSamples * sizeof(float) : 0;
+  if (ml.wsplit <= 1) return 0;
+  if (ml.mfma) return (size_t)cp.mgroups * cp.nct * 16 * ml.tile() * sizeof(float);
+  return (size_t)cp.ngroups * cp.nout * ml.tile() * sizeof(float);
 }
 
-template <int NOUT, bool STRICT>
+template <int NCT, int NRT>
+static void launch_mfma_t(const GainMixParams &P, dim3 grid, dim3 block, size_t lds,
+                          hipStream_t s) {
+  hipLaunchKernelGGL((k_gain_mix_mfma<NCT, NRT>), grid, block, lds, s, P);
+}
+
+template <int NOUT, int SPL, bool STRICT>
 static void launch_mix_t(const GainMixParams &P, dim3 grid, dim3 block, size_t lds,
                          hipStream_t s) {
-  hipLaunchKernelGGL((k_gain_mix<NOUT, STRICT>), grid, block, lds, s, P);
+  hipLaunchKernelGGL((k_gain_mix<NOUT, SPL, STRICT>), grid, block, lds, s, P);
 }
 
 void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, bool strict,
@@ -33,7 +43,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const int total = M * ml.ntiles;
     if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
     hipLaunchKernelGGL(k_seg_prep, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ps, M,
-                       ml.ntiles, t_call, t_call + nsamples, desc);
+                       ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
     if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   }
   GainMixParams P;
@@ -49,25 +59,40 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   P.ntiles = ml.ntiles;
   P.M = M;
   P.ncols = cs.ncols();
-  P.ngroups = cp.ngroups;
+  P.ngroups = ml.mfma ? cp.mgroups : cp.ngroups;
   P.wsplit = ml.wsplit;
   P.vec_ok = (in_stride % 4 == 0 && out_stride % 4 == 0 && part_stride % 4 == 0 &&
               ((uintptr_t)in_dev & 15) == 0 && ((uintptr_t)out_dev & 15) == 0)
                  ? 1
                  : 0;
-  const dim3 grid(ml.ntiles, ml.gsplit, cp.nz);
-  const dim3 block(64 * cp.ngroups * ml.wsplit);
+  const dim3 grid(ml.ntiles, ml.gsplit, ml.mfma ? cp.mnz : cp.nz);
+  const dim3 block(64 * P.ngroups * ml.wsplit);
   const size_t lds = mix_lds_bytes(cp, ml);
   if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
-  switch (cp.nout * 2 + (strict ? 1 : 0)) {
-    case 16: launch_mix_t<8, false>(P, grid, block, lds, ctx->stream); break;
-    case 17: launch_mix_t<8, true>(P, grid, block, lds, ctx->stream); break;
-    case 32: launch_mix_t<16, false>(P, grid, block, lds, ctx->stream); break;
-    case 33: launch_mix_t<16, true>(P, grid, block, lds, ctx->stream); break;
-    case 48: launch_mix_t<24, false>(P, grid, block, lds, ctx->stream); break;
-    case 49: launch_mix_t<24, true>(P, grid, block, lds, ctx->stream); break;
-    default: fail_internal("no gain_mix instantiation for this column plan");
+#define EARHIP_MIX_CASE(NOUT_, SPL_, STRICT_)                                   \
+  if (cp.nout == NOUT_ && ml.spl == SPL_ && strict == STRICT_) {                 \
+    launch_mix_t<NOUT_, SPL_, STRICT_>(P, grid, block, lds, ctx->stream);        \
+    launched = true;                                                             \
   }
+  bool launched = false;
+#define EARHIP_MFMA_CASE(NCT_, NRT_)                                            \
+  if (ml.mfma && cp.nct == NCT_ && ml.nrt == NRT_) {                             \
+    launch_mfma_t<NCT_, NRT_>(P, grid, block, lds, ctx->stream);                 \
+    launched = true;                                                             \
+  }
+  EARHIP_MFMA_CASE(1, 8) EARHIP_MFMA_CASE(2, 8) EARHIP_MFMA_CASE(3, 8)
+  EARHIP_MFMA_CASE(1, 4) EARHIP_MFMA_CASE(2, 4) EARHIP_MFMA_CASE(3, 4)
+#undef EARHIP_MFMA_CASE
+  if (!ml.mfma) {
+  EARHIP_MIX_CASE(8, 4, false) EARHIP_MIX_CASE(8, 4, true)
+  EARHIP_MIX_CASE(16, 4, false) EARHIP_MIX_CASE(16, 4, true)
+  EARHIP_MIX_CASE(24, 4, false) EARHIP_MIX_CASE(24, 4, true)
+  EARHIP_MIX_CASE(8, 2, false) EARHIP_MIX_CASE(8, 2, true)
+  EARHIP_MIX_CASE(16, 2, false) EARHIP_MIX_CASE(16, 2, true)
+  EARHIP_MIX_CASE(24, 2, false) EARHIP_MIX_CASE(24, 2, true)
+  }
+#undef EARHIP_MIX_CASE
+  if (!launched) fail_internal("no gain_mix instantiation for this column plan");
   if (ev) EARHIP_HIP(hipEventRecord(ev[3], ctx->stream));
   EARHIP_HIP(hipGetLastError());
 }
@@ -193,6 +218,15 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
     hipDeviceProp_t prop;
     EARHIP_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("EARHIP_SPL")) {  // tuning knob: samples per lane in gain_mix
+      const int v = atoi(e);
+      if (v == 2 || v == 4) c->spl = v;
+    }
+    if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e) != 0;
+    if (const char *e = getenv("EARHIP_NRT")) {
+      const int v = atoi(e);
+      if (v == 4 || v == 8) c->nrt = v;
+    }
     *out = c.release();
   });
 }

@@ -219,14 +219,14 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->L = 2 * r->B;
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
     const size_t max_samples = (size_t)r->T * r->B;
-    const size_t max_tiles = (max_samples + kTileSamples - 1) / kTileSamples;
+    const size_t max_tiles = (max_samples + 63) / 64;  // smallest tile: 4 row tiles of 16 samples
     r->desc.alloc((size_t)r->M * max_tiles);
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits
     // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps
     // gsplit * ntiles < 4 * num_cus, so gsplit * nsamples < 4 * num_cus * 256.
     r->max_gsplit = 32;
     const size_t pad_samples = (max_samples + 3) & ~(size_t)3;
-    const size_t split_samples = (size_t)4 * ctx->num_cus * kTileSamples + 4 * r->max_gsplit;
+    const size_t split_samples = (size_t)4 * ctx->num_cus * 256 + 4 * r->max_gsplit;
     r->bus.alloc_zero((size_t)r->K * r->N * std::max(pad_samples, split_samples), ctx->stream);
     if (r->K == 2) {
       const auto tw = make_twiddles(r->L);

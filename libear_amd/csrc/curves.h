@@ -14,10 +14,15 @@ namespace earhip {
 
 // column tiling of the K*N output columns over waves
 struct ColumnPlan {
+  // VALU kernel (k_gain_mix): SGPR-operand FMAs
   int nout = 24;     // columns per wave (8, 16 or 24)
   int ngroups = 1;   // column groups per workgroup
   int nz = 1;        // column super-groups (grid.z)
-  int row = 24;      // padded row length = nz * ngroups * nout
+  // MFMA kernel (k_gain_mix_mfma): 16-column tiles
+  int nct = 1;       // column tiles per wave (1..3)
+  int mgroups = 1;   // column groups per workgroup
+  int mnz = 1;       // column super-groups (grid.z)
+  int row = 24;      // padded row length, covers both tilings
   static ColumnPlan make(int ncols) {
     ColumnPlan p;
     int groups = (ncols + 23) / 24;
@@ -26,7 +31,11 @@ struct ColumnPlan {
     groups = (ncols + p.nout - 1) / p.nout;
     p.ngroups = std::min(groups, 8);
     p.nz = (groups + p.ngroups - 1) / p.ngroups;
-    p.row = p.nz * p.ngroups * p.nout;
+    int mg = (ncols + 47) / 48;
+    p.nct = mg > 1 ? 3 : (ncols + 15) / 16;
+    p.mgroups = std::min(mg, 8);
+    p.mnz = (mg + p.mgroups - 1) / p.mgroups;
+    p.row = std::max(p.nz * p.ngroups * p.nout, p.mnz * p.mgroups * p.nct * 16);
     return p;
   }
 };
@@ -59,6 +68,7 @@ class CurveSet {
                   const uint8_t *flat_override = nullptr) {
     if (m < 0 || m >= M_) fail_invalid("object index out of range");
     if (npoints < 1) fail_invalid("interp_points must not be empty");
+    if (npoints > kMaxPointsPerObject) fail_invalid("too many interpolation points for one object");
     for (int k = 1; k < npoints; k++) {
       if (times[k] < times[k - 1]) fail_invalid("interpolation points are not sorted");
       if (times[k] - times[k - 1] > (int64_t)0x7fffffff)
@@ -148,26 +158,34 @@ class CurveSet {
 
 // How K1 is spread over the chip for one call.
 struct MixLaunch {
+  bool mfma;                   // matrix-core kernel (default) or VALU kernel (strict mode)
+  int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
+  int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
+  int tile() const { return mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit) {
   MixLaunch L;
-  L.ntiles = (nsamples + kTileSamples - 1) / kTileSamples;
+  L.mfma = !strict && ctx->use_mfma;
+  L.spl = ctx->spl;
+  L.nrt = ctx->nrt;
+  L.ntiles = (nsamples + L.tile() - 1) / L.tile();
   if (strict) {
     L.wsplit = 1;
     L.gsplit = 1;
     return L;
   }
   // 8 waves per workgroup: what the column groups leave goes to object splits
-  L.wsplit = std::max(1, std::min(8 / cp.ngroups, std::max(1, M / 8)));
+  const int groups = L.mfma ? cp.mgroups : cp.ngroups;
+  L.wsplit = std::max(1, std::min(8 / groups, std::max(1, M / 8)));
   // few tiles (block mode): split the objects across workgroups as well until
   // the grid covers the chip about twice over
   const int per_wg = std::max(1, M / L.wsplit);
   int g = 1;
   const int want = 2 * ctx->num_cus;
-  while (g < max_gsplit && L.ntiles * cp.nz * g < want && per_wg / (g * 2) >= 8) g *= 2;
+  while (g < max_gsplit && L.ntiles * (L.mfma ? cp.mnz : cp.nz) * g < want && per_wg / (g * 2) >= 8) g *= 2;
   L.gsplit = g;
   return L;
 }

@@ -41,19 +41,23 @@ struct PointStore {
                          // extrapolated outside (LinearInterp*::apply_interp as called directly)
 };
 
-// What one (object, 256-sample tile) pair has to do; written by K0.
+// What one (object, sample tile) pair has to do; written by K0.  A tile is
+// 64 lanes x SPL samples (SPL = 2 or 4).
 struct SegDesc {
   int32_t row;    // first gain row to load (ramp: start point; constant: the point)
   int32_t d0;     // ramp: tile_start - curve_start (>= 0, < 2^31)
   float scale;    // ramp: 1.0f / (float)(end - start)
   int32_t info;   // bit0 ramp, bit1 the segment ends inside this tile, bits 2-3 per-bus
-                  // "constant" flags, bits 4..: segment index
+                  // "constant" flags, bits 4-12 end of this piece relative to the tile
+                  // start (samples, <= 256), bits 13..: segment index k
 };
 static_assert(sizeof(SegDesc) == 16, "SegDesc is loaded as one dwordx4");
 
-constexpr int kTileSamples = 256;  // samples per tile = 64 lanes x 4
 constexpr int kSegRamp = 1;
 constexpr int kSegMulti = 2;
+constexpr int kMaxPointsPerObject = 1 << 18;
+__host__ __device__ __forceinline__ int seg_r1(int info) { return (info >> 4) & 0x1ff; }
+__host__ __device__ __forceinline__ int seg_k(int info) { return info >> 13; }
 
 // number of points of object m with time <= t  (= libear's find_block result)
 __device__ __forceinline__ int upper_bound_time(const int64_t *t, int n, int64_t v) {
@@ -66,23 +70,21 @@ __device__ __forceinline__ int upper_bound_time(const int64_t *t, int n, int64_t
   return lo;
 }
 
-// Describe segment k of an object for samples starting at absolute time t0.
+// Describe segment k of an object for the tile [t0, t_end) (absolute times).
 __device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int base,
                                                     int n, int k, int64_t t0,
                                                     int64_t t_end) {
   // (k, t_end are adjusted below in policy mode)
   SegDesc d;
-  if (ps.force_ramp) {
-    k = 1;
-    t_end = t0;  // never "multi"
-  }
+  if (ps.force_ramp) k = 1;
   const int allflat = (1 << ps.nbus) - 1;
   const int fb = (k > 0 && k < n) ? (ps.flat[base + k] & allflat) : allflat;
   // constant before the first / after the last point or between equal points
   // (gain_interpolator.hpp:68-75)
   const bool ramp = ps.force_ramp || fb != allflat;
-  const bool multi = k < n && ps.time[base + k] < t_end;
-  d.info = (k << 4) | (fb << 2) | (multi ? kSegMulti : 0) | (ramp ? kSegRamp : 0);
+  const bool multi = !ps.force_ramp && k < n && ps.time[base + k] < t_end;
+  const int r1 = (int)((multi ? ps.time[base + k] : t_end) - t0);
+  d.info = (k << 13) | (r1 << 4) | (fb << 2) | (multi ? kSegMulti : 0) | (ramp ? kSegRamp : 0);
   if (ramp) {
     const int64_t start = ps.time[base + k - 1], end = ps.time[base + k];
     d.row = base + k - 1;
@@ -97,14 +99,14 @@ __device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int ba
 }
 
 // K0: one thread per (object, tile).
-static __global__ void k_seg_prep(PointStore ps, int M, int ntiles, int64_t t_call,
-                           int64_t t_call_end, SegDesc *desc) {
+static __global__ void k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples,
+                                  int64_t t_call, int64_t t_call_end, SegDesc *desc) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * ntiles) return;
   const int m = idx / ntiles, tile = idx - m * ntiles;
   const int base = ps.off[m], n = ps.off[m + 1] - base;
-  const int64_t t0 = t_call + (int64_t)tile * kTileSamples;
-  int64_t t_end = t0 + kTileSamples;
+  const int64_t t0 = t_call + (int64_t)tile * tile_samples;
+  int64_t t_end = t0 + tile_samples;
   if (t_end > t_call_end) t_end = t_call_end;
   const int k = upper_bound_time(ps.time + base, n, t0);
   desc[idx] = describe_segment(ps, base, n, k, t0, t_end);
@@ -125,22 +127,21 @@ struct GainMixParams {
   int ncols;            // valid output columns (<= row)
   int ngroups;          // column groups per workgroup (waves: group-major)
   int wsplit;           // object splits inside a workgroup
-  int vec_ok;           // in/out rows are 16-byte aligned: float4 accesses allowed
+  int vec_ok;           // in/out rows are 16-byte aligned: vector accesses allowed
 };
 
 // accumulate one segment piece of one object into acc
-template <int NOUT, bool STRICT>
-__device__ __forceinline__ void accumulate_piece(float (&acc)[NOUT][4], const float4 x,
+template <int NOUT, int SPL, bool STRICT>
+__device__ __forceinline__ void accumulate_piece(float (&acc)[NOUT][SPL], const float (&xs)[SPL],
                                                  const SegDesc d, const float *__restrict__ rows,
                                                  int rowlen, int lane, int col0, int bus_cols) {
-  const float xs[4] = {x.x, x.y, x.z, x.w};
   const bool ramp = d.info & kSegRamp;
   const float *__restrict__ S = rows;
   const float *__restrict__ E = rows + (ramp ? rowlen : 0);
-  float p[4], q[4];
+  float p[SPL], q[SPL];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    p[i] = (float)(d.d0 + lane * 4 + i) * d.scale;  // gain_interpolator.hpp:193,224,272
+  for (int i = 0; i < SPL; i++) {
+    p[i] = (float)(d.d0 + lane * SPL + i) * d.scale;  // gain_interpolator.hpp:193,224,272
     q[i] = 1.0f - p[i];
   }
   if (STRICT) {
@@ -151,15 +152,15 @@ __device__ __forceinline__ void accumulate_piece(float (&acc)[NOUT][4], const fl
       // apply_constant with the segment's end point (gain_interpolator.hpp:68-75)
       const bool cflat = !ramp || ((d.info >> (2 + (col0 + j >= bus_cols ? 1 : 0))) & 1);
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < SPL; i++) {
         const float g = cflat ? e : q[i] * s + p[i] * e;  // un-contracted (-ffp-contract=off)
         acc[j][i] = acc[j][i] + xs[i] * g;
       }
     }
   } else {
-    float a[4], b[4];
+    float a[SPL], b[SPL];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < SPL; i++) {
       a[i] = ramp ? xs[i] * q[i] : xs[i];
       b[i] = xs[i] * p[i];
     }
@@ -167,24 +168,26 @@ __device__ __forceinline__ void accumulate_piece(float (&acc)[NOUT][4], const fl
     for (int j = 0; j < NOUT; j++) {
       const float s = S[j];
 #pragma unroll
-      for (int i = 0; i < 4; i++) acc[j][i] = __builtin_fmaf(a[i], s, acc[j][i]);
+      for (int i = 0; i < SPL; i++) acc[j][i] = __builtin_fmaf(a[i], s, acc[j][i]);
     }
     if (ramp) {
 #pragma unroll
       for (int j = 0; j < NOUT; j++) {
         const float e = E[j];
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc[j][i] = __builtin_fmaf(b[i], e, acc[j][i]);
+        for (int i = 0; i < SPL; i++) acc[j][i] = __builtin_fmaf(b[i], e, acc[j][i]);
       }
     }
   }
 }
 
 // K1.  grid = (ntiles, grid-level object splits, column super-groups)
-// block = 64 * ngroups * wsplit threads.
-template <int NOUT, bool STRICT>
+// block = 64 * ngroups * wsplit threads; tile = 64 * SPL samples.
+template <int NOUT, int SPL, bool STRICT>
 __global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [ngroups][NOUT][256]
+  constexpr int TS = 64 * SPL;
+  typedef float vec_t __attribute__((ext_vector_type(SPL)));
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [ngroups][NOUT][TS]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = wave % P.ngroups;           // column group inside the workgroup
@@ -196,75 +199,83 @@ __global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
   const int m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
   const int col0 = (blockIdx.z * P.ngroups + g) * NOUT;
 
-  const int s0 = tile * kTileSamples + lane * 4;  // first sample of this lane
-  const int64_t tile_t0 = P.t_call + (int64_t)tile * kTileSamples;
-  int64_t tile_t1 = tile_t0 + kTileSamples;
+  const int s0 = tile * TS + lane * SPL;  // first sample of this lane
+  const int64_t tile_t0 = P.t_call + (int64_t)tile * TS;
+  int64_t tile_t1 = tile_t0 + TS;
   if (tile_t1 > P.t_call + P.nsamples) tile_t1 = P.t_call + P.nsamples;
-  const bool full = P.vec_ok && s0 + 3 < P.nsamples;
+  const bool full = P.vec_ok && s0 + SPL - 1 < P.nsamples;  // whole-vector stores allowed
 
-  float acc[NOUT][4];
+  float acc[NOUT][SPL];
 #pragma unroll
   for (int j = 0; j < NOUT; j++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc[j][i] = 0.0f;
+    for (int i = 0; i < SPL; i++) acc[j][i] = 0.0f;
+
+  // Input tile of object m for this lane, branch-free so the load can be hoisted:
+  // lanes past the end of the call re-read the last valid vector (clamped
+  // address) and are zeroed by selects.
+  const int nvec = (P.nsamples + SPL - 1) / SPL * SPL;
+  const int s0c = min(s0, nvec - SPL);
+  const int last_s = P.nsamples - 1;
 
   for (int m = m_lo; m < m_hi; m++) {
     SegDesc d = P.desc[(size_t)m * P.ntiles + tile];
-    const float *xp = P.in + (size_t)m * P.in_stride + s0;
-    float4 x;
-    if (full) {
-      x = *reinterpret_cast<const float4 *>(xp);
+    const float *xrow = P.in + (size_t)m * P.in_stride;
+    float x[SPL];
+    if (P.vec_ok) {  // rows aligned, stride % 4 == 0: the vector at s0c is in bounds
+      const vec_t v = *reinterpret_cast<const vec_t *>(xrow + s0c);
+#pragma unroll
+      for (int i = 0; i < SPL; i++) x[i] = v[i];
     } else {
-      x.x = s0 + 0 < P.nsamples ? xp[0] : 0.0f;
-      x.y = s0 + 1 < P.nsamples ? xp[1] : 0.0f;
-      x.z = s0 + 2 < P.nsamples ? xp[2] : 0.0f;
-      x.w = s0 + 3 < P.nsamples ? xp[3] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < SPL; i++) x[i] = xrow[min(s0 + i, last_s)];
     }
+#pragma unroll
+    for (int i = 0; i < SPL; i++) x[i] = s0 + i < P.nsamples ? x[i] : 0.0f;
+
     // Usually the whole tile lies inside one curve segment and the loop body
     // runs once.  If a curve point falls inside the tile, walk the segments
     // like GainInterpolator::process (gain_interpolator.hpp:58-86), masking the
     // lanes outside each piece.
     int64_t cur = tile_t0;
     for (;;) {
-      float4 xm = x;
+      float xm[SPL];
+#pragma unroll
+      for (int i = 0; i < SPL; i++) xm[i] = x[i];
       int64_t seg_end = tile_t1;
       if (d.info & kSegMulti) {
-        const int base = P.ps.off[m], k = d.info >> 4;
-        seg_end = P.ps.time[base + k];
-        const int r0 = (int)(cur - tile_t0), r1 = (int)(seg_end - tile_t0);
-        xm.x = (lane * 4 + 0 >= r0 && lane * 4 + 0 < r1) ? x.x : 0.0f;
-        xm.y = (lane * 4 + 1 >= r0 && lane * 4 + 1 < r1) ? x.y : 0.0f;
-        xm.z = (lane * 4 + 2 >= r0 && lane * 4 + 2 < r1) ? x.z : 0.0f;
-        xm.w = (lane * 4 + 3 >= r0 && lane * 4 + 3 < r1) ? x.w : 0.0f;
+        seg_end = tile_t0 + seg_r1(d.info);
+        const int r0 = (int)(cur - tile_t0), r1 = seg_r1(d.info);
+#pragma unroll
+        for (int i = 0; i < SPL; i++)
+          xm[i] = (lane * SPL + i >= r0 && lane * SPL + i < r1) ? x[i] : 0.0f;
       } else if (cur != tile_t0) {
         const int r0 = (int)(cur - tile_t0);
-        xm.x = lane * 4 + 0 >= r0 ? x.x : 0.0f;
-        xm.y = lane * 4 + 1 >= r0 ? x.y : 0.0f;
-        xm.z = lane * 4 + 2 >= r0 ? x.z : 0.0f;
-        xm.w = lane * 4 + 3 >= r0 ? x.w : 0.0f;
+#pragma unroll
+        for (int i = 0; i < SPL; i++) xm[i] = lane * SPL + i >= r0 ? x[i] : 0.0f;
       }
       if (seg_end > cur)  // duplicate times make empty segments (steps)
-        accumulate_piece<NOUT, STRICT>(acc, xm, d, P.ps.gain + (size_t)d.row * P.ps.row + col0,
-                                       P.ps.row, lane, col0, P.ps.bus_cols);
+        accumulate_piece<NOUT, SPL, STRICT>(acc, xm, d,
+                                            P.ps.gain + (size_t)d.row * P.ps.row + col0,
+                                            P.ps.row, lane, col0, P.ps.bus_cols);
       if (!(d.info & kSegMulti)) break;
       cur = seg_end;
       const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
-      d = describe_segment(P.ps, base, n, (d.info >> 4) + 1, tile_t0, tile_t1);
+      d = describe_segment(P.ps, base, n, seg_k(d.info) + 1, tile_t0, tile_t1);
     }
   }
 
   // combine the in-workgroup object splits through LDS, highest split first
-  float *slab = lds + (size_t)g * NOUT * kTileSamples + lane * 4;
+  float *slab = lds + (size_t)g * NOUT * TS + lane * SPL;
   for (int r = P.wsplit - 1; r >= 1; r--) {
     if (ws == r) {
 #pragma unroll
       for (int j = 0; j < NOUT; j++) {
-        float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-        if (r != P.wsplit - 1) {
-          const float4 o = *reinterpret_cast<const float4 *>(slab + j * kTileSamples);
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        *reinterpret_cast<float4 *>(slab + j * kTileSamples) = v;
+        vec_t v;
+#pragma unroll
+        for (int i = 0; i < SPL; i++) v[i] = acc[j][i];
+        if (r != P.wsplit - 1) v += *reinterpret_cast<const vec_t *>(slab + j * TS);
+        *reinterpret_cast<vec_t *>(slab + j * TS) = v;
       }
     }
     __syncthreads();
@@ -275,19 +286,17 @@ __global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
 #pragma unroll
   for (int j = 0; j < NOUT; j++) {
     if (col0 + j >= P.ncols) break;
-    float4 v = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-    if (P.wsplit > 1) {
-      const float4 o = *reinterpret_cast<const float4 *>(slab + j * kTileSamples);
-      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-    }
+    vec_t v;
+#pragma unroll
+    for (int i = 0; i < SPL; i++) v[i] = acc[j][i];
+    if (P.wsplit > 1) v += *reinterpret_cast<const vec_t *>(slab + j * TS);
     float *o = op + (size_t)(col0 + j) * P.out_stride;
     if (full) {
-      *reinterpret_cast<float4 *>(o) = v;
+      *reinterpret_cast<vec_t *>(o) = v;
     } else {
-      if (s0 + 0 < P.nsamples) o[0] = v.x;
-      if (s0 + 1 < P.nsamples) o[1] = v.y;
-      if (s0 + 2 < P.nsamples) o[2] = v.z;
-      if (s0 + 3 < P.nsamples) o[3] = v.w;
+#pragma unroll
+      for (int i = 0; i < SPL; i++)
+        if (s0 + i < P.nsamples) o[i] = v[i];
     }
   }
 }

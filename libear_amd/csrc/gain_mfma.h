@@ -1,0 +1,243 @@
+// gain_mfma.h — K1 on the matrix cores: the bus-forming contraction
+//
+//     bus[col][s] = sum_m  a_m(s) * S_m[col] + b_m(s) * E_m[col],
+//     a_m(s) = x_m(s) * (1 - p_m(s)),  b_m(s) = x_m(s) * p_m(s)
+//
+// is a dense [samples x 2M] . [2M x columns] product in fp32 (libear's
+// LinearInterpMatrix accumulation, include/ear/dsp/gain_interpolator.hpp:264-277,
+// with the ramp folded into the input).  It runs on v_mfma_f32_16x16x4_f32, which
+// is exact fp32 (a k-ordered fmaf chain, same rounding as the VALU formulation)
+// at the full fp32 rate of the chip, and — unlike the VALU formulation — takes
+// the gains as an ordinary per-lane operand:
+//
+//   A fragment (1 VGPR): lane l holds A[sample l&15][k = l>>4]
+//   B fragment (1 VGPR): lane l holds B[k = l>>4][column l&15]
+//   k = 0..3 of one step = {a, b} of two consecutive objects
+//
+// so the gain rows arrive through plain coalesced vector loads (deep, in-order
+// prefetch) instead of wave-uniform scalar loads, whose cache cannot sustain a
+// 200 MB stream of misses (measured: the SGPR-operand kernel idles 69% of its
+// wave cycles in s_waitcnt, profiles/r01_*).
+//
+// One wave owns NRT x 16 samples x NCT x 16 columns (NRT*NCT float4 accumulators)
+// and walks its share of the objects two at a time; the waves of a workgroup
+// split the objects and are combined through LDS in a fixed order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gain_kernels.h"
+
+namespace earhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PairRegs {
+  int row, d0, info;  // per-lane copy of the SegDesc of "its" object (lanes 0-31 / 32-63)
+  float scale;
+};
+
+template <int NCT, int NRT>
+__global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
+  constexpr int TS = 16 * NRT;      // samples per tile
+  constexpr int NC = 16 * NCT;      // columns per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [ngroups][NRT*NCT][64][4]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = wave % P.ngroups;
+  const int ws = wave / P.ngroups;
+  const int tile = blockIdx.x;
+  const int nparts = P.wsplit * gridDim.y;
+  const int part = blockIdx.y * P.wsplit + ws;
+  const int m_lo = (int)(((int64_t)P.M * part) / nparts);
+  const int m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
+  const int col0 = (blockIdx.z * P.ngroups + g) * NC;
+
+  const int li = lane & 15;        // sample (A) / column (B) index inside a 16-tile
+  const int kk = lane >> 4;        // k index of this lane: object slot kk>>1, {a,b} = kk&1
+  const int slot = kk >> 1;
+  const bool is_b = kk & 1;
+  const int tile_s0 = tile * TS;   // first sample of the tile inside the call
+  const int tile_len = min(TS, P.nsamples - tile_s0);
+  const int64_t tile_t0 = P.t_call + tile_s0;
+  const int64_t tile_t1 = tile_t0 + tile_len;
+
+  f32x4 acc[NRT][NCT];
+#pragma unroll
+  for (int r = 0; r < NRT; r++)
+#pragma unroll
+    for (int c = 0; c < NCT; c++) acc[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  auto mma = [&](const float (&a)[NRT], const float (&gv)[NCT]) {
+#pragma unroll
+    for (int r = 0; r < NRT; r++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++)
+        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], acc[r][c], 0, 0, 0);
+  };
+
+  // Generic (slow) path: the pieces of ONE object from segment k on, starting at
+  // sample `cur` of the tile, one MFMA step per piece with the lanes of the
+  // second object slot idle.  Walks the segments like GainInterpolator::process
+  // (gain_interpolator.hpp:58-86).  Used for partial tiles, an odd last object
+  // and for curves with points inside the tile (after their first piece).
+  auto single_object = [&](int m, int k, int cur) {
+    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
+    while (cur < tile_len) {
+      const SegDesc dk = describe_segment(P.ps, base, n, k, tile_t0, tile_t1);
+      const int r1 = min(seg_r1(dk.info), tile_len);
+      if (r1 > cur) {  // duplicate times make empty segments (steps)
+        const bool ramp = dk.info & kSegRamp;
+        float a[NRT], gv[NCT];
+#pragma unroll
+        for (int r = 0; r < NRT; r++) {
+          const int s = r * 16 + li;
+          const float x = row[min(s, tile_len - 1)];
+          const float p = (float)(dk.d0 + s) * dk.scale;  // gain_interpolator.hpp:272
+          float coef = ramp ? (is_b ? p : 1.0f - p) : (is_b ? 0.0f : 1.0f);
+          coef = (slot == 0 && s >= cur && s < r1) ? coef : 0.0f;
+          a[r] = x * coef;
+        }
+        const int grow = dk.row + ((ramp && is_b && slot == 0) ? 1 : 0);
+        const float *gp = P.ps.gain + (size_t)grow * P.ps.row + col0 + li;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
+        mma(a, gv);
+        cur = r1;
+      }
+      if (!(dk.info & kSegMulti)) break;
+      k++;
+    }
+  };
+  auto whole_object = [&](int m) {
+    const SegDesc d = P.desc[(size_t)m * P.ntiles + tile];
+    single_object(m, seg_k(d.info), 0);
+  };
+
+  const int npairs = (m_hi - m_lo) >> 1;
+  if (tile_len < TS) {
+    for (int m = m_lo; m < m_hi; m++) whole_object(m);  // last, partial tile of a call
+  } else if (npairs > 0) {
+    // Fast path, full tile: two-deep software pipeline over object pairs.  All
+    // addresses are (wave-uniform base) + (loop-invariant 32-bit lane offset), so a
+    // step costs no address arithmetic on the VALU; descriptors are fetched two
+    // steps ahead, inputs and gain rows one step ahead of the MFMAs that use them.
+    const unsigned xoff = (unsigned)slot * (unsigned)P.in_stride + (unsigned)li;
+    const unsigned doff = (unsigned)slot * (unsigned)P.ntiles;
+    const unsigned goff0 = (unsigned)(col0 + li);
+    const float c0 = is_b ? 0.0f : 1.0f;       // constant segment: a = x, b = 0
+    const float c1r = is_b ? 1.0f : -1.0f;     // ramp: coef = c0 + c1 * p  (= p or 1 - p)
+    auto pair_index = [&](int i) { return m_lo + 2 * min(i, npairs - 1); };
+    auto load_desc = [&](int i) {
+      const int4 *db = reinterpret_cast<const int4 *>(P.desc + (size_t)pair_index(i) * P.ntiles + tile);
+      return db[doff];
+    };
+    auto load_x = [&](int i, float (&x)[NRT]) {
+      const float *xb = P.in + (size_t)pair_index(i) * P.in_stride + tile_s0;
+#pragma unroll
+      for (int r = 0; r < NRT; r++) x[r] = xb[xoff + r * 16];
+    };
+    auto load_g = [&](const int4 d, float (&gv)[NCT]) {
+      // ramp: k even -> start row, k odd -> end row; constant: the one row (b = 0)
+      const unsigned row = (unsigned)d.x + (((d.w & kSegRamp) && is_b) ? 1u : 0u);
+      const unsigned go = row * (unsigned)P.ps.row + goff0;
+#pragma unroll
+      for (int c = 0; c < NCT; c++) gv[c] = P.ps.gain[go + c * 16];
+    };
+    // consume pair i: (d, x, g) were loaded earlier
+    auto consume = [&](int i, const int4 d, const float (&x)[NRT], const float (&gv)[NCT]) {
+      const bool ramp = d.w & kSegRamp;
+      const float c1 = ramp ? c1r : 0.0f;
+      const float scale = __int_as_float(d.z);
+      const int idx0 = d.y + li;
+      float a[NRT];
+#pragma unroll
+      for (int r = 0; r < NRT; r++) {
+        const float p = (float)(idx0 + r * 16) * scale;  // gain_interpolator.hpp:272
+        a[r] = x[r] * __builtin_fmaf(c1, p, c0);
+      }
+      const unsigned long long multi = __ballot(d.w & kSegMulti);
+      if (multi) {  // rare: a curve point inside the tile; first piece = samples [0, r1)
+        const int r1 = seg_r1(d.w);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) a[r] = (r * 16 + li < r1) ? a[r] : 0.0f;
+      }
+      mma(a, gv);
+      if (multi) {
+        const int m0 = m_lo + 2 * i;
+        if (multi & 1ull) {
+          const int info = __builtin_amdgcn_readlane(d.w, 0);
+          single_object(m0, seg_k(info) + 1, seg_r1(info));
+        }
+        if (multi >> 32) {
+          const int info = __builtin_amdgcn_readlane(d.w, 32);
+          single_object(m0 + 1, seg_k(info) + 1, seg_r1(info));
+        }
+      }
+    };
+
+    int4 dA = load_desc(0), dB = load_desc(1);
+    float xA[NRT], gA[NCT], xB[NRT], gB[NCT];
+    load_x(0, xA);
+    load_g(dA, gA);
+    for (int i = 0; i < npairs; i += 2) {
+      // even step: consume A, fetch B
+      int4 dC = load_desc(i + 2);
+      load_x(i + 1, xB);
+      load_g(dB, gB);
+      consume(i, dA, xA, gA);
+      if (i + 1 >= npairs) break;
+      // odd step: consume B, fetch A
+      dA = load_desc(i + 3);
+      load_x(i + 2, xA);
+      load_g(dC, gA);
+      consume(i + 1, dB, xB, gB);
+      dB = dA;
+      dA = dC;
+    }
+    if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
+  } else if (m_lo < m_hi) {
+    whole_object(m_lo);
+  }
+
+  // combine the in-workgroup object splits through LDS, highest split first;
+  // accumulators keep their fragment layout: [frag][lane] float4
+  f32x4 *slab = reinterpret_cast<f32x4 *>(lds) + (size_t)g * NRT * NCT * 64 + lane;
+  for (int r = P.wsplit - 1; r >= 1; r--) {
+    if (ws == r) {
+#pragma unroll
+      for (int f = 0; f < NRT * NCT; f++) {
+        f32x4 v = acc[f / NCT][f % NCT];
+        if (r != P.wsplit - 1) v += slab[f * 64];
+        slab[f * 64] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (ws != 0) return;
+
+  // D fragment: lane holds column l&15, samples (l>>4)*4 .. +3 of each 16x16 tile
+  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0 + kk * 4;
+#pragma unroll
+  for (int c = 0; c < NCT; c++) {
+    const int col = col0 + c * 16 + li;
+    if (col >= P.ncols) continue;
+#pragma unroll
+    for (int r = 0; r < NRT; r++) {
+      f32x4 v = acc[r][c];
+      if (P.wsplit > 1) v += slab[(r * NCT + c) * 64];
+      float *o = op + (size_t)col * P.out_stride + r * 16;
+      const int s = r * 16 + kk * 4;
+      if (P.vec_ok && s + 3 < tile_len) {
+        *reinterpret_cast<f32x4 *>(o) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (s + i < tile_len) o[i] = v[i];
+      }
+    }
+  }
+}
+
+}  // namespace earhip
