@@ -134,67 +134,71 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       return db[doff];
     };
     auto load_x = [&](int i, float (&x)[NRT]) {
-      const float *xb = P.in + (size_t)pair_index(i) * P.in_stride + tile_s0;
+      const float *xp = P.in + (size_t)pair_index(i) * P.in_stride + tile_s0 + xoff;
 #pragma unroll
-      for (int r = 0; r < NRT; r++) x[r] = xb[xoff + r * 16];
+      for (int r = 0; r < NRT; r++) x[r] = xp[r * 16];
     };
     auto load_g = [&](const int4 d, float (&gv)[NCT]) {
       // ramp: k even -> start row, k odd -> end row; constant: the one row (b = 0)
       const unsigned row = (unsigned)d.x + (((d.w & kSegRamp) && is_b) ? 1u : 0u);
-      const unsigned go = row * (unsigned)P.ps.row + goff0;
+      const float *gp = P.ps.gain + (row * (unsigned)P.ps.row + goff0);
 #pragma unroll
-      for (int c = 0; c < NCT; c++) gv[c] = P.ps.gain[go + c * 16];
+      for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
     };
-    // consume pair i: (d, x, g) were loaded earlier
-    auto consume = [&](int i, const int4 d, const float (&x)[NRT], const float (&gv)[NCT]) {
+    // A fragments of pair i from its inputs x and descriptor d
+    auto make_a = [&](const int4 d, const float (&x)[NRT], float (&a)[NRT]) {
       const bool ramp = d.w & kSegRamp;
       const float c1 = ramp ? c1r : 0.0f;
       const float scale = __int_as_float(d.z);
       const int idx0 = d.y + li;
-      float a[NRT];
 #pragma unroll
       for (int r = 0; r < NRT; r++) {
         const float p = (float)(idx0 + r * 16) * scale;  // gain_interpolator.hpp:272
         a[r] = x[r] * __builtin_fmaf(c1, p, c0);
       }
-      const unsigned long long multi = __ballot(d.w & kSegMulti);
+    };
+    // One step: consume pair i (inputs x, gains gv, descriptor dcur), and refill
+    // the same registers for pair i+2 as soon as they are free: x right after the
+    // A fragments are built, the gain rows right after the MFMAs were issued.
+    int4 dcur = load_desc(0), dnext = load_desc(1), dn2 = load_desc(2);
+    auto step = [&](int i, float (&x)[NRT], float (&gv)[NCT]) {
+      float a[NRT];
+      make_a(dcur, x, a);
+      load_x(i + 2, x);
+      const unsigned long long multi = __ballot(dcur.w & kSegMulti);
       if (multi) {  // rare: a curve point inside the tile; first piece = samples [0, r1)
-        const int r1 = seg_r1(d.w);
+        const int r1 = seg_r1(dcur.w);
 #pragma unroll
         for (int r = 0; r < NRT; r++) a[r] = (r * 16 + li < r1) ? a[r] : 0.0f;
       }
       mma(a, gv);
+      load_g(dn2, gv);
+      const int4 dnew = load_desc(i + 3);
       if (multi) {
         const int m0 = m_lo + 2 * i;
         if (multi & 1ull) {
-          const int info = __builtin_amdgcn_readlane(d.w, 0);
+          const int info = __builtin_amdgcn_readlane(dcur.w, 0);
           single_object(m0, seg_k(info) + 1, seg_r1(info));
         }
         if (multi >> 32) {
-          const int info = __builtin_amdgcn_readlane(d.w, 32);
+          const int info = __builtin_amdgcn_readlane(dcur.w, 32);
           single_object(m0 + 1, seg_k(info) + 1, seg_r1(info));
         }
       }
+      dcur = dnext;
+      dnext = dn2;
+      dn2 = dnew;
     };
 
-    int4 dA = load_desc(0), dB = load_desc(1);
     float xA[NRT], gA[NCT], xB[NRT], gB[NCT];
     load_x(0, xA);
-    load_g(dA, gA);
+    load_x(1, xB);
+    load_g(dcur, gA);
+    load_g(dnext, gB);
     for (int i = 0; i < npairs; i += 2) {
-      // even step: consume A, fetch B
-      int4 dC = load_desc(i + 2);
-      load_x(i + 1, xB);
-      load_g(dB, gB);
-      consume(i, dA, xA, gA);
+      step(i, xA, gA);
       if (i + 1 >= npairs) break;
-      // odd step: consume B, fetch A
-      dA = load_desc(i + 3);
-      load_x(i + 2, xA);
-      load_g(dC, gA);
-      consume(i + 1, dB, xB, gB);
-      dB = dA;
-      dA = dC;
+      step(i + 1, xB, gB);
     }
     if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
   } else if (m_lo < m_hi) {
