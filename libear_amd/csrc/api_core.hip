@@ -223,6 +223,10 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
       if (v == 2 || v == 4) c->spl = v;
     }
     if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e) != 0;
+    if (const char *e = getenv("EARHIP_WAVES")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 8) c->max_waves = v;
+    }
     if (const char *e = getenv("EARHIP_NRT")) {
       const int v = atoi(e);
       if (v == 4 || v == 8) c->nrt = v;

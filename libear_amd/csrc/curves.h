@@ -179,7 +179,7 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   }
   // 8 waves per workgroup: what the column groups leave goes to object splits
   const int groups = L.mfma ? cp.mgroups : cp.ngroups;
-  L.wsplit = std::max(1, std::min(8 / groups, std::max(1, M / 8)));
+  L.wsplit = std::max(1, std::min(std::max(1, ctx->max_waves / groups), std::max(1, M / 8)));
   // few tiles (block mode): split the objects across workgroups as well until
   // the grid covers the chip about twice over
   const int per_wg = std::max(1, M / L.wsplit);

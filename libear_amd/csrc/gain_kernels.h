@@ -59,6 +59,14 @@ constexpr int kMaxPointsPerObject = 1 << 18;
 __host__ __device__ __forceinline__ int seg_r1(int info) { return (info >> 4) & 0x1ff; }
 __host__ __device__ __forceinline__ int seg_k(int info) { return info >> 13; }
 
+// blockIdx.x -> tile such that the workgroups of one XCD (b % 8) cover a
+// contiguous range of tiles; identity for the ragged tail
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int per = n >> 3;  // tiles per XCD
+  if (b >= per * 8) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
 // number of points of object m with time <= t  (= libear's find_block result)
 __device__ __forceinline__ int upper_bound_time(const int64_t *t, int n, int64_t v) {
   int lo = 0, hi = n;

@@ -46,7 +46,10 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = wave % P.ngroups;
   const int ws = wave / P.ngroups;
-  const int tile = blockIdx.x;
+  // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Tiles that are
+  // neighbours in time share gain rows, so give every XCD one contiguous run of
+  // tiles instead of every 8th tile (speed only; any mapping is correct).
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int nparts = P.wsplit * gridDim.y;
   const int part = blockIdx.y * P.wsplit + ws;
   const int m_lo = (int)(((int64_t)P.M * part) / nparts);
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
 #pragma unroll
       for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
     };
-    // A fragments of pair i from its inputs x and descriptor d
+    // A fragments of a pair from its inputs x and descriptor d
     auto make_a = [&](const int4 d, const float (&x)[NRT], float (&a)[NRT]) {
       const bool ramp = d.w & kSegRamp;
       const float c1 = ramp ? c1r : 0.0f;
@@ -157,48 +160,68 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
         a[r] = x[r] * __builtin_fmaf(c1, p, c0);
       }
     };
-    // One step: consume pair i (inputs x, gains gv, descriptor dcur), and refill
-    // the same registers for pair i+2 as soon as they are free: x right after the
-    // A fragments are built, the gain rows right after the MFMAs were issued.
-    int4 dcur = load_desc(0), dnext = load_desc(1), dn2 = load_desc(2);
-    auto step = [&](int i, float (&x)[NRT], float (&gv)[NCT]) {
-      float a[NRT];
-      make_a(dcur, x, a);
-      load_x(i + 2, x);
-      const unsigned long long multi = __ballot(dcur.w & kSegMulti);
-      if (multi) {  // rare: a curve point inside the tile; first piece = samples [0, r1)
-        const int r1 = seg_r1(dcur.w);
+    // rare: curve points inside the tile.  The pair's A fragments keep only the
+    // first piece [0, r1); the later pieces go through the generic path.
+    auto fix_multi = [&](int i, const int4 d, float (&a)[NRT]) {
+      const unsigned long long multi = __ballot(d.w & kSegMulti);
+      if (multi) {
+        const int r1 = seg_r1(d.w);
 #pragma unroll
         for (int r = 0; r < NRT; r++) a[r] = (r * 16 + li < r1) ? a[r] : 0.0f;
-      }
-      mma(a, gv);
-      load_g(dn2, gv);
-      const int4 dnew = load_desc(i + 3);
-      if (multi) {
         const int m0 = m_lo + 2 * i;
         if (multi & 1ull) {
-          const int info = __builtin_amdgcn_readlane(dcur.w, 0);
+          const int info = __builtin_amdgcn_readlane(d.w, 0);
           single_object(m0, seg_k(info) + 1, seg_r1(info));
         }
         if (multi >> 32) {
-          const int info = __builtin_amdgcn_readlane(dcur.w, 32);
+          const int info = __builtin_amdgcn_readlane(d.w, 32);
           single_object(m0 + 1, seg_k(info) + 1, seg_r1(info));
         }
       }
-      dcur = dnext;
-      dnext = dn2;
-      dn2 = dnew;
     };
 
-    float xA[NRT], gA[NCT], xB[NRT], gB[NCT];
-    load_x(0, xA);
-    load_x(1, xB);
-    load_g(dcur, gA);
-    load_g(dnext, gB);
+    // Steady state of step i (one basic block): the 24 MFMAs of pair i, and,
+    // woven between them by the scheduling directives below, everything pair
+    // i+1 .. i+3 needs next: A fragments of pair i+1 (its inputs arrived a step
+    // ago), the refill of those input registers for pair i+3, the gain rows of
+    // pair i+2 and the descriptor of pair i+3.  A single wave can keep the
+    // matrix pipe busy this way; the second wave per SIMD hides HBM latency.
+    int4 d1 = load_desc(1), d2 = load_desc(2);
+    auto step = [&](int i, const float (&a_cur)[NRT], float (&a_nxt)[NRT], float (&g_cur)[NCT],
+                    float (&x_nxt)[NRT]) {
+      mma(a_cur, g_cur);
+      make_a(d1, x_nxt, a_nxt);
+      load_x(i + 3, x_nxt);
+      load_g(d2, g_cur);
+      const int4 d3 = load_desc(i + 3);
+#pragma unroll
+      for (int k = 0; k < NRT * NCT; k++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
+        if (k < NRT + NCT + 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+      }
+      if (i + 1 < npairs) fix_multi(i + 1, d1, a_nxt);  // the pair after the last one is a phantom
+      d1 = d2;
+      d2 = d3;
+    };
+
+    float aA[NRT], aB[NRT], gA[NCT], gB[NCT], xA[NRT], xB[NRT];
+    {
+      const int4 d0 = load_desc(0);
+      load_x(0, xA);
+      load_x(1, xB);
+      load_g(d0, gA);
+      load_g(d1, gB);
+      make_a(d0, xA, aA);
+      load_x(2, xA);
+      fix_multi(0, d0, aA);
+    }
+    // even steps: consume (aA, gA), build aB from xB (pair i+1), xB <- pair i+3, gA <- pair i+2
+    // odd steps : consume (aB, gB), build aA from xA (pair i+1), xA <- pair i+3, gB <- pair i+2
     for (int i = 0; i < npairs; i += 2) {
-      step(i, xA, gA);
+      step(i, aA, aB, gA, xB);
       if (i + 1 >= npairs) break;
-      step(i + 1, xB, gB);
+      step(i + 1, aB, aA, gB, xA);
     }
     if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
   } else if (m_lo < m_hi) {
