@@ -1,0 +1,102 @@
+// ear/dsp/block_convolver.hpp — Context / Filter / BlockConvolver with libear's
+// interface (include/ear/dsp/block_convolver.hpp:28-112) over the device
+// implementation (earhip_conv_*).
+#pragma once
+#include <complex>
+#include <cstddef>
+#include <memory>
+
+#include "../fft.hpp"
+#include "../hip.hpp"
+
+namespace ear {
+  namespace dsp {
+    namespace block_convolver {
+      using real_t = float;
+      using complex_t = std::complex<real_t>;
+
+      namespace detail {
+        struct CtxHandle {
+          earhip_conv_ctx *h = nullptr;
+          ~CtxHandle() { earhip_conv_ctx_destroy(h); }
+        };
+        struct FilterHandle {
+          std::shared_ptr<CtxHandle> ctx;  // keeps the context alive
+          earhip_conv_filter *h = nullptr;
+          ~FilterHandle() { earhip_conv_filter_destroy(h); }
+        };
+      }  // namespace detail
+
+      /// Static data for one block size; shareable between Filters and BlockConvolvers.
+      class Context {
+       public:
+        /// The FFT implementation argument is part of libear's signature; the
+        /// device path always uses its own transform, so it is ignored.
+        Context(size_t block_size, FFTImpl<real_t> &) : Context(block_size) {}
+        explicit Context(size_t block_size) : impl(std::make_shared<detail::CtxHandle>()) {
+          hip::check(earhip_conv_ctx_create(hip::default_context().get(), block_size, &impl->h));
+        }
+
+       private:
+        std::shared_ptr<detail::CtxHandle> impl;
+        friend class Filter;
+        friend class BlockConvolver;
+      };
+
+      /// Pre-transformed filter partitions; shareable between BlockConvolvers.
+      class Filter {
+       public:
+        Filter(const Context &ctx, size_t n, const real_t *filter)
+            : impl(std::make_shared<detail::FilterHandle>()) {
+          impl->ctx = ctx.impl;
+          hip::check(earhip_conv_filter_create(ctx.impl->h, n, filter, &impl->h));
+        }
+        size_t num_blocks() const { return earhip_conv_filter_num_blocks(impl->h); }
+
+       private:
+        std::shared_ptr<detail::FilterHandle> impl;
+        friend class BlockConvolver;
+      };
+
+      /// Partitioned overlap-add convolution with click-free filter changes.
+      class BlockConvolver {
+       public:
+        BlockConvolver(const Context &ctx, size_t num_blocks) : ctx_(ctx.impl) {
+          hip::check(earhip_conv_create(ctx_->h, nullptr, num_blocks, &h_));
+        }
+        BlockConvolver(const Context &ctx, const Filter &filter, size_t num_blocks = 0)
+            : ctx_(ctx.impl) {
+          hip::check(earhip_conv_create(ctx_->h, filter.impl->h, num_blocks, &h_));
+          for (auto &f : live_) f = filter.impl;
+        }
+        ~BlockConvolver() { earhip_conv_destroy(h_); }
+        BlockConvolver(const BlockConvolver &) = delete;
+        BlockConvolver &operator=(const BlockConvolver &) = delete;
+
+        /// in: block_size samples or nullptr (silence); out: block_size samples
+        void process(const float *in, float *out) { hip::check(earhip_conv_process(h_, in, out)); }
+        void crossfade_filter(const Filter &filter) {
+          hip::check(earhip_conv_crossfade_filter(h_, filter.impl->h));
+          keep(filter.impl);
+        }
+        void fade_down() { hip::check(earhip_conv_crossfade_filter(h_, nullptr)); }
+        void set_filter(const Filter &filter) {
+          hip::check(earhip_conv_set_filter(h_, filter.impl->h));
+          keep(filter.impl);
+        }
+        void unset_filter() { hip::check(earhip_conv_set_filter(h_, nullptr)); }
+
+       private:
+        // libear holds shared_ptrs to the filters in its queue; keep the most
+        // recent ones alive in the same spirit (a filter must outlive its use)
+        void keep(const std::shared_ptr<detail::FilterHandle> &f) {
+          live_[next_++ % 4] = f;
+        }
+        std::shared_ptr<detail::CtxHandle> ctx_;
+        earhip_conv *h_ = nullptr;
+        std::shared_ptr<detail::FilterHandle> live_[4];
+        size_t next_ = 0;
+      };
+    }  // namespace block_convolver
+  }  // namespace dsp
+}  // namespace ear

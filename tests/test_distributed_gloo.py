@@ -1,0 +1,90 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Objects are sharded by rank, every rank
+renders its shard completely, the partial loudspeaker buses are summed by the one exchange step
+(libear_amd/distributed.py) and every rank ends up owning its slice of the channels.  The CPU
+oracle stands in for the device renderer here (the collective, the sharding arithmetic and the
+linearity argument are what is under test); the GPU suite checks the same decomposition with the
+real renderer on one device (tests/test_gpu_render.py::test_c4_size_vs_oracle_and_shard_linearity)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _oracle
+    import scenes
+    from layouts import LAYOUTS
+    from libear_amd.distributed import channel_range, exchange, shard_range
+
+    names = LAYOUTS["4+5+0"]
+    m, n, block, nblocks = 24, len(names), 512, 3
+    dec = _oracle.design_decorrelators(names)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks)
+    lo, hi = shard_range(m, rank, world)
+    o = _oracle.ObjectsRenderer(hi - lo, n, block, dec, 255)
+    for i, (t, d, f) in enumerate(curves[lo:hi]):
+        o.set_points(i, 0, t, d)
+        o.set_points(i, 1, t, f)
+    partial = torch.from_numpy(o.process(x[lo:hi]))
+    owned, work = exchange(partial, async_op=True)
+    work.wait()
+    clo, chi = channel_range(n, rank, world)
+    assert owned.shape[0] == chi - clo
+    np.save(os.path.join(tmp, f"owned_{rank}.npy"), owned.numpy())
+    if rank == 0:
+        full = _oracle.ObjectsRenderer(m, n, block, dec, 255)
+        for i, (t, d, f) in enumerate(curves):
+            full.set_points(i, 0, t, d)
+            full.set_points(i, 1, t, f)
+        np.save(os.path.join(tmp, "full.npy"), full.process(x))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_exchange_world_size_2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    full = np.load(tmp_path / "full.npy")
+    got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(world)], axis=0)
+    assert got.shape == full.shape
+    err = np.linalg.norm(got.astype(np.float64) - full) / np.linalg.norm(full)
+    assert err <= 1e-6, err
+
+
+def test_shard_ranges_cover_everything():
+    sys.path.insert(0, ROOT)
+    from libear_amd.distributed import channel_range, shard_range
+    for m in (1, 7, 64, 1024, 1023):
+        for world in (1, 2, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_range(m, r, world)
+                cover.extend(range(lo, hi))
+            assert cover == list(range(m))
+    for world in (1, 2, 4, 8):
+        cover = []
+        for r in range(world):
+            lo, hi = channel_range(24, r, world)
+            cover.extend(range(lo, hi))
+        assert cover == list(range(24))
