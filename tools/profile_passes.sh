@@ -10,10 +10,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 "$@" -d $OUT/$name -o p -- python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-blocks 0 $EXTRA > $OUT/$name.log 2>&1
+  timeout 150 rocprofv3 "$@" -d $OUT/$name -o p -- python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-blocks 0 $EXTRA > $OUT/$name.log 2>&1
 }
 EXTRA="$*"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o p -- python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-blocks 0 $EXTRA > $OUT/stats.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/stats -o p -- python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-blocks 0 $EXTRA > $OUT/stats.log 2>&1
 run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY
 run sq2 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_LDS
 run ta --pmc TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum
