@@ -10,9 +10,17 @@
 // at the full fp32 rate of the chip, and — unlike the VALU formulation — takes
 // the gains as an ordinary per-lane operand:
 //
-//   A fragment (1 VGPR): lane l holds A[sample l&15][k = l>>4]
+//   A fragment (1 VGPR): lane l holds A[row l&15][k = l>>4]
 //   B fragment (1 VGPR): lane l holds B[k = l>>4][column l&15]
 //   k = 0..3 of one step = {a, b} of two consecutive objects
+//
+// Which sample an MFMA row stands for, and which bus column an MFMA column, is
+// free to choose.  Row i of row-tile r is sample i*NRT + r and column j of
+// column-tile c is bus column j*NCT + c, so that a lane's NRT inputs and its NCT
+// gains are CONTIGUOUS in memory: one 16-byte load of x and one 12-byte load of
+// gains per step and lane instead of NRT + NCT dword loads (the texture-address
+// unit was 54% busy with those), and the D fragments of the NRT row tiles
+// interleave back into runs of NRT consecutive samples for the stores.
 //
 // so the gain rows arrive through plain coalesced vector loads (deep, in-order
 // prefetch) instead of wave-uniform scalar loads, whose cache cannot sustain a
@@ -95,7 +103,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
         float a[NRT], gv[NCT];
 #pragma unroll
         for (int r = 0; r < NRT; r++) {
-          const int s = r * 16 + li;
+          const int s = li * NRT + r;
           const float x = row[min(s, tile_len - 1)];
           const float p = (float)(dk.d0 + s) * dk.scale;  // gain_interpolator.hpp:272
           float coef = ramp ? (is_b ? p : 1.0f - p) : (is_b ? 0.0f : 1.0f);
@@ -103,9 +111,9 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
           a[r] = x * coef;
         }
         const int grow = dk.row + ((ramp && is_b && slot == 0) ? 1 : 0);
-        const float *gp = P.ps.gain + (size_t)grow * P.ps.row + col0 + li;
+        const float *gp = P.ps.gain + (size_t)grow * P.ps.row + col0 + li * NCT;
 #pragma unroll
-        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c];
         mma(a, gv);
         cur = r1;
       }
@@ -121,14 +129,14 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   const int npairs = (m_hi - m_lo) >> 1;
   if (tile_len < TS) {
     for (int m = m_lo; m < m_hi; m++) whole_object(m);  // last, partial tile of a call
-  } else if (npairs > 0) {
-    // Fast path, full tile: two-deep software pipeline over object pairs.  All
+  } else if (npairs > 0 && P.vec_ok) {
+    // Fast path, full tile, 16-byte aligned rows: two-deep software pipeline over object pairs.  All
     // addresses are (wave-uniform base) + (loop-invariant 32-bit lane offset), so a
     // step costs no address arithmetic on the VALU; descriptors are fetched two
     // steps ahead, inputs and gain rows one step ahead of the MFMAs that use them.
-    const unsigned xoff = (unsigned)slot * (unsigned)P.in_stride + (unsigned)li;
+    const unsigned xoff = (unsigned)slot * (unsigned)P.in_stride + (unsigned)(li * NRT);
     const unsigned doff = (unsigned)slot * (unsigned)P.ntiles;
-    const unsigned goff0 = (unsigned)(col0 + li);
+    const unsigned goff0 = (unsigned)(col0 + li * NCT);
     const float c0 = is_b ? 0.0f : 1.0f;       // constant segment: a = x, b = 0
     const float c1r = is_b ? 1.0f : -1.0f;     // ramp: coef = c0 + c1 * p  (= p or 1 - p)
     auto pair_index = [&](int i) { return m_lo + 2 * min(i, npairs - 1); };
@@ -137,26 +145,31 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       return db[doff];
     };
     auto load_x = [&](int i, float (&x)[NRT]) {
-      const float *xp = P.in + (size_t)pair_index(i) * P.in_stride + tile_s0 + xoff;
+      const f32x4 *xp = reinterpret_cast<const f32x4 *>(P.in + (size_t)pair_index(i) * P.in_stride +
+                                                        tile_s0 + xoff);
 #pragma unroll
-      for (int r = 0; r < NRT; r++) x[r] = xp[r * 16];
+      for (int q = 0; q < NRT / 4; q++) {
+        const f32x4 v = xp[q];
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[q * 4 + e] = v[e];
+      }
     };
     auto load_g = [&](const int4 d, float (&gv)[NCT]) {
       // ramp: k even -> start row, k odd -> end row; constant: the one row (b = 0)
       const unsigned row = (unsigned)d.x + (((d.w & kSegRamp) && is_b) ? 1u : 0u);
       const float *gp = P.ps.gain + (row * (unsigned)P.ps.row + goff0);
 #pragma unroll
-      for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
+      for (int c = 0; c < NCT; c++) gv[c] = gp[c];
     };
     // A fragments of a pair from its inputs x and descriptor d
     auto make_a = [&](const int4 d, const float (&x)[NRT], float (&a)[NRT]) {
       const bool ramp = d.w & kSegRamp;
       const float c1 = ramp ? c1r : 0.0f;
       const float scale = __int_as_float(d.z);
-      const int idx0 = d.y + li;
+      const int idx0 = d.y + li * NRT;
 #pragma unroll
       for (int r = 0; r < NRT; r++) {
-        const float p = (float)(idx0 + r * 16) * scale;  // gain_interpolator.hpp:272
+        const float p = (float)(idx0 + r) * scale;  // gain_interpolator.hpp:272
         a[r] = x[r] * __builtin_fmaf(c1, p, c0);
       }
     };
@@ -167,7 +180,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       if (multi) {
         const int r1 = seg_r1(d.w);
 #pragma unroll
-        for (int r = 0; r < NRT; r++) a[r] = (r * 16 + li < r1) ? a[r] : 0.0f;
+        for (int r = 0; r < NRT; r++) a[r] = (li * NRT + r < r1) ? a[r] : 0.0f;
         const int m0 = m_lo + 2 * i;
         if (multi & 1ull) {
           const int info = __builtin_amdgcn_readlane(d.w, 0);
@@ -198,7 +211,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       for (int k = 0; k < NRT * NCT; k++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
-        if (k < NRT + NCT + 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+        if (k < NRT / 4 + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
       }
       if (i + 1 < npairs) fix_multi(i + 1, d1, a_nxt);  // the pair after the last one is a phantom
       d1 = d2;
@@ -224,8 +237,8 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       step(i + 1, aB, aA, gB, xA);
     }
     if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
-  } else if (m_lo < m_hi) {
-    whole_object(m_lo);
+  } else {
+    for (int m = m_lo; m < m_hi; m++) whole_object(m);  // single object or unaligned rows
   }
 
   // combine the in-workgroup object splits through LDS, highest split first;
@@ -244,24 +257,34 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   }
   if (ws != 0) return;
 
-  // D fragment: lane holds column l&15, samples (l>>4)*4 .. +3 of each 16x16 tile
-  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0 + kk * 4;
+  // D fragment of row-tile r: lane holds bus column col0 + li*NCT + c and MFMA rows
+  // kk*4 + e (e = 0..3), i.e. samples (kk*4 + e)*NRT + r: for fixed e the NRT row
+  // tiles form a run of NRT consecutive samples
+  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
 #pragma unroll
   for (int c = 0; c < NCT; c++) {
-    const int col = col0 + c * 16 + li;
-    if (col >= P.ncols) continue;
+    const int col = col0 + li * NCT + c;
+    f32x4 v[NRT];
 #pragma unroll
     for (int r = 0; r < NRT; r++) {
-      f32x4 v = acc[r][c];
-      if (P.wsplit > 1) v += slab[(r * NCT + c) * 64];
-      float *o = op + (size_t)col * P.out_stride + r * 16;
-      const int s = r * 16 + kk * 4;
-      if (P.vec_ok && s + 3 < tile_len) {
-        *reinterpret_cast<f32x4 *>(o) = v;
-      } else {
+      v[r] = acc[r][c];
+      if (P.wsplit > 1) v[r] += slab[(r * NCT + c) * 64];
+    }
+    if (col >= P.ncols) continue;
+    float *o = op + (size_t)col * P.out_stride;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (s + i < tile_len) o[i] = v[i];
+    for (int e = 0; e < 4; e++) {
+      const int s = (kk * 4 + e) * NRT;
+#pragma unroll
+      for (int q = 0; q < NRT / 4; q++) {
+        const f32x4 w = {v[q * 4 + 0][e], v[q * 4 + 1][e], v[q * 4 + 2][e], v[q * 4 + 3][e]};
+        if (P.vec_ok && s + q * 4 + 3 < tile_len) {
+          *reinterpret_cast<f32x4 *>(o + s + q * 4) = w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (s + q * 4 + i < tile_len) o[s + q * 4 + i] = w[i];
+        }
       }
     }
   }
