@@ -60,6 +60,9 @@ int earhip_ctx_synchronize(earhip_ctx *ctx);
  * so M->N results are bit-identical to the CPU path.  Default 0: fused
  * multiply-adds and tree accumulation (faster, within 1e-6 relative RMS). */
 int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
+/* tuning aid: enqueue a 1-thread kernel that writes {shader-cycle counter,
+ * constant-rate counter} (2 x uint64) to device memory */
+int earhip_debug_clock_probe(earhip_ctx *ctx, void *out_dev);
 
 /* ------------------------------------------------------------------------
  * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector

@@ -16,7 +16,7 @@ void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml) {
   if (ml.wsplit <= 1) return 0;
-  if (ml.mfma) return (size_t)cp.mgroups * cp.nct * 16 * ml.tile() * sizeof(float);
+  if (ml.mfma) return (size_t)cp.mgroups * ml.tpw * cp.nct * 16 * ml.tile() * sizeof(float);
   return (size_t)cp.ngroups * cp.nout * ml.tile() * sizeof(float);
 }
 
@@ -61,12 +61,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   P.ncols = cs.ncols();
   P.ngroups = ml.mfma ? cp.mgroups : cp.ngroups;
   P.wsplit = ml.wsplit;
+  P.tiles_per_wg = ml.mfma ? ml.tpw : 1;
   P.vec_ok = (in_stride % 4 == 0 && out_stride % 4 == 0 && part_stride % 4 == 0 &&
               ((uintptr_t)in_dev & 15) == 0 && ((uintptr_t)out_dev & 15) == 0)
                  ? 1
                  : 0;
-  const dim3 grid(ml.ntiles, ml.gsplit, ml.mfma ? cp.mnz : cp.nz);
-  const dim3 block(64 * P.ngroups * ml.wsplit);
+  const dim3 grid(ml.mfma ? (ml.ntiles + ml.tpw - 1) / ml.tpw : ml.ntiles, ml.gsplit,
+                  ml.mfma ? cp.mnz : cp.nz);
+  const dim3 block(64 * P.ngroups * P.tiles_per_wg * ml.wsplit);
   const size_t lds = mix_lds_bytes(cp, ml);
   if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
 #define EARHIP_MIX_CASE(NOUT_, SPL_, STRICT_)                                   \
@@ -182,7 +184,25 @@ static PolicyCache *policy_cache(earhip_ctx *ctx) {
   return g_policy.back().second.get();
 }
 
+static __global__ void k_clock_probe(unsigned long long *out) {
+  out[0] = clock64();       // shader clock (s_memtime)
+  out[1] = wall_clock64();  // constant-rate counter
+}
+
 extern "C" {
+
+// Tuning aid: enqueue a probe that samples the shader-cycle and the constant-rate
+// counters into device memory `out_dev[2]` (two probes bracket a region to get
+// the average shader clock).  wall_clock64 rate: hipDeviceAttributeWallClockRate.
+int earhip_debug_clock_probe(earhip_ctx *ctx, void *out_dev) {
+  return guarded([&] {
+    require(ctx != nullptr && out_dev != nullptr, "NULL argument");
+    ctx->use();
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(1), 0, ctx->stream,
+                       (unsigned long long *)out_dev);
+    EARHIP_HIP(hipGetLastError());
+  });
+}
 
 int earhip_version(void) { return EARHIP_VERSION; }
 const char *earhip_last_error(void) { return g_last_error.c_str(); }
@@ -226,6 +246,10 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
     if (const char *e = getenv("EARHIP_WAVES")) {
       const int v = atoi(e);
       if (v >= 1 && v <= 8) c->max_waves = v;
+    }
+    if (const char *e = getenv("EARHIP_TPW")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 8) c->tiles_per_wg = v;
     }
     if (const char *e = getenv("EARHIP_NRT")) {
       const int v = atoi(e);

@@ -120,7 +120,8 @@ struct earhip_ctx {
   int spl = 4;  // samples per lane of the VALU gain_mix kernel (2 or 4)
   bool use_mfma = true;  // default (non-strict) gain stage on the matrix cores
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
-  int nrt = 4;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)
+  int tiles_per_wg = 1;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
+  int nrt = 8;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)
   int num_cus = 256;
   // staging for the host-pointer entry points (grown at first use / create)
   earhip::PinBuf<float> pin_in, pin_out;

@@ -162,6 +162,7 @@ struct MixLaunch {
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
+  int tpw = 1;                 // MFMA: adjacent tiles per workgroup
   int tile() const { return mfma ? 16 * nrt : 64 * spl; }
 };
 
@@ -179,13 +180,14 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   }
   // 8 waves per workgroup: what the column groups leave goes to object splits
   const int groups = L.mfma ? cp.mgroups : cp.ngroups;
-  L.wsplit = std::max(1, std::min(std::max(1, ctx->max_waves / groups), std::max(1, M / 8)));
+  if (L.mfma) L.tpw = std::max(1, std::min(std::min(ctx->tiles_per_wg, L.ntiles), ctx->max_waves / groups));
+  L.wsplit = std::max(1, std::min(std::max(1, ctx->max_waves / (groups * L.tpw)), std::max(1, M / 8)));
   // few tiles (block mode): split the objects across workgroups as well until
   // the grid covers the chip about twice over
   const int per_wg = std::max(1, M / L.wsplit);
   int g = 1;
   const int want = 2 * ctx->num_cus;
-  while (g < max_gsplit && L.ntiles * (L.mfma ? cp.mnz : cp.nz) * g < want && per_wg / (g * 2) >= 8) g *= 2;
+  while (g < max_gsplit && (L.ntiles / L.tpw) * (L.mfma ? cp.mnz : cp.nz) * g < want && per_wg / (g * 2) >= 8) g *= 2;
   L.gsplit = g;
   return L;
 }

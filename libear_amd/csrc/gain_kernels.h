@@ -135,6 +135,7 @@ struct GainMixParams {
   int ncols;            // valid output columns (<= row)
   int ngroups;          // column groups per workgroup (waves: group-major)
   int wsplit;           // object splits inside a workgroup
+  int tiles_per_wg;     // MFMA kernel: adjacent tiles handled by one workgroup
   int vec_ok;           // in/out rows are 16-byte aligned: vector accesses allowed
 };
 

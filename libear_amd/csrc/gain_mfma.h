@@ -52,12 +52,19 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [ngroups][NRT*NCT][64][4]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // waves of a workgroup = column groups x adjacent tiles x object splits.  Waves
+  // on adjacent tiles walk the SAME objects, so their gain-row loads (identical
+  // addresses, a few hundred cycles apart) are served by the CU's L1 instead of
+  // L2: at 64-sample tiles the gain rows are otherwise the larger L2->L1 stream.
   const int g = wave % P.ngroups;
-  const int ws = wave / P.ngroups;
+  const int tw = (wave / P.ngroups) % P.tiles_per_wg;
+  const int ws = wave / (P.ngroups * P.tiles_per_wg);
   // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Tiles that are
   // neighbours in time share gain rows, so give every XCD one contiguous run of
   // tiles instead of every 8th tile (speed only; any mapping is correct).
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile_raw = xcd_tile(blockIdx.x, gridDim.x) * P.tiles_per_wg + tw;
+  const bool idle = tile_raw >= P.ntiles;  // ragged last workgroup
+  const int tile = idle ? P.ntiles - 1 : tile_raw;
   const int nparts = P.wsplit * gridDim.y;
   const int part = blockIdx.y * P.wsplit + ws;
   const int m_lo = (int)(((int64_t)P.M * part) / nparts);
@@ -126,8 +133,9 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     single_object(m, seg_k(d.info), 0);
   };
 
-  const int npairs = (m_hi - m_lo) >> 1;
-  if (tile_len < TS) {
+  const int npairs = idle ? 0 : (m_hi - m_lo) >> 1;
+  if (idle) {
+  } else if (tile_len < TS) {
     for (int m = m_lo; m < m_hi; m++) whole_object(m);  // last, partial tile of a call
   } else if (npairs > 0 && P.vec_ok) {
     // Fast path, full tile, 16-byte aligned rows: two-deep software pipeline over object pairs.  All
@@ -199,14 +207,19 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     // ago), the refill of those input registers for pair i+3, the gain rows of
     // pair i+2 and the descriptor of pair i+3.  A single wave can keep the
     // matrix pipe busy this way; the second wave per SIMD hides HBM latency.
-    int4 d1 = load_desc(1), d2 = load_desc(2);
+    // Prefetch depths (in steps of 12/24 MFMAs): inputs 4, descriptors 3 (2 before
+    // the gain-row address they feed is needed), gain rows 1.  Memory-only and
+    // compute-only ablations of this loop run in 0.71 and 0.83 ms; at depth 2 the
+    // combined loop took 1.10 ms because HBM latency under load (~2 us) exceeded
+    // the lead time.
+    int4 d1 = load_desc(1), d2 = load_desc(2), d3 = load_desc(3);
     auto step = [&](int i, const float (&a_cur)[NRT], float (&a_nxt)[NRT], float (&g_cur)[NCT],
                     float (&x_nxt)[NRT]) {
       mma(a_cur, g_cur);
       make_a(d1, x_nxt, a_nxt);
-      load_x(i + 3, x_nxt);
+      load_x(i + 5, x_nxt);
       load_g(d2, g_cur);
-      const int4 d3 = load_desc(i + 3);
+      const int4 d4 = load_desc(i + 4);
 #pragma unroll
       for (int k = 0; k < NRT * NCT; k++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -216,25 +229,33 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       if (i + 1 < npairs) fix_multi(i + 1, d1, a_nxt);  // the pair after the last one is a phantom
       d1 = d2;
       d2 = d3;
+      d3 = d4;
     };
 
-    float aA[NRT], aB[NRT], gA[NCT], gB[NCT], xA[NRT], xB[NRT];
+    // x ring: set j holds the inputs of the pairs p with p % 4 == j
+    float aA[NRT], aB[NRT], gA[NCT], gB[NCT], x0[NRT], x1[NRT], x2[NRT], x3[NRT];
     {
       const int4 d0 = load_desc(0);
-      load_x(0, xA);
-      load_x(1, xB);
+      load_x(0, x0);
+      load_x(1, x1);
+      load_x(2, x2);
+      load_x(3, x3);
       load_g(d0, gA);
       load_g(d1, gB);
-      make_a(d0, xA, aA);
-      load_x(2, xA);
+      make_a(d0, x0, aA);
+      load_x(4, x0);
       fix_multi(0, d0, aA);
     }
-    // even steps: consume (aA, gA), build aB from xB (pair i+1), xB <- pair i+3, gA <- pair i+2
-    // odd steps : consume (aB, gB), build aA from xA (pair i+1), xA <- pair i+3, gB <- pair i+2
-    for (int i = 0; i < npairs; i += 2) {
-      step(i, aA, aB, gA, xB);
+    // step i consumes (a, g) of pair i, builds the A fragments of pair i+1 from its
+    // ring slot and refills that slot with pair i+5, refills g with pair i+2
+    for (int i = 0; i < npairs; i += 4) {
+      step(i, aA, aB, gA, x1);
       if (i + 1 >= npairs) break;
-      step(i + 1, aB, aA, gB, xA);
+      step(i + 1, aB, aA, gB, x2);
+      if (i + 2 >= npairs) break;
+      step(i + 2, aA, aB, gA, x3);
+      if (i + 3 >= npairs) break;
+      step(i + 3, aB, aA, gB, x0);
     }
     if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
   } else {
@@ -243,7 +264,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
 
   // combine the in-workgroup object splits through LDS, highest split first;
   // accumulators keep their fragment layout: [frag][lane] float4
-  f32x4 *slab = reinterpret_cast<f32x4 *>(lds) + (size_t)g * NRT * NCT * 64 + lane;
+  f32x4 *slab = reinterpret_cast<f32x4 *>(lds) + (size_t)(g * P.tiles_per_wg + tw) * NRT * NCT * 64 + lane;
   for (int r = P.wsplit - 1; r >= 1; r--) {
     if (ws == r) {
 #pragma unroll
@@ -255,7 +276,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     }
     __syncthreads();
   }
-  if (ws != 0) return;
+  if (ws != 0 || idle) return;
 
   // D fragment of row-tile r: lane holds bus column col0 + li*NCT + c and MFMA rows
   // kk*4 + e (e = 0..3), i.e. samples (kk*4 + e)*NRT + r: for fixed e the NRT row
