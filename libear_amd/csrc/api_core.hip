@@ -40,10 +40,9 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const PointStore ps = cs.device();
   const int M = cs.M();
   {
-    const int total = M * ml.ntiles;
     if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_seg_prep, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ps, M,
-                       ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
+    hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
+                       ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
     if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   }
   GainMixParams P;

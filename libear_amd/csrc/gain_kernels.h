@@ -106,18 +106,29 @@ __device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int ba
   return d;
 }
 
-// K0: one thread per (object, tile).
-static __global__ void k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples,
-                                  int64_t t_call, int64_t t_call_end, SegDesc *desc) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * ntiles) return;
-  const int m = idx / ntiles, tile = idx - m * ntiles;
-  const int base = ps.off[m], n = ps.off[m + 1] - base;
-  const int64_t t0 = t_call + (int64_t)tile * tile_samples;
-  int64_t t_end = t0 + tile_samples;
-  if (t_end > t_call_end) t_end = t_call_end;
-  const int k = upper_bound_time(ps.time + base, n, t0);
-  desc[idx] = describe_segment(ps, base, n, k, t0, t_end);
+// K0: one thread per (object, tile); a 256-thread block covers 16 objects x 16
+// tiles.  Lanes that are neighbours in `tile` share their object's time array
+// (the searches hit the same lines); the block transposes through LDS so that
+// the descriptors land TILE-MAJOR, desc[tile][M]: K1 walks the objects of one
+// tile and reads them as one contiguous stream.
+static __global__ void __launch_bounds__(256)
+k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end,
+           SegDesc *desc) {
+  __shared__ SegDesc sh[16][17];
+  const int ti = threadIdx.x & 15, oi = threadIdx.x >> 4;
+  const int tile = blockIdx.x * 16 + ti, m = blockIdx.y * 16 + oi;
+  if (tile < ntiles && m < M) {
+    const int base = ps.off[m], n = ps.off[m + 1] - base;
+    const int64_t t0 = t_call + (int64_t)tile * tile_samples;
+    int64_t t_end = t0 + tile_samples;
+    if (t_end > t_call_end) t_end = t_call_end;
+    const int k = upper_bound_time(ps.time + base, n, t0);
+    sh[ti][oi] = describe_segment(ps, base, n, k, t0, t_end);
+  }
+  __syncthreads();
+  const int to = threadIdx.x >> 4, oo = threadIdx.x & 15;
+  const int tile_o = blockIdx.x * 16 + to, m_o = blockIdx.y * 16 + oo;
+  if (tile_o < ntiles && m_o < M) desc[(size_t)tile_o * M + m_o] = sh[to][oo];
 }
 
 struct GainMixParams {
@@ -126,7 +137,7 @@ struct GainMixParams {
   float *out;           // [part][col][out_stride]
   size_t out_stride;
   size_t part_stride;   // floats between the slabs of two grid-level splits
-  const SegDesc *desc;  // [M][ntiles]
+  const SegDesc *desc;  // [ntiles][M], tile-major
   PointStore ps;
   int64_t t_call;       // absolute sample time of sample 0
   int nsamples;         // samples in this call
@@ -228,7 +239,7 @@ __global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
   const int last_s = P.nsamples - 1;
 
   for (int m = m_lo; m < m_hi; m++) {
-    SegDesc d = P.desc[(size_t)m * P.ntiles + tile];
+    SegDesc d = P.desc[(size_t)tile * P.M + m];
     const float *xrow = P.in + (size_t)m * P.in_stride;
     float x[SPL];
     if (P.vec_ok) {  // rows aligned, stride % 4 == 0: the vector at s0c is in bounds

@@ -129,11 +129,12 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     }
   };
   auto whole_object = [&](int m) {
-    const SegDesc d = P.desc[(size_t)m * P.ntiles + tile];
+    const SegDesc d = P.desc[(size_t)tile * P.M + m];
     single_object(m, seg_k(d.info), 0);
   };
 
   const int npairs = idle ? 0 : (m_hi - m_lo) >> 1;
+  const int m_last_obj = m_hi - 1;
   if (idle) {
   } else if (tile_len < TS) {
     for (int m = m_lo; m < m_hi; m++) whole_object(m);  // last, partial tile of a call
@@ -143,14 +144,28 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     // step costs no address arithmetic on the VALU; descriptors are fetched two
     // steps ahead, inputs and gain rows one step ahead of the MFMAs that use them.
     const unsigned xoff = (unsigned)slot * (unsigned)P.in_stride + (unsigned)(li * NRT);
-    const unsigned doff = (unsigned)slot * (unsigned)P.ntiles;
     const unsigned goff0 = (unsigned)(col0 + li * NCT);
     const float c0 = is_b ? 0.0f : 1.0f;       // constant segment: a = x, b = 0
     const float c1r = is_b ? 1.0f : -1.0f;     // ramp: coef = c0 + c1 * p  (= p or 1 - p)
     auto pair_index = [&](int i) { return m_lo + 2 * min(i, npairs - 1); };
+    // Descriptors of this tile are contiguous over objects: lane j of batch b
+    // holds the descriptor of object m_lo + 64*b + j (one coalesced 1 KB load per
+    // 32 steps, issued a whole batch ahead), and a step picks the two it needs with
+    // a cross-lane read.  No per-step descriptor load, and the gain-row address no
+    // longer waits on memory.
+    const int4 *dtile = reinterpret_cast<const int4 *>(P.desc + (size_t)tile * P.M);
+    auto load_batch = [&](int b) { return dtile[min(m_lo + 64 * b + lane, m_last_obj)]; };
+    int4 batch0 = load_batch(0), batch1 = load_batch(1);
     auto load_desc = [&](int i) {
-      const int4 *db = reinterpret_cast<const int4 *>(P.desc + (size_t)pair_index(i) * P.ntiles + tile);
-      return db[doff];
+      const int p = min(i, npairs - 1);
+      const bool odd = (p >> 5) & 1;
+      const int src = 2 * (p & 31) + slot;
+      int4 d;
+      d.x = __shfl(odd ? batch1.x : batch0.x, src, 64);
+      d.y = __shfl(odd ? batch1.y : batch0.y, src, 64);
+      d.z = __shfl(odd ? batch1.z : batch0.z, src, 64);
+      d.w = __shfl(odd ? batch1.w : batch0.w, src, 64);
+      return d;
     };
     auto load_x = [&](int i, float (&x)[NRT]) {
       const f32x4 *xp = reinterpret_cast<const f32x4 *>(P.in + (size_t)pair_index(i) * P.in_stride +
@@ -249,6 +264,11 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     // step i consumes (a, g) of pair i, builds the A fragments of pair i+1 from its
     // ring slot and refills that slot with pair i+5, refills g with pair i+2
     for (int i = 0; i < npairs; i += 4) {
+      if ((i & 31) == 0 && i > 0) {  // entered batch i/32: the register of batch i/32 - 1 is free
+        const int b = (i >> 5) + 1;
+        if (b & 1) batch1 = load_batch(b);
+        else batch0 = load_batch(b);
+      }
       step(i, aA, aB, gA, x1);
       if (i + 1 >= npairs) break;
       step(i + 1, aB, aA, gB, x2);
