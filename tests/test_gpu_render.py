@@ -110,6 +110,44 @@ def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
         assert scenes.rel_rms(want, truth) <= 1e-6
 
 
+def test_mixed_hoa_bed_and_objects_scene_block_1024():
+    """BASELINE config 5 shape at reduced object count: a 16-channel HOA bed through a constant
+    16 x 24 decode matrix (LinearInterpMatrix, never interpolated: docs/dsp.rst:73-89) plus ramped
+    objects, block 1024 (FFT 2048).  The bed channels are rendered as inputs with a single gain
+    point on the direct bus and zero diffuse gains, so they share the 255-sample compensation delay
+    with the objects' direct path."""
+    layout, block, nblocks, n_hoa, n_obj = "9+10+3", 1024, 3, 16, 48
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    rng = np.random.default_rng(55)
+    decode = rng.uniform(-0.5, 0.5, (n_hoa, n)).astype(np.float32)
+    curves = [(np.zeros(1, np.int64), decode[c:c + 1], np.zeros((1, n), np.float32)) for c in range(n_hoa)]
+    curves += scenes.dense_curves(n_obj, n, block, nblocks)
+    x = scenes.audio(n_hoa + n_obj, block * nblocks)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(got, want) <= 1e-6
+    step = run_hip(curves, x, n, block, dec, 255, [1, 2])
+    assert scenes.rel_rms(step, want) <= 1e-6
+    # the bed alone: out = delayed(decode^T . hoa), bit-exact in strict mode against the oracle
+    bed = run_hip(curves[:n_hoa], x[:n_hoa], n, block, None, 0, [nblocks], strict=True)
+    assert np.array_equal(bed, run_oracle(curves[:n_hoa], x[:n_hoa], n, block, None, 0))
+
+
+def test_odd_sizes_and_unaligned_tails():
+    """object counts that are odd / not multiples of the wave split, 5 loudspeakers, 7 blocks of 64:
+    exercises the single-object path, partial column tiles and short calls"""
+    for m, n, block, nblocks in ((1, 5, 64, 7), (3, 5, 64, 7), (17, 9, 128, 5), (130, 24, 64, 3)):
+        dec = np.random.default_rng(m).uniform(-0.1, 0.1, (n, min(block, 64))).astype(np.float32)
+        curves = scenes.ragged_curves(m, n, block * nblocks, seed=m)
+        x = scenes.audio(m, block * nblocks, seed=m)
+        want = run_oracle(curves, x, n, block, dec, 31)
+        got = run_hip(curves, x, n, block, dec, 31, [nblocks])
+        assert scenes.rel_rms(got, want) <= 1e-6, (m, n, block)
+        got1 = run_hip(curves, x, n, block, dec, 31, [2, 1, nblocks - 3])
+        assert scenes.rel_rms(got1, want) <= 1e-6, (m, n, block)
+
+
 def test_strict_full_chain_matches_oracle_closely():
     """strict gain stage + device FFT: only the FFT rounding differs from the CPU path"""
     m, layout, block, nblocks = 32, "9+10+3", 512, 3
