@@ -188,6 +188,31 @@ def main():
                            "fp32_peak_tflops": FP32_PEAK_TFLOPS},
         }
 
+        # ---- block mode (the latency figure): ONE 512-sample block per call through the host-pointer
+        # entry point, i.e. including H2D of the inputs, K0/K1/K2 and D2H of the outputs.  Reported
+        # beside the stream-mode value, never as `value`.
+        if world == 1:
+            rb = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=1)
+            for m, (t, d, f) in enumerate(curves):
+                rb.set_object_points(m, t[:34], d[:34], f[:34])
+            rb.commit()
+            import ctypes
+            xb = np.ascontiguousarray(x[:, :B].cpu().numpy())
+            ob = np.zeros((N, B), np.float32)
+            ip, op = capi._chan_ptrs(xb), capi._chan_ptrs(ob)  # built once: not part of a call
+            lib = capi.load()
+            for _ in range(3):
+                capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
+            nb_calls = 50
+            b0 = time.perf_counter()
+            for _ in range(nb_calls):
+                capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
+            bdt = (time.perf_counter() - b0) / nb_calls
+            rb.close()
+            result["block_mode"] = {"ms_per_block": round(bdt * 1e3, 4), "rtf": round((B / SAMPLE_RATE) / bdt, 1),
+                                    "Msamples_per_s": round(M * B / bdt / 1e6, 1),
+                                    "note": "one block per call from host channel pointers: staging copy, H2D, K0/K1/K2, D2H, sync"}
+
         # ---- parity gate in the same run: first two blocks against the CPU oracle -------------
         import _oracle  # the checker; used only below (parity gate and cpu_baseline)
         nb = 2

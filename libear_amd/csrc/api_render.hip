@@ -2,6 +2,7 @@
 // K0 segment prep -> K1 gain_mix (direct + diffuse buses) -> K2
 // decorrelate_delay_mix, `nblocks` blocks per call, state resident in HBM.
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "common.h"
@@ -217,6 +218,10 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->D = cfg->delay;
     r->T = cfg->max_blocks;
     r->L = 2 * r->B;
+    if (const char *e = getenv("EARHIP_RUN")) {  // tuning knob: blocks per decorrelator run (odd)
+      const int v = atoi(e);
+      if (v >= 1 && v <= 255) r->run_len = v | 1;
+    }
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
     const size_t max_samples = (size_t)r->T * r->B;
     const size_t max_tiles = (max_samples + 63) / 64;  // smallest tile: 4 row tiles of 16 samples

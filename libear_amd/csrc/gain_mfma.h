@@ -186,15 +186,17 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     };
     // A fragments of a pair from its inputs x and descriptor d
     auto make_a = [&](const int4 d, const float (&x)[NRT], float (&a)[NRT]) {
+      // coef(s) = c0 + c1 * p(s), p(s) = (float)(d0 + s) * scale (gain_interpolator.hpp:272).
+      // The lane's NRT samples are consecutive, so coef advances by c1*scale per
+      // sample: one conversion + NRT fused steps instead of NRT conversions (the
+      // difference to converting every index is one rounding of p, ~6e-8 relative).
       const bool ramp = d.w & kSegRamp;
       const float c1 = ramp ? c1r : 0.0f;
       const float scale = __int_as_float(d.z);
-      const int idx0 = d.y + li * NRT;
+      const float cs = c1 * scale;
+      const float coef0 = __builtin_fmaf(c1, (float)(d.y + li * NRT) * scale, c0);
 #pragma unroll
-      for (int r = 0; r < NRT; r++) {
-        const float p = (float)(idx0 + r) * scale;  // gain_interpolator.hpp:272
-        a[r] = x[r] * __builtin_fmaf(c1, p, c0);
-      }
+      for (int r = 0; r < NRT; r++) a[r] = x[r] * __builtin_fmaf((float)r, cs, coef0);
     };
     // rare: curve points inside the tile.  The pair's A fragments keep only the
     // first piece [0, r1); the later pieces go through the generic path.
