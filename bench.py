@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--layout", default="9+10+3")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
+    ap.add_argument("--stream-only", action="store_true",
+                    help="only the timed stream-mode steps (no block-mode, parity or CPU legs): for PMC profiling passes")
     args = ap.parse_args()
 
     import numpy as np
@@ -191,7 +193,7 @@ def main():
         # ---- block mode (the latency figure): ONE 512-sample block per call through the host-pointer
         # entry point, i.e. including H2D of the inputs, K0/K1/K2 and D2H of the outputs.  Reported
         # beside the stream-mode value, never as `value`.
-        if world == 1:
+        if world == 1 and not args.stream_only:
             rb = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=1)
             for m, (t, d, f) in enumerate(curves):
                 rb.set_object_points(m, t[:34], d[:34], f[:34])
@@ -214,25 +216,26 @@ def main():
                                     "note": "one block per call from host channel pointers: staging copy, H2D, K0/K1/K2, D2H, sync"}
 
         # ---- parity gate in the same run: first two blocks against the CPU oracle -------------
-        import _oracle  # the checker; used only below (parity gate and cpu_baseline)
-        nb = 2
-        xs = x[:, :nb * B].cpu().numpy()
-        rr = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=nb)
-        for m, (t, d, f) in enumerate(curves):
-            rr.set_object_points(m, t[:nb + 1], d[:nb + 1], f[:nb + 1])
-        got = rr.process(xs)
-        rr.close()
-        o = _oracle.ObjectsRenderer(M, N, B, dec, 255)
-        for m, (t, d, f) in enumerate(curves):
-            o.set_points(m, 0, t[:nb + 1], d[:nb + 1])
-            o.set_points(m, 1, t[:nb + 1], f[:nb + 1])
-        want = o.process(xs)
-        result["parity"] = {"rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
-                            "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
-                            "tolerance": 1e-6}
+        if not args.stream_only:
+            import _oracle  # the checker; used only below (parity gate and cpu_baseline)
+            nb = 2
+            xs = x[:, :nb * B].cpu().numpy()
+            rr = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=nb)
+            for m, (t, d, f) in enumerate(curves):
+                rr.set_object_points(m, t[:nb + 1], d[:nb + 1], f[:nb + 1])
+            got = rr.process(xs)
+            rr.close()
+            o = _oracle.ObjectsRenderer(M, N, B, dec, 255)
+            for m, (t, d, f) in enumerate(curves):
+                o.set_points(m, 0, t[:nb + 1], d[:nb + 1])
+                o.set_points(m, 1, t[:nb + 1], f[:nb + 1])
+            want = o.process(xs)
+            result["parity"] = {"rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
+                                "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
+                                "tolerance": 1e-6}
 
         # ---- CPU baseline: the scalar restatement on this host, bounded sample -----------------
-        if world == 1 and args.cpu_blocks > 0:
+        if world == 1 and args.cpu_blocks > 0 and not args.stream_only:
             cb = min(args.cpu_blocks, T)
             xc = x[:, :cb * B].cpu().numpy()
             res = {}

@@ -29,6 +29,17 @@ def main():
             print(f"{'kernel':72s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
             for name, calls, total, avg, pct in rows[:12]:
                 print(f"{short(name):72s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:6.2f}")
+        try:  # per launch shape: bench.py launches the same kernels in stream mode, block mode and the parity gate
+            rows = list(cur.execute(
+                "select name, grid_x, grid_y, grid_z, workgroup_x, count(*), sum(duration), avg(duration), min(duration), "
+                "max(duration) from kernels where name like '%earhip%' group by name, grid_x, grid_y, grid_z, workgroup_x "
+                "order by sum(duration) desc"))
+        except sqlite3.OperationalError:
+            rows = []
+        if rows:
+            print(f"{'kernel (per launch shape)':44s} {'grid':>22s} {'wg':>5s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
+            for name, gx, gy, gz, wx, n, tot, avg, mn, mx in rows[:16]:
+                print(f"{short(name, 44):44s} {str((gx, gy, gz)):>22s} {wx:5d} {n:6d} {avg / 1e3:10.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f}")
         try:
             rows = list(cur.execute(
                 "select kernel_name, counter_name, count(*), avg(value), avg(duration), "
