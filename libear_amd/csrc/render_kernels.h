@@ -44,7 +44,14 @@ template <int L>
 __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   constexpr int B = L / 2;
   constexpr int NT = 256;
-  __shared__ __attribute__((aligned(16))) cf lds[2 * L];
+  constexpr int EPT = B / NT > 0 ? B / NT : 1;  // input / output samples per thread and block
+  constexpr int BPT = L / 4 / NT > 0 ? L / 4 / NT : 1;  // radix-4 butterflies per thread and pass
+  // The kernel is latency-bound (83% of its wave cycles in s_waitcnt/barriers), so
+  // nothing on the per-pass critical path may come from global memory: twiddles
+  // live in LDS (up to L = 2048), the channel's spectrum H in registers, and the
+  // next pair's bus samples are requested before the current pair's passes start.
+  constexpr bool kTwInLds = L <= 2048;
+  __shared__ __attribute__((aligned(16))) cf lds[2 * L + (kTwInLds ? L : 0)];
   __shared__ float tail[B];
   cf *a = lds, *b = lds + L;
   const int tid = threadIdx.x;
@@ -56,6 +63,12 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   const float *direct = P.bus + (size_t)n * P.bus_stride;
   const float *diffuse = P.bus + (size_t)(P.N + n) * P.bus_stride;
   float *out = P.out + (size_t)n * P.out_stride;
+  const cf *tw = P.tw;
+  if (kTwInLds) {
+    cf *twl = lds + 2 * L;
+    for (int i = tid; i < L; i += NT) twl[i] = P.tw[i];
+    tw = twl;  // visible after the first barrier below
+  }
 
   auto bus_at = [&](const float *row, int s) {
     float v = row[s];
@@ -67,46 +80,85 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
     const int sd = s - P.D;
     return sd >= 0 ? bus_at(direct, sd) : P.dly_in[(size_t)n * P.D + (sd + P.D)];
   };
+  // this thread's input samples of the pair (tb, tb+1): real part block tb, imaginary tb+1
+  auto load_pair = [&](int tb, cf (&z)[EPT]) {
+    const bool have_re = tb >= 0 && tb < last, have_im = tb + 1 < last;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int i = tid + e * NT;
+      z[e] = cf_make(0.0f, 0.0f);
+      if (i < B) {
+        if (have_re) z[e].x = bus_at(diffuse, tb * B + i);
+        if (have_im) z[e].y = bus_at(diffuse, (tb + 1) * B + i);
+      }
+    }
+  };
+
+  // H of the butterflies this thread multiplies in the first inverse pass
+  cf h[BPT][4];
+#pragma unroll
+  for (int q = 0; q < BPT; q++) {
+    const int j = tid + q * NT;
+#pragma unroll
+    for (int r = 0; r < 4; r++) h[q][r] = j < L / 4 ? H[j + r * (L / 4)] : cf_make(0.0f, 0.0f);
+  }
 
   if (first == 0)
     for (int i = tid; i < B; i += NT) tail[i] = P.tail_in[(size_t)n * B + i];
 
+  cf z[EPT];
+  load_pair(first - 1, z);
   for (int tb = first - 1; tb < last; tb += 2) {
     const bool have_re = tb >= 0, have_im = tb + 1 < last;
     __syncthreads();  // previous pair's reads of a/b are finished
-    for (int i = tid; i < L; i += NT) {
-      cf v = cf_make(0.0f, 0.0f);
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int i = tid + e * NT;
       if (i < B) {
-        if (have_re) v.x = bus_at(diffuse, tb * B + i);
-        if (have_im) v.y = bus_at(diffuse, (tb + 1) * B + i);
+        a[i] = z[e];
+        a[i + B] = cf_make(0.0f, 0.0f);  // zero padding of both blocks
       }
-      a[i] = v;
     }
-    cf *Z = fft_run_passes<L, -1, NT>(a, b, P.tw, 0, tid);
+    // request the next pair and this pair's delayed direct-bus samples now; they
+    // are consumed after the ten passes below
+    load_pair(tb + 2, z);
+    float dre[EPT], dim[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int i = tid + e * NT;
+      dre[e] = (i < B && have_re && tb >= first) ? delayed(tb * B + i) : 0.0f;
+      dim[e] = (i < B && have_im) ? delayed((tb + 1) * B + i) : 0.0f;
+    }
+    cf *Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
     cf *W = Z == a ? b : a;
     __syncthreads();
     // first inverse pass with the spectral multiply folded into its loads
-    if (fft_r4_passes(L) > 0) {
-      for (int j = tid; j < L / 4; j += NT)
-        r4_core<L, +1>(cf_mul(Z[j], H[j]), cf_mul(Z[j + L / 4], H[j + L / 4]),
-                       cf_mul(Z[j + L / 2], H[j + L / 2]),
-                       cf_mul(Z[j + 3 * L / 4], H[j + 3 * L / 4]), W, P.tw, 1, j);
+#pragma unroll
+    for (int q = 0; q < BPT; q++) {
+      const int j = tid + q * NT;
+      if (j < L / 4)
+        r4_core<L, +1>(cf_mul(Z[j], h[q][0]), cf_mul(Z[j + L / 4], h[q][1]),
+                       cf_mul(Z[j + L / 2], h[q][2]), cf_mul(Z[j + 3 * L / 4], h[q][3]), W, tw,
+                       1, j);
     }
-    cf *y = fft_run_passes<L, +1, NT>(W, Z, P.tw, 1, tid);
+    cf *y = fft_run_passes<L, +1, NT>(W, Z, tw, 1, tid);
     __syncthreads();
     // real part = block tb, imaginary part = block tb+1
-    for (int i = tid; i < B; i += NT) {
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      const int i = tid + e * NT;
+      if (i >= B) continue;
       float tl = tail[i];
       if (have_re) {
         if (tb >= first) {
           const float dec = (y[i].x + tl) * norm;  // :223-226
-          out[tb * B + i] = dec + delayed(tb * B + i);
+          out[tb * B + i] = dec + dre[e];
         }
         tl = y[B + i].x;  // :224
       }
       if (have_im) {
         const float dec = (y[i].y + tl) * norm;
-        out[(tb + 1) * B + i] = dec + delayed((tb + 1) * B + i);
+        out[(tb + 1) * B + i] = dec + dim[e];
         tl = y[B + i].y;
       }
       tail[i] = tl;
