@@ -70,7 +70,7 @@ struct earhip_render {
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
-  int run_len = 15;
+  int run_len = 11;
 
   DevBuf<SegDesc> desc;
   DevBuf<float> bus;  // [gsplit][K*N][bus_stride], strides chosen per call
