@@ -156,17 +156,17 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     const int4 *dtile = reinterpret_cast<const int4 *>(P.desc + (size_t)tile * P.M);
     auto load_batch = [&](int b) { return dtile[min(m_lo + 64 * b + lane, m_last_obj)]; };
     int4 batch0 = load_batch(0), batch1 = load_batch(1);
-    auto load_desc = [&](int i) {
-      const int p = min(i, npairs - 1);
-      const bool odd = (p >> 5) & 1;
-      const int src = 2 * (p & 31) + slot;
+    // descriptor of pair i out of the batch register that holds it
+    auto desc_from = [&](const int4 &reg, int i) {
+      const int src = 2 * (min(i, npairs - 1) & 31) + slot;
       int4 d;
-      d.x = __shfl(odd ? batch1.x : batch0.x, src, 64);
-      d.y = __shfl(odd ? batch1.y : batch0.y, src, 64);
-      d.z = __shfl(odd ? batch1.z : batch0.z, src, 64);
-      d.w = __shfl(odd ? batch1.w : batch0.w, src, 64);
+      d.x = __shfl(reg.x, src, 64);
+      d.y = __shfl(reg.y, src, 64);
+      d.z = __shfl(reg.z, src, 64);
+      d.w = __shfl(reg.w, src, 64);
       return d;
     };
+    auto load_desc = [&](int i) { return desc_from(batch0, i); };  // prologue: pairs 0..3
     auto load_x = [&](int i, float (&x)[NRT]) {
       const f32x4 *xp = reinterpret_cast<const f32x4 *>(P.in + (size_t)pair_index(i) * P.in_stride +
                                                         tile_s0 + xoff);
@@ -190,60 +190,41 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       // The lane's NRT samples are consecutive, so coef advances by c1*scale per
       // sample: one conversion + NRT fused steps instead of NRT conversions (the
       // difference to converting every index is one rounding of p, ~6e-8 relative).
+      // An object whose curve has a point inside this tile ("multi") contributes
+      // nothing here; it is rendered by the generic path after the loop.
       const bool ramp = d.w & kSegRamp;
-      const float c1 = ramp ? c1r : 0.0f;
+      const bool multi = d.w & kSegMulti;
+      const float c1 = (ramp && !multi) ? c1r : 0.0f;
+      const float c0m = multi ? 0.0f : c0;
       const float scale = __int_as_float(d.z);
       const float cs = c1 * scale;
-      const float coef0 = __builtin_fmaf(c1, (float)(d.y + li * NRT) * scale, c0);
+      const float coef0 = __builtin_fmaf(c1, (float)(d.y + li * NRT) * scale, c0m);
 #pragma unroll
       for (int r = 0; r < NRT; r++) a[r] = x[r] * __builtin_fmaf((float)r, cs, coef0);
     };
-    // rare: curve points inside the tile.  The pair's A fragments keep only the
-    // first piece [0, r1); the later pieces go through the generic path.
-    auto fix_multi = [&](int i, const int4 d, float (&a)[NRT]) {
-      const unsigned long long multi = __ballot(d.w & kSegMulti);
-      if (multi) {
-        const int r1 = seg_r1(d.w);
-#pragma unroll
-        for (int r = 0; r < NRT; r++) a[r] = (li * NRT + r < r1) ? a[r] : 0.0f;
-        const int m0 = m_lo + 2 * i;
-        if (multi & 1ull) {
-          const int info = __builtin_amdgcn_readlane(d.w, 0);
-          single_object(m0, seg_k(info) + 1, seg_r1(info));
-        }
-        if (multi >> 32) {
-          const int info = __builtin_amdgcn_readlane(d.w, 32);
-          single_object(m0 + 1, seg_k(info) + 1, seg_r1(info));
-        }
-      }
-    };
 
-    // Steady state of step i (one basic block): the 24 MFMAs of pair i, and,
-    // woven between them by the scheduling directives below, everything pair
-    // i+1 .. i+3 needs next: A fragments of pair i+1 (its inputs arrived a step
-    // ago), the refill of those input registers for pair i+3, the gain rows of
-    // pair i+2 and the descriptor of pair i+3.  A single wave can keep the
-    // matrix pipe busy this way; the second wave per SIMD hides HBM latency.
-    // Prefetch depths (in steps of 12/24 MFMAs): inputs 4, descriptors 3 (2 before
-    // the gain-row address they feed is needed), gain rows 1.  Memory-only and
-    // compute-only ablations of this loop run in 0.71 and 0.83 ms; at depth 2 the
-    // combined loop took 1.10 ms because HBM latency under load (~2 us) exceeded
-    // the lead time.
+    // One step = the MFMAs of pair i and, woven between them by the scheduling
+    // directives, everything later pairs need: the A fragments of pair i+1 (its
+    // inputs were requested 4 steps ago), the refill of that input slot with pair
+    // i+5, the gain rows of pair i+2 and the descriptor of pair i+4 (cross-lane
+    // reads, no memory).  The loop around it must stay free of other branches: with
+    // a rare-path branch or the batch reload inside, the compiler's wait-count
+    // insertion fell back to `s_waitcnt vmcnt(0)` at the top of every step, which
+    // silently cancelled the whole prefetch pipeline.
     int4 d1 = load_desc(1), d2 = load_desc(2), d3 = load_desc(3);
     auto step = [&](int i, const float (&a_cur)[NRT], float (&a_nxt)[NRT], float (&g_cur)[NCT],
-                    float (&x_nxt)[NRT]) {
+                    float (&x_nxt)[NRT], const int4 &dreg) {
       mma(a_cur, g_cur);
       make_a(d1, x_nxt, a_nxt);
       load_x(i + 5, x_nxt);
       load_g(d2, g_cur);
-      const int4 d4 = load_desc(i + 4);
+      const int4 d4 = desc_from(dreg, i + 4);
 #pragma unroll
       for (int k = 0; k < NRT * NCT; k++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
         if (k < NRT / 4 + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
       }
-      if (i + 1 < npairs) fix_multi(i + 1, d1, a_nxt);  // the pair after the last one is a phantom
       d1 = d2;
       d2 = d3;
       d3 = d4;
@@ -261,23 +242,54 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       load_g(d1, gB);
       make_a(d0, x0, aA);
       load_x(4, x0);
-      fix_multi(0, d0, aA);
     }
     // step i consumes (a, g) of pair i, builds the A fragments of pair i+1 from its
     // ring slot and refills that slot with pair i+5, refills g with pair i+2
-    for (int i = 0; i < npairs; i += 4) {
-      if ((i & 31) == 0 && i > 0) {  // entered batch i/32: the register of batch i/32 - 1 is free
-        const int b = (i >> 5) + 1;
-        if (b & 1) batch1 = load_batch(b);
-        else batch0 = load_batch(b);
+    // A batch register must not be touched while its reload is in flight (even a
+    // select that reads it would force a wait), so the groups of a batch name their
+    // register statically: the first 7 groups of 4 steps read descriptors (pairs
+    // i+4..i+7) from the current batch's register, the 8th from the next batch's,
+    // whose reload was requested 28 steps earlier.
+    auto group = [&](int i, const int4 &dreg) {  // branch-free
+      step(i, aA, aB, gA, x1, dreg);
+      step(i + 1, aB, aA, gB, x2, dreg);
+      step(i + 2, aA, aB, gA, x3, dreg);
+      step(i + 3, aB, aA, gB, x0, dreg);
+    };
+    // batch0 = descriptors of the current batch, batch1 = of the next one
+    for (int ib = 0; ib + 4 <= npairs; ib += 32) {
+      if (ib > 0) {  // batch1 was requested 32 steps ago
+        batch0 = batch1;
+        batch1 = load_batch((ib >> 5) + 1);
       }
-      step(i, aA, aB, gA, x1);
-      if (i + 1 >= npairs) break;
-      step(i + 1, aB, aA, gB, x2);
-      if (i + 2 >= npairs) break;
-      step(i + 2, aA, aB, gA, x3);
-      if (i + 3 >= npairs) break;
-      step(i + 3, aB, aA, gB, x0);
+      const int iend = min(ib + 32, npairs & ~3);
+      const int isplit = min(iend, ib + 28);
+      int i = ib;
+#pragma unroll 1
+      for (; i < isplit; i += 4) group(i, batch0);
+      if (i < iend) group(i, batch1);
+    }
+    {
+      const int i = npairs & ~3;
+      if (i < npairs) {  // 1..3 remaining pairs (descriptor register chosen at run time)
+        // batch0 holds the batch of pair i; later pairs of a clamped index stay in it
+        const int4 reg = batch0;
+        step(i, aA, aB, gA, x1, reg);
+        if (i + 1 < npairs) {
+          step(i + 1, aB, aA, gB, x2, reg);
+          if (i + 2 < npairs) step(i + 2, aA, aB, gA, x3, reg);
+        }
+      }
+    }
+    // objects with curve points inside this tile: all their pieces, generic path
+    for (int b0 = 0; b0 < 2 * npairs; b0 += 64) {
+      const int4 db = dtile[min(m_lo + b0 + lane, m_last_obj)];
+      unsigned long long multi = __ballot((db.w & kSegMulti) && b0 + lane < 2 * npairs);
+      while (multi) {
+        const int j = __builtin_ctzll(multi);
+        multi &= multi - 1;
+        whole_object(m_lo + b0 + j);
+      }
     }
     if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
   } else {
