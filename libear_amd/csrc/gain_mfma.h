@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
                                                         tile_s0 + xoff);
 #pragma unroll
       for (int q = 0; q < NRT / 4; q++) {
-        const f32x4 v = xp[q];
+        const f32x4 v = __builtin_nontemporal_load(xp + q);  // streamed once: keep L2 for gain rows
 #pragma unroll
         for (int e = 0; e < 4; e++) x[q * 4 + e] = v[e];
       }
