@@ -14,9 +14,9 @@ block is a full-length ramp between dense uniform(0,1) gain vectors (worst case,
 
 Rank 0 prints ONE JSON line.  `value` = object-samples consumed per second over all GPUs
 (Msamples/s = M*B*T / t_step / 1e6); `rtf` = real-time factor (B*T/48000) / t_step.
-Multi-GPU: objects are sharded (1024 per rank, weak scaling), each rank renders its shard and the
-partial loudspeaker buses are summed by one RCCL reduce-scatter over the channel axis, overlapped
-with the next step's render.
+Multi-GPU: objects are sharded (1024 per rank, weak scaling; `--scaling strong` splits 1024 objects
+over the ranks instead), each rank renders its shard and the partial loudspeaker buses are summed by
+one RCCL reduce-scatter over the channel axis, overlapped with the next step's render.
 """
 import argparse
 import json
@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--layout", default="9+10+3")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --objects per GPU (default); strong: --objects in total, split over the GPUs")
     ap.add_argument("--stream-only", action="store_true",
                     help="only the timed stream-mode steps (no block-mode, parity or CPU legs): for PMC profiling passes")
     args = ap.parse_args()
@@ -77,8 +79,14 @@ def main():
     from libear_amd import capi
     from libear_amd.distributed import exchange
 
+    from libear_amd.distributed import shard_range
     names = LAYOUTS[args.layout]
-    M, N, B, T, K = args.objects, len(names), args.block_size, args.blocks, 2
+    N, B, T, K = len(names), args.block_size, args.blocks, 2
+    if args.scaling == "strong":  # the scene has --objects in total; this rank renders its shard
+        lo, hi = shard_range(args.objects, rank, world)
+        M, M_total = hi - lo, args.objects
+    else:
+        M, M_total = args.objects, args.objects * world
     total = B * T
 
     # decorrelator FIRs: designed natively (libearhip group G, setup path)
@@ -145,7 +153,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     t_step = dt / args.steps
-    value = world * M * total / t_step / 1e6
+    value = M_total * total / t_step / 1e6
     rtf = (total / SAMPLE_RATE) / t_step
 
     result = None
@@ -168,13 +176,13 @@ def main():
         result = {
             "metric": "Msamples/s", "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rtf": round(rtf, 1),
             "config": {
                 "workload": f"{M} objects/GPU -> {args.layout} ({N} ch), block {B}, 48 kHz: ramped direct+diffuse "
                             f"gains, {N} decorrelators (512 taps), delay 255, mix; stream of {T} blocks per step",
-                "objects_per_gpu": M, "objects_total": M * world, "channels": N, "block": B,
+                "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
                 "blocks_per_step": T, "buses": K, "gains": "dense uniform(0,1), full-length ramp every block",
                 "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels",
                 "strict": bool(args.strict)},
@@ -183,6 +191,11 @@ def main():
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": gain_b * T,
                          "avg_launch_ms": round(k1_ms, 4)},
+            "roofline_mfma": {"bound": "mfma", "kernel": "k_gain_mix", "achieved": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2),
+                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                              "note": "executed f32 MFMA flops (2 MACs per object, column and sample for a ramp); the "
+                                      "f32-in MFMA runs at the vector rate, so this, not HBM, is the kernel's higher floor"},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
             "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
