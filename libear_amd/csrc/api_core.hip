@@ -8,6 +8,7 @@
 #include "curves.h"
 #include "gain_kernels.h"
 #include "gain_mfma.h"
+#include "gain_bf3.h"
 
 namespace earhip {
 
@@ -15,7 +16,7 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml) {
-  if (ml.wsplit <= 1) return 0;
+  if (ml.wsplit <= 1 || ml.bf3) return 0;
   if (ml.mfma) return (size_t)cp.mgroups * ml.tpw * cp.nct * 16 * ml.tile() * sizeof(float);
   return (size_t)cp.ngroups * cp.nout * ml.tile() * sizeof(float);
 }
@@ -70,14 +71,21 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const dim3 block(64 * P.ngroups * P.tiles_per_wg * ml.wsplit);
   const size_t lds = mix_lds_bytes(cp, ml);
   if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
+  bool launched = false;
+  if (ml.bf3) {
+    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+    if (cp.nct == 1) hipLaunchKernelGGL(k_gain_mix_bf3<1>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
+    if (cp.nct == 2) hipLaunchKernelGGL(k_gain_mix_bf3<2>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
+    if (cp.nct == 3) hipLaunchKernelGGL(k_gain_mix_bf3<3>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
+    launched = true;
+  }
 #define EARHIP_MIX_CASE(NOUT_, SPL_, STRICT_)                                   \
   if (cp.nout == NOUT_ && ml.spl == SPL_ && strict == STRICT_) {                 \
     launch_mix_t<NOUT_, SPL_, STRICT_>(P, grid, block, lds, ctx->stream);        \
     launched = true;                                                             \
   }
-  bool launched = false;
 #define EARHIP_MFMA_CASE(NCT_, NRT_)                                            \
-  if (ml.mfma && cp.nct == NCT_ && ml.nrt == NRT_) {                             \
+  if (ml.mfma && !ml.bf3 && cp.nct == NCT_ && ml.nrt == NRT_) {                             \
     launch_mfma_t<NCT_, NRT_>(P, grid, block, lds, ctx->stream);                 \
     launched = true;                                                             \
   }
@@ -241,7 +249,7 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
       const int v = atoi(e);
       if (v == 2 || v == 4) c->spl = v;
     }
-    if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e) != 0;
+    if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e);
     if (const char *e = getenv("EARHIP_WAVES")) {
       const int v = atoi(e);
       if (v >= 1 && v <= 8) c->max_waves = v;

@@ -106,7 +106,8 @@ class CurveSet {
     std::vector<int32_t> off(M_ + 1);
     std::vector<int64_t> time(P);
     std::vector<uint8_t> flat(P);
-    std::vector<float> gain(P * plan_.row);
+    std::vector<float> gain((P + 1) * plan_.row);  // + one all-zero row (k_gain_mix_bf3)
+    npoints_ = (int)P;
     size_t at = 0;
     for (int m = 0; m < M_; m++) {
       off[m] = (int32_t)at;
@@ -138,6 +139,7 @@ class CurveSet {
     ps.row = plan_.row;
     ps.bus_cols = ncols_ / nbus_;
     ps.nbus = nbus_;
+    ps.zero_row = npoints_;
     ps.force_ramp = force_ramp_ ? 1 : 0;
     return ps;
   }
@@ -150,6 +152,7 @@ class CurveSet {
   std::vector<std::vector<float>> gains_;
   std::vector<std::vector<uint8_t>> flat_;
   bool dirty_ = true;
+  int npoints_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
@@ -159,20 +162,33 @@ class CurveSet {
 // How K1 is spread over the chip for one call.
 struct MixLaunch {
   bool mfma;                   // matrix-core kernel (default) or VALU kernel (strict mode)
+  bool bf3 = false;            // matrix-core kernel on bf16x3 operands (gain_bf3.h); tile = 256 samples
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
   int tpw = 1;                 // MFMA: adjacent tiles per workgroup
-  int tile() const { return mfma ? 16 * nrt : 64 * spl; }
+  int tile() const { return bf3 ? 256 : mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit) {
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
+  L.bf3 = L.mfma && ctx->use_mfma == 2 && M >= 32;
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
+  if (L.bf3) {
+    // one workgroup = 4 adjacent 64-sample tiles x all objects of its grid-level
+    // split; few tiles (block mode): split the objects across workgroups
+    L.wsplit = 1;
+    L.tpw = 1;
+    int g = 1;
+    const int nz = cp.mnz * cp.mgroups;
+    while (g < max_gsplit && L.ntiles * nz * g < 2 * ctx->num_cus && M / (g * 2) >= 64) g *= 2;
+    L.gsplit = g;
+    return L;
+  }
   if (strict) {
     L.wsplit = 1;
     L.gsplit = 1;

@@ -37,6 +37,7 @@ struct PointStore {
   int row;               // floats per row (multiple of 4)
   int bus_cols;          // columns per bus (columns [b*bus_cols, (b+1)*bus_cols) = bus b)
   int nbus;              // 1 or 2; each bus is one libear GainInterpolator
+  int zero_row;          // index of an all-zero gain row (after the last point)
   int force_ramp;        // policy mode: every object is ONE ramp through its 2 points,
                          // extrapolated outside (LinearInterp*::apply_interp as called directly)
 };
