@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--layout", default="9+10+3")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
+    ap.add_argument("--scene", choices=("dense", "adm"), default="dense",
+                    help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
+                         "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --objects per GPU (default); strong: --objects in total, split over the GPUs")
     ap.add_argument("--stream-only", action="store_true",
@@ -93,7 +96,10 @@ def main():
     dec = capi.design_decorrelators(names)
 
     # ---- scene: resident in HBM before the timed region --------------------------------------
-    curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
+    if args.scene == "adm":
+        curves = scenes.adm_curves(M, N, total, seed=11 + rank)
+    else:
+        curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     x = torch.rand((M, total), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
@@ -183,7 +189,9 @@ def main():
                 "workload": f"{M} objects/GPU -> {args.layout} ({N} ch), block {B}, 48 kHz: ramped direct+diffuse "
                             f"gains, {N} decorrelators (512 taps), delay 255, mix; stream of {T} blocks per step",
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
-                "blocks_per_step": T, "buses": K, "gains": "dense uniform(0,1), full-length ramp every block",
+                "blocks_per_step": T, "buses": K,
+                "gains": "dense uniform(0,1), full-length ramp every block" if args.scene == "dense" else
+                         "dense uniform(0,1); metadata every 960 samples at a per-object phase, 240-sample ramp then constant",
                 "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels",
                 "strict": bool(args.strict)},
             "roofline": {"bound": "hbm", "kernel": "k_gain_mix", "achieved": round(achieved, 1),

@@ -44,9 +44,25 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
     hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
                        ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
-    if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   }
+  // piece lists of the objects with curve points inside a tile (f32 MFMA kernel);
+  // they live behind the descriptors in the same buffer (desc_units())
+  PieceList pl;
+  pl.d = nullptr;
+  pl.m = nullptr;
+  pl.count = nullptr;
+  pl.cap = M;
+  if (ml.mfma && !ml.bf3) {
+    const size_t nd = (size_t)M * ml.ntiles;
+    pl.d = desc + nd;
+    pl.m = reinterpret_cast<int *>(desc + 2 * nd);
+    pl.count = pl.m + nd;
+    hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
+                       t_call, t_call + nsamples, desc, pl);
+  }
+  if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
+  P.pl = pl;
   P.in = in_dev;
   P.in_stride = in_stride;
   P.out = out_dev;
@@ -125,7 +141,7 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32);
-    desc.reserve((size_t)n_in * ml.ntiles);
+    desc.reserve(desc_units(n_in, ml.ntiles));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,
                       out_stride, 0, desc.p, nullptr);

@@ -225,7 +225,7 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
     const size_t max_samples = (size_t)r->T * r->B;
     const size_t max_tiles = (max_samples + 63) / 64;  // smallest tile: 4 row tiles of 16 samples
-    r->desc.alloc((size_t)r->M * max_tiles);
+    r->desc.alloc(desc_units(r->M, max_tiles));
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits
     // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps
     // gsplit * ntiles < 4 * num_cus, so gsplit * nsamples < 4 * num_cus * 256.

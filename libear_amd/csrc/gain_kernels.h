@@ -56,9 +56,27 @@ static_assert(sizeof(SegDesc) == 16, "SegDesc is loaded as one dwordx4");
 
 constexpr int kSegRamp = 1;
 constexpr int kSegMulti = 2;
+constexpr int kSegSlow = (int)0x80000000u;  // multi, and its pieces did not fit the tile's piece list
 constexpr int kMaxPointsPerObject = 1 << 18;
 __host__ __device__ __forceinline__ int seg_r1(int info) { return (info >> 4) & 0x1ff; }
-__host__ __device__ __forceinline__ int seg_k(int info) { return info >> 13; }
+__host__ __device__ __forceinline__ int seg_k(int info) { return (info >> 13) & 0x3ffff; }
+
+// Pieces of the objects whose curve has a point INSIDE a tile ("multi"), one
+// compact list per tile in object order (deterministic), written by k_piece_list.
+// A piece is a SegDesc whose info holds, instead of the segment index, the first
+// sample of the piece: bit0 ramp, bits 2-3 flat, bits 4-12 r1, bits 13-21 r0.
+struct PieceList {
+  SegDesc *d;   // [ntiles][cap]
+  int *m;       // [ntiles][cap] object of each piece
+  int *count;   // [ntiles]; nullptr: no piece lists (every multi object takes the slow path)
+  int cap;      // = M
+};
+__host__ __device__ __forceinline__ int piece_r0(int info) { return (info >> 13) & 0x1ff; }
+// SegDesc units a descriptor buffer needs for `ntiles` tiles of M objects: the
+// descriptors, the piece lists (cap = M) and their object / count arrays
+__host__ __device__ inline size_t desc_units(size_t M, size_t ntiles) {
+  return 2 * M * ntiles + (M * ntiles * 4 + ntiles * 4 + 15) / 16 + 1;
+}
 
 // blockIdx.x -> tile such that the workgroups of one XCD (b % 8) cover a
 // contiguous range of tiles; identity for the ragged tail
@@ -132,6 +150,76 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
   if (tile_o < ntiles && m_o < M) desc[(size_t)tile_o * M + m_o] = sh[to][oo];
 }
 
+// K0b: one workgroup per tile; splits every multi object of the tile into its
+// pieces (the walk of GainInterpolator::process, gain_interpolator.hpp:58-86) and
+// appends them to the tile's list at offsets from an ordered block scan.
+static __global__ void __launch_bounds__(256)
+k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end,
+             SegDesc *desc, PieceList pl) {
+  __shared__ int scan[256];
+  __shared__ int base_off, written;
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int64_t t0 = t_call + (int64_t)tile * tile_samples;
+  int64_t t_end = t0 + tile_samples;
+  if (t_end > t_call_end) t_end = t_call_end;
+  if (tid == 0) {
+    base_off = 0;
+    written = 0;
+  }
+  __syncthreads();
+  // pass = 0 counts, pass = 1 writes (same walk)
+  auto walk = [&](int m, const SegDesc &d, SegDesc *out, int *out_m) {
+    const int base = ps.off[m], n = ps.off[m + 1] - base;
+    int k = seg_k(d.info), cur = 0, c = 0;
+    for (;;) {
+      const SegDesc dk = describe_segment(ps, base, n, k, t0, t_end);
+      const int r1 = seg_r1(dk.info);
+      if (r1 > cur) {  // duplicate times make empty segments (steps)
+        if (out) {
+          SegDesc e = dk;
+          e.info = (dk.info & (kSegRamp | 0xc)) | (r1 << 4) | (cur << 13);
+          out[c] = e;
+          out_m[c] = m;
+        }
+        c++;
+        cur = r1;
+      }
+      if (!(dk.info & kSegMulti)) break;
+      k++;
+    }
+    return c;
+  };
+  for (int mb = 0; mb < M; mb += 256) {
+    const int m = mb + tid;
+    SegDesc d;
+    d.info = 0;
+    if (m < M) d = desc[(size_t)tile * M + m];
+    const bool multi = m < M && (d.info & kSegMulti);
+    const int c = multi ? walk(m, d, nullptr, nullptr) : 0;
+    scan[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int v = tid >= o ? scan[tid - o] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    const int off = base_off + scan[tid] - c;
+    if (multi) {
+      if (off + c <= pl.cap) {
+        walk(m, d, pl.d + (size_t)tile * pl.cap + off, pl.m + (size_t)tile * pl.cap + off);
+        atomicMax(&written, off + c);
+      } else {
+        desc[(size_t)tile * M + m].info = d.info | kSegSlow;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) base_off += scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) pl.count[tile] = written;
+}
+
 struct GainMixParams {
   const float *in;      // [M][in_stride] planar input, sample 0 = call start
   size_t in_stride;
@@ -149,6 +237,7 @@ struct GainMixParams {
   int wsplit;           // object splits inside a workgroup
   int tiles_per_wg;     // MFMA kernel: adjacent tiles handled by one workgroup
   int vec_ok;           // in/out rows are 16-byte aligned: vector accesses allowed
+  PieceList pl;         // MFMA kernel: pieces of the multi objects (count == nullptr: none)
 };
 
 // accumulate one segment piece of one object into acc

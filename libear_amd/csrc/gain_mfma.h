@@ -281,17 +281,94 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
         }
       }
     }
-    // objects with curve points inside this tile: all their pieces, generic path
+    // Objects with curve points inside this tile ("multi", zeroed above): their pieces
+    // were laid out by k_piece_list as one compact list per tile.  Two pieces per MFMA
+    // step (k = {a, b} of two pieces), shared evenly by all waves that work on this
+    // tile, whatever objects they own; each piece masks the samples outside [r0, r1).
+    const bool have_list = P.pl.count != nullptr;
+    if (have_list) {
+      const int n_e = P.pl.count[tile];
+      const int e_lo = (int)(((int64_t)n_e * part) / nparts);
+      const int e_hi = (int)(((int64_t)n_e * (part + 1)) / nparts);
+      const int4 *pd = reinterpret_cast<const int4 *>(P.pl.d + (size_t)tile * P.pl.cap);
+      const int *pm = P.pl.m + (size_t)tile * P.pl.cap;
+      struct Piece {
+        int4 d;
+        int m;
+      };
+      auto load_piece = [&](int e) {
+        const int idx = min(e + slot, max(e_hi - 1, 0));
+        Piece p;
+        p.d = pd[idx];
+        p.m = pm[idx];
+        if (e + slot >= e_hi) p.d.w = 0;  // r0 = r1 = 0: contributes nothing
+        return p;
+      };
+      auto load_px = [&](const Piece &p, float (&x)[NRT]) {
+        const f32x4 *xp = reinterpret_cast<const f32x4 *>(P.in + (size_t)p.m * P.in_stride + tile_s0 + li * NRT);
+#pragma unroll
+        for (int q = 0; q < NRT / 4; q++) {
+          const f32x4 v = xp[q];
+#pragma unroll
+          for (int e = 0; e < 4; e++) x[q * 4 + e] = v[e];
+        }
+      };
+      auto load_pg = [&](const Piece &p, float (&gv)[NCT]) {
+        const unsigned row = (unsigned)p.d.x + (((p.d.w & kSegRamp) && is_b) ? 1u : 0u);
+        const float *gp = P.ps.gain + (row * (unsigned)P.ps.row + goff0);
+#pragma unroll
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c];
+      };
+      auto piece_a = [&](const Piece &p, const float (&x)[NRT], float (&a)[NRT]) {
+        const bool ramp = p.d.w & kSegRamp;
+        const int r0 = piece_r0(p.d.w), r1 = seg_r1(p.d.w);
+        const float scale = __int_as_float(p.d.z);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) {
+          const int s = li * NRT + r;
+          const float pp = (float)(p.d.y + s) * scale;  // gain_interpolator.hpp:272
+          float coef = ramp ? (is_b ? pp : 1.0f - pp) : c0;
+          coef = (s >= r0 && s < r1) ? coef : 0.0f;
+          a[r] = x[r] * coef;
+        }
+      };
+      if (e_lo < e_hi) {
+        Piece p0 = load_piece(e_lo), p1 = load_piece(e_lo + 2);
+        float px0[NRT], pg0[NCT];
+        load_px(p0, px0);
+        load_pg(p0, pg0);
+        for (int e = e_lo; e < e_hi; e += 2) {
+          const Piece p2 = load_piece(e + 4);
+          float px1[NRT], pg1[NCT], a[NRT];
+          load_px(p1, px1);
+          load_pg(p1, pg1);
+          piece_a(p0, px0, a);
+          mma(a, pg0);
+          p0 = p1;
+          p1 = p2;
+#pragma unroll
+          for (int r = 0; r < NRT; r++) px0[r] = px1[r];
+#pragma unroll
+          for (int c = 0; c < NCT; c++) pg0[c] = pg1[c];
+        }
+      }
+    }
+    // multi objects without a piece list (none built, or the tile's list was full):
+    // all their pieces through the generic path
     for (int b0 = 0; b0 < 2 * npairs; b0 += 64) {
       const int4 db = dtile[min(m_lo + b0 + lane, m_last_obj)];
-      unsigned long long multi = __ballot((db.w & kSegMulti) && b0 + lane < 2 * npairs);
+      const bool slow = (db.w & kSegMulti) && (!have_list || (db.w & kSegSlow));
+      unsigned long long multi = __ballot(slow && b0 + lane < 2 * npairs);
       while (multi) {
         const int j = __builtin_ctzll(multi);
         multi &= multi - 1;
         whole_object(m_lo + b0 + j);
       }
     }
-    if ((m_hi - m_lo) & 1) whole_object(m_hi - 1);  // odd object count: last one alone
+    if ((m_hi - m_lo) & 1) {  // odd object count: the last one alone (unless its pieces are listed)
+      const int iw = P.desc[(size_t)tile * P.M + m_hi - 1].info;
+      if (!(iw & kSegMulti) || !have_list || (iw & kSegSlow)) whole_object(m_hi - 1);
+    }
   } else {
     for (int m = m_lo; m < m_hi; m++) whole_object(m);  // single object or unaligned rows
   }

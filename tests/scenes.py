@@ -86,6 +86,30 @@ def ragged_curves(n_obj, n_out, total, seed=10):
     return curves
 
 
+def adm_curves(n_obj, n_out, total, period=960, ramp=240, seed=11):
+    """ADM-like metadata that ignores the render block grid: every `period` samples (20 ms at
+    48 kHz), at a per-object phase, an object gets new gain vectors, reaches them over `ramp`
+    samples (interpolationLength) and then holds them until its next metadata block."""
+    rng = np.random.default_rng(seed)
+    curves = []
+    for m in range(n_obj):
+        phase = int(rng.integers(0, period))
+        starts = np.arange(phase - period, total + period, period, dtype=np.int64)
+        t = np.empty(2 * len(starts), np.int64)
+        t[0::2] = starts
+        t[1::2] = starts + ramp
+        vals_d = rng.uniform(0.0, 1.0, (len(starts) + 1, n_out)).astype(np.float32)
+        vals_f = rng.uniform(0.0, 1.0, (len(starts) + 1, n_out)).astype(np.float32)
+        d = np.empty((2 * len(starts), n_out), np.float32)
+        f = np.empty((2 * len(starts), n_out), np.float32)
+        d[0::2] = vals_d[:-1]  # block start: still the previous target
+        d[1::2] = vals_d[1:]   # end of the ramp: the new target, held until the next block
+        f[0::2] = vals_f[:-1]
+        f[1::2] = vals_f[1:]
+        curves.append((t, d, f))
+    return curves
+
+
 def rel_rms(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)

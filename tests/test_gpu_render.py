@@ -110,6 +110,42 @@ def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
         assert scenes.rel_rms(want, truth) <= 1e-6
 
 
+@pytest.mark.parametrize("m,nblocks,calls", [(64, 8, [8]), (65, 8, [3, 5]), (200, 4, [4]), (33, 2, [1, 1])])
+def test_unaligned_metadata_piece_lists(m, nblocks, calls):
+    """ADM-like curves whose points ignore the tile grid: a quarter of all (tile, object) pairs
+    has a curve point inside the tile and is rendered from the per-tile piece lists (K0b); odd
+    object counts put such an object last; several calls restart the lists mid-curve."""
+    layout, block = "9+10+3", 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=300, ramp=77, seed=m)
+    x = scenes.audio(m, total, seed=m)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, calls)
+    assert scenes.rel_rms(got, want) <= 1e-6
+    strict = run_hip(curves, x, n, block, None, 0, calls, strict=True)
+    assert np.array_equal(strict, run_oracle(curves, x, n, block, None, 0))
+
+
+def test_piece_list_overflow_takes_generic_path():
+    """More pieces in one tile than its list holds (cap = number of objects): the objects that
+    do not fit are flagged by K0b and rendered by the generic path; the result is the same."""
+    m, n, block, nblocks = 16, 24, 512, 2
+    total = block * nblocks
+    rng = np.random.default_rng(5)
+    curves = []
+    for i in range(m):
+        t = np.sort(rng.integers(0, total, 60)).astype(np.int64)  # ~7 points per 128-sample tile
+        curves.append((t, rng.uniform(0, 1, (60, n)).astype(np.float32),
+                       rng.uniform(0, 1, (60, n)).astype(np.float32)))
+    x = scenes.audio(m, total, seed=3)
+    dec = decorrelators("9+10+3")
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(got, want) <= 1e-6
+
+
 def test_mixed_hoa_bed_and_objects_scene_block_1024():
     """BASELINE config 5 shape at reduced object count: a 16-channel HOA bed through a constant
     16 x 24 decode matrix (LinearInterpMatrix, never interpolated: docs/dsp.rst:73-89) plus ramped
