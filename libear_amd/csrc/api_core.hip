@@ -12,6 +12,8 @@
 
 namespace earhip {
 
+static_assert(kBf3Tile == 256, "MixLaunch::tile() and tiles_aligned(256, ...) assume the bf16x3 tile");
+
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
@@ -140,7 +142,8 @@ struct GainStage {
     curves.commit(ctx);
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
-    MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32);
+    MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
+                            curves.tiles_aligned(256, t_call));
     desc.reserve(desc_units(n_in, ml.ntiles));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

@@ -131,7 +131,8 @@ struct earhip_render {
     const int nsamples = (int)(nblocks * (size_t)B);
     curves->commit(ctx);
     const bool strict = ctx->strict;
-    MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit);
+    MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit,
+                            curves->tiles_aligned(256, t));
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");

@@ -108,6 +108,20 @@ class CurveSet {
     std::vector<uint8_t> flat(P);
     std::vector<float> gain((P + 1) * plan_.row);  // + one all-zero row (k_gain_mix_bf3)
     npoints_ = (int)P;
+    // common grid of all point times: every time is t_ref_ + k * grid_ (grid_ = 0: all equal)
+    t_ref_ = P ? times_[0][0] : 0;
+    uint64_t g = 0;
+    for (int m = 0; m < M_; m++)
+      for (int64_t t : times_[m]) {
+        uint64_t a = (uint64_t)(t >= t_ref_ ? t - t_ref_ : t_ref_ - t), b = g;
+        while (a) {
+          const uint64_t r = b % a;
+          b = a;
+          a = r;
+        }
+        g = b;
+      }
+    grid_ = g;
     size_t at = 0;
     for (int m = 0; m < M_; m++) {
       off[m] = (int32_t)at;
@@ -128,6 +142,13 @@ class CurveSet {
     EARHIP_HIP(hipMemcpy(d_flat_.p, flat.data(), P, hipMemcpyHostToDevice));
     EARHIP_HIP(hipMemcpy(d_gain_.p, gain.data(), gain.size() * sizeof(float), hipMemcpyHostToDevice));
     dirty_ = false;
+  }
+
+  // true when no curve point can fall strictly inside a tile of `tile` samples of a
+  // call that starts at t_call (all point times lie on tile boundaries)
+  bool tiles_aligned(int tile, int64_t t_call) const {
+    const int64_t d = t_call >= t_ref_ ? t_call - t_ref_ : t_ref_ - t_call;
+    return d % tile == 0 && grid_ % (uint64_t)tile == 0;
   }
 
   PointStore device() const {
@@ -153,6 +174,8 @@ class CurveSet {
   std::vector<std::vector<uint8_t>> flat_;
   bool dirty_ = true;
   int npoints_ = 0;
+  int64_t t_ref_ = 0;
+  uint64_t grid_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
@@ -171,10 +194,11 @@ struct MixLaunch {
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
-                          bool strict, int max_gsplit) {
+                          bool strict, int max_gsplit, bool aligned = false) {
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
-  L.bf3 = L.mfma && ctx->use_mfma == 2 && M >= 32;
+  // bf16x3 kernel: forced (2) or, by default (3), whenever no curve point falls inside a tile
+  L.bf3 = L.mfma && M >= 32 && (ctx->use_mfma == 2 || (ctx->use_mfma == 3 && aligned));
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
