@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3  # vector / f32-MFMA peak, same guide
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
 SAMPLE_RATE = 48000.0
 
 
@@ -41,6 +42,20 @@ def algorithmic_bytes(m, n, b, k, ramp=True):
     dec = n * (4 * b + 8 * p * (b + 1) + 2 * 8 * p * (b + 1) + 2 * 4 * b + 4 * b) if k == 2 else 0
     dm = n * (4 * b + 2 * 4 * d + 4 * b + 4 * b) if k == 2 else 0
     return gain, dec, dm
+
+
+GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 2: "k_gain_mix_bf3 (bf16x3 MFMA)"}
+
+
+def mfma_roofline(kind, macs_per_term, k1_ms):
+    """The gain kernel against the matrix pipe it runs on (secondary to the HBM roofline)."""
+    if kind == 2:   # 2 operands (B0, B1) x 6 bf16 partial products per object, column and sample
+        flops, peak, what = 24.0 * macs_per_term, BF16_PEAK_TFLOPS, "bf16 MFMA flops: 6 partial products x {gain at tile start, slope}"
+    else:           # 2 f32 MACs (start, end gain row) per object, column and sample
+        flops, peak, what = 4.0 * macs_per_term, FP32_PEAK_TFLOPS, "f32 flops: 2 MACs per object, column and sample for a ramp"
+    ach = flops / (k1_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": GAIN_KERNELS.get(kind, "?"), "achieved": round(ach, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "note": "executed " + what}
 
 
 def main():
@@ -152,6 +167,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing = r.get_timing()
+    gain_kernel = r.gain_kernel()
     r.enable_timing(False)
 
     if world > 1:
@@ -194,21 +210,16 @@ def main():
                          "dense uniform(0,1); metadata every 960 samples at a per-object phase, 240-sample ramp then constant",
                 "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels",
                 "strict": bool(args.strict)},
-            "roofline": {"bound": "hbm", "kernel": "k_gain_mix", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"), "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": gain_b * T,
                          "avg_launch_ms": round(k1_ms, 4)},
-            "roofline_mfma": {"bound": "mfma", "kernel": "k_gain_mix", "achieved": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2),
-                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                              "note": "executed f32 MFMA flops (2 MACs per object, column and sample for a ramp); the "
-                                      "f32-in MFMA runs at the vector rate, so this, not HBM, is the kernel's higher floor"},
+            "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
             "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
-                           "gain_fp32_tflops_executed": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2),
-                           "fp32_peak_tflops": FP32_PEAK_TFLOPS},
+                           "gain_fp32_equivalent_tflops": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2)},
         }
 
         # ---- block mode (the latency figure): ONE 512-sample block per call through the host-pointer

@@ -243,6 +243,10 @@ int earhip_render_enable_timing(earhip_render *r, int enable);
  * delay/mix kernel ms, [3] its launches, [4] segment-prep kernel ms, [5] its
  * launches.  Synchronises the stream. */
 int earhip_render_get_timing(earhip_render *r, double out[6]);
+/* Which gain kernel the last process call used: 0 = VALU with libear's exact
+ * arithmetic (strict mode), 1 = f32 MFMA, 2 = bf16x3 MFMA (all curve points on
+ * tile boundaries); -1 before the first call. */
+int earhip_render_gain_kernel(const earhip_render *r, int *kind);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ struct earhip_render {
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
+  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 bf16x3 MFMA
   int run_len = 11;
 
   DevBuf<SegDesc> desc;
@@ -133,6 +134,7 @@ struct earhip_render {
     const bool strict = ctx->strict;
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit,
                             curves->tiles_aligned(256, t));
+    last_kind = ml.bf3 ? 2 : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");
@@ -372,6 +374,13 @@ int earhip_render_get_timing(earhip_render *r, double out[6]) {
     out[0] = r->acc_ms[0]; out[1] = r->acc_n[0];
     out[2] = r->acc_ms[1]; out[3] = r->acc_n[1];
     out[4] = r->acc_ms[2]; out[5] = r->acc_n[2];
+  });
+}
+
+int earhip_render_gain_kernel(const earhip_render *r, int *kind) {
+  return guarded([&] {
+    require(r != nullptr && kind != nullptr, "NULL argument");
+    *kind = r->last_kind;
   });
 }
 
