@@ -181,9 +181,12 @@ def main():
     result = None
     if rank == 0:
         gain_b, dec_b, dm_b = algorithmic_bytes(M, N, B, K)
-        k1_ms = timing["gain_mix_ms"] / max(timing["gain_mix_launches"], 1)
-        k2_ms = timing["decor_ms"] / max(timing["decor_launches"], 1)
-        k0_ms = timing["prep_ms"] / max(timing["prep_launches"], 1)
+        # a long call is cut into chunks (K1 of chunk c+1 overlaps K2 of chunk c): per-step sums for
+        # the kernel table, per-launch figures for the roofline (what rocprofv3 averages)
+        k1_launches = max(timing["gain_mix_launches"], 1) / args.steps
+        k1_ms = timing["gain_mix_ms"] / args.steps
+        k2_ms = timing["decor_ms"] / args.steps
+        k0_ms = timing["prep_ms"] / args.steps
         achieved = gain_b * T / (k1_ms * 1e-3) / 1e9
         whole = (gain_b + dec_b + dm_b) * T / t_step / 1e9
         traffic = None
@@ -192,7 +195,8 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("objects") == M and tj.get("blocks") == T and tj.get("block_size") == B:
-                    traffic = tj.get("gain_mix_hbm_bytes_per_launch")
+                    # measured per step (all K1 launches of one pass over T blocks), reported per launch
+                    traffic = int(tj.get("gain_mix_hbm_bytes_per_step") / k1_launches)
             except Exception:
                 traffic = None
         result = {
@@ -213,8 +217,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"), "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": gain_b * T,
-                         "avg_launch_ms": round(k1_ms, 4)},
+                         "launches_per_step": round(k1_launches, 2),
+                         "algorithmic_bytes_per_launch": int(gain_b * T / k1_launches),
+                         "avg_launch_ms": round(k1_ms / k1_launches, 4)},
             "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
