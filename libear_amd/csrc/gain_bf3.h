@@ -214,24 +214,19 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
         E[q] = *reinterpret_cast<const float *>(gb + (size_t)re * rowlen * sizeof(float) + bcol);
       }
     };
-    auto store_b = [&](const ChunkDesc &D, const float (&S)[8], const float (&E)[8], int buf) {
-      float b0[8], b1[8];
+    // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's 8 objects -> LDS
+    auto store_b = [&](const ChunkDesc &D, const float (&S)[8], const float (&E)[8], int buf, int part) {
+      float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        b0[q] = __builtin_fmaf(1.0f - D.p0[q], S[q], D.p0[q] * E[q]);
-        b1[q] = D.scale[q] * (E[q] - S[q]);
-      }
+      for (int q = 0; q < 8; q++)
+        v[q] = part == 0 ? __builtin_fmaf(1.0f - D.p0[q], S[q], D.p0[q] * E[q])
+                         : D.scale[q] * (E[q] - S[q]);
       u32x4 h, m, l;
-      split_bf16x3(b0, h, m, l);
-      u32x4 *f0 = &bfrag[buf][bfr][blane];
-      f0[0] = h;
-      f0[64] = m;
-      f0[128] = l;
-      split_bf16x3(b1, h, m, l);
-      u32x4 *f1 = f0 + bfr1 * 64;
-      f1[0] = h;
-      f1[64] = m;
-      f1[128] = l;
+      split_bf16x3(v, h, m, l);
+      u32x4 *f = &bfrag[buf][bfr][blane] + (part ? bfr1 * 64 : 0);
+      f[0] = h;
+      f[64] = m;
+      f[128] = l;
     };
 
     // (s - s0) of the rows of this lane's D fragments: sample 64w + 16kg + 4e + r
@@ -245,7 +240,8 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
       L = load_desc(0);
       load_gains(L, D, S, E);
       load_x(0, xc);
-      store_b(D, S, E, 0);
+      store_b(D, S, E, 0, 0);
+      store_b(D, S, E, 0, 1);
       L = load_desc(1);
     }
 #pragma unroll 1
@@ -266,43 +262,83 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
                             xc[4][r], xc[5][r], xc[6][r], xc[7][r]};
         split_bf16x3(v, ah[r], am[r], al[r]);
       }
+      // 2*NCT blocks (column tile ct = blk >> 1, operand blk & 1: B0 / B1) of 24 MFMAs:
+      // six partial products per operand pair, smallest first, accumulated from zero.
+      // A VALU instruction costs its 4 cycles on top of the MFMAs unless it sits
+      // directly behind one (tools/experiments/coissue2.hip: one is free per MFMA), so
+      // everything that does not depend on this chunk's MFMAs is woven between them:
+      // the fold of the previous block, the conversion of the next chunk's gains and
+      // the hand-over of the next chunk's inputs.
+      __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
+      constexpr int NBLK = 2 * NCT;
+      u32x4 b[2][3];
+      f32x4 t[2][NRT];
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      auto load_b = [&](int blk, u32x4 (&bb)[3]) {
 #pragma unroll
-      for (int ct = 0; ct < NCT; ct++) {
-        u32x4 b[2][3];
+        for (int q = 0; q < 3; q++) bb[q] = bfrag[buf][((blk & 1) * NCT + (blk >> 1)) * 3 + q][lane];
+      };
+      auto fold = [&](int blk, const f32x4 (&tt)[NRT]) {
+        const int ct = blk >> 1;
 #pragma unroll
-        for (int p = 0; p < 2; p++)
+        for (int r = 0; r < NRT; r++)
 #pragma unroll
-          for (int t = 0; t < 3; t++) b[p][t] = bfrag[buf][(p * NCT + ct) * 3 + t][lane];
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        // six partial products per operand pair, smallest first, accumulated from
-        // zero; the B0 and the B1 product share one set of temporaries
+          for (int e = 0; e < 4; e++) {
+            if ((blk & 1) == 0) tot[r][ct][e] += tt[r][e];
+            else tot[r][ct][e] = __builtin_fmaf(wf0 + (float)(4 * e + r), tt[r][e], tot[r][ct][e]);
+          }
+      };
+      load_b(0, b[0]);
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-          f32x4 t[NRT];
+      for (int blk = 0; blk < NBLK; blk++) {
+        u32x4(&bc)[3] = b[blk & 1];
+        f32x4(&tc)[NRT] = t[blk & 1];
+        if (blk + 1 < NBLK) load_b(blk + 1, b[(blk + 1) & 1]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) t[r] = mfma_bf16(al[r], b[p][0], zero);
+        for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(al[r], bc[0], zero);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) t[r] = mfma_bf16(am[r], b[p][1], t[r]);
+        for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(am[r], bc[1], tc[r]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) t[r] = mfma_bf16(ah[r], b[p][2], t[r]);
+        for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(ah[r], bc[2], tc[r]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) t[r] = mfma_bf16(am[r], b[p][0], t[r]);
+        for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(am[r], bc[0], tc[r]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) t[r] = mfma_bf16(ah[r], b[p][1], t[r]);
+        for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(ah[r], bc[1], tc[r]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) t[r] = mfma_bf16(ah[r], b[p][0], t[r]);
+        for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(ah[r], bc[0], tc[r]);
+        if (blk > 0) fold(blk - 1, t[(blk - 1) & 1]);
+        const bool conv0 = blk == 1, conv1 = blk == NBLK - 1, copy = blk == (NBLK > 2 ? NBLK - 2 : 0);
+        if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
+        if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
+        if (copy) {
 #pragma unroll
-          for (int r = 0; r < NRT; r++)
+          for (int q = 0; q < 8; q++) xc[q] = xn[q];
+        }
+        // issue order: the LDS reads first, then every MFMA followed by 1-3 VALU instructions
+        if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (conv0 || conv1) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              if (p == 0) tot[r][ct][e] += t[r][e];
-              else tot[r][ct][e] = __builtin_fmaf(wf0 + (float)(4 * e + r), t[r][e], tot[r][ct][e]);
-            }
+          for (int k = 0; k < 24; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          }
+        } else if (copy && blk > 0) {
+#pragma unroll
+          for (int k = 0; k < 24; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+        } else if (blk > 0 || copy) {
+#pragma unroll
+          for (int k = 0; k < 24; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
         }
       }
-      store_b(D, S, E, buf ^ 1);  // (after the last chunk: written, never read)
-#pragma unroll
-      for (int q = 0; q < 8; q++) xc[q] = xn[q];
+      fold(NBLK - 1, t[(NBLK - 1) & 1]);
     }
 
     // objects with curve points inside this workgroup tile (zero rows above)
