@@ -42,29 +42,24 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const ColumnPlan &cp = cs.plan();
   const PointStore ps = cs.device();
   const int M = cs.M();
-  {
-    if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
-                       ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
-  }
-  // piece lists of the objects with curve points inside a tile (f32 MFMA kernel);
-  // they live behind the descriptors in the same buffer (desc_units())
-  PieceList pl;
-  pl.d = nullptr;
-  pl.m = nullptr;
-  pl.count = nullptr;
-  pl.cap = M;
-  if (ml.mfma && !ml.bf3) {
-    const size_t nd = (size_t)M * ml.ntiles;
-    pl.d = desc + nd;
-    pl.m = reinterpret_cast<int *>(desc + 2 * nd);
-    pl.count = pl.m + nd;
-    hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
-                       t_call, t_call + nsamples, desc, pl);
-  }
+  const bool slots = ml.mfma && !ml.bf3;
+  if (slots && M > kMaxSlotObjects) fail_invalid("more than 65536 input channels in one gain stage");
+  if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
+  // K0: segment descriptors; for the f32 MFMA kernel K0s then turns them into the
+  // tiles' slot lists, which live behind the descriptors in the same buffer (desc_units())
+  hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
+                     ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
+  SlotLists sl;
+  sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
+  sl.count = reinterpret_cast<int *>(sl.slots + (size_t)4 * M * ml.ntiles);
+  sl.ovf = sl.count + (size_t)4 * ml.ntiles;
+  sl.M = M;
+  if (slots)
+    hipLaunchKernelGGL(k_slot_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
+                       t_call, t_call + nsamples, desc, sl);
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
-  P.pl = pl;
+  P.sl = sl;
   P.in = in_dev;
   P.in_stride = in_stride;
   P.out = out_dev;

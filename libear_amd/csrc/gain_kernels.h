@@ -56,27 +56,10 @@ static_assert(sizeof(SegDesc) == 16, "SegDesc is loaded as one dwordx4");
 
 constexpr int kSegRamp = 1;
 constexpr int kSegMulti = 2;
-constexpr int kSegSlow = (int)0x80000000u;  // multi, and its pieces did not fit the tile's piece list
 constexpr int kMaxPointsPerObject = 1 << 18;
 __host__ __device__ __forceinline__ int seg_r1(int info) { return (info >> 4) & 0x1ff; }
 __host__ __device__ __forceinline__ int seg_k(int info) { return (info >> 13) & 0x3ffff; }
 
-// Pieces of the objects whose curve has a point INSIDE a tile ("multi"), one
-// compact list per tile in object order (deterministic), written by k_piece_list.
-// A piece is a SegDesc whose info holds, instead of the segment index, the first
-// sample of the piece: bit0 ramp, bits 2-3 flat, bits 4-12 r1, bits 13-21 r0.
-struct PieceList {
-  SegDesc *d;   // [ntiles][cap]
-  int *m;       // [ntiles][cap] object of each piece
-  int *count;   // [ntiles]; nullptr: no piece lists (every multi object takes the slow path)
-  int cap;      // = M
-};
-__host__ __device__ __forceinline__ int piece_r0(int info) { return (info >> 13) & 0x1ff; }
-// SegDesc units a descriptor buffer needs for `ntiles` tiles of M objects: the
-// descriptors, the piece lists (cap = M) and their object / count arrays
-__host__ __device__ inline size_t desc_units(size_t M, size_t ntiles) {
-  return 2 * M * ntiles + (M * ntiles * 4 + ntiles * 4 + 15) / 16 + 1;
-}
 
 // blockIdx.x -> tile such that the workgroups of one XCD (b % 8) cover a
 // contiguous range of tiles; identity for the ragged tail
@@ -150,74 +133,159 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
   if (tile_o < ntiles && m_o < M) desc[(size_t)tile_o * M + m_o] = sh[to][oo];
 }
 
-// K0b: one workgroup per tile; splits every multi object of the tile into its
-// pieces (the walk of GainInterpolator::process, gain_interpolator.hpp:58-86) and
-// appends them to the tile's list at offsets from an ordered block scan.
+// ---------------------------------------------------------------------------
+// Slot lists (f32 MFMA kernel).  The contraction  bus[col][s] = sum_k c_k(s) * x_{m(k)}(s) *
+// G[row(k)][col]  runs over "slots" k: one (input channel, gain row, coefficient
+// function) triple per MFMA k index.  A constant piece of a curve is ONE slot
+// (c = 1, its row), a ramp piece two (c = 1 - p on the start row, c = p on the end
+// row, gain_interpolator.hpp:272-274), with c(s) = alpha + beta * s for the samples
+// [r0, r1) of the tile and 0 elsewhere.  k_slot_list writes, per tile and in object
+// order (deterministic), the slots of the pieces that cover the whole tile ("plain",
+// no masking needed) and those of the pieces that do not ("masked": curve points
+// inside the tile, the partial last tile of a call).
+struct Slot {
+  uint32_t mr;   // object m | r0 << 16 | (r1 - 1) << 24
+  int32_t row;   // gain row
+  float alpha, beta;
+};
+static_assert(sizeof(Slot) == 16, "Slot is loaded as one dwordx4");
+constexpr int kMaxSlotObjects = 1 << 16;
+struct SlotLists {
+  Slot *slots;   // [ntiles][4*M]: plain slots from 0, masked slots from 2*M
+  int *count;    // [ntiles][4]: plain, masked, overflowed objects, -
+  int *ovf;      // [ntiles][M]: objects whose masked slots did not fit (generic path)
+  int M;
+};
+// 16-byte units of a buffer holding the descriptors (SegDesc[ntiles][M]) and, behind
+// them, the slot lists of `ntiles` tiles of M objects
+__host__ __device__ inline size_t desc_units(size_t M, size_t ntiles) {
+  return 5 * M * ntiles + (16 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
+}
+
+// K0s: one workgroup per tile, threads over objects, behind k_seg_prep: turns the
+// tile's descriptors (coalesced reads, no searching) into its slot lists.  Offsets
+// come from ordered scans over the objects, so the lists are deterministic.
 static __global__ void __launch_bounds__(256)
-k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end,
-             SegDesc *desc, PieceList pl) {
-  __shared__ int scan[256];
-  __shared__ int base_off, written;
-  const int tile = blockIdx.x, tid = threadIdx.x;
+k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end,
+            const SegDesc *desc, SlotLists sl) {
+  __shared__ unsigned wsum[4];
+  __shared__ int base_p, base_m, base_o, written_m, any_over;
+  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t t0 = t_call + (int64_t)tile * tile_samples;
   int64_t t_end = t0 + tile_samples;
   if (t_end > t_call_end) t_end = t_call_end;
+  Slot *plain = sl.slots + (size_t)tile * 4 * M;
+  Slot *masked = plain + 2 * (size_t)M;
+  int *ovf = sl.ovf + (size_t)tile * M;
   if (tid == 0) {
-    base_off = 0;
-    written = 0;
+    base_p = 0;
+    base_m = 0;
+    base_o = 0;
+    written_m = 0;
   }
   __syncthreads();
-  // pass = 0 counts, pass = 1 writes (same walk)
-  auto walk = [&](int m, const SegDesc &d, SegDesc *out, int *out_m) {
+  // the pieces of object m inside the tile, first one described by d (k_seg_prep), the
+  // others found by walking on (GainInterpolator::process, gain_interpolator.hpp:58-86);
+  // op / om == nullptr: count only
+  auto walk = [&](int m, SegDesc dk, Slot *op, Slot *om, int &cp, int &cm) {
     const int base = ps.off[m], n = ps.off[m + 1] - base;
-    int k = seg_k(d.info), cur = 0, c = 0;
+    int k = seg_k(dk.info), cur = 0;
+    cp = 0;
+    cm = 0;
     for (;;) {
-      const SegDesc dk = describe_segment(ps, base, n, k, t0, t_end);
       const int r1 = seg_r1(dk.info);
       if (r1 > cur) {  // duplicate times make empty segments (steps)
-        if (out) {
-          SegDesc e = dk;
-          e.info = (dk.info & (kSegRamp | 0xc)) | (r1 << 4) | (cur << 13);
-          out[c] = e;
-          out_m[c] = m;
-        }
+        const bool ramp = dk.info & kSegRamp;
+        const bool whole = cur == 0 && r1 == tile_samples;
+        Slot a;
+        a.mr = (uint32_t)m | ((uint32_t)cur << 16) | ((uint32_t)(r1 - 1) << 24);
+        a.row = dk.row;
+        const float p0 = (float)dk.d0 * dk.scale;  // p(s) = (float)(d0 + s) * scale, :272
+        a.alpha = ramp ? 1.0f - p0 : 1.0f;
+        a.beta = ramp ? -dk.scale : 0.0f;
+        Slot *o = whole ? op : om;
+        int &c = whole ? cp : cm;
+        if (o) o[c] = a;
         c++;
+        if (ramp) {
+          Slot b = a;
+          b.row = dk.row + 1;
+          b.alpha = p0;
+          b.beta = dk.scale;
+          if (o) o[c] = b;
+          c++;
+        }
         cur = r1;
       }
       if (!(dk.info & kSegMulti)) break;
       k++;
+      dk = describe_segment(ps, base, n, k, t0, t_end);
     }
-    return c;
+  };
+  // inclusive scan over the 256 threads; total returned through `total`
+  auto block_scan = [&](unsigned v, unsigned &total) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(v, o, 64);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    unsigned pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const unsigned x = wsum[w];
+      if (w < wv) pre += x;
+      tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return v + pre;
   };
   for (int mb = 0; mb < M; mb += 256) {
     const int m = mb + tid;
     SegDesc d;
     d.info = 0;
-    if (m < M) d = desc[(size_t)tile * M + m];
-    const bool multi = m < M && (d.info & kSegMulti);
-    const int c = multi ? walk(m, d, nullptr, nullptr) : 0;
-    scan[tid] = c;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-      const int v = tid >= o ? scan[tid - o] : 0;
-      __syncthreads();
-      scan[tid] += v;
-      __syncthreads();
+    int cp = 0, cm = 0;
+    if (m < M) {
+      d = desc[(size_t)tile * M + m];
+      walk(m, d, nullptr, nullptr, cp, cm);
     }
-    const int off = base_off + scan[tid] - c;
-    if (multi) {
-      if (off + c <= pl.cap) {
-        walk(m, d, pl.d + (size_t)tile * pl.cap + off, pl.m + (size_t)tile * pl.cap + off);
-        atomicMax(&written, off + c);
-      } else {
-        desc[(size_t)tile * M + m].info = d.info | kSegSlow;
+    // cp <= 2, cm <= 2 * 129 per object: 10 + 17 bits of one word per 256 objects
+    unsigned last;
+    const unsigned incl = block_scan((unsigned)cp | ((unsigned)cm << 10), last);
+    const int off_p = base_p + (int)(incl & 1023u) - cp;
+    const int off_m = base_m + (int)(incl >> 10) - cm;
+    const bool over = cm > 0 && off_m + cm > 2 * M;
+    if (tid == 0) any_over = 0;
+    __syncthreads();
+    if (over) any_over = 1;
+    __syncthreads();
+    unsigned oincl = 0, olast = 0;
+    if (any_over) oincl = block_scan(over ? 1u : 0u, olast);  // (uniform branch)
+    if (m < M) {
+      if (over) {
+        ovf[base_o + (int)oincl - 1] = m;
+      } else if (cp + cm > 0) {
+        int a, b;
+        walk(m, d, plain + off_p, masked + off_m, a, b);
+        if (cm > 0) atomicMax(&written_m, off_m + cm);
       }
     }
     __syncthreads();
-    if (tid == 0) base_off += scan[255];
+    if (tid == 0) {
+      base_p += (int)(last & 1023u);
+      base_m += (int)(last >> 10);
+      base_o += (int)olast;
+    }
     __syncthreads();
   }
-  if (tid == 0) pl.count[tile] = written;
+  if (tid == 0) {
+    // (once an object's masked slots do not fit, none of the later ones do)
+    sl.count[tile * 4 + 0] = base_p;
+    sl.count[tile * 4 + 1] = written_m;
+    sl.count[tile * 4 + 2] = base_o;
+  }
 }
 
 struct GainMixParams {
@@ -237,7 +305,7 @@ struct GainMixParams {
   int wsplit;           // object splits inside a workgroup
   int tiles_per_wg;     // MFMA kernel: adjacent tiles handled by one workgroup
   int vec_ok;           // in/out rows are 16-byte aligned: vector accesses allowed
-  PieceList pl;         // MFMA kernel: pieces of the multi objects (count == nullptr: none)
+  SlotLists sl;         // f32 MFMA kernel: the tile's slot lists (k_slot_list)
 };
 
 // accumulate one segment piece of one object into acc
