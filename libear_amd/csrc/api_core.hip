@@ -138,7 +138,7 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
-                            curves.tiles_aligned(256, t_call));
+                            curves.tiles_aligned(256, t_call), curves.ramp_share());
     desc.reserve(desc_units(n_in, ml.ntiles));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

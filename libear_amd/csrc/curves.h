@@ -122,6 +122,17 @@ class CurveSet {
         g = b;
       }
     grid_ = g;
+    // share of the curves' time spans spent in ramps (the rest is constant)
+    double span = 0, ramp = 0;
+    const int allflat = (1 << nbus_) - 1;
+    for (int m = 0; m < M_; m++) {
+      const auto &t = times_[m];
+      for (size_t k = 1; k < t.size(); k++) {
+        span += (double)(t[k] - t[k - 1]);
+        if ((flat_[m][k] & allflat) != allflat) ramp += (double)(t[k] - t[k - 1]);
+      }
+    }
+    ramp_share_ = span > 0 ? ramp / span : 0.0;
     size_t at = 0;
     for (int m = 0; m < M_; m++) {
       off[m] = (int32_t)at;
@@ -151,6 +162,9 @@ class CurveSet {
     return d % tile == 0 && grid_ % (uint64_t)tile == 0;
   }
 
+  // fraction of the curves' time in ramps; 0 for static gains
+  double ramp_share() const { return ramp_share_; }
+
   PointStore device() const {
     PointStore ps;
     ps.off = d_off_.p;
@@ -176,6 +190,7 @@ class CurveSet {
   int npoints_ = 0;
   int64_t t_ref_ = 0;
   uint64_t grid_ = 0;
+  double ramp_share_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
@@ -194,11 +209,15 @@ struct MixLaunch {
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
-                          bool strict, int max_gsplit, bool aligned = false) {
+                          bool strict, int max_gsplit, bool aligned = false, double ramp_share = 1.0) {
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
-  // bf16x3 kernel: forced (2) or, by default (3), whenever no curve point falls inside a tile
-  L.bf3 = L.mfma && M >= 32 && (ctx->use_mfma == 2 || (ctx->use_mfma == 3 && aligned));
+  // bf16x3 kernel: forced (2) or, by default (3), when no curve point falls inside a tile
+  // and the curves are mostly ramps: its cost does not depend on the curves, while the
+  // f32 kernel's slot lists make constant pieces half as expensive as ramps (break-even
+  // at about one third of the time in ramps)
+  L.bf3 = L.mfma && M >= 32 &&
+          (ctx->use_mfma == 2 || (ctx->use_mfma == 3 && aligned && ramp_share >= 0.35));
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
