@@ -227,7 +227,9 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     }
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
     const size_t max_samples = (size_t)r->T * r->B;
-    const size_t max_tiles = (max_samples + 63) / 64;  // smallest tile: 4 row tiles of 16 samples
+    // smallest tile any gain kernel of this context uses (f32 MFMA: 16 * nrt samples)
+    const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
+    const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
     r->desc.alloc(desc_units(r->M, max_tiles));
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits
     // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps

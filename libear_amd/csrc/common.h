@@ -121,7 +121,7 @@ struct earhip_ctx {
   int use_mfma = 3;  // non-strict gain stage: 0 VALU, 1 f32 MFMA, 2 bf16x3 MFMA, 3 (default) bf16x3
                      // when all curve points lie on tile boundaries, else f32 MFMA
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
-  int tiles_per_wg = 1;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
+  int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
   int nrt = 8;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)
   int num_cus = 256;
   // staging for the host-pointer entry points (grown at first use / create)
