@@ -43,7 +43,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const PointStore ps = cs.device();
   const int M = cs.M();
   const bool slots = ml.mfma && !ml.bf3;
-  if (slots && M > kMaxSlotObjects) fail_invalid("more than 65536 input channels in one gain stage");
+  if (slots && M > kMaxSlotObjects) fail_internal("slot lists address objects with 16 bits");
   if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
   // K0: segment descriptors; for the f32 MFMA kernel K0s then turns them into the
   // tiles' slot lists, which live behind the descriptors in the same buffer (desc_units())

@@ -218,6 +218,8 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // at about one third of the time in ramps)
   L.bf3 = L.mfma && M >= 32 &&
           (ctx->use_mfma == 2 || (ctx->use_mfma == 3 && aligned && ramp_share >= 0.35));
+  // the slot lists of the f32 MFMA kernel address objects with 16 bits
+  if (L.mfma && !L.bf3 && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
