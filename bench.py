@@ -244,13 +244,20 @@ def main():
             lib = capi.load()
             for _ in range(3):
                 capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
-            nb_calls = 50
-            b0 = time.perf_counter()
-            for _ in range(nb_calls):
+            for _ in range(20):
                 capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
-            bdt = (time.perf_counter() - b0) / nb_calls
+            nb_calls = 200  # >= 200 timed blocks after 20 warm-up, median and p95
+            lat = []
+            for _ in range(nb_calls):
+                b0 = time.perf_counter()
+                capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
+                lat.append(time.perf_counter() - b0)
+            lat.sort()
+            bdt = lat[len(lat) // 2]
             rb.close()
-            result["block_mode"] = {"ms_per_block": round(bdt * 1e3, 4), "rtf": round((B / SAMPLE_RATE) / bdt, 1),
+            result["block_mode"] = {"ms_per_block": round(bdt * 1e3, 4), "p95_ms": round(lat[int(0.95 * len(lat))] * 1e3, 4),
+                                    "mean_ms": round(sum(lat) / len(lat) * 1e3, 4), "calls": nb_calls,
+                                    "rtf": round((B / SAMPLE_RATE) / bdt, 1),
                                     "Msamples_per_s": round(M * B / bdt / 1e6, 1),
                                     "note": "one block per call from host channel pointers: staging copy, H2D, K0/K1/K2, D2H, sync"}
 

@@ -40,6 +40,47 @@ struct DecorParams {
   int N, T, R, D;
 };
 
+// radix-4 butterfly with the three twiddles given (already conjugated for DIR > 0 by
+// the caller's table): r4_core of fft_lds.h without its table reads
+template <int DIR>
+__device__ __forceinline__ void r4_core_w(cf v0, cf v1, cf v2, cf v3, cf *out, int Ns, int j,
+                                          const cf (&w)[3]) {
+  const int k = j & (Ns - 1);
+  v1 = cf_mul(v1, DIR > 0 ? cf_conj(w[0]) : w[0]);
+  v2 = cf_mul(v2, DIR > 0 ? cf_conj(w[1]) : w[1]);
+  v3 = cf_mul(v3, DIR > 0 ? cf_conj(w[2]) : w[2]);
+  const cf a0 = cf_add(v0, v2), a1 = cf_sub(v0, v2);
+  const cf a2 = cf_add(v1, v3), a3 = cf_mul_i<DIR>(cf_sub(v1, v3));
+  const int base = ((j - k) << 2) + k;
+  out[base] = cf_add(a0, a2);
+  out[base + Ns] = cf_add(a1, a3);
+  out[base + 2 * Ns] = cf_sub(a0, a2);
+  out[base + 3 * Ns] = cf_sub(a1, a3);
+}
+
+// fft_run_passes of fft_lds.h for a power-of-four L with one butterfly per thread and
+// the twiddles of this thread's butterflies held in registers (twr[p - 1] for pass p)
+template <int L, int DIR, int NT>
+__device__ __forceinline__ cf *fft_run_passes_w(cf *src, cf *dst, const cf (&twr)[fft_r4_passes(L) - 1][3],
+                                                int first, int tid) {
+  constexpr int NR4 = fft_r4_passes(L);
+  static_assert(!fft_has_r2(L) && L / 4 == NT, "power-of-four length, one butterfly per thread");
+  int Ns = 1;
+  for (int p = 0; p < first; ++p) Ns *= 4;
+#pragma unroll
+  for (int p = 0; p < NR4; ++p) {
+    if (p < first) continue;
+    __syncthreads();
+    if (p == 0) stockham_r4<L, DIR>(src, dst, nullptr, 1, tid);
+    else r4_core_w<DIR>(src[tid], src[tid + L / 4], src[tid + L / 2], src[tid + 3 * L / 4], dst, Ns, tid, twr[p - 1]);
+    cf *t = src;
+    src = dst;
+    dst = t;
+    Ns *= 4;
+  }
+  return src;
+}
+
 template <int L>
 __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   constexpr int B = L / 2;
@@ -50,7 +91,11 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   // nothing on the per-pass critical path may come from global memory: twiddles
   // live in LDS (up to L = 2048), the channel's spectrum H in registers, and the
   // next pair's bus samples are requested before the current pair's passes start.
-  constexpr bool kTwInLds = L <= 2048;
+  // At one butterfly per thread (L = 1024) the twiddles of a thread's butterflies are
+  // 12 constants: held in registers they take 30 % off the LDS traffic of a pass, which
+  // is what six co-resident workgroups per CU are bound by.
+  constexpr bool kTwInRegs = L == 4 * NT;
+  constexpr bool kTwInLds = L <= 2048 && !kTwInRegs;
   __shared__ __attribute__((aligned(16))) cf lds[2 * L + (kTwInLds ? L : 0)];
   __shared__ float tail[B];
   cf *a = lds, *b = lds + L;
@@ -68,6 +113,19 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
     cf *twl = lds + 2 * L;
     for (int i = tid; i < L; i += NT) twl[i] = P.tw[i];
     tw = twl;  // visible after the first barrier below
+  }
+
+  cf twr[kTwInRegs ? fft_r4_passes(L) - 1 : 1][3];
+  if constexpr (kTwInRegs) {
+    int Ns = 4;
+#pragma unroll
+    for (int p = 1; p < fft_r4_passes(L); p++) {
+      const int k = tid & (Ns - 1), step = L / (Ns * 4);
+      twr[p - 1][0] = P.tw[k * step];
+      twr[p - 1][1] = P.tw[2 * k * step];
+      twr[p - 1][2] = P.tw[3 * k * step];
+      Ns *= 4;
+    }
   }
 
   auto bus_at = [&](const float *row, int s) {
@@ -129,7 +187,9 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       dre[e] = (i < B && have_re && tb >= first) ? delayed(tb * B + i) : 0.0f;
       dim[e] = (i < B && have_im) ? delayed((tb + 1) * B + i) : 0.0f;
     }
-    cf *Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
+    cf *Z;
+    if constexpr (kTwInRegs) Z = fft_run_passes_w<L, -1, NT>(a, b, twr, 0, tid);
+    else Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
     cf *W = Z == a ? b : a;
     __syncthreads();
     // first inverse pass with the spectral multiply folded into its loads
@@ -141,7 +201,9 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
                        cf_mul(Z[j + L / 2], h[q][2]), cf_mul(Z[j + 3 * L / 4], h[q][3]), W, tw,
                        1, j);
     }
-    cf *y = fft_run_passes<L, +1, NT>(W, Z, tw, 1, tid);
+    cf *y;
+    if constexpr (kTwInRegs) y = fft_run_passes_w<L, +1, NT>(W, Z, twr, 1, tid);
+    else y = fft_run_passes<L, +1, NT>(W, Z, tw, 1, tid);
     __syncthreads();
     // real part = block tb, imaginary part = block tb+1
 #pragma unroll
