@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--layout", default="9+10+3")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
-    ap.add_argument("--scene", choices=("dense", "adm", "static"), default="dense",
+    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving"), default="dense",
                     help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
                          "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -113,6 +113,8 @@ def main():
     # ---- scene: resident in HBM before the timed region --------------------------------------
     if args.scene == "adm":
         curves = scenes.adm_curves(M, N, total, seed=11 + rank)
+    elif args.scene == "moving":  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
+        curves = scenes.adm_curves(M, N, total, period=240, ramp=240, seed=12 + rank)
     elif args.scene == "static":  # one gain vector per object and bus, never changing
         curves = scenes.constant_curves(M, N, seed=8 + rank)
     else:

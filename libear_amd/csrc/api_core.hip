@@ -51,7 +51,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
                      ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
-  sl.count = reinterpret_cast<int *>(sl.slots + (size_t)4 * M * ml.ntiles);
+  sl.count = reinterpret_cast<int *>(sl.slots + (size_t)kTileSlots * M * ml.ntiles);
   sl.ovf = sl.count + (size_t)4 * ml.ntiles;
   sl.M = M;
   if (slots)

@@ -150,8 +150,11 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "Slot is loaded as one dwordx4");
 constexpr int kMaxSlotObjects = 1 << 16;
+constexpr int kPlainSlots = 2;    // per object and tile: at most one whole-tile ramp
+constexpr int kMaskedSlots = 6;   // per object and tile on average; beyond: generic path
+constexpr int kTileSlots = kPlainSlots + kMaskedSlots;
 struct SlotLists {
-  Slot *slots;   // [ntiles][4*M]: plain slots from 0, masked slots from 2*M
+  Slot *slots;   // [ntiles][kTileSlots*M]: plain slots from 0, masked slots from kPlainSlots*M
   int *count;    // [ntiles][4]: plain, masked, overflowed objects, -
   int *ovf;      // [ntiles][M]: objects whose masked slots did not fit (generic path)
   int M;
@@ -159,7 +162,7 @@ struct SlotLists {
 // 16-byte units of a buffer holding the descriptors (SegDesc[ntiles][M]) and, behind
 // them, the slot lists of `ntiles` tiles of M objects
 __host__ __device__ inline size_t desc_units(size_t M, size_t ntiles) {
-  return 5 * M * ntiles + (16 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
+  return (1 + kTileSlots) * M * ntiles + (16 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
 }
 
 // K0s: one workgroup per tile, threads over objects, behind k_seg_prep: turns the
@@ -174,8 +177,8 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
   const int64_t t0 = t_call + (int64_t)tile * tile_samples;
   int64_t t_end = t0 + tile_samples;
   if (t_end > t_call_end) t_end = t_call_end;
-  Slot *plain = sl.slots + (size_t)tile * 4 * M;
-  Slot *masked = plain + 2 * (size_t)M;
+  Slot *plain = sl.slots + (size_t)tile * kTileSlots * M;
+  Slot *masked = plain + kPlainSlots * (size_t)M;
   int *ovf = sl.ovf + (size_t)tile * M;
   if (tid == 0) {
     base_p = 0;
@@ -251,12 +254,12 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
       d = desc[(size_t)tile * M + m];
       walk(m, d, nullptr, nullptr, cp, cm);
     }
-    // cp <= 2, cm <= 2 * 129 per object: 10 + 17 bits of one word per 256 objects
+    // cp <= 2, cm <= 2 * 257 per object: 10 + 18 bits of one word per 256 objects
     unsigned last;
     const unsigned incl = block_scan((unsigned)cp | ((unsigned)cm << 10), last);
     const int off_p = base_p + (int)(incl & 1023u) - cp;
     const int off_m = base_m + (int)(incl >> 10) - cm;
-    const bool over = cm > 0 && off_m + cm > 2 * M;
+    const bool over = cm > 0 && off_m + cm > kMaskedSlots * M;
     if (tid == 0) any_over = 0;
     __syncthreads();
     if (over) any_over = 1;

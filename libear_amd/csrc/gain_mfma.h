@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   } else if (!P.vec_ok) {
     for (int m = m_lo; m < m_hi; m++) single_object(m);  // unaligned rows: objects split over the waves
   } else {
-    const Slot *plain = P.sl.slots + (size_t)tile * 4 * P.M;
+    const Slot *plain = P.sl.slots + (size_t)tile * kTileSlots * P.M;
     const int *cnt = P.sl.count + tile * 4;
     // lane-constant input offsets: the NRT samples of this lane, as float4 loads;
     // lanes past the end of the call re-read the last vector (their slots are masked)
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       }
     };
     run(plain, cnt[0], std::false_type{});
-    run(plain + 2 * (size_t)P.M, cnt[1], std::true_type{});
+    run(plain + kPlainSlots * (size_t)P.M, cnt[1], std::true_type{});
     // objects whose masked slots did not fit the list: generic path, one wave per
     // tile and column group
     if (part == 0) {
