@@ -3,7 +3,10 @@
 // decorrelate_delay_mix, `nblocks` blocks per call, state resident in HBM.
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <memory>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 #include "curves.h"
@@ -347,9 +350,39 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     r->p_out.reserve(cap * r->N);
     r->d_in.reserve(cap * r->M);
     r->d_out.reserve(cap * r->N);
-    for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + m * n, in[m], sizeof(float) * n);
-    EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, sizeof(float) * n * r->M,
-                              hipMemcpyHostToDevice, ctx->stream));
+    const size_t in_bytes = sizeof(float) * n * r->M;
+    if (in_bytes < ((size_t)16 << 20) || r->M < 16) {
+      for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + m * n, in[m], sizeof(float) * n);
+      EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      // Long calls: the staging copy is what bounds the host-pointer path, so several
+      // threads gather the channels into the pinned buffer, group of channels by group,
+      // and each group's H2D transfer starts while the next group is being gathered.
+      const int G = 8;
+      const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+      std::atomic<int> done[G];
+      for (auto &d : done) d.store(0);
+      auto group_lo = [&](int g) { return (int)((int64_t)r->M * g / G); };
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&, t] {
+          for (int g = 0; g < G; g++) {
+            for (int m = group_lo(g) + t; m < group_lo(g + 1); m += nthreads)
+              std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
+            done[g].fetch_add(1, std::memory_order_release);
+          }
+        });
+      hipError_t err = hipSuccess;
+      for (int g = 0; g < G; g++) {
+        while (done[g].load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
+        const size_t lo = (size_t)group_lo(g) * n, hi = (size_t)group_lo(g + 1) * n;
+        if (err == hipSuccess && hi > lo)
+          err = hipMemcpyAsync(r->d_in.p + lo, r->p_in.p + lo, sizeof(float) * (hi - lo),
+                               hipMemcpyHostToDevice, ctx->stream);
+      }
+      for (auto &th : pool) th.join();
+      EARHIP_HIP(err);
+    }
     r->process_device(nblocks, r->d_in.p, n, r->d_out.p, n);
     EARHIP_HIP(hipMemcpyAsync(r->p_out.p, r->d_out.p, sizeof(float) * n * r->N,
                               hipMemcpyDeviceToHost, ctx->stream));

@@ -128,6 +128,22 @@ def test_unaligned_metadata_piece_lists(m, nblocks, calls):
     assert np.array_equal(strict, run_oracle(curves, x, n, block, None, 0))
 
 
+def test_long_host_call_threaded_staging():
+    """>= 16 MB of input per call: the host-pointer entry point gathers the channels with several
+    threads, group by group, overlapping the transfers; same result as the oracle and as short calls."""
+    m, layout, block, nblocks = 64, "0+5+0", 512, 128  # 64 x 65536 x 4 B = 16.8 MB
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, seed=3)
+    x = scenes.audio(m, total, seed=4)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(got, want) <= 1e-6
+    short = run_hip(curves, x, n, block, dec, 255, [32] * 4)
+    assert scenes.rel_rms(short, got) <= 1e-6
+
+
 def test_piece_list_overflow_takes_generic_path():
     """More pieces in one tile than its list holds (cap = number of objects): the objects that
     do not fit are flagged by K0b and rendered by the generic path; the result is the same."""
