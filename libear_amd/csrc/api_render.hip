@@ -352,7 +352,9 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     r->d_out.reserve(cap * r->N);
     const size_t in_bytes = sizeof(float) * n * r->M;
     if (in_bytes < ((size_t)16 << 20) || r->M < 16) {
-      for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + m * n, in[m], sizeof(float) * n);
+      // short calls (block mode): one gather, one transfer (splitting a 2 MB block into
+      // overlapped groups costs more in transfer calls than it hides)
+      for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
       EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
       // Long calls: the staging copy is what bounds the host-pointer path, so several
