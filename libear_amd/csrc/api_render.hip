@@ -238,6 +238,10 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps
     // gsplit * ntiles < 4 * num_cus, so gsplit * nsamples < 4 * num_cus * 256.
     r->max_gsplit = 32;
+    if (const char *e = getenv("EARHIP_GSPLIT")) {  // tuning knob: grid-level splits of short calls
+      const int v = atoi(e);
+      if (v >= 1 && v <= 32) r->max_gsplit = v;
+    }
     const size_t pad_samples = (max_samples + 3) & ~(size_t)3;
     const size_t split_samples = (size_t)4 * ctx->num_cus * 256 + 4 * r->max_gsplit;
     r->bus.alloc_zero((size_t)r->K * r->N * std::max(pad_samples, split_samples), ctx->stream);
