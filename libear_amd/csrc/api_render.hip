@@ -237,7 +237,7 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits
     // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps
     // gsplit * ntiles < 4 * num_cus, so gsplit * nsamples < 4 * num_cus * 256.
-    r->max_gsplit = 32;
+    r->max_gsplit = 16;  // block mode: more splits make K2 sum more partial slabs than K1 gains
     if (const char *e = getenv("EARHIP_GSPLIT")) {  // tuning knob: grid-level splits of short calls
       const int v = atoi(e);
       if (v >= 1 && v <= 32) r->max_gsplit = v;
