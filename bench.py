@@ -86,11 +86,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; EARHIP_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional
+    # check of the multi-rank control flow on a single-GPU box, not a measurement)
+    backend = os.environ.get("EARHIP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import scenes
     from layouts import LAYOUTS
@@ -127,7 +134,7 @@ def main():
         if world > 1 else None
 
     stream = torch.cuda.current_stream(dev)
-    ctx = capi.Context(local_rank, stream.cuda_stream)
+    ctx = capi.Context(dev_index, stream.cuda_stream)
     ctx.set_strict(args.strict)
     r = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=T)
     for m, (t, d, f) in enumerate(curves):
@@ -178,6 +185,20 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # multi-rank self-check (outside the timed region, all ranks take part): the slice this rank
+    # owns after the reduce-scatter equals the sum of all ranks' partial outputs
+    exchange_err = None
+    if world > 1 and (backend == "nccl" or os.environ.get("EARHIP_BENCH_CHECK") == "force"):
+        from libear_amd.distributed import channel_range
+        w = min(total, 4096)
+        last = (args.steps - 1) % 2
+        ref = outs[last][:, :w].clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        lo, hi = channel_range(N, rank, world)
+        got = owned[last][:, :w] if backend == "nccl" else outs[last][lo:hi, :w]
+        err = ((got - ref[lo:hi]).abs().max() / ref.abs().max().clamp_min(1e-30)).to(torch.float64).reshape(1)
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+        exchange_err = float(err.item())
     t_step = dt / args.steps
     value = M_total * total / t_step / 1e6
     rtf = (total / SAMPLE_RATE) / t_step
@@ -225,6 +246,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(gain_b * T / k1_launches),
                          "avg_launch_ms": round(k1_ms / k1_launches, 4)},
             "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
+            "exchange_check": None if exchange_err is None else
+                              {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}")},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
             "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
