@@ -301,7 +301,10 @@ def main():
                 o.set_points(m, 0, t[:nb + 1], d[:nb + 1])
                 o.set_points(m, 1, t[:nb + 1], f[:nb + 1])
             want = o.process(xs)
+            truth = scenes.render_f64([(t[:nb + 1], d[:nb + 1], f[:nb + 1]) for t, d, f in curves], xs, N, dec, 255)
             result["parity"] = {"rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
+                                "gpu_rel_rms_vs_float64": float(f"{scenes.rel_rms(got, truth):.3e}"),
+                                "cpu_rel_rms_vs_float64": float(f"{scenes.rel_rms(want, truth):.3e}"),
                                 "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
                                 "tolerance": 1e-6}
 
