@@ -190,9 +190,15 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
   // the pieces of object m inside the tile, first one described by d (k_seg_prep), the
   // others found by walking on (GainInterpolator::process, gain_interpolator.hpp:58-86);
   // op / om == nullptr: count only
-  auto walk = [&](int m, SegDesc dk, Slot *op, Slot *om, int &cp, int &cm) {
-    const int base = ps.off[m], n = ps.off[m + 1] - base;
-    int k = seg_k(dk.info), cur = 0;
+  // nx[0..1]: descriptors of the 2nd and 3rd segment, kept in registers between the
+  // counting and the writing pass (fill: written by this call; else: read)
+  auto walk = [&](int m, SegDesc dk, Slot *op, Slot *om, int &cp, int &cm, SegDesc (&nx)[2], bool fill) {
+    int base = 0, n = 0;
+    if (dk.info & kSegMulti) {
+      base = ps.off[m];
+      n = ps.off[m + 1] - base;
+    }
+    int k = seg_k(dk.info), cur = 0, step = 0;
     cp = 0;
     cm = 0;
     for (;;) {
@@ -222,7 +228,13 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
       }
       if (!(dk.info & kSegMulti)) break;
       k++;
-      dk = describe_segment(ps, base, n, k, t0, t_end);
+      if (step < 2 && !fill) {
+        dk = nx[step];
+      } else {
+        dk = describe_segment(ps, base, n, k, t0, t_end);
+        if (step < 2) nx[step] = dk;
+      }
+      step++;
     }
   };
   // inclusive scan over the 256 threads; total returned through `total`
@@ -247,12 +259,12 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
   };
   for (int mb = 0; mb < M; mb += 256) {
     const int m = mb + tid;
-    SegDesc d;
+    SegDesc d, nx[2];
     d.info = 0;
     int cp = 0, cm = 0;
     if (m < M) {
       d = desc[(size_t)tile * M + m];
-      walk(m, d, nullptr, nullptr, cp, cm);
+      walk(m, d, nullptr, nullptr, cp, cm, nx, true);
     }
     // cp <= 2, cm <= 2 * 257 per object: 10 + 18 bits of one word per 256 objects
     unsigned last;
@@ -271,7 +283,7 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
         ovf[base_o + (int)oincl - 1] = m;
       } else if (cp + cm > 0) {
         int a, b;
-        walk(m, d, plain + off_p, masked + off_m, a, b);
+        walk(m, d, plain + off_p, masked + off_m, a, b, nx, false);
         if (cm > 0) atomicMax(&written_m, off_m + cm);
       }
     }
