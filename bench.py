@@ -74,6 +74,8 @@ def main():
                          "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --objects per GPU (default); strong: --objects in total, split over the GPUs")
+    ap.add_argument("--row-pad", type=int, default=0,
+                    help="floats of padding between the input rows (row stride = samples + pad; multiple of 4)")
     ap.add_argument("--stream-only", action="store_true",
                     help="only the timed stream-mode steps (no block-mode, parity or CPU legs): for PMC profiling passes")
     args = ap.parse_args()
@@ -128,7 +130,9 @@ def main():
         curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    x = torch.rand((M, total), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    in_stride = total + args.row_pad
+    x_full = torch.rand((M, in_stride), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    x = x_full[:, :total]  # planar rows, in_stride floats apart
     outs = [torch.zeros((N, total), device=dev, dtype=torch.float32) for _ in range(2)]
     owned = [torch.zeros((N // world, total), device=dev, dtype=torch.float32) for _ in range(2)] \
         if world > 1 else None
@@ -149,7 +153,7 @@ def main():
             pending[buf].wait()
             pending[buf] = None
         r.reset(0)
-        r.process_device(T, x.data_ptr(), total, outs[buf].data_ptr(), total)
+        r.process_device(T, x.data_ptr(), in_stride, outs[buf].data_ptr(), total)
         if world > 1:
             _, work = exchange(outs[buf], owned[buf], async_op=True)
             pending[buf] = work
