@@ -187,22 +187,32 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
       int row_s, row_e;
       float p0, scale;
     };
+    // the raw descriptor is only fetched here; it is digested (digest_desc) one chunk
+    // later, right before its fields are broadcast.  Digesting at once would put a wait
+    // for THIS load — the youngest one, so in effect vmcnt(0) — into the chunk that has
+    // just requested its inputs, and serialise the whole input prefetch.
     auto load_desc = [&](int c) {
       const int cc = min(c, nch - 1);
       const int m = chunk_base(cc) + w * 8 + (lane & 7);
-      const SegDesc d = dtile[m];
-      const bool valid = m >= m_lo + cc * CH && !(d.info & kSegMulti);
+      return *reinterpret_cast<const int4 *>(dtile + m);
+    };
+    auto digest_desc = [&](const int4 &d, int c) {
+      const int cc = min(c, nch - 1);
+      const int m = chunk_base(cc) + w * 8 + (lane & 7);
+      const bool valid = m >= m_lo + cc * CH && !(d.w & kSegMulti);
       LaneDesc L;
-      L.row_s = valid ? d.row : zero_row;
-      L.row_e = L.row_s + ((valid && (d.info & kSegRamp)) ? 1 : 0);
-      L.p0 = (float)d.d0 * d.scale;  // gain_interpolator.hpp:272 at the tile start
-      L.scale = d.scale;             // constant segments: scale = 0, d0 = 0
+      L.row_s = valid ? d.x : zero_row;
+      L.row_e = L.row_s + ((valid && (d.w & kSegRamp)) ? 1 : 0);
+      const float scale = __int_as_float(d.z);
+      L.p0 = (float)d.y * scale;  // gain_interpolator.hpp:272 at the tile start
+      L.scale = scale;            // constant segments: scale = 0, d0 = 0
       return L;
     };
     struct ChunkDesc {
       float p0[8], scale[8];
     };
-    auto load_gains = [&](const LaneDesc &L, ChunkDesc &D, float (&S)[8], float (&E)[8]) {
+    auto load_gains = [&](const int4 &raw, int c, ChunkDesc &D, float (&S)[8], float (&E)[8]) {
+      const LaneDesc L = digest_desc(raw, c);
       const char *gb = reinterpret_cast<const char *>(gain);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
@@ -233,12 +243,12 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
     const float wf0 = (float)(w * TS + kg * 16);
 
     f32x4 xc[8], xn[8];
-    LaneDesc L;
+    int4 L;
     {
       float S[8], E[8];
       ChunkDesc D;
       L = load_desc(0);
-      load_gains(L, D, S, E);
+      load_gains(L, 0, D, S, E);
       load_x(0, xc);
       store_b(D, S, E, 0, 0);
       store_b(D, S, E, 0, 1);
@@ -250,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
       __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free
       float S[8], E[8];
       ChunkDesc D;
-      load_gains(L, D, S, E);  // chunk c+1 (its descriptors were fetched one chunk ago)
+      load_gains(L, c + 1, D, S, E);  // chunk c+1 (its descriptors were fetched one chunk ago)
       load_x(min(c + 1, nch - 1), xn);
       L = load_desc(c + 2);
 
