@@ -9,6 +9,8 @@ Bars:
   * streamed (T blocks per call) == block-at-a-time within 1e-6 relative RMS; state carries over;
   * full BASELINE sizes: size-independent properties (shard linearity, silence, impulse -> FIR).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -275,3 +277,48 @@ def test_render_errors():
     with pytest.raises(capi.InvalidArgument):
         r.set_object_points(0, [5, 1], np.zeros((2, 6)), np.zeros((2, 6)))
     r.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EARHIP_FUZZ_SEEDS", "16")))))
+def test_random_scenes_vs_oracle(seed):
+    """Randomised shapes: object count (odd, below/above the 32-object chunk of the bf16x3 kernel),
+    layout, block size, call partition, curve families (aligned ramps, ADM-like, ragged, static) and
+    call start times; every output within 1e-6 relative RMS of the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    layout = ["0+5+0", "4+5+0", "9+10+3"][int(rng.integers(0, 3))]
+    n = len(LAYOUTS[layout])
+    block = int([128, 256, 512, 1024][int(rng.integers(0, 4))])
+    nblocks = int(rng.integers(2, 9))
+    m = int(rng.choice([3, 17, 31, 32, 33, 47, 64, 65, 100, 129]))
+    total = block * nblocks
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        curves = scenes.dense_curves(m, n, block, nblocks, seed=seed)
+    elif kind == 1:
+        curves = scenes.adm_curves(m, n, total, period=int(rng.integers(100, 900)), ramp=int(rng.integers(1, 99)),
+                                   seed=seed)
+    elif kind == 2:
+        curves = scenes.ragged_curves(m, n, total, seed=seed)
+    elif kind == 3:
+        curves = scenes.constant_curves(m, n, seed=seed)
+    else:  # aligned to 256 but sparse in time: mostly constant with occasional ramps
+        curves = []
+        for i in range(m):
+            grid = np.arange(0, total + 256, 256)
+            k = min(int(rng.integers(2, 6)), len(grid))
+            t = np.sort(rng.choice(grid, size=k, replace=False)).astype(np.int64)
+            curves.append((t, rng.uniform(0, 1, (k, n)).astype(np.float32), rng.uniform(0, 1, (k, n)).astype(np.float32)))
+    dec = decorrelators(layout)
+    if block < 512:
+        dec = dec[:, :block].copy()
+    x = scenes.audio(m, total, seed=seed)
+    # random partition of the blocks into calls
+    calls = []
+    left = nblocks
+    while left > 0:
+        c = int(rng.integers(1, left + 1))
+        calls.append(c)
+        left -= c
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, calls)
+    assert scenes.rel_rms(got, want) <= 1e-6, (layout, block, nblocks, m, kind, calls)
