@@ -132,6 +132,49 @@ def test_matrix_dense_ramps(m, n, length, strict):
         assert rel_rms(got, want) <= 1e-6
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_matrix_random_curves_and_call_partitions(seed):
+    """Whole-curve GainInterpolator<LinearInterpMatrix>: random point times (duplicates, negative, beyond
+    the end), random start time and call sizes; strict mode bit-exact, default mode <= 1e-6."""
+    from libear_amd import capi
+    rng = np.random.default_rng(50 + seed)
+    m = int(rng.choice([1, 2, 9, 31, 32, 40, 65]))
+    n = int(rng.choice([1, 3, 10, 24]))
+    length = int(rng.integers(50, 2500))
+    t0 = int(rng.integers(-500, 500))
+    npts = int(rng.integers(1, 12))
+    times = np.sort(rng.integers(t0 - 200, t0 + length + 200, npts))
+    if npts > 3 and seed % 2:
+        times[2] = times[1]  # a step
+    vals = rng.uniform(0, 1, (npts, m, n)).astype(np.float32)
+    if npts > 2 and seed % 3 == 0:
+        vals[-1] = vals[-2]  # a constant segment
+    x = rng.uniform(-1, 1, (m, length)).astype(np.float32)
+    calls, left = [], length
+    while left > 0:
+        c = int(rng.integers(1, left + 1))
+        calls.append(c)
+        left -= c
+    want = _oracle.gain_interp("matrix", times, vals, x, calls, t0=t0)
+    for strict in (True, False):
+        ctx().set_strict(strict)
+        try:
+            gi = capi.GainInterp(ctx(), m, n)
+            gi.set_points(times, vals)
+            parts, at = [], 0
+            for c in calls:
+                parts.append(gi.process(t0 + at, x[:, at:at + c]))
+                at += c
+            got = np.concatenate(parts, axis=1)
+            gi.close()
+        finally:
+            ctx().set_strict(False)
+        if strict:
+            assert np.array_equal(got, want), (m, n, length, t0, calls)
+        else:
+            assert rel_rms(got, want) <= 1e-6, (m, n, length, t0, calls)
+
+
 def test_errors():
     from libear_amd import capi
     gi = capi.GainInterp(ctx(), 1, 1)
