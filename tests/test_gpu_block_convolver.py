@@ -59,6 +59,49 @@ def test_other_block_sizes_dense_input(block):
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-6
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_filter_schedules(seed):
+    """Random block size, partition count, filter lengths and a random schedule of silent blocks (None),
+    crossfades, hard switches, fade-downs and unsets: same operations on the HIP convolver and on the
+    CPU oracle (restated block_convolver_impl.cpp), every sample within abs 1e-6 / rel 1e-6."""
+    ConvCtx, ConvFilter, BlockConvolver = _hip_classes()
+    rng = np.random.default_rng(300 + seed)
+    block = int(rng.choice([32, 64, 128, 512]))
+    nparts = int(rng.integers(1, 5))
+    nblk = int(rng.integers(6, 14))
+    x = rng.uniform(-1, 1, nblk * block).astype(np.float32)
+    irs = [rng.uniform(-1, 1, int(rng.integers(1, nparts * block + 1))).astype(np.float32) / 8 for _ in range(3)]
+    ops = [(int(rng.integers(0, nblk)), str(rng.choice(["crossfade", "set", "fade_down", "unset", "silent"])),
+            int(rng.integers(0, 3))) for _ in range(int(rng.integers(1, 6)))]
+
+    def run(c, F, BC):
+        f = [F(c, ir) for ir in irs]
+        conv = BC(c, f[0] if seed % 2 else None, nparts)
+        out = np.zeros_like(x)
+        for b in range(nblk):
+            silent = False
+            for at, op, which in ops:
+                if at != b:
+                    continue
+                if op == "crossfade":
+                    conv.crossfade_filter(f[which])
+                elif op == "set":
+                    conv.set_filter(f[which])
+                elif op == "fade_down":
+                    conv.fade_down()
+                elif op == "unset":
+                    conv.unset_filter()
+                else:
+                    silent = True
+            out[b * block:(b + 1) * block] = conv.process(None if silent else x[b * block:(b + 1) * block])
+        return out
+
+    got = run(ConvCtx(ctx(), block), ConvFilter, BlockConvolver)
+    ref = run(_oracle.ConvCtx(block), _oracle.ConvFilter, _oracle.BlockConvolver)
+    assert np.max(np.abs(got - ref)) < 2e-6, (block, nparts, nblk, ops)
+    assert np.linalg.norm(got - ref) <= 1e-6 * max(np.linalg.norm(ref), 1e-3), (block, nparts, nblk, ops)
+
+
 def test_errors():
     from libear_amd import capi
     ConvCtx, ConvFilter, BlockConvolver = _hip_classes()
