@@ -57,6 +57,9 @@ class CurveSet {
     }
     dirty_ = true;
   }
+  ~CurveSet() {
+    if (staged_) (void)hipEventDestroy(staged_);
+  }
   int M() const { return M_; }
   int ncols() const { return ncols_; }
   const ColumnPlan &plan() const { return plan_; }
@@ -98,15 +101,41 @@ class CurveSet {
     dirty_ = true;
   }
 
-  // flatten and upload (setup-time; synchronous)
+  // Flatten and upload.  The image is staged in pinned memory and copied on the
+  // context's stream: kernels already enqueued still see the old image (stream order),
+  // the caller does not wait for the GPU.  Only growing a device buffer, or re-using
+  // the staging buffers while their last copy is still in flight, synchronises.
   void commit(earhip_ctx *ctx) {
     if (!dirty_) return;
     size_t P = 0;
     for (int m = 0; m < M_; m++) P += times_[m].size();
-    std::vector<int32_t> off(M_ + 1);
-    std::vector<int64_t> time(P);
-    std::vector<uint8_t> flat(P);
-    std::vector<float> gain((P + 1) * plan_.row);  // + one all-zero row (k_gain_mix_bf3)
+    const size_t row = (size_t)plan_.row;
+    if (staged_) EARHIP_HIP(hipEventSynchronize(staged_));  // staging buffers free again
+    if (M_ + 1 > (int)h_off_.n || P > h_time_.n || (P + 1) * row > h_gain_.n) {
+      const size_t cap = P + P / 2 + 16;  // grow with headroom: appending points stays cheap
+      h_off_.reserve(M_ + 1);
+      h_time_.reserve(cap);
+      h_flat_.reserve(cap);
+      h_gain_.reserve((cap + 1) * row);
+    }
+    if (P > d_time_.n || (P + 1) * row > d_gain_.n || (size_t)M_ + 1 > d_off_.n) {
+      EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // the old image may still be in use
+      d_off_.reserve(M_ + 1);
+      d_time_.reserve(h_time_.n);
+      d_flat_.reserve(h_flat_.n);
+      d_gain_.reserve(h_gain_.n);
+    }
+    size_t at = 0;
+    for (int m = 0; m < M_; m++) {
+      h_off_.p[m] = (int32_t)at;
+      const size_t n = times_[m].size();
+      std::memcpy(h_time_.p + at, times_[m].data(), n * sizeof(int64_t));
+      std::memcpy(h_gain_.p + at * row, gains_[m].data(), n * row * sizeof(float));
+      std::memcpy(h_flat_.p + at, flat_[m].data(), n);
+      at += n;
+    }
+    h_off_.p[M_] = (int32_t)at;
+    std::memset(h_gain_.p + P * row, 0, row * sizeof(float));  // the all-zero row (k_gain_mix_bf3)
     npoints_ = (int)P;
     // common grid of all point times: every time is t_ref_ + k * grid_ (grid_ = 0: all equal)
     t_ref_ = P ? times_[0][0] : 0;
@@ -133,25 +162,12 @@ class CurveSet {
       }
     }
     ramp_share_ = span > 0 ? ramp / span : 0.0;
-    size_t at = 0;
-    for (int m = 0; m < M_; m++) {
-      off[m] = (int32_t)at;
-      const size_t n = times_[m].size();
-      std::memcpy(&time[at], times_[m].data(), n * sizeof(int64_t));
-      std::memcpy(&gain[at * plan_.row], gains_[m].data(), n * plan_.row * sizeof(float));
-      std::memcpy(&flat[at], flat_[m].data(), n);
-      at += n;
-    }
-    off[M_] = (int32_t)at;
-    EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // old image may still be in use
-    d_off_.reserve(off.size());
-    d_time_.reserve(P);
-    d_flat_.reserve(P);
-    d_gain_.reserve(gain.size());
-    EARHIP_HIP(hipMemcpy(d_off_.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    EARHIP_HIP(hipMemcpy(d_time_.p, time.data(), P * sizeof(int64_t), hipMemcpyHostToDevice));
-    EARHIP_HIP(hipMemcpy(d_flat_.p, flat.data(), P, hipMemcpyHostToDevice));
-    EARHIP_HIP(hipMemcpy(d_gain_.p, gain.data(), gain.size() * sizeof(float), hipMemcpyHostToDevice));
+    EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, (M_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, P * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, P, hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, (P + 1) * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (!staged_) EARHIP_HIP(hipEventCreateWithFlags(&staged_, hipEventDisableTiming));
+    EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
     dirty_ = false;
   }
 
@@ -195,6 +211,11 @@ class CurveSet {
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
   DevBuf<float> d_gain_;
+  PinBuf<int32_t> h_off_;
+  PinBuf<int64_t> h_time_;
+  PinBuf<uint8_t> h_flat_;
+  PinBuf<float> h_gain_;
+  hipEvent_t staged_ = nullptr;
 };
 
 // How K1 is spread over the chip for one call.
