@@ -322,3 +322,33 @@ def test_random_scenes_vs_oracle(seed):
     want = run_oracle(curves, x, n, block, dec, 255)
     got = run_hip(curves, x, n, block, dec, 255, calls)
     assert scenes.rel_rms(got, want) <= 1e-6, (layout, block, nblocks, m, kind, calls)
+
+
+@pytest.mark.parametrize("seed", list(range(4)))
+def test_random_large_scenes_vs_oracle(seed):
+    """Like test_random_scenes_vs_oracle at object counts and stream lengths where the kernels run
+    many pipeline groups per wave and short calls split the objects over workgroups."""
+    rng = np.random.default_rng(7000 + seed)
+    layout, block = "9+10+3", 512
+    n = len(LAYOUTS[layout])
+    m = int([257, 600, 1023, 1100][seed])
+    nblocks = int(rng.integers(12, 33))
+    total = block * nblocks
+    if seed % 3 == 0:
+        curves = scenes.adm_curves(m, n, total, period=int(rng.integers(300, 1500)), ramp=int(rng.integers(10, 290)), seed=seed)
+    elif seed % 3 == 1:
+        curves = scenes.dense_curves(m, n, block, nblocks, seed=seed)
+    else:
+        curves = scenes.ragged_curves(m, n, total, seed=seed)
+    dec = decorrelators(layout)
+    x = scenes.audio(m, total, seed=seed)
+    calls, left = [], nblocks
+    while left > 0:
+        c = int(rng.integers(1, min(left, 16) + 1))
+        calls.append(c)
+        left -= c
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, calls)
+    assert scenes.rel_rms(got, want) <= 1e-6, (m, nblocks, calls)
+    whole = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(whole, want) <= 1e-6
