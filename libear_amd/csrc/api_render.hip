@@ -318,11 +318,10 @@ int earhip_render_reset(earhip_render *r, int64_t sample_time) {
     require(r != nullptr, "render must not be NULL");
     r->ctx->use();
     r->t = sample_time;
-    if (r->K == 2)
-      for (int i = 0; i < 2; i++) {
-        EARHIP_HIP(hipMemsetAsync(r->tail[i].p, 0, r->tail[i].n * sizeof(float), r->ctx->stream));
-        EARHIP_HIP(hipMemsetAsync(r->dly[i].p, 0, r->dly[i].n * sizeof(float), r->ctx->stream));
-      }
+    if (r->K == 2) {  // only the buffers the next call reads; it rewrites the other pair completely
+      EARHIP_HIP(hipMemsetAsync(r->tail[r->cur].p, 0, r->tail[r->cur].n * sizeof(float), r->ctx->stream));
+      EARHIP_HIP(hipMemsetAsync(r->dly[r->cur].p, 0, r->dly[r->cur].n * sizeof(float), r->ctx->stream));
+    }
   });
 }
 
