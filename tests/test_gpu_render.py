@@ -352,3 +352,21 @@ def test_random_large_scenes_vs_oracle(seed):
     assert scenes.rel_rms(got, want) <= 1e-6, (m, nblocks, calls)
     whole = run_hip(curves, x, n, block, dec, 255, [nblocks])
     assert scenes.rel_rms(whole, want) <= 1e-6
+
+
+@pytest.mark.parametrize("block,nblocks,m", [(64, 12, 40), (4096, 2, 24), (2048, 3, 33)])
+def test_block_size_limits(block, nblocks, m):
+    """smallest and largest block sizes of the fused render (FFT lengths 128 and 8192)"""
+    layout = "4+5+0"
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    if block < 512:
+        dec = dec[:, :block].copy()
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=777, ramp=100, seed=block)
+    x = scenes.audio(m, total, seed=block)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(got, want) <= 1e-6
+    step = run_hip(curves, x, n, block, dec, 255, [1] * nblocks)
+    assert scenes.rel_rms(step, want) <= 1e-6
