@@ -58,18 +58,32 @@ __device__ __forceinline__ void r4_core_w(cf v0, cf v1, cf v2, cf v3, cf *out, i
   out[base + 3 * Ns] = cf_sub(a1, a3);
 }
 
+// the same butterfly with its four results returned instead of stored
+template <int DIR>
+__device__ __forceinline__ void r4_vals_w(cf v0, cf v1, cf v2, cf v3, const cf (&w)[3], cf (&o)[4]) {
+  v1 = cf_mul(v1, DIR > 0 ? cf_conj(w[0]) : w[0]);
+  v2 = cf_mul(v2, DIR > 0 ? cf_conj(w[1]) : w[1]);
+  v3 = cf_mul(v3, DIR > 0 ? cf_conj(w[2]) : w[2]);
+  const cf a0 = cf_add(v0, v2), a1 = cf_sub(v0, v2);
+  const cf a2 = cf_add(v1, v3), a3 = cf_mul_i<DIR>(cf_sub(v1, v3));
+  o[0] = cf_add(a0, a2);
+  o[1] = cf_add(a1, a3);
+  o[2] = cf_sub(a0, a2);
+  o[3] = cf_sub(a1, a3);
+}
+
 // fft_run_passes of fft_lds.h for a power-of-four L with one butterfly per thread and
 // the twiddles of this thread's butterflies held in registers (twr[p - 1] for pass p)
 template <int L, int DIR, int NT>
 __device__ __forceinline__ cf *fft_run_passes_w(cf *src, cf *dst, const cf (&twr)[fft_r4_passes(L) - 1][3],
-                                                int first, int tid) {
+                                                int first, int stop, int tid) {
   constexpr int NR4 = fft_r4_passes(L);
   static_assert(!fft_has_r2(L) && L / 4 == NT, "power-of-four length, one butterfly per thread");
   int Ns = 1;
   for (int p = 0; p < first; ++p) Ns *= 4;
 #pragma unroll
   for (int p = 0; p < NR4; ++p) {
-    if (p < first) continue;
+    if (p < first || p >= stop) continue;
     __syncthreads();
     if (p == 0) stockham_r4<L, DIR>(src, dst, nullptr, 1, tid);
     else r4_core_w<DIR>(src[tid], src[tid + L / 4], src[tid + L / 2], src[tid + 3 * L / 4], dst, Ns, tid, twr[p - 1]);
@@ -169,12 +183,20 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   for (int tb = first - 1; tb < last; tb += 2) {
     const bool have_re = tb >= 0, have_im = tb + 1 < last;
     __syncthreads();  // previous pair's reads of a/b are finished
+    if constexpr (kTwInRegs) {
+      // One butterfly per thread: the first forward pass takes this thread's own two
+      // samples (inputs 2 and 3 of its butterfly are the zero padding) straight from
+      // registers — no staging of the block in LDS, no padding writes.
+      static_assert(!kTwInRegs || EPT == 2, "two samples per thread and block");
+      r4_core<L, -1>(z[0], z[EPT - 1], cf_make(0.0f, 0.0f), cf_make(0.0f, 0.0f), b, tw, 1, tid);
+    } else {
 #pragma unroll
-    for (int e = 0; e < EPT; e++) {
-      const int i = tid + e * NT;
-      if (i < B) {
-        a[i] = z[e];
-        a[i + B] = cf_make(0.0f, 0.0f);  // zero padding of both blocks
+      for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * NT;
+        if (i < B) {
+          a[i] = z[e];
+          a[i + B] = cf_make(0.0f, 0.0f);  // zero padding of both blocks
+        }
       }
     }
     // request the next pair and this pair's delayed direct-bus samples now; they
@@ -188,7 +210,7 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       dim[e] = (i < B && have_im) ? delayed((tb + 1) * B + i) : 0.0f;
     }
     cf *Z;
-    if constexpr (kTwInRegs) Z = fft_run_passes_w<L, -1, NT>(a, b, twr, 0, tid);
+    if constexpr (kTwInRegs) Z = fft_run_passes_w<L, -1, NT>(b, a, twr, 1, fft_r4_passes(L), tid);
     else Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
     cf *W = Z == a ? b : a;
     __syncthreads();
@@ -201,29 +223,43 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
                        cf_mul(Z[j + L / 2], h[q][2]), cf_mul(Z[j + 3 * L / 4], h[q][3]), W, tw,
                        1, j);
     }
-    cf *y;
-    if constexpr (kTwInRegs) y = fft_run_passes_w<L, +1, NT>(W, Z, twr, 1, tid);
-    else y = fft_run_passes<L, +1, NT>(W, Z, tw, 1, tid);
-    __syncthreads();
     // real part = block tb, imaginary part = block tb+1
-#pragma unroll
-    for (int e = 0; e < EPT; e++) {
+    auto overlap_add = [&](int e, cf y_lo, cf y_hi) {  // y[i], y[B + i] of sample i = tid + e*NT
       const int i = tid + e * NT;
-      if (i >= B) continue;
       float tl = tail[i];
       if (have_re) {
         if (tb >= first) {
-          const float dec = (y[i].x + tl) * norm;  // :223-226
+          const float dec = (y_lo.x + tl) * norm;  // :223-226
           out[tb * B + i] = dec + dre[e];
         }
-        tl = y[B + i].x;  // :224
+        tl = y_hi.x;  // :224
       }
       if (have_im) {
-        const float dec = (y[i].y + tl) * norm;
+        const float dec = (y_lo.y + tl) * norm;
         out[(tb + 1) * B + i] = dec + dim[e];
-        tl = y[B + i].y;
+        tl = y_hi.y;
       }
       tail[i] = tl;
+    };
+    if constexpr (kTwInRegs) {
+      // ... and the last inverse pass hands its four results (samples tid, tid + 256 and
+      // their tails at + B) to the overlap-add in registers instead of through LDS
+      constexpr int NR4 = fft_r4_passes(L);
+      cf *src = fft_run_passes_w<L, +1, NT>(W, Z, twr, 1, NR4 - 1, tid);
+      __syncthreads();
+      cf o[4];
+      r4_vals_w<+1>(src[tid], src[tid + L / 4], src[tid + L / 2], src[tid + 3 * L / 4], twr[NR4 - 2], o);
+      overlap_add(0, o[0], o[2]);
+      overlap_add(1, o[1], o[3]);
+    } else {
+      cf *y = fft_run_passes<L, +1, NT>(W, Z, tw, 1, tid);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * NT;
+        if (i >= B) continue;
+        overlap_add(e, y[i], y[B + i]);
+      }
     }
   }
 
