@@ -209,19 +209,32 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       dre[e] = (i < B && have_re && tb >= first) ? delayed(tb * B + i) : 0.0f;
       dim[e] = (i < B && have_im) ? delayed((tb + 1) * B + i) : 0.0f;
     }
-    cf *Z;
-    if constexpr (kTwInRegs) Z = fft_run_passes_w<L, -1, NT>(b, a, twr, 1, fft_r4_passes(L), tid);
-    else Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
-    cf *W = Z == a ? b : a;
-    __syncthreads();
-    // first inverse pass with the spectral multiply folded into its loads
+    cf *Z, *W;
+    if constexpr (kTwInRegs) {
+      // The last forward pass produces bins tid + r*L/4, exactly the four inputs of this
+      // thread's butterfly in the first inverse pass: multiply by H and go on in registers.
+      constexpr int NR4 = fft_r4_passes(L);
+      cf *src = fft_run_passes_w<L, -1, NT>(b, a, twr, 1, NR4 - 1, tid);
+      __syncthreads();
+      cf o[4];
+      r4_vals_w<-1>(src[tid], src[tid + L / 4], src[tid + L / 2], src[tid + 3 * L / 4], twr[NR4 - 2], o);
+      W = src == a ? b : a;
+      Z = src;
+      r4_core<L, +1>(cf_mul(o[0], h[0][0]), cf_mul(o[1], h[0][1]), cf_mul(o[2], h[0][2]),
+                     cf_mul(o[3], h[0][3]), W, tw, 1, tid);
+    } else {
+      Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
+      W = Z == a ? b : a;
+      __syncthreads();
+      // first inverse pass with the spectral multiply folded into its loads
 #pragma unroll
-    for (int q = 0; q < BPT; q++) {
-      const int j = tid + q * NT;
-      if (j < L / 4)
-        r4_core<L, +1>(cf_mul(Z[j], h[q][0]), cf_mul(Z[j + L / 4], h[q][1]),
-                       cf_mul(Z[j + L / 2], h[q][2]), cf_mul(Z[j + 3 * L / 4], h[q][3]), W, tw,
-                       1, j);
+      for (int q = 0; q < BPT; q++) {
+        const int j = tid + q * NT;
+        if (j < L / 4)
+          r4_core<L, +1>(cf_mul(Z[j], h[q][0]), cf_mul(Z[j + L / 4], h[q][1]),
+                         cf_mul(Z[j + L / 2], h[q][2]), cf_mul(Z[j + 3 * L / 4], h[q][3]), W, tw,
+                         1, j);
+      }
     }
     // real part = block tb, imaginary part = block tb+1
     auto overlap_add = [&](int e, cf y_lo, cf y_hi) {  // y[i], y[B + i] of sample i = tid + e*NT
