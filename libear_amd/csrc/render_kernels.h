@@ -142,9 +142,18 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
     }
   }
 
+  // one bus sample = sum of the partial slabs of a short call's object splits, four loads
+  // in flight at a time (a dependent chain of up to 16 loads cost block mode 14 us)
   auto bus_at = [&](const float *row, int s) {
-    float v = row[s];
-    for (int p = 1; p < P.nparts; p++) v += row[(size_t)p * P.part_stride + s];
+    const float *q = row + s;
+    float v = q[0];
+    int p = 1;
+    for (; p + 3 < P.nparts; p += 4) {
+      const float a = q[(size_t)p * P.part_stride], b = q[(size_t)(p + 1) * P.part_stride];
+      const float c = q[(size_t)(p + 2) * P.part_stride], d = q[(size_t)(p + 3) * P.part_stride];
+      v += (a + b) + (c + d);
+    }
+    for (; p < P.nparts; p++) v += q[(size_t)p * P.part_stride];
     return v;
   };
   // direct bus delayed by D: sample s of the call (s may reach back into state)
