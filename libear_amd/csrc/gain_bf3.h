@@ -261,7 +261,6 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
       float S[8], E[8];
       ChunkDesc D;
       load_gains(L, c + 1, D, S, E);  // chunk c+1 (its descriptors were fetched one chunk ago)
-      load_x(min(c + 1, nch - 1), xn);
       L = load_desc(c + 2);
 
       // A fragments: row tile r = sample 4*li + r of the 8 objects of this lane
@@ -317,12 +316,17 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
 #pragma unroll
         for (int r = 0; r < NRT; r++) tc[r] = mfma_bf16(ah[r], bc[0], tc[r]);
         if (blk > 0) fold(blk - 1, t[(blk - 1) & 1]);
-        const bool conv0 = blk == 1, conv1 = blk == NBLK - 1, copy = blk == (NBLK > 2 ? NBLK - 2 : 0);
+        // The vector-memory counter is in order: a wait for one load waits for every older
+        // one.  So the gain rows (requested at the top of the chunk) are consumed FIRST, in
+        // blocks 0 and 1, and only then are the next chunk's inputs requested; they are waited
+        // for at the hand-over after the last block.  (With the inputs requested at the top,
+        // the first use of a gain row waited for them too and serialised the prefetch.)
+        const bool conv0 = blk == 0, conv1 = blk == 1, copy = false;
         if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
         if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
-        if (copy) {
-#pragma unroll
-          for (int q = 0; q < 8; q++) xc[q] = xn[q];
+        if (blk == (NBLK > 2 ? 2 : 1)) {
+          load_x(min(c + 1, nch - 1), xn);
+          __builtin_amdgcn_sched_barrier(0);  // keep the requests here, not at the end of the chunk
         }
         // issue order: the LDS reads first, then every MFMA followed by 1-3 VALU instructions
         if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
@@ -349,6 +353,8 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
         }
       }
       fold(NBLK - 1, t[(NBLK - 1) & 1]);
+#pragma unroll
+      for (int q = 0; q < 8; q++) xc[q] = xn[q];
     }
 
     // objects with curve points inside this workgroup tile (zero rows above)
