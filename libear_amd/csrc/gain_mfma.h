@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
     const unsigned goff0 = (unsigned)(col0 + li * NCT);
     const float lif = (float)(li * NRT);
 
-    // Software pipeline over the steps [lo, hi) of one slot list: slots 6 steps
+    // Software pipeline over the steps [lo, hi) of one slot list: slots 8 steps
     // ahead, inputs 4, gain rows 2, next step's A fragments woven between the MFMAs.
     // Steps are issued in groups of 8 with fixed ring positions (no branches and no
     // register moves inside a group); steps past `hi` and slots past `n` get zero
@@ -158,15 +158,10 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       const int hi = (int)(((int64_t)nsteps * (part + 1)) / nparts);
       if (lo >= hi) return;
       const int4 *sp = reinterpret_cast<const int4 *>(base);
-      auto load_slot = [&](int i) {
-        const int idx = 4 * i + kk;
-        int4 sv = sp[min(idx, n - 1)];
-        if (idx >= n || i >= hi) {
-          sv.z = 0;  // alpha = beta = 0
-          sv.w = 0;
-        }
-        return sv;
-      };
+      // (the loaded slot is not touched here: anything that reads it would wait for this,
+      // the youngest, load — i.e. for ALL loads in flight — and serialise the prefetch;
+      // slots past the list or past this wave's share are zeroed in make_a instead)
+      auto load_slot = [&](int i) { return sp[min(4 * i + kk, n - 1)]; };
       auto load_x = [&](const int4 &sv, float (&x)[NRT]) {
         const float *xr = P.in + (size_t)(sv.x & 0xffff) * P.in_stride;
 #pragma unroll
@@ -181,8 +176,9 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
 #pragma unroll
         for (int c = 0; c < NCT; c++) gv[c] = gp[c];
       };
-      auto make_a = [&](const int4 &sv, const float (&x)[NRT], float (&a)[NRT]) {
-        const float alpha = __int_as_float(sv.z), beta = __int_as_float(sv.w);
+      auto make_a = [&](const int4 &sv, int step, const float (&x)[NRT], float (&a)[NRT]) {
+        const bool live = 4 * step + kk < n && step < hi;
+        const float alpha = live ? __int_as_float(sv.z) : 0.0f, beta = live ? __int_as_float(sv.w) : 0.0f;
         const float c0 = __builtin_fmaf(beta, lif, alpha);  // coefficient of the lane's first sample
         const int r0 = (sv.x >> 16) & 0xff;
         const int rel = li * NRT - r0;                          // s - r0 of the lane's first sample
@@ -197,13 +193,12 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       int4 S[8];
       float X[4][NRT], A[2][NRT], G[2][NCT];
 #pragma unroll
-      for (int j = 0; j < 6; j++) S[j] = load_slot(lo + j);
-      S[6] = S[7] = S[0];
+      for (int j = 0; j < 8; j++) S[j] = load_slot(lo + j);
 #pragma unroll
       for (int j = 0; j < 4; j++) load_x(S[j], X[j]);
       load_g(S[0], G[0]);
       load_g(S[1], G[1]);
-      make_a(S[0], X[0], A[0]);
+      make_a(S[0], lo, X[0], A[0]);
       load_x(S[4], X[0]);
 #pragma unroll 1
       for (int i = lo; i < hi; i += 8) {
@@ -211,16 +206,22 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
         for (int j = 0; j < 8; j++) {
           // step i + j: slot ring position j, inputs (j+1)&3 next, gains j&1
           mma(A[j & 1], G[j & 1]);
-          make_a(S[(j + 1) & 7], X[(j + 1) & 3], A[(j + 1) & 1]);
-          load_x(S[(j + 5) & 7], X[(j + 1) & 3]);
+          make_a(S[(j + 1) & 7], i + j + 1, X[(j + 1) & 3], A[(j + 1) & 1]);
+          // requests in the order they are consumed (the vector-memory counter is in order:
+          // waiting for a gain row also waits for everything requested before it)
           load_g(S[(j + 2) & 7], G[j & 1]);
-          S[(j + 6) & 7] = load_slot(i + j + 6);
+          load_x(S[(j + 5) & 7], X[(j + 1) & 3]);
+          S[j] = load_slot(i + j + 8);  // first used (input address) three steps from now
 #pragma unroll
           for (int k = 0; k < NRT * NCT; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, MASKED ? 4 : 2, 0);  // VALU
             if (k < NRT / 4 + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
           }
+          // nothing moves across a step: otherwise the address arithmetic of a later step's
+          // input load is scheduled right behind the slot load it depends on, and the wait it
+          // needs there (the youngest load, so vmcnt(0)) stalls on every load in flight
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
