@@ -51,6 +51,8 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   constexpr int TS = 16 * NRT;      // samples per tile
   constexpr int NC = 16 * NCT;      // columns per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [ngroups][NRT*NCT][64][4]
+  // per wave: two batches of 64 slots (16 steps), see run()
+  __shared__ int4 slot_stage[8][2][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // waves of a workgroup = column groups x adjacent tiles x object splits.  Waves
@@ -158,10 +160,17 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       const int hi = (int)(((int64_t)nsteps * (part + 1)) / nparts);
       if (lo >= hi) return;
       const int4 *sp = reinterpret_cast<const int4 *>(base);
-      // (the loaded slot is not touched here: anything that reads it would wait for this,
-      // the youngest, load — i.e. for ALL loads in flight — and serialise the prefetch;
-      // slots past the list or past this wave's share are zeroed in make_a instead)
-      auto load_slot = [&](int i) { return sp[min(4 * i + kk, n - 1)]; };
+      // Slots reach the lanes through LDS: one coalesced 1 KB load brings the 64 slots of
+      // 16 steps into a wave-private buffer a whole batch ahead, and each step reads its
+      // four slots from there (LDS has its own counter).  Loading a slot per step and lane
+      // from global memory put a dependent load (slot -> input address) into the in-order
+      // vector-memory stream, and every wait for it also waited for the inputs in flight.
+      int4(&stage)[2][64] = slot_stage[threadIdx.x >> 6];
+      auto batch_load = [&](int b) { return sp[min(4 * (lo + 16 * b) + lane, n - 1)]; };
+      auto read_slot = [&](int step) {
+        const int r = step - lo;
+        return stage[(r >> 4) & 1][((r & 15) << 2) + kk];
+      };
       auto load_x = [&](const int4 &sv, float (&x)[NRT]) {
         const float *xr = P.in + (size_t)(sv.x & 0xffff) * P.in_stride;
 #pragma unroll
@@ -192,8 +201,10 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       };
       int4 S[8];
       float X[4][NRT], A[2][NRT], G[2][NCT];
+      stage[0][lane] = batch_load(0);
+      int4 gnext = batch_load(1);
 #pragma unroll
-      for (int j = 0; j < 8; j++) S[j] = load_slot(lo + j);
+      for (int j = 0; j < 8; j++) S[j] = read_slot(lo + j);
 #pragma unroll
       for (int j = 0; j < 4; j++) load_x(S[j], X[j]);
       load_g(S[0], G[0]);
@@ -201,27 +212,28 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
       make_a(S[0], lo, X[0], A[0]);
       load_x(S[4], X[0]);
 #pragma unroll 1
-      for (int i = lo; i < hi; i += 8) {
+      for (int i = lo; i < hi; i += 16) {
+        // batch (i - lo)/16 + 1 becomes readable (the steps below look 8 steps ahead), the
+        // one after it is requested
+        stage[(((i - lo) >> 4) + 1) & 1][lane] = gnext;
+        gnext = batch_load(((i - lo) >> 4) + 2);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          // step i + j: slot ring position j, inputs (j+1)&3 next, gains j&1
+        for (int j = 0; j < 16; j++) {
+          // step i + j: slot ring position j & 7, inputs (j+1)&3 next, gains j&1
           mma(A[j & 1], G[j & 1]);
           make_a(S[(j + 1) & 7], i + j + 1, X[(j + 1) & 3], A[(j + 1) & 1]);
           // requests in the order they are consumed (the vector-memory counter is in order:
           // waiting for a gain row also waits for everything requested before it)
           load_g(S[(j + 2) & 7], G[j & 1]);
           load_x(S[(j + 5) & 7], X[(j + 1) & 3]);
-          S[j] = load_slot(i + j + 8);  // first used (input address) three steps from now
+          S[j & 7] = read_slot(i + j + 8);
 #pragma unroll
           for (int k = 0; k < NRT * NCT; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, MASKED ? 4 : 2, 0);  // VALU
-            if (k < NRT / 4 + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+            if (k < NRT / 4 + 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
           }
-          // nothing moves across a step: otherwise the address arithmetic of a later step's
-          // input load is scheduled right behind the slot load it depends on, and the wait it
-          // needs there (the youngest load, so vmcnt(0)) stalls on every load in flight
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);  // nothing moves across a step
         }
       }
     };
