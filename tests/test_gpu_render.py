@@ -370,3 +370,37 @@ def test_block_size_limits(block, nblocks, m):
     assert scenes.rel_rms(got, want) <= 1e-6
     step = run_hip(curves, x, n, block, dec, 255, [1] * nblocks)
     assert scenes.rel_rms(step, want) <= 1e-6
+
+
+def test_gain_kernel_choice_follows_the_curves():
+    """bf16x3 kernel (2) for block-aligned ramps, f32 slot kernel (1) for curves that ignore the tile
+    grid or are mostly constant, VALU kernel (0) in strict mode; small object counts never use (2)."""
+    from libear_amd import capi
+    layout, block, nblocks = "0+5+0", 512, 4
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+
+    def kernel_for(m, curves, strict=False, t0=0):
+        ctx().set_strict(strict)
+        try:
+            r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+            set_renderer_curves(r, curves, True)
+            r.reset(t0)
+            r.process(scenes.audio(m, total))
+            k = r.gain_kernel()
+            r.close()
+        finally:
+            ctx().set_strict(False)
+        return k
+
+    forced = os.environ.get("EARHIP_MFMA")
+    if forced not in (None, "3"):
+        pytest.skip("kernel forced by EARHIP_MFMA")
+    dense = scenes.dense_curves(64, n, block, nblocks)
+    assert kernel_for(64, dense) == 2
+    assert kernel_for(64, dense, t0=17) == 1          # same curves, call grid shifted off the points
+    assert kernel_for(64, dense, strict=True) == 0
+    assert kernel_for(16, scenes.dense_curves(16, n, block, nblocks)) == 1   # fewer than 32 objects
+    assert kernel_for(64, scenes.adm_curves(64, n, total, seed=1)) == 1
+    assert kernel_for(64, scenes.constant_curves(64, n)) == 1
