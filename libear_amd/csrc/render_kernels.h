@@ -95,6 +95,25 @@ __device__ __forceinline__ cf *fft_run_passes_w(cf *src, cf *dst, const cf (&twr
   return src;
 }
 
+// radix-4 passes [first, stop) of fft_run_passes (fft_lds.h) with table twiddles and several
+// butterflies per thread; the trailing radix-2 pass of an odd log2(L) is left to the caller
+template <int L, int DIR, int NT>
+__device__ __forceinline__ cf *fft_r4_range(cf *src, cf *dst, const cf *tw, int first, int stop, int tid) {
+  int Ns = 1;
+  for (int p = 0; p < first; ++p) Ns *= 4;
+#pragma unroll
+  for (int p = 0; p < fft_r4_passes(L); ++p) {
+    if (p < first || p >= stop) continue;
+    __syncthreads();
+    for (int j = tid; j < L / 4; j += NT) stockham_r4<L, DIR>(src, dst, tw, Ns, j);
+    cf *t = src;
+    src = dst;
+    dst = t;
+    Ns *= 4;
+  }
+  return src;
+}
+
 template <int L>
 __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   constexpr int B = L / 2;
@@ -109,6 +128,9 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   // 12 constants: held in registers they take 30 % off the LDS traffic of a pass, which
   // is what six co-resident workgroups per CU are bound by.
   constexpr bool kTwInRegs = L == 4 * NT;
+  // 2048 points: two radix-4 butterflies and four radix-2 butterflies per thread; the same three
+  // pass boundaries stay in registers (table twiddles from LDS)
+  constexpr bool kFused2k = L == 2048 && NT == 256;
   constexpr bool kTwInLds = L <= 2048 && !kTwInRegs;
   __shared__ __attribute__((aligned(16))) cf lds[2 * L + (kTwInLds ? L : 0)];
   __shared__ float tail[B];
@@ -198,6 +220,10 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       // registers — no staging of the block in LDS, no padding writes.
       static_assert(!kTwInRegs || EPT == 2, "two samples per thread and block");
       r4_core<L, -1>(z[0], z[EPT - 1], cf_make(0.0f, 0.0f), cf_make(0.0f, 0.0f), b, tw, 1, tid);
+    } else if constexpr (kFused2k) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)  // butterfly tid + 256 q: samples tid + 256 q and + 512; the rest is padding
+        r4_core<L, -1>(z[q], z[q + 2], cf_make(0.0f, 0.0f), cf_make(0.0f, 0.0f), b, tw, 1, tid + q * NT);
     } else {
 #pragma unroll
       for (int e = 0; e < EPT; e++) {
@@ -231,6 +257,24 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       Z = src;
       r4_core<L, +1>(cf_mul(o[0], h[0][0]), cf_mul(o[1], h[0][1]), cf_mul(o[2], h[0][2]),
                      cf_mul(o[3], h[0][3]), W, tw, 1, tid);
+    } else if constexpr (kFused2k) {
+      constexpr int NR4 = fft_r4_passes(L);
+      cf *src = fft_r4_range<L, -1, NT>(b, a, tw, 1, NR4, tid);
+      __syncthreads();
+      cf o[4][2];  // radix-2 pass (Ns = L/2): bins tid + 256 q and + 1024
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = tid + q * NT;
+        const cf v0 = src[j], v1 = cf_mul(src[j + L / 2], tw[j]);
+        o[q][0] = cf_add(v0, v1);
+        o[q][1] = cf_sub(v0, v1);
+      }
+      W = src == a ? b : a;
+      Z = src;
+#pragma unroll
+      for (int q = 0; q < 2; q++)  // first inverse butterfly tid + 256 q: bins j, j + 512, j + 1024, j + 1536
+        r4_core<L, +1>(cf_mul(o[q][0], h[q][0]), cf_mul(o[q + 2][0], h[q][1]), cf_mul(o[q][1], h[q][2]),
+                       cf_mul(o[q + 2][1], h[q][3]), W, tw, 1, tid + q * NT);
     } else {
       Z = fft_run_passes<L, -1, NT>(a, b, tw, 0, tid);
       W = Z == a ? b : a;
@@ -273,6 +317,16 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       r4_vals_w<+1>(src[tid], src[tid + L / 4], src[tid + L / 2], src[tid + 3 * L / 4], twr[NR4 - 2], o);
       overlap_add(0, o[0], o[2]);
       overlap_add(1, o[1], o[3]);
+    } else if constexpr (kFused2k) {
+      constexpr int NR4 = fft_r4_passes(L);
+      cf *src = fft_r4_range<L, +1, NT>(W, Z, tw, 1, NR4, tid);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; q++) {  // last (radix-2) pass: samples i = tid + 256 q and their tails at + B
+        const int j = tid + q * NT;
+        const cf v0 = src[j], v1 = cf_mul(src[j + L / 2], cf_conj(tw[j]));
+        overlap_add(q, cf_add(v0, v1), cf_sub(v0, v1));
+      }
     } else {
       cf *y = fft_run_passes<L, +1, NT>(W, Z, tw, 1, tid);
       __syncthreads();
