@@ -265,12 +265,27 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
 
       // A fragments: row tile r = sample 4*li + r of the 8 objects of this lane
       u32x4 ah[NRT], am[NRT], al[NRT];
+      // Split in 2 x 2 blocks: a bf16 pair packs two OBJECTS (q, q+1) of one row tile, while
+      // the exact residual subtractions pair two SAMPLES (r, r+1) of one object, which are
+      // neighbours in the loaded float4 — packed subtractions without operand moves.
 #pragma unroll
-      for (int r = 0; r < NRT; r++) {
-        const float v[8] = {xc[0][r], xc[1][r], xc[2][r], xc[3][r],
-                            xc[4][r], xc[5][r], xc[6][r], xc[7][r]};
-        split_bf16x3(v, ah[r], am[r], al[r]);
-      }
+      for (int qp = 0; qp < 4; qp++)
+#pragma unroll
+        for (int rp = 0; rp < NRT; rp += 2) {
+          const f32x4 &x0 = xc[2 * qp], &x1 = xc[2 * qp + 1];
+          const uint32_t H0 = pack_bf16(x0[rp], x1[rp]), H1 = pack_bf16(x0[rp + 1], x1[rp + 1]);
+          const f32x2 r0 = f32x2{x0[rp], x0[rp + 1]} - f32x2{bf16_lo(H0), bf16_lo(H1)};  // object 2qp
+          const f32x2 r1 = f32x2{x1[rp], x1[rp + 1]} - f32x2{bf16_hi(H0), bf16_hi(H1)};  // object 2qp+1
+          const uint32_t M0 = pack_bf16(r0[0], r1[0]), M1 = pack_bf16(r0[1], r1[1]);
+          const f32x2 t0 = r0 - f32x2{bf16_lo(M0), bf16_lo(M1)};
+          const f32x2 t1 = r1 - f32x2{bf16_hi(M0), bf16_hi(M1)};
+          ah[rp][qp] = H0;
+          ah[rp + 1][qp] = H1;
+          am[rp][qp] = M0;
+          am[rp + 1][qp] = M1;
+          al[rp][qp] = pack_bf16(t0[0], t1[0]);
+          al[rp + 1][qp] = pack_bf16(t0[1], t1[1]);
+        }
       // 2*NCT blocks (column tile ct = blk >> 1, operand blk & 1: B0 / B1) of 24 MFMAs:
       // six partial products per operand pair, smallest first, accumulated from zero.
       // A VALU instruction costs its 4 cycles on top of the MFMAs unless it sits
