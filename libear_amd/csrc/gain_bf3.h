@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
     const int nvec = (P.nsamples + 3) & ~3;
     const unsigned xs = (unsigned)min(tile_s0 + li * NRT, nvec - 4);
     const unsigned xlane = ((unsigned)(kg * 8) * (unsigned)P.in_stride + xs) * 4u;
-    const unsigned bcol = (unsigned)(col0 + min(lane, 16 * NCT - 1)) * 4u;
+    const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
     // fragment this lane fills: B0 pieces at bfr .. bfr+2, B1 pieces NCT*3 further
     const int blane = w * 16 + (lane & 15);
     const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;
@@ -213,15 +213,17 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
     };
     auto load_gains = [&](const int4 &raw, int c, ChunkDesc &D, float (&S)[8], float (&E)[8]) {
       const LaneDesc L = digest_desc(raw, c);
-      const char *gb = reinterpret_cast<const char *>(gain);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const unsigned rs = (unsigned)__builtin_amdgcn_readlane(L.row_s, q);
         const unsigned re = (unsigned)__builtin_amdgcn_readlane(L.row_e, q);
         D.p0[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.p0), q));
         D.scale[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.scale), q));
-        S[q] = *reinterpret_cast<const float *>(gb + (size_t)rs * rowlen * sizeof(float) + bcol);
-        E[q] = *reinterpret_cast<const float *>(gb + (size_t)re * rowlen * sizeof(float) + bcol);
+        // wave-uniform row pointer (scalar arithmetic) + the lane's column as a 32-bit offset:
+        // no vector instructions for the addresses
+        const float *rps = gain + (size_t)rs * rowlen, *rpe = gain + (size_t)re * rowlen;
+        S[q] = rps[bcol_e];
+        E[q] = rpe[bcol_e];
       }
     };
     // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's 8 objects -> LDS
