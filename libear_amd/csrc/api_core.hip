@@ -47,8 +47,13 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
   // K0: segment descriptors; for the f32 MFMA kernel K0s then turns them into the
   // tiles' slot lists, which live behind the descriptors in the same buffer (desc_units())
-  hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
-                     ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
+  // short curves (static or nearly static gains, <= 8 points per object on average): K0s finds
+  // the segments itself and the descriptor pass is skipped; with long curves the 16-lanes-per-
+  // object search of k_seg_prep is the faster one (measured both ways)
+  const bool fused_prep = slots && (size_t)ps.zero_row <= (size_t)8 * M;
+  if (!fused_prep)
+    hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
+                       ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
   sl.count = reinterpret_cast<int *>(sl.slots + (size_t)kTileSlots * M * ml.ntiles);
@@ -56,7 +61,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   sl.M = M;
   if (slots)
     hipLaunchKernelGGL(k_slot_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
-                       t_call, t_call + nsamples, desc, sl);
+                       t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
   P.sl = sl;

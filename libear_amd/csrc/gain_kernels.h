@@ -302,7 +302,12 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
     d.info = 0;
     int cp = 0, cm = 0;
     if (m < M) {
-      d = desc[(size_t)tile * M + m];
+      if (desc) {
+        d = desc[(size_t)tile * M + m];
+      } else {  // no descriptor pass: find the segment here
+        const int base = ps.off[m], n = ps.off[m + 1] - base;
+        d = describe_segment(ps, base, n, upper_bound_time_guess(ps.time + base, n, t0), t0, t_end);
+      }
       walk(m, d, nullptr, nullptr, cp, cm, nx, true);
     }
     // cp <= 2, cm <= 2 * 257 per object: 10 + 18 bits of one word per 256 objects
