@@ -26,6 +26,8 @@
 
 #include <cstdint>
 
+#include "search.h"
+
 namespace earhip {
 
 // Flattened gain curves of all objects (device pointers).
@@ -67,56 +69,6 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
   const int per = n >> 3;  // tiles per XCD
   if (b >= per * 8) return b;
   return (b & 7) * per + (b >> 3);
-}
-
-// number of points of object m with time <= t  (= libear's find_block result)
-__device__ __forceinline__ int upper_bound_time(const int64_t *t, int n, int64_t v) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (t[mid] <= v) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
-// Same result, started from where v would lie if the points were evenly spaced
-// (metadata usually is): a bracket is grown around the guess in doubling steps and
-// then bisected, so a good guess costs 3-4 dependent loads instead of log2(n) + 1.
-__device__ __forceinline__ int upper_bound_time_guess(const int64_t *t, int n, int64_t v) {
-  if (n < 8) return upper_bound_time(t, n, v);
-  const int64_t first = t[0], last = t[n - 1];
-  if (v < first) return 0;
-  if (v >= last) return n;
-  // first <= v < last: the answer k is in [1, n-1] with t[k-1] <= v < t[k]
-  int g = (int)((double)(v - first) / (double)(last - first) * (double)(n - 1));
-  g = g < 0 ? 0 : (g > n - 2 ? n - 2 : g);
-  int lo, hi;  // invariant: t[lo] <= v < t[hi]
-  if (t[g] <= v) {
-    lo = g;
-    int step = 1;
-    hi = g + 1;
-    while (hi < n - 1 && t[hi] <= v) {
-      lo = hi;
-      step <<= 1;
-      hi = hi + step > n - 1 ? n - 1 : hi + step;
-    }
-  } else {
-    hi = g;
-    int step = 1;
-    lo = g - 1;
-    while (lo > 0 && t[lo] > v) {
-      hi = lo;
-      step <<= 1;
-      lo = lo - step < 0 ? 0 : lo - step;
-    }
-  }
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (t[mid] <= v) lo = mid;
-    else hi = mid;
-  }
-  return hi;
 }
 
 // Describe segment k of an object for the tile [t0, t_end) (absolute times).

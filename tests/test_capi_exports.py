@@ -95,3 +95,13 @@ def test_fft_pass_algebra_on_cpu(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O2", src, "-o", str(exe)], check=True)
     res = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
     assert res.returncode == 0, res.stdout
+
+
+def test_segment_search_on_cpu(tmp_path):
+    """libear_amd/csrc/search.h: the guess-started search == plain upper bound (libear's find_block)"""
+    exe = tmp_path / "test_search"
+    src = os.path.join(ROOT, "tests", "cpp", "test_search.cpp")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "libear_amd", "csrc"),
+                    src, "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+    assert res.returncode == 0, res.stdout
