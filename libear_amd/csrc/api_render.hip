@@ -59,7 +59,14 @@ static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s) 
     case 128: launch_decor_t<128>(P, grid, s); break;
     case 256: launch_decor_t<256>(P, grid, s); break;
     case 512: launch_decor_t<512>(P, grid, s); break;
-    case 1024: launch_decor_t<1024>(P, grid, s); break;
+    case 1024:
+      if (getenv("EARHIP_K2_WG")) {  // the workgroup-per-run kernel (tuning / comparison)
+        launch_decor_t<1024>(P, grid, s);
+      } else {  // one wave per run, kDecorWaves runs per workgroup
+        hipLaunchKernelGGL(k_decorrelate_wave, dim3((grid.x + kDecorWaves - 1) / kDecorWaves, grid.y),
+                           dim3(64 * kDecorWaves), 0, s, P);
+      }
+      break;
     case 2048: launch_decor_t<2048>(P, grid, s); break;
     case 4096: launch_decor_t<4096>(P, grid, s); break;
     case 8192: launch_decor_t<8192>(P, grid, s); break;
@@ -68,13 +75,35 @@ static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s) 
   EARHIP_HIP(hipGetLastError());
 }
 
+// Run length (odd, so that the warm-up block pairs with the first one) of k_decorrelate_wave for a
+// call of T blocks on N loudspeakers.  A run of R blocks costs (R+1)/2 pair transforms, each
+// workgroup puts one wave on every SIMD, and a CU holds three workgroups (LDS): the cost of a
+// round of k = 1..3 resident workgroups per CU is pairs x c[k] with the measured pair times
+// c = 6.9, 9.3, 12.2 us (latency-bound at this occupancy).  DESIGN.md section 4, K2.
+static int wave_run_len(int T, int N, int num_cus) {
+  const double c[4] = {0.0, 6.9, 9.3, 12.2};
+  int best = 1;
+  double best_cost = 1e30;
+  for (int R = 1; R <= 31; R += 2) {
+    const long runs = (T + R - 1) / R;
+    const long wgs = (runs + earhip::kDecorWaves - 1) / earhip::kDecorWaves * N;
+    const long full = wgs / (3L * num_cus), rem = wgs - full * 3L * num_cus;
+    const double pairs = (R + 1) / 2;
+    const double cost = pairs * (full * c[3] + c[(rem + num_cus - 1) / num_cus]);
+    if (cost <= best_cost) best_cost = cost, best = R;  // (ties: the longer run does less warm-up work)
+    if (runs == 1) break;
+  }
+  return best;
+}
+
 struct earhip_render {
   earhip_ctx *ctx = nullptr;
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 bf16x3 MFMA
-  int run_len = 11;
+  int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
+  bool run_len_set = false;  // EARHIP_RUN given: also fixes the run length of the wave kernel
 
   DevBuf<SegDesc> desc;
   DevBuf<float> bus;  // [gsplit][K*N][bus_stride], strides chosen per call
@@ -179,9 +208,11 @@ struct earhip_render {
       P.dly_out = dly[cur ^ 1].p;
       P.N = N;
       P.T = (int)nblocks;
-      P.R = run_len;
+      const bool wave_k2 = L == 1024 && !getenv("EARHIP_K2_WG");
+      const int R = wave_k2 && !run_len_set ? wave_run_len((int)nblocks, N, ctx->num_cus) : run_len;
+      P.R = R;
       P.D = D;
-      const dim3 grid((unsigned)((nblocks + run_len - 1) / run_len), N);
+      const dim3 grid((unsigned)((nblocks + R - 1) / R), N);
       if (evp) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
       launch_decor(L, P, grid, ctx->stream);
       if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
@@ -226,7 +257,7 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->L = 2 * r->B;
     if (const char *e = getenv("EARHIP_RUN")) {  // tuning knob: blocks per decorrelator run (odd)
       const int v = atoi(e);
-      if (v >= 1 && v <= 255) r->run_len = v | 1;
+      if (v >= 1 && v <= 255) r->run_len = v | 1, r->run_len_set = true;
     }
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
     const size_t max_samples = (size_t)r->T * r->B;

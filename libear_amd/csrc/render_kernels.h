@@ -346,6 +346,242 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// K2 for 512-sample blocks, one WAVE per (loudspeaker, run of blocks): the 1024-point
+// transforms are Stockham passes of radix 16, 16 and 4 with 16 values per lane (indices
+// lane + 64 m — the same layout on input and output, so forward, x H and inverse chain
+// in registers), exchanged twice per transform through wave-private LDS.  No workgroup
+// barriers, 4 instead of 8 LDS round trips per pair of blocks, and the overlap-add tail
+// stays in registers.  (tools/experiments/wavefft.hip: 1.0e-7 from a double DFT.)
+//
+// Complex values live in aligned VGPR pairs (v2f) and every complex operation is ONE or TWO packed-f32
+// instructions whose op_sel / neg modifiers do the swaps and sign changes (left to itself the
+// compiler pairs real parts of different values and spends a v_mov per operand on it).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// a * w (DIR < 0) or a * conj(w) (DIR > 0): t = (ai wi, ai wr); r = (ar wr -/+ t.lo, +/- ar wi + t.hi)
+template <int DIR>
+__device__ __forceinline__ v2f wave_cmul(v2f a, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  if (DIR < 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+// the same with a wave-uniform constant w held in an SGPR pair
+template <int DIR>
+__device__ __forceinline__ v2f wave_cmul_k(v2f a, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+  if (DIR < 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  return r;
+}
+__device__ __forceinline__ v2f wave_add_i(v2f a, v2f t) {  // a + i t = (a.x - t.y, a.y + t.x)
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+__device__ __forceinline__ v2f wave_sub_i(v2f a, v2f t) {  // a - i t = (a.x + t.y, a.y - t.x)
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+// radix-4 butterfly; the forward transform multiplies the odd difference by -i, the inverse by +i
+template <int DIR>
+__device__ __forceinline__ void wave_r4(v2f &a, v2f &b, v2f &c, v2f &d) {
+  const v2f a0 = a + c, a1 = a - c, a2 = b + d, t = b - d;
+  a = a0 + a2;
+  c = a0 - a2;
+  b = DIR < 0 ? wave_sub_i(a1, t) : wave_add_i(a1, t);
+  d = DIR < 0 ? wave_add_i(a1, t) : wave_sub_i(a1, t);
+}
+
+// 16-point DFT in registers, natural order in and out (n = 4 n1 + n2, k = k1 + 4 k2)
+template <int DIR>
+__device__ __forceinline__ void wave_dft16(v2f (&v)[16]) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r2 = 0.70710678118654752f;
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) wave_r4<DIR>(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]);
+  const v2f W1 = {c1, -s1}, W2 = {r2, -r2}, W3 = {s1, -c1}, W4 = {0.0f, -1.0f}, W6 = {-r2, -r2}, W9 = {-c1, s1};
+  v[5] = wave_cmul_k<DIR>(v[5], W1);  // W16^{n2 k1}
+  v[6] = wave_cmul_k<DIR>(v[6], W2);
+  v[7] = wave_cmul_k<DIR>(v[7], W3);
+  v[9] = wave_cmul_k<DIR>(v[9], W2);
+  v[10] = wave_cmul_k<DIR>(v[10], W4);
+  v[11] = wave_cmul_k<DIR>(v[11], W6);
+  v[13] = wave_cmul_k<DIR>(v[13], W3);
+  v[14] = wave_cmul_k<DIR>(v[14], W6);
+  v[15] = wave_cmul_k<DIR>(v[15], W9);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) wave_r4<DIR>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  v2f t;
+#define EARHIP_SW(a, b) t = v[a], v[a] = v[b], v[b] = t;
+  EARHIP_SW(1, 4) EARHIP_SW(2, 8) EARHIP_SW(3, 12) EARHIP_SW(6, 9) EARHIP_SW(7, 13) EARHIP_SW(11, 14)
+#undef EARHIP_SW
+}
+
+__device__ __forceinline__ int wave_pad(int i) { return i + (i >> 4); }  // 17-word rows: conflict-free exchanges
+
+// v[m] <-> index lane + 64 m.  t1[r-1] = W256^{r (lane & 15)}, t2[256 (r-1) + j] = W1024^{r j} (both in LDS).
+template <int DIR>
+__device__ __forceinline__ void wave_fft1024(v2f (&v)[16], v2f *lds, const v2f *t1, const v2f *t2, int lane) {
+  wave_dft16<DIR>(v);  // radix 16, Ns = 1: out[16 lane + r]
+#pragma unroll
+  for (int r = 0; r < 16; r++) lds[wave_pad(16 * lane + r)] = v[r];
+#pragma unroll
+  for (int r = 0; r < 16; r++) v[r] = lds[wave_pad(lane + 64 * r)];  // radix 16, Ns = 16
+  __builtin_amdgcn_sched_barrier(0);  // (keeps the twiddle reads from being hoisted: register pressure)
+#pragma unroll
+  for (int r = 1; r < 16; r++) {
+    v[r] = wave_cmul<DIR>(v[r], t1[r - 1]);
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_dft16<DIR>(v);
+  __builtin_amdgcn_sched_barrier(0);
+  const int ob = (lane >> 4) * 256 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 16; r++) lds[wave_pad(ob + 16 * r)] = v[r];
+#pragma unroll
+  for (int q = 0; q < 4; q++)  // radix 4, Ns = 256: butterfly lane + 64 q
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[q + 4 * r] = lds[wave_pad(lane + 64 * q + 256 * r)];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int r = 1; r < 4; r++) v[q + 4 * r] = wave_cmul<DIR>(v[q + 4 * r], t2[256 * (r - 1) + lane + 64 * q]);
+    wave_r4<DIR>(v[q], v[q + 4], v[q + 8], v[q + 12]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+constexpr int kDecorWaves = 4;  // waves (= runs) per workgroup of k_decorrelate_wave
+
+// grid = (ceil(runs / kDecorWaves), N); same parameters and semantics as k_decorrelate_delay_mix<1024>
+__global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) k_decorrelate_wave(DecorParams P) {
+  constexpr int L = 1024, B = 512;
+  __shared__ v2f lds_all[kDecorWaves][L + L / 16];
+  __shared__ v2f h_lds[L + L / 16];   // the loudspeaker's spectrum (all runs of a workgroup share it)
+  __shared__ v2f t1_lds[16][17];    // W256^{r k}: row k = lane & 15, column r - 1 (r = 1..15)
+  __shared__ v2f t2_lds[3 * 256];    // W1024^{r j}: [256 (r - 1) + j], r = 1..3, j < 256
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v2f *lds = lds_all[w];
+  auto to_v2f = [](cf c) { return v2f{c.x, c.y}; };
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < L; i += 64 * kDecorWaves) h_lds[wave_pad(i)] = to_v2f(P.H[(size_t)n * L + i]);
+  if (threadIdx.x < 240) {
+    const int k = threadIdx.x / 15, r = threadIdx.x % 15 + 1;
+    t1_lds[k][r - 1] = to_v2f(P.tw[(4 * r * k) & (L - 1)]);
+  }
+  for (int i = threadIdx.x; i < 3 * 256; i += 64 * kDecorWaves) t2_lds[i] = to_v2f(P.tw[((i >> 8) + 1) * (i & 255)]);
+  __syncthreads();
+  const int first = (blockIdx.x * kDecorWaves + w) * P.R;
+  if (first >= P.T) return;  // (no workgroup barriers below)
+  const int last = min(first + P.R, P.T);
+  const float norm = 1.0f / (float)(2 * B);  // block_convolver_impl.cpp:212
+  const float *direct = P.bus + (size_t)n * P.bus_stride;
+  const float *diffuse = P.bus + (size_t)(P.N + n) * P.bus_stride;
+  float *out = P.out + (size_t)n * P.out_stride;
+
+  const v2f *t1 = t1_lds[lane & 15];
+  const v2f *t2 = t2_lds;
+
+  auto bus_at = [&](const float *row, int s) {
+    const float *q = row + s;
+    float v = q[0];
+    for (int p = 1; p < P.nparts; p++) v += q[(size_t)p * P.part_stride];
+    return v;
+  };
+  // acc[m] = bus sample s0 + lane + 64 m summed over the object splits (8 loads in flight per split)
+  auto bus_at8 = [&](const float *row, int s0, float (&acc)[8]) {
+    const float *q = row + s0 + lane;
+#pragma unroll
+    for (int m = 0; m < 8; m++) acc[m] = q[64 * m];
+    for (int p = 1; p < P.nparts; p++) {
+      q += P.part_stride;
+#pragma unroll
+      for (int m = 0; m < 8; m++) acc[m] += q[64 * m];
+    }
+  };
+  auto delayed = [&](int s) {  // direct bus delayed by D
+    const int sd = s - P.D;
+    return sd >= 0 ? bus_at(direct, sd) : P.dly_in[(size_t)n * P.D + (sd + P.D)];
+  };
+  auto delayed8 = [&](int tb, float (&acc)[8]) {  // block tb of the delayed direct bus
+    if (tb * B >= P.D) {
+      bus_at8(direct, tb * B - P.D, acc);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) acc[m] = delayed(tb * B + lane + 64 * m);
+    }
+  };
+
+  float tl[8];  // un-normalised overlap-add tail of the previous block, samples lane + 64 m
+#pragma unroll
+  for (int m = 0; m < 8; m++) tl[m] = first == 0 ? P.tail_in[(size_t)n * B + lane + 64 * m] : 0.0f;
+
+  // real part = diffuse block tb, imaginary part = block tb+1
+  auto load_pair = [&](int tb, float (&re)[8], float (&im)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) re[m] = im[m] = 0.0f;
+    if (tb >= 0 && tb < last) bus_at8(diffuse, tb * B, re);
+    if (tb + 1 < last) bus_at8(diffuse, (tb + 1) * B, im);
+  };
+  float zre[8], zim[8];
+  load_pair(first - 1, zre, zim);
+  for (int tb = first - 1; tb < last; tb += 2) {
+    const bool have_re = tb >= 0, have_im = tb + 1 < last;
+    v2f v[16];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      v[m] = v2f{zre[m], zim[m]};
+      v[m + 8] = v2f{0.0f, 0.0f};  // zero padding to 2 B
+    }
+    // loads issued ahead of the transforms: the next pair, and this pair's delayed direct samples
+    load_pair(tb + 2, zre, zim);
+    float dre[8], dim[8];
+    if (have_re && tb >= first) delayed8(tb, dre);
+    if (have_im) delayed8(tb + 1, dim);
+    wave_fft1024<-1>(v, lds, t1, t2, lane);
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      v[m] = wave_cmul<-1>(v[m], h_lds[wave_pad(lane + 64 * m)]);
+      if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_fft1024<+1>(v, lds, t1, t2, lane);
+    if (have_re) {  // :223-226
+      if (tb >= first) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) out[tb * B + lane + 64 * m] = (v[m].x + tl[m]) * norm + dre[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 8; m++) tl[m] = v[m + 8].x;  // :224
+    }
+    if (have_im) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        out[(tb + 1) * B + lane + 64 * m] = (v[m].y + tl[m]) * norm + dim[m];
+        tl[m] = v[m + 8].y;
+      }
+    }
+  }
+  if (last == P.T) {  // this wave owns the end of the call: publish the state
+#pragma unroll
+    for (int m = 0; m < 8; m++) P.tail_out[(size_t)n * B + lane + 64 * m] = tl[m];
+    const int total = P.T * B;
+    for (int j = lane; j < P.D; j += 64) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+  }
+}
+
 // n_buses == 2 without decorrelators is not a libear configuration; n_buses == 1
 // (direct bus only) never reaches this kernel: K1 writes the output directly.
 

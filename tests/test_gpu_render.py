@@ -372,6 +372,40 @@ def test_block_size_limits(block, nblocks, m):
     assert scenes.rel_rms(step, want) <= 1e-6
 
 
+@pytest.mark.parametrize("m,nblocks,calls,run", [(24, 37, [37], None), (24, 37, [1, 20, 3, 13], "3"),
+                                                 (200, 9, [9], "5"), (24, 40, [40], "1")])
+def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
+    """block 512 has two K2 kernels: one wave per run of blocks (default) and the workgroup
+    kernel (EARHIP_K2_WG, read per launch).  Both against the oracle, over run boundaries (several
+    runs per call, odd run lengths through EARHIP_RUN) and over object splits of short calls."""
+    layout, block = "4+5+0", 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=1500, ramp=300, seed=nblocks)
+    x = scenes.audio(m, total, seed=m)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    keep = {k: os.environ.get(k) for k in ("EARHIP_K2_WG", "EARHIP_RUN")}
+    try:
+        outs = []
+        for wg in (False, True):
+            os.environ.pop("EARHIP_K2_WG", None)
+            os.environ.pop("EARHIP_RUN", None)
+            if wg:
+                os.environ["EARHIP_K2_WG"] = "1"
+            if run:
+                os.environ["EARHIP_RUN"] = run
+            outs.append(run_hip(curves, x, n, block, dec, 255, calls))
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert scenes.rel_rms(outs[0], want) <= 1e-6
+    assert scenes.rel_rms(outs[1], want) <= 1e-6
+    assert scenes.rel_rms(outs[0], outs[1]) <= 1e-6
+
+
 def test_gain_kernel_choice_follows_the_curves():
     """bf16x3 kernel (2) for block-aligned ramps, f32 slot kernel (1) for curves that ignore the tile
     grid or are mostly constant, VALU kernel (0) in strict mode; small object counts never use (2)."""
