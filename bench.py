@@ -44,13 +44,16 @@ def algorithmic_bytes(m, n, b, k, ramp=True):
     return gain, dec, dm
 
 
-GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 2: "k_gain_mix_bf3 (bf16x3 MFMA)"}
+GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 2: "k_gain_mix_bf3 (bf16x3 MFMA)",
+                3: "k_gain_mix_h2 (f16x2 MFMA)"}
 
 
 def mfma_roofline(kind, macs_per_term, k1_ms):
     """The gain kernel against the matrix pipe it runs on (secondary to the HBM roofline)."""
     if kind == 2:   # 2 operands (B0, B1) x 6 bf16 partial products per object, column and sample
         flops, peak, what = 24.0 * macs_per_term, BF16_PEAK_TFLOPS, "bf16 MFMA flops: 6 partial products x {gain at tile start, slope}"
+    elif kind == 3:  # 2 operands (B0, B1) x 3 f16 partial products per object, column and sample
+        flops, peak, what = 12.0 * macs_per_term, BF16_PEAK_TFLOPS, "f16 MFMA flops: 3 partial products x {gain at tile start, slope}"
     else:           # 2 f32 MACs (start, end gain row) per object, column and sample
         flops, peak, what = 4.0 * macs_per_term, FP32_PEAK_TFLOPS, "f32 flops: 2 MACs per object, column and sample for a ramp"
     ach = flops / (k1_ms * 1e-3) / 1e12

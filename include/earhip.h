@@ -244,8 +244,8 @@ int earhip_render_enable_timing(earhip_render *r, int enable);
  * launches.  Synchronises the stream. */
 int earhip_render_get_timing(earhip_render *r, double out[6]);
 /* Which gain kernel the last process call used: 0 = VALU with libear's exact
- * arithmetic (strict mode), 1 = f32 MFMA, 2 = bf16x3 MFMA (all curve points on
- * tile boundaries); -1 before the first call. */
+ * arithmetic (strict mode), 1 = f32 MFMA, 2 = bf16x3 MFMA, 3 = f16x2 MFMA (2, 3: all
+ * curve points on tile boundaries); -1 before the first call. */
 int earhip_render_gain_kernel(const earhip_render *r, int *kind);
 
 #ifdef __cplusplus

@@ -9,6 +9,7 @@
 #include "gain_kernels.h"
 #include "gain_mfma.h"
 #include "gain_bf3.h"
+#include "gain_h2.h"
 
 namespace earhip {
 
@@ -90,7 +91,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const size_t lds = mix_lds_bytes(cp, ml);
   if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
   bool launched = false;
-  if (ml.bf3) {
+  if (ml.bf3 && ml.h2) {
+    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+    const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale();
+    if (cp.nct == 1) hipLaunchKernelGGL(k_gain_mix_h2<1>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);
+    if (cp.nct == 2) hipLaunchKernelGGL(k_gain_mix_h2<2>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);
+    if (cp.nct == 3) hipLaunchKernelGGL(k_gain_mix_h2<3>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);
+    launched = true;
+  } else if (ml.bf3) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     if (cp.nct == 1) hipLaunchKernelGGL(k_gain_mix_bf3<1>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
     if (cp.nct == 2) hipLaunchKernelGGL(k_gain_mix_bf3<2>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
@@ -143,7 +151,7 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
-                            curves.tiles_aligned(256, t_call), curves.ramp_share());
+                            curves.tiles_aligned(256, t_call), curves.ramp_share(), curves.gain_scale());
     desc.reserve(desc_units(n_in, ml.ntiles));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,
@@ -269,6 +277,10 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
       if (v == 2 || v == 4) c->spl = v;
     }
     if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e);
+    if (const char *e = getenv("EARHIP_XSCALE")) {  // f16x2 kernel: log2 of the input prescale
+      const int v = atoi(e);
+      if (v >= -64 && v <= 64) c->x_scale_log2 = v;
+    }
     if (const char *e = getenv("EARHIP_WAVES")) {
       const int v = atoi(e);
       if (v >= 1 && v <= 8) c->max_waves = v;

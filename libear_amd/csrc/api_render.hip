@@ -101,7 +101,7 @@ struct earhip_render {
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
-  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 bf16x3 MFMA
+  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 bf16x3 MFMA, 3 f16x2 MFMA
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
   bool run_len_set = false;  // EARHIP_RUN given: also fixes the run length of the wave kernel
 
@@ -165,8 +165,8 @@ struct earhip_render {
     curves->commit(ctx);
     const bool strict = ctx->strict;
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit,
-                            curves->tiles_aligned(256, t), curves->ramp_share());
-    last_kind = ml.bf3 ? 2 : ml.mfma ? 1 : 0;
+                            curves->tiles_aligned(256, t), curves->ramp_share(), curves->gain_scale());
+    last_kind = ml.bf3 ? (ml.h2 ? 3 : 2) : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");

@@ -3,6 +3,8 @@
 // the launcher of K0/K1 over them.
 #pragma once
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -162,6 +164,13 @@ class CurveSet {
       }
     }
     ramp_share_ = span > 0 ? ramp / span : 0.0;
+    // largest |gain| (k_gain_mix_h2 scales the gains to the top of the f16 range); NaN / inf count as huge
+    float gmax = 0.0f;
+    for (size_t i = 0; i < P * row; i++) {
+      const float a = std::fabs(h_gain_.p[i]);
+      gmax = a <= gmax ? gmax : a;  // (a NaN replaces gmax)
+    }
+    gain_max_ = gmax;
     EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, (M_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, P * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, P, hipMemcpyHostToDevice, ctx->stream));
@@ -180,6 +189,16 @@ class CurveSet {
 
   // fraction of the curves' time in ramps; 0 for static gains
   double ramp_share() const { return ramp_share_; }
+
+  // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
+  // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
+  float gain_scale() const {
+    if (!(gain_max_ < 1e30f)) return 0.0f;
+    if (gain_max_ < 1e-30f) return 1.0f;
+    int e;
+    std::frexp(gain_max_, &e);  // gain_max_ = f * 2^e, 0.5 <= f < 1
+    return std::ldexp(1.0f, 14 - e);
+  }
 
   PointStore device() const {
     PointStore ps;
@@ -207,6 +226,7 @@ class CurveSet {
   int64_t t_ref_ = 0;
   uint64_t grid_ = 0;
   double ramp_share_ = 0;
+  float gain_max_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
@@ -221,7 +241,8 @@ class CurveSet {
 // How K1 is spread over the chip for one call.
 struct MixLaunch {
   bool mfma;                   // matrix-core kernel (default) or VALU kernel (strict mode)
-  bool bf3 = false;            // matrix-core kernel on bf16x3 operands (gain_bf3.h); tile = 256 samples
+  bool bf3 = false;            // matrix-core kernel on split operands (gain_bf3.h / gain_h2.h); tile = 256 samples
+  bool h2 = false;             // with bf3: the f16x2 kernel (gain_h2.h) instead of the bf16x3 one
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
@@ -230,7 +251,8 @@ struct MixLaunch {
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
-                          bool strict, int max_gsplit, bool aligned = false, double ramp_share = 1.0) {
+                          bool strict, int max_gsplit, bool aligned = false, double ramp_share = 1.0,
+                          float gain_scale = 0.0f) {
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
   // bf16x3 kernel: forced (2) or, by default (3), when no curve point falls inside a tile
@@ -238,7 +260,9 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // f32 kernel's slot lists make constant pieces half as expensive as ramps (break-even
   // at about one third of the time in ramps)
   L.bf3 = L.mfma && M >= 32 &&
-          (ctx->use_mfma == 2 || (ctx->use_mfma == 3 && aligned && ramp_share >= 0.35));
+          (ctx->use_mfma == 2 || ctx->use_mfma == 4 || (ctx->use_mfma == 3 && aligned && ramp_share >= 0.35));
+  // f16x2 (default; 4 forces it, 2 forces bf16x3) needs gains a power-of-two scale can bring into f16 range
+  L.h2 = L.bf3 && ctx->use_mfma != 2 && gain_scale > 0.0f;
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
   if (L.mfma && !L.bf3 && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;

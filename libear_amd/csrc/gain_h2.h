@@ -1,0 +1,368 @@
+// gain_h2.h — K1 on the f16 matrix cores with every fp32 operand split into TWO f16
+// pieces after an exact power-of-two prescale ("f16x2"): the same bus-forming contraction
+// and the same tiling as gain_bf3.h,
+//
+//     bus[col][s] = sum_m x_m(s) * (B0_m,col + (s - s0) * B1_m,col)      (gain_bf3.h, top)
+//
+// with HALF the matrix instructions and half the operand-splitting arithmetic:
+//
+//   * v * 2^k = h + l with f16 pieces (11 + 11 significand bits, RNE, residual exact in
+//     fp32) is good to 2^-22 relative as long as l is a normal f16, i.e. over 2^16 / 2^-3
+//     = 19 binades below the top of the f16 range; below that the error is 2^-25 ABSOLUTE
+//     in scaled units.  The prescale puts the operands at the top of the range: the gains
+//     by 2^14 / (largest |gain| of the curve set, rounded up to a power of two; known at
+//     commit), the inputs by the context's input scale (default 2^14: full-scale audio,
+//     |x| < 4, is exact to 2^-22 down to about -100 dBFS, and 2^-39 absolute below);
+//   * of the four partial products the three of order >= 2^-11 are kept: xl*bh, xh*bl,
+//     xh*bh (relative error of the contraction on the headline scene: 7e-8, see
+//     tests/test_gpu_render.py and DESIGN.md section 4);
+//   * products of f16 pairs are exact in the fp32 accumulate of
+//     v_mfma_f32_16x16x32_f16, so the chunks accumulate straight into two running sets of
+//     accumulators (B0 terms and B1 terms: no per-chunk fold), in scaled units; the ramp
+//     factor (s - s0) and the inverse scale are applied once per tile;
+//   * an input outside the f16 range after the prescale (|x| * scale >= 65520, or a
+//     non-finite sample) turns the tile's accumulators non-finite: the wave then
+//     recomputes its tile with the exact f32 MFMA path, unscaled.  Correct for any input,
+//     fast for audio.
+//
+// Fragment layouts: as gain_bf3.h (v_mfma_f32_16x16x32_f16 has the bf16 instruction's).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gain_bf3.h"
+
+namespace earhip {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+// two floats -> packed f16 pair, round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ float f16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
+__device__ __forceinline__ float f16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
+
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                0, 0, 0);
+}
+
+// P.ntiles / P.desc refer to WORKGROUP tiles of kBf3Tile samples.  x_scale, g_scale: exact
+// powers of two (see above); zero_row: index of an all-zero gain row.
+template <int NCT>
+__global__ void __launch_bounds__(256, 2)
+k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
+  constexpr int NRT = 4, TS = 16 * NRT, CH = kBf3Chunk;
+  constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
+  __shared__ u32x4 bfrag[2][NFRAG + 4][64];  // + 4 never-read fragments: the lanes without a column write there
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
+  const int nparts = gridDim.y;
+  const int part = blockIdx.y;
+  const int m_lo = (int)(((int64_t)P.M * part) / nparts);
+  const int m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
+  const int col0 = blockIdx.z * 16 * NCT;
+  const int tile_s0 = wgtile * kBf3Tile + w * TS;  // first sample of this wave's tile
+  const int tile_len = max(0, min(TS, P.nsamples - tile_s0));
+  const int64_t tile_t0 = P.t_call + tile_s0;
+  const int64_t tile_t1 = tile_t0 + tile_len;
+  const SegDesc *__restrict__ dtile = P.desc + (size_t)wgtile * P.M;
+  const float *__restrict__ gain = P.ps.gain;
+  const unsigned rowlen = (unsigned)P.ps.row;
+
+  // running totals in scaled units: bus = (tot0 + (s - s0) tot1) / (x_scale g_scale)
+  f32x4 tot0[NRT][NCT], tot1[NRT][NCT];
+  auto clear_totals = [&]() {
+#pragma unroll
+    for (int r = 0; r < NRT; r++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++) tot0[r][c] = tot1[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  clear_totals();
+
+  // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
+  // with k = {a, b} of ONE object (gain_bf3.h), accumulated into tot0 times sc
+  auto single_object = [&](int m, float sc) {
+    if (tile_len <= 0) return;
+    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
+    const bool is_b = kg & 1;
+    const bool slot0 = kg < 2;
+    int k = upper_bound_time(P.ps.time + base, n, tile_t0);
+    int cur = 0;
+    while (cur < tile_len) {
+      const SegDesc dk = describe_segment(P.ps, base, n, k, tile_t0, tile_t1);
+      const int r1 = min(seg_r1(dk.info), tile_len);
+      if (r1 > cur) {  // duplicate times make empty segments (steps)
+        const bool ramp = dk.info & kSegRamp;
+        float a[NRT], gv[NCT];
+#pragma unroll
+        for (int r = 0; r < NRT; r++) {
+          const int s = li * NRT + r;
+          const float x = row[min(s, tile_len - 1)];
+          const float p = (float)(dk.d0 + s) * dk.scale;  // gain_interpolator.hpp:272
+          float coef = ramp ? (is_b ? p : 1.0f - p) : (is_b ? 0.0f : 1.0f);
+          coef = (slot0 && s >= cur && s < r1) ? coef : 0.0f;
+          a[r] = (x * coef) * sc;
+        }
+        const int grow = dk.row + ((ramp && is_b && slot0) ? 1 : 0);
+        const float *gp = gain + (size_t)grow * rowlen + col0 + li;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
+#pragma unroll
+        for (int r = 0; r < NRT; r++)
+#pragma unroll
+          for (int c = 0; c < NCT; c++)
+            tot0[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot0[r][c], 0, 0, 0);
+        cur = r1;
+      }
+      if (!(dk.info & kSegMulti)) break;
+      k++;
+    }
+  };
+
+  const int nobj = m_hi - m_lo;
+  const int nch = (P.vec_ok && nobj >= CH) ? (nobj + CH - 1) / CH : 0;
+  const float unit = x_scale * g_scale;
+  float inv = 1.0f / unit;  // exact: powers of two
+
+  if (nch > 0) {
+    // (addressing, descriptor hand-over and load order: see the comments in gain_bf3.h)
+    const int nvec = (P.nsamples + 3) & ~3;
+    const unsigned xs = (unsigned)min(tile_s0 + li * NRT, nvec - 4);
+    const unsigned xlane = ((unsigned)(kg * 8) * (unsigned)P.in_stride + xs) * 4u;
+    const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
+    // fragment this lane fills: B0 pieces at bfr, bfr+1, B1 pieces NCT*2 further
+    const int blane = w * 16 + (lane & 15);
+    const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;
+    const int bfr1 = lane < 16 * NCT ? NCT * 2 : 2;
+    auto chunk_base = [&](int c) { return min(m_lo + c * CH, m_hi - CH); };
+
+    auto load_x = [&](int c, f32x4 (&x)[8]) {
+      const char *bp = reinterpret_cast<const char *>(P.in + (size_t)chunk_base(c) * P.in_stride);
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
+            bp + (size_t)q * P.in_stride * sizeof(float) + xlane));
+    };
+    struct LaneDesc {
+      int row_s, row_e;
+      float p0, scale;
+    };
+    auto load_desc = [&](int c) {
+      const int cc = min(c, nch - 1);
+      const int m = chunk_base(cc) + w * 8 + (lane & 7);
+      return *reinterpret_cast<const int4 *>(dtile + m);
+    };
+    auto digest_desc = [&](const int4 &d, int c) {
+      const int cc = min(c, nch - 1);
+      const int m = chunk_base(cc) + w * 8 + (lane & 7);
+      const bool valid = m >= m_lo + cc * CH && !(d.w & kSegMulti);
+      LaneDesc L;
+      L.row_s = valid ? d.x : zero_row;
+      L.row_e = L.row_s + ((valid && (d.w & kSegRamp)) ? 1 : 0);
+      const float scale = __int_as_float(d.z);
+      L.p0 = (float)d.y * scale;  // gain_interpolator.hpp:272 at the tile start
+      L.scale = scale;            // constant segments: scale = 0, d0 = 0
+      return L;
+    };
+    struct ChunkDesc {
+      float p0[8], scale[8];
+    };
+    auto load_gains = [&](const int4 &raw, int c, ChunkDesc &D, float (&S)[8], float (&E)[8]) {
+      const LaneDesc L = digest_desc(raw, c);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const unsigned rs = (unsigned)__builtin_amdgcn_readlane(L.row_s, q);
+        const unsigned re = (unsigned)__builtin_amdgcn_readlane(L.row_e, q);
+        D.p0[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.p0), q));
+        D.scale[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.scale), q));
+        const float *rps = gain + (size_t)rs * rowlen, *rpe = gain + (size_t)re * rowlen;
+        S[q] = rps[bcol_e];
+        E[q] = rpe[bcol_e];
+      }
+    };
+    // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's 8 objects,
+    // scaled and split -> LDS
+    auto store_b = [&](const ChunkDesc &D, const float (&S)[8], const float (&E)[8], int buf, int part) {
+      u32x4 h, l;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float v[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int q = 2 * i + j;
+          v[j] = (part == 0 ? __builtin_fmaf(1.0f - D.p0[q], S[q], D.p0[q] * E[q]) : D.scale[q] * (E[q] - S[q])) *
+                 g_scale;
+        }
+        const uint32_t H = pack_f16(v[0], v[1]);
+        h[i] = H;
+        l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+      }
+      u32x4 *f = &bfrag[buf][bfr][blane] + (part ? bfr1 * 64 : 0);
+      f[0] = h;
+      f[64] = l;
+    };
+
+    f32x4 xc[8], xn[8];
+    int4 L;
+    {
+      float S[8], E[8];
+      ChunkDesc D;
+      L = load_desc(0);
+      load_gains(L, 0, D, S, E);
+      load_x(0, xc);
+      store_b(D, S, E, 0, 0);
+      store_b(D, S, E, 0, 1);
+      L = load_desc(1);
+    }
+#pragma unroll 1
+    for (int c = 0; c < nch; c++) {
+      const int buf = c & 1;
+      __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free
+      float S[8], E[8];
+      ChunkDesc D;
+      load_gains(L, c + 1, D, S, E);  // chunk c+1 (its descriptors were fetched one chunk ago)
+      L = load_desc(c + 2);
+
+      // A fragments: row tile r = sample 4*li + r of the 8 objects of this lane.  2 x 2
+      // blocks: an f16 pair packs two OBJECTS (q, q+1) of one row tile, the scaling and the
+      // exact residual subtractions pair two SAMPLES (r, r+1) of one object (neighbours in
+      // the loaded float4: packed arithmetic without operand moves).
+      u32x4 ah[NRT], al[NRT];
+#pragma unroll
+      for (int qp = 0; qp < 4; qp++)
+#pragma unroll
+        for (int rp = 0; rp < NRT; rp += 2) {
+          const f32x2 s0 = f32x2{xc[2 * qp][rp], xc[2 * qp][rp + 1]} * x_scale;          // object 2qp
+          const f32x2 s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;  // object 2qp+1
+          const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
+          const f32x2 r0 = s0 - f32x2{f16_lo(H0), f16_lo(H1)};  // exact
+          const f32x2 r1 = s1 - f32x2{f16_hi(H0), f16_hi(H1)};
+          ah[rp][qp] = H0;
+          ah[rp + 1][qp] = H1;
+          al[rp][qp] = pack_f16(r0[0], r1[0]);
+          al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
+        }
+      // 2*NCT blocks (column tile ct = blk >> 1, operand blk & 1: B0 / B1) of 12 MFMAs: three
+      // partial products per operand pair, smallest first.  MFMA and VALU instructions do not
+      // overlap except for one VALU instruction directly behind an MFMA
+      // (tools/experiments/coissue2.hip), so the conversion of the next chunk's gains is
+      // woven between the MFMAs of blocks 0 and 1.
+      __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
+      constexpr int NBLK = 2 * NCT;
+      u32x4 b[2][2];
+      auto load_b = [&](int blk, u32x4 (&bb)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][((blk & 1) * NCT + (blk >> 1)) * 2 + q][lane];
+      };
+      load_b(0, b[0]);
+#pragma unroll
+      for (int blk = 0; blk < NBLK; blk++) {
+        u32x4(&bc)[2] = b[blk & 1];
+        const int ct = blk >> 1;
+        if (blk + 1 < NBLK) load_b(blk + 1, b[(blk + 1) & 1]);
+        if ((blk & 1) == 0) {
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(al[r], bc[0], tot0[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(ah[r], bc[1], tot0[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(ah[r], bc[0], tot0[r][ct]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(al[r], bc[0], tot1[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[1], tot1[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[0], tot1[r][ct]);
+        }
+        // in-order vector-memory counter: the gain rows (requested at the top of the chunk)
+        // are consumed first, in blocks 0 and 1, and only then are the next chunk's inputs
+        // requested (gain_bf3.h)
+        const bool conv0 = blk == 0, conv1 = blk == 1;
+        if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
+        if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
+        if (blk == (NBLK > 2 ? 2 : 1)) {
+          load_x(min(c + 1, nch - 1), xn);
+          __builtin_amdgcn_sched_barrier(0);  // keep the requests here, not at the end of the chunk
+        }
+        // issue order: the LDS reads first, then every MFMA followed by VALU instructions
+        if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (conv0 || conv1) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) xc[q] = xn[q];
+    }
+
+    // objects with curve points inside this workgroup tile (zero rows above)
+    for (int b0 = 0; b0 < nobj; b0 += 64) {
+      const SegDesc db = dtile[min(m_lo + b0 + lane, m_hi - 1)];
+      unsigned long long multi = __ballot((db.info & kSegMulti) && b0 + lane < nobj);
+      while (multi) {
+        const int j = __builtin_ctzll(multi);
+        multi &= multi - 1;
+        single_object(m_lo + b0 + j, unit);
+      }
+    }
+    // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the
+    // wave's tile exactly, unscaled
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < NRT; r++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
+    if (__ballot(bad)) {
+      clear_totals();
+      inv = 1.0f;
+      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f);
+    }
+  } else {
+    inv = 1.0f;
+    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f);  // unaligned rows
+  }
+
+  if (tile_len <= 0) return;
+  // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
+  // four row tiles are 4 consecutive samples.  (s - s0) of the rows: sample 64w + 16kg + 4e + r.
+  const float wf0 = (float)(w * TS + kg * 16);
+  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
+#pragma unroll
+  for (int c = 0; c < NCT; c++) {
+    const int col = col0 + c * 16 + li;
+    if (col >= P.ncols) continue;
+    float *o = op + (size_t)col * P.out_stride;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int s = kg * 16 + e * 4;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < NRT; r++)
+        v[r] = __builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv;
+      if (P.vec_ok && s + 3 < tile_len) {
+        *reinterpret_cast<f32x4 *>(o + s) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (s + i < tile_len) o[s + i] = v[i];
+      }
+    }
+  }
+}
+
+}  // namespace earhip

@@ -407,8 +407,8 @@ def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
 
 
 def test_gain_kernel_choice_follows_the_curves():
-    """bf16x3 kernel (2) for block-aligned ramps, f32 slot kernel (1) for curves that ignore the tile
-    grid or are mostly constant, VALU kernel (0) in strict mode; small object counts never use (2)."""
+    """f16x2 kernel (3) for block-aligned ramps, f32 slot kernel (1) for curves that ignore the tile
+    grid or are mostly constant, VALU kernel (0) in strict mode; small object counts never use (3); bf16x3 (2) only when forced."""
     from libear_amd import capi
     layout, block, nblocks = "0+5+0", 512, 4
     n = len(LAYOUTS[layout])
@@ -432,7 +432,7 @@ def test_gain_kernel_choice_follows_the_curves():
     if forced not in (None, "3"):
         pytest.skip("kernel forced by EARHIP_MFMA")
     dense = scenes.dense_curves(64, n, block, nblocks)
-    assert kernel_for(64, dense) == 2
+    assert kernel_for(64, dense) == 3
     assert kernel_for(64, dense, t0=17) == 1          # same curves, call grid shifted off the points
     assert kernel_for(64, dense, strict=True) == 0
     assert kernel_for(16, scenes.dense_curves(16, n, block, nblocks)) == 1   # fewer than 32 objects
