@@ -94,9 +94,15 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (ml.bf3 && ml.h2) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale();
-    if (cp.nct == 1) hipLaunchKernelGGL(k_gain_mix_h2<1>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);
-    if (cp.nct == 2) hipLaunchKernelGGL(k_gain_mix_h2<2>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);
-    if (cp.nct == 3) hipLaunchKernelGGL(k_gain_mix_h2<3>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);
+#define EARHIP_H2_CASE(NCT_)                                                                                        \
+  if (cp.nct == NCT_) {                                                                                             \
+    if (ml.tile() == 512)                                                                                           \
+      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, ps.zero_row, xs, gs);       \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);       \
+  }
+    EARHIP_H2_CASE(1) EARHIP_H2_CASE(2) EARHIP_H2_CASE(3)
+#undef EARHIP_H2_CASE
     launched = true;
   } else if (ml.bf3) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
@@ -151,7 +157,7 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
-                            curves.tiles_aligned(256, t_call), curves.ramp_share(), curves.gain_scale());
+                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale());
     desc.reserve(desc_units(n_in, ml.ntiles));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

@@ -165,7 +165,7 @@ struct earhip_render {
     curves->commit(ctx);
     const bool strict = ctx->strict;
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit,
-                            curves->tiles_aligned(256, t), curves->ramp_share(), curves->gain_scale());
+                            curves->aligned_tile(t), curves->ramp_share(), curves->gain_scale());
     last_kind = ml.bf3 ? (ml.h2 ? 3 : 2) : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;

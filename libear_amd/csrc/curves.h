@@ -187,6 +187,9 @@ class CurveSet {
     return d % tile == 0 && grid_ % (uint64_t)tile == 0;
   }
 
+  // largest tile of the split-operand kernels (512, 256) with no curve point strictly inside; 0: none
+  int aligned_tile(int64_t t_call) const { return tiles_aligned(512, t_call) ? 512 : tiles_aligned(256, t_call) ? 256 : 0; }
+
   // fraction of the curves' time in ramps; 0 for static gains
   double ramp_share() const { return ramp_share_; }
 
@@ -243,16 +246,18 @@ struct MixLaunch {
   bool mfma;                   // matrix-core kernel (default) or VALU kernel (strict mode)
   bool bf3 = false;            // matrix-core kernel on split operands (gain_bf3.h / gain_h2.h); tile = 256 samples
   bool h2 = false;             // with bf3: the f16x2 kernel (gain_h2.h) instead of the bf16x3 one
+  bool wide = false;           // with h2: 8 waves on 512-sample tiles
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
   int tpw = 1;                 // MFMA: adjacent tiles per workgroup
-  int tile() const { return bf3 ? 256 : mfma ? 16 * nrt : 64 * spl; }
+  int tile() const { return bf3 ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
-                          bool strict, int max_gsplit, bool aligned = false, double ramp_share = 1.0,
+                          bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
                           float gain_scale = 0.0f) {
+  const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
   // bf16x3 kernel: forced (2) or, by default (3), when no curve point falls inside a tile
@@ -263,6 +268,8 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
           (ctx->use_mfma == 2 || ctx->use_mfma == 4 || (ctx->use_mfma == 3 && aligned && ramp_share >= 0.35));
   // f16x2 (default; 4 forces it, 2 forces bf16x3) needs gains a power-of-two scale can bring into f16 range
   L.h2 = L.bf3 && ctx->use_mfma != 2 && gain_scale > 0.0f;
+  // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (four rounds of workgroups or more)
+  L.wide = L.h2 && aligned_tile >= 512 && nsamples / 512 >= 4 * ctx->num_cus && !getenv("EARHIP_H2_NARROW");
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
   if (L.mfma && !L.bf3 && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;

@@ -52,10 +52,14 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 
 // P.ntiles / P.desc refer to WORKGROUP tiles of kBf3Tile samples.  x_scale, g_scale: exact
 // powers of two (see above); zero_row: index of an all-zero gain row.
-template <int NCT>
-__global__ void __launch_bounds__(256, 2)
+// NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
+// conversion of a chunk's gains is shared by the whole workgroup, so the 512-sample tile halves that
+// work (and the gain rows' L2 traffic) when no curve point falls inside 512-sample tiles.
+template <int NCT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kBf3Chunk;
+  constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
   constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
   __shared__ u32x4 bfrag[2][NFRAG + 4][64];  // + 4 never-read fragments: the lanes without a column write there
   const int lane = threadIdx.x & 63;
@@ -67,7 +71,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
   const int m_lo = (int)(((int64_t)P.M * part) / nparts);
   const int m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
   const int col0 = blockIdx.z * 16 * NCT;
-  const int tile_s0 = wgtile * kBf3Tile + w * TS;  // first sample of this wave's tile
+  const int tile_s0 = wgtile * (TS * NW) + w * TS;  // first sample of this wave's tile
   const int tile_len = max(0, min(TS, P.nsamples - tile_s0));
   const int64_t tile_t0 = P.t_call + tile_s0;
   const int64_t tile_t1 = tile_t0 + tile_len;
@@ -138,7 +142,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
     const unsigned xlane = ((unsigned)(kg * 8) * (unsigned)P.in_stride + xs) * 4u;
     const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
     // fragment this lane fills: B0 pieces at bfr, bfr+1, B1 pieces NCT*2 further
-    const int blane = w * 16 + (lane & 15);
+    const int blane = (w * NQ / 8) * 16 + (lane & 15);
     const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;
     const int bfr1 = lane < 16 * NCT ? NCT * 2 : 2;
     auto chunk_base = [&](int c) { return min(m_lo + c * CH, m_hi - CH); };
@@ -150,49 +154,56 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
         x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
             bp + (size_t)q * P.in_stride * sizeof(float) + xlane));
     };
-    struct LaneDesc {
-      int row_s, row_e;
-      float p0, scale;
+    // What this WAVE converts for chunk c: objects chunk_base + NQ w + q.  Their descriptors are
+    // wave-uniform: scalar loads (requested one chunk ahead), scalar row arithmetic, and the
+    // gain rows come in as (scalar row pointer) + (the lane's column).
+    // (read through the constant address space: the compiler cannot prove that nothing in the kernel
+    // writes the descriptors — K0 wrote them, this kernel only reads — and would otherwise use vector
+    // loads and vector row arithmetic for these uniform values)
+    typedef const SegDesc __attribute__((address_space(4))) *ConstDesc;
+    struct ChunkDesc {
+      SegDesc d[NQ];
     };
     auto load_desc = [&](int c) {
       const int cc = min(c, nch - 1);
-      const int m = chunk_base(cc) + w * 8 + (lane & 7);
-      return *reinterpret_cast<const int4 *>(dtile + m);
-    };
-    auto digest_desc = [&](const int4 &d, int c) {
-      const int cc = min(c, nch - 1);
-      const int m = chunk_base(cc) + w * 8 + (lane & 7);
-      const bool valid = m >= m_lo + cc * CH && !(d.w & kSegMulti);
-      LaneDesc L;
-      L.row_s = valid ? d.x : zero_row;
-      L.row_e = L.row_s + ((valid && (d.w & kSegRamp)) ? 1 : 0);
-      const float scale = __int_as_float(d.z);
-      L.p0 = (float)d.y * scale;  // gain_interpolator.hpp:272 at the tile start
-      L.scale = scale;            // constant segments: scale = 0, d0 = 0
-      return L;
-    };
-    struct ChunkDesc {
-      float p0[8], scale[8];
-    };
-    auto load_gains = [&](const int4 &raw, int c, ChunkDesc &D, float (&S)[8], float (&E)[8]) {
-      const LaneDesc L = digest_desc(raw, c);
+      ConstDesc dp = (ConstDesc)(dtile + chunk_base(cc) + w * NQ);
+      ChunkDesc D;
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const unsigned rs = (unsigned)__builtin_amdgcn_readlane(L.row_s, q);
-        const unsigned re = (unsigned)__builtin_amdgcn_readlane(L.row_e, q);
-        D.p0[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.p0), q));
-        D.scale[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(L.scale), q));
+      for (int q = 0; q < NQ; q++) {
+        D.d[q].row = dp[q].row;
+        D.d[q].d0 = dp[q].d0;
+        D.d[q].scale = dp[q].scale;
+        D.d[q].info = dp[q].info;
+      }
+      return D;
+    };
+    struct ChunkCoef {
+      float p0[NQ], scale[NQ];
+    };
+    auto load_gains = [&](const ChunkDesc &R, int c, ChunkCoef &D, float (&S)[NQ], float (&E)[NQ]) {
+      const int cc = min(c, nch - 1);
+      const int m0 = chunk_base(cc) + w * NQ;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const SegDesc d = R.d[q];
+        // objects the previous chunk already covered (last chunk moved back) and objects with
+        // curve points inside the tile (slow path) get the all-zero row
+        const bool valid = m0 + q >= m_lo + cc * CH && !(d.info & kSegMulti);
+        const unsigned rs = (unsigned)(valid ? d.row : zero_row);
+        const unsigned re = rs + ((valid && (d.info & kSegRamp)) ? 1u : 0u);
+        D.p0[q] = (float)d.d0 * d.scale;  // gain_interpolator.hpp:272 at the tile start
+        D.scale[q] = d.scale;             // constant segments: scale = 0, d0 = 0
         const float *rps = gain + (size_t)rs * rowlen, *rpe = gain + (size_t)re * rowlen;
         S[q] = rps[bcol_e];
         E[q] = rpe[bcol_e];
       }
     };
-    // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's 8 objects,
-    // scaled and split -> LDS
-    auto store_b = [&](const ChunkDesc &D, const float (&S)[8], const float (&E)[8], int buf, int part) {
-      u32x4 h, l;
+    // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's NQ objects,
+    // scaled and split -> LDS (k = 8 kgw + 2 i + j of the fragment entry of lane 16 kgw + column)
+    auto store_b = [&](const ChunkCoef &D, const float (&S)[NQ], const float (&E)[NQ], int buf, int part) {
+      uint32_t h[NQ / 2], l[NQ / 2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NQ / 2; i++) {
         float v[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -205,30 +216,44 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
         l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
       }
       u32x4 *f = &bfrag[buf][bfr][blane] + (part ? bfr1 * 64 : 0);
-      f[0] = h;
-      f[64] = l;
+      if constexpr (NQ == 8) {
+        f[0] = u32x4{h[0], h[1], h[2], h[3]};
+        f[64] = u32x4{l[0], l[1], l[2], l[3]};
+      } else {  // half an entry: words 2 (w & 1), + 1
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 *g = reinterpret_cast<u32x2 *>(f) + (w & 1);
+        g[0] = u32x2{h[0], h[1]};
+        g[128] = u32x2{l[0], l[1]};
+      }
     };
 
-    f32x4 xc[8], xn[8];
-    int4 L;
+    // Inputs are requested TWO chunks ahead (a chunk is about 1 us of work for the wave, less
+    // than the memory latency under load) into the registers the operand split has just
+    // freed; the chunk loop is unrolled twice so that the two register sets need no moves.
+    // The vector-memory counter is in order (a wait for one load waits for every older one),
+    // so per chunk the gain rows of the next chunk are requested BEFORE the inputs and
+    // converted while those are in flight.
+    f32x4 X0[8], X1[8];
+    ChunkDesc L;
     {
-      float S[8], E[8];
-      ChunkDesc D;
+      float S[NQ], E[NQ];
+      ChunkCoef D;
       L = load_desc(0);
       load_gains(L, 0, D, S, E);
-      load_x(0, xc);
+      load_x(0, X0);
+      load_x(min(1, nch - 1), X1);
       store_b(D, S, E, 0, 0);
       store_b(D, S, E, 0, 1);
       L = load_desc(1);
     }
-#pragma unroll 1
-    for (int c = 0; c < nch; c++) {
-      const int buf = c & 1;
+    // chunk c: inputs in xc, B fragments in bfrag[buf]
+    auto chunk = [&](int c, int buf, f32x4 (&xc)[8]) {
       __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free
-      float S[8], E[8];
-      ChunkDesc D;
+      float S[NQ], E[NQ];
+      ChunkCoef D;
       load_gains(L, c + 1, D, S, E);  // chunk c+1 (its descriptors were fetched one chunk ago)
       L = load_desc(c + 2);
+      __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input (see above)
 
       // A fragments: row tile r = sample 4*li + r of the 8 objects of this lane.  2 x 2
       // blocks: an f16 pair packs two OBJECTS (q, q+1) of one row tile, the scaling and the
@@ -249,6 +274,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
           al[rp][qp] = pack_f16(r0[0], r1[0]);
           al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
         }
+      load_x(min(c + 2, nch - 1), xc);  // (the last two chunks re-request the last one: never used)
       // 2*NCT blocks (column tile ct = blk >> 1, operand blk & 1: B0 / B1) of 12 MFMAs: three
       // partial products per operand pair, smallest first.  MFMA and VALU instructions do not
       // overlap except for one VALU instruction directly behind an MFMA
@@ -262,6 +288,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
         for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][((blk & 1) * NCT + (blk >> 1)) * 2 + q][lane];
       };
       load_b(0, b[0]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // (block 0's reads; each block below places the NEXT block's)
 #pragma unroll
       for (int blk = 0; blk < NBLK; blk++) {
         u32x4(&bc)[2] = b[blk & 1];
@@ -282,16 +309,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
 #pragma unroll
           for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[0], tot1[r][ct]);
         }
-        // in-order vector-memory counter: the gain rows (requested at the top of the chunk)
-        // are consumed first, in blocks 0 and 1, and only then are the next chunk's inputs
-        // requested (gain_bf3.h)
-        const bool conv0 = blk == 0, conv1 = blk == 1;
+        const bool conv0 = blk == NBLK - 2, conv1 = blk == NBLK - 1;
         if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
         if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
-        if (blk == (NBLK > 2 ? 2 : 1)) {
-          load_x(min(c + 1, nch - 1), xn);
-          __builtin_amdgcn_sched_barrier(0);  // keep the requests here, not at the end of the chunk
-        }
         // issue order: the LDS reads first, then every MFMA followed by VALU instructions
         if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         if (conv0 || conv1) {
@@ -304,8 +324,11 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
           __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
       }
-#pragma unroll
-      for (int q = 0; q < 8; q++) xc[q] = xn[q];
+    };
+#pragma unroll 1
+    for (int c = 0; c < nch; c += 2) {
+      chunk(c, 0, X0);
+      if (c + 1 < nch) chunk(c + 1, 1, X1);
     }
 
     // objects with curve points inside this workgroup tile (zero rows above)
