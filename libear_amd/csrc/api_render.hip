@@ -198,6 +198,17 @@ struct earhip_render {
       P.bus_stride = bus_stride;
       P.part_stride = part_stride;
       P.nparts = ml.gsplit;
+      const bool wave_k2 = L == 1024 && !getenv("EARHIP_K2_WG");
+      if (wave_k2 && ml.gsplit > 1) {
+        // The wave kernel has one wave per run: summing the object splits there is a chain of
+        // dependent loads on the call's critical path (block mode).  Sum them into slab 0 with the
+        // whole chip first (K N rows; in place: a thread reads and writes its own sample only).
+        if (evp) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
+        hipLaunchKernelGGL(k_sum_parts, dim3((nsamples + 255) / 256, K * N), dim3(256), 0, ctx->stream, bus.p,
+                           part_stride, ml.gsplit, bus_stride, K * N, nsamples, bus.p, bus_stride);
+        EARHIP_HIP(hipGetLastError());
+        P.nparts = 1;
+      }
       P.out = out_dev;
       P.out_stride = out_stride;
       P.H = H.p;
@@ -208,12 +219,11 @@ struct earhip_render {
       P.dly_out = dly[cur ^ 1].p;
       P.N = N;
       P.T = (int)nblocks;
-      const bool wave_k2 = L == 1024 && !getenv("EARHIP_K2_WG");
       const int R = wave_k2 && !run_len_set ? wave_run_len((int)nblocks, N, ctx->num_cus) : run_len;
       P.R = R;
       P.D = D;
       const dim3 grid((unsigned)((nblocks + R - 1) / R), N);
-      if (evp) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
+      if (evp && P.nparts == ml.gsplit) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
       launch_decor(L, P, grid, ctx->stream);
       if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
       cur ^= 1;

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
@@ -269,7 +270,10 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // f16x2 (default; 4 forces it, 2 forces bf16x3) needs gains a power-of-two scale can bring into f16 range
   L.h2 = L.bf3 && ctx->use_mfma != 2 && gain_scale > 0.0f;
   // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (four rounds of workgroups or more)
-  L.wide = L.h2 && aligned_tile >= 512 && nsamples / 512 >= 4 * ctx->num_cus && !getenv("EARHIP_H2_NARROW");
+  // (EARHIP_H2_TILE=256|512 forces one of them where the curves allow it: tests, tuning)
+  const char *force_tile = getenv("EARHIP_H2_TILE");
+  const int forced = force_tile ? atoi(force_tile) : 0;
+  L.wide = L.h2 && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 4 * ctx->num_cus);
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
   if (L.mfma && !L.bf3 && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;

@@ -490,16 +490,23 @@ __global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
   }
 }
 
-// sum grid-level partial slabs: out[c][s] = sum_p part[p][c][s]  (only used
-// when the buses go straight to the caller, i.e. no decorrelate/mix kernel)
+// sum grid-level partial slabs: out[c][s] = sum_p part[p][c][s]  (when the buses go straight
+// to the caller, and ahead of the wave decorrelator kernel in block mode; out may be slab 0)
 static __global__ void k_sum_parts(const float *parts, size_t part_stride, int nparts,
                             size_t row_stride, int ncols, int nsamples, float *out,
                             size_t out_stride) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = blockIdx.y;
   if (s >= nsamples || c >= ncols) return;
-  float v = 0.0f;
-  for (int p = 0; p < nparts; p++) v += parts[(size_t)p * part_stride + (size_t)c * row_stride + s];
+  const float *q = parts + (size_t)c * row_stride + s;
+  float v = q[0];
+  int p = 1;
+  for (; p + 3 < nparts; p += 4) {  // four loads in flight, summed part after part
+    const float a = q[(size_t)p * part_stride], b = q[(size_t)(p + 1) * part_stride];
+    const float c2 = q[(size_t)(p + 2) * part_stride], d = q[(size_t)(p + 3) * part_stride];
+    v = (((v + a) + b) + c2) + d;
+  }
+  for (; p < nparts; p++) v += q[(size_t)p * part_stride];
   out[(size_t)c * out_stride + s] = v;
 }
 

@@ -519,9 +519,18 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
   auto delayed8 = [&](int tb, float (&acc)[8]) {  // block tb of the delayed direct bus
     if (tb * B >= P.D) {
       bus_at8(direct, tb * B - P.D, acc);
-    } else {
+    } else {  // first block of a call: the head comes from the delay state
+      const int s0 = tb * B - P.D + lane;
+      const float *q = direct + s0;
 #pragma unroll
-      for (int m = 0; m < 8; m++) acc[m] = delayed(tb * B + lane + 64 * m);
+      for (int m = 0; m < 8; m++)
+        acc[m] = s0 + 64 * m < 0 ? P.dly_in[(size_t)n * P.D + (s0 + 64 * m + P.D)] : q[64 * m];
+      for (int p = 1; p < P.nparts; p++) {
+        q += P.part_stride;
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+          if (s0 + 64 * m >= 0) acc[m] += q[64 * m];
+      }
     }
   };
 
@@ -578,7 +587,41 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
 #pragma unroll
     for (int m = 0; m < 8; m++) P.tail_out[(size_t)n * B + lane + 64 * m] = tl[m];
     const int total = P.T * B;
-    for (int j = lane; j < P.D; j += 64) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+    if (total >= P.D && P.D <= 256) {
+      // the last D samples of the direct bus, four per lane, summed over the object splits with
+      // 4 x 4 loads in flight (block mode: 16 splits, and this is on the call's critical path)
+      const float *q = direct + (total - P.D) + lane;
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) ok[k] = lane + 64 * k < P.D;
+      int p = 0;
+      for (; p + 3 < P.nparts; p += 4) {
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) t[j][k] = ok[k] ? q[(size_t)(p + j) * P.part_stride + 64 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // same order as bus_at: part after part
+          acc[k] = p == 0 ? t[0][k] : acc[k] + t[0][k];
+          acc[k] += t[1][k];
+          acc[k] += t[2][k];
+          acc[k] += t[3][k];
+        }
+      }
+      for (; p < P.nparts; p++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float v = ok[k] ? q[(size_t)p * P.part_stride + 64 * k] : 0.0f;
+          acc[k] = p == 0 ? v : acc[k] + v;
+        }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (ok[k]) P.dly_out[(size_t)n * P.D + lane + 64 * k] = acc[k];
+    } else {
+      for (int j = lane; j < P.D; j += 64) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+    }
   }
 }
 

@@ -406,6 +406,76 @@ def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
     assert scenes.rel_rms(outs[0], outs[1]) <= 1e-6
 
 
+def _with_env(env, fn):
+    keep = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        return fn()
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("tile", ["256", "512"])
+@pytest.mark.parametrize("m,layout", [(96, "9+10+3"), (40, "0+5+0"), (130, "4+5+0")])
+def test_f16x2_kernel_both_tiles_vs_oracle(tile, m, layout):
+    """k_gain_mix_h2 on 256-sample tiles (4 waves) and 512-sample tiles (8 waves; chosen by itself only
+    for long calls) against the oracle, block-aligned ramps, object counts that are not multiples of 32."""
+    if os.environ.get("EARHIP_MFMA") not in (None, "3", "4"):
+        pytest.skip("kernel forced by EARHIP_MFMA")
+    block, nblocks = 512, 5
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks, seed=m)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = _with_env({"EARHIP_H2_TILE": tile}, lambda: run_hip(curves, x, n, block, dec, 255, [nblocks]))
+    assert scenes.rel_rms(got, want) <= 1e-6
+    parts = _with_env({"EARHIP_H2_TILE": tile}, lambda: run_hip(curves, x, n, block, dec, 255, [2, 1, 2]))
+    assert scenes.rel_rms(parts, want) <= 1e-6
+
+
+@pytest.mark.parametrize("amp,gamp", [(1e-4, 1.0), (300.0, 1.0), (1.0, 2000.0), (1.0, 3e-4), (1e-3, 50.0)])
+def test_f16x2_kernel_operand_ranges(amp, gamp):
+    """The f16x2 kernel scales the gains by their own maximum and the inputs by a fixed 2^14: quiet
+    inputs keep 1e-6, inputs beyond the f16 range after the prescale (|x| >= 4) take the exact
+    in-kernel fallback, large and small gains are absorbed by the gain scale."""
+    layout, block, nblocks, m = "4+5+0", 512, 3, 64
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    base = scenes.dense_curves(m, n, block, nblocks)
+    curves = [(t, (d * np.float32(gamp)).astype(np.float32), (f * np.float32(gamp)).astype(np.float32))
+              for t, d, f in base]
+    x = (scenes.audio(m, block * nblocks, seed=7) * np.float32(amp)).astype(np.float32)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert np.isfinite(got).all()
+    assert scenes.rel_rms(got, want) <= 1e-6
+
+
+def test_f16x2_kernel_non_finite_input_stays_local():
+    """an infinite input sample poisons the outputs of the blocks that see it (through the exact fallback
+    of the gain kernel) and at most the block before (K2 transforms two blocks as one complex signal),
+    nothing earlier"""
+    layout, block, nblocks, m = "0+5+0", 512, 4, 64
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks, seed=3)
+    x[5, 3 * block + 17] = np.inf
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    clean = slice(0, 2 * block)
+    assert np.isfinite(got[:, clean]).all()
+    assert scenes.rel_rms(got[:, clean], want[:, clean]) <= 1e-6
+    assert (~np.isfinite(got[:, 3 * block:])).any()
+
+
 def test_gain_kernel_choice_follows_the_curves():
     """f16x2 kernel (3) for block-aligned ramps, f32 slot kernel (1) for curves that ignore the tile
     grid or are mostly constant, VALU kernel (0) in strict mode; small object counts never use (3); bf16x3 (2) only when forced."""
