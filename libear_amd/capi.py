@@ -361,7 +361,7 @@ class Renderer:
                 "decor_launches": out[3], "prep_ms": out[4], "prep_launches": out[5]}
 
     def gain_kernel(self):
-        """0 strict VALU, 1 f32 MFMA, 2 bf16x3 MFMA: the gain kernel of the last call"""
+        """0 strict VALU, 1 f32 MFMA, 2 bf16x3 MFMA, 3 f16x2 MFMA: the gain kernel of the last call"""
         kind = C.c_int(-1)
         check(load().earhip_render_gain_kernel(self.h, C.byref(kind)))
         return kind.value
