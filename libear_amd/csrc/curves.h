@@ -261,14 +261,17 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
-  // bf16x3 kernel: forced (2) or, by default (3), when no curve point falls inside a tile
-  // and the curves are mostly ramps: its cost does not depend on the curves, while the
-  // f32 kernel's slot lists make constant pieces half as expensive as ramps (break-even
-  // at about one third of the time in ramps)
+  // Split-operand kernels (tile = 256 or 512 samples, no curve point inside a tile): f16x2 by default
+  // (3; 4 forces it) when the gains can be scaled into f16 range — its cost does not depend on the
+  // curves and is below the f32 slot kernel's even for static gains; bf16x3 when forced (2), or as the
+  // fallback for non-finite gains when the curves are mostly ramps (the slot lists of the f32 kernel
+  // make constant pieces half as expensive as ramps: break-even with bf16x3 at about one third of the
+  // time in ramps).
+  const bool can_h2 = gain_scale > 0.0f && ctx->use_mfma != 2;
   L.bf3 = L.mfma && M >= 32 &&
-          (ctx->use_mfma == 2 || ctx->use_mfma == 4 || (ctx->use_mfma == 3 && aligned && ramp_share >= 0.35));
-  // f16x2 (default; 4 forces it, 2 forces bf16x3) needs gains a power-of-two scale can bring into f16 range
-  L.h2 = L.bf3 && ctx->use_mfma != 2 && gain_scale > 0.0f;
+          (ctx->use_mfma == 2 || ctx->use_mfma == 4 ||
+           (ctx->use_mfma == 3 && aligned && (can_h2 || ramp_share >= 0.35)));
+  L.h2 = L.bf3 && can_h2;
   // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (four rounds of workgroups or more)
   // (EARHIP_H2_TILE=256|512 forces one of them where the curves allow it: tests, tuning)
   const char *force_tile = getenv("EARHIP_H2_TILE");

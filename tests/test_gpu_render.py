@@ -477,8 +477,8 @@ def test_f16x2_kernel_non_finite_input_stays_local():
 
 
 def test_gain_kernel_choice_follows_the_curves():
-    """f16x2 kernel (3) for block-aligned ramps, f32 slot kernel (1) for curves that ignore the tile
-    grid or are mostly constant, VALU kernel (0) in strict mode; small object counts never use (3); bf16x3 (2) only when forced."""
+    """f16x2 kernel (3) for curves without points inside the tiles (block-aligned ramps, static gains),
+    f32 slot kernel (1) for curves that ignore the tile grid, VALU kernel (0) in strict mode; small object counts never use (3); bf16x3 (2) only when forced."""
     from libear_amd import capi
     layout, block, nblocks = "0+5+0", 512, 4
     n = len(LAYOUTS[layout])
@@ -507,4 +507,4 @@ def test_gain_kernel_choice_follows_the_curves():
     assert kernel_for(64, dense, strict=True) == 0
     assert kernel_for(16, scenes.dense_curves(16, n, block, nblocks)) == 1   # fewer than 32 objects
     assert kernel_for(64, scenes.adm_curves(64, n, total, seed=1)) == 1
-    assert kernel_for(64, scenes.constant_curves(64, n)) == 1
+    assert kernel_for(64, scenes.constant_curves(64, n)) == 3   # static gains: no point inside any tile
