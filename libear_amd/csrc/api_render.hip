@@ -110,6 +110,8 @@ struct earhip_render {
   int max_gsplit = 1;
   DevBuf<cf> H, tw;
   DevBuf<float> tail[2], dly[2];
+  DevBuf<float> ztail, zdly;  // all-zero state, never written: what the first call after a reset reads
+  bool fresh = true;          // no call since create / reset: the state is zero
   int cur = 0;  // which state buffer holds the current state
   // host-pointer staging
   DevBuf<float> d_in, d_out;
@@ -213,9 +215,9 @@ struct earhip_render {
       P.out_stride = out_stride;
       P.H = H.p;
       P.tw = tw.p;
-      P.tail_in = tail[cur].p;
+      P.tail_in = fresh ? ztail.p : tail[cur].p;
       P.tail_out = tail[cur ^ 1].p;
-      P.dly_in = dly[cur].p;
+      P.dly_in = fresh ? zdly.p : dly[cur].p;
       P.dly_out = dly[cur ^ 1].p;
       P.N = N;
       P.T = (int)nblocks;
@@ -227,6 +229,7 @@ struct earhip_render {
       launch_decor(L, P, grid, ctx->stream);
       if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
       cur ^= 1;
+      fresh = false;
     }
     if (timing) pending.push_back(pd);
     t += nsamples;
@@ -311,6 +314,10 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
       for (int i = 0; i < 2; i++) {
         r->tail[i].alloc_zero((size_t)r->N * r->B, ctx->stream);
         r->dly[i].alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
+        if (i == 0) {
+          r->ztail.alloc_zero((size_t)r->N * r->B, ctx->stream);
+          r->zdly.alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
+        }
       }
     }
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
@@ -359,10 +366,7 @@ int earhip_render_reset(earhip_render *r, int64_t sample_time) {
     require(r != nullptr, "render must not be NULL");
     r->ctx->use();
     r->t = sample_time;
-    if (r->K == 2) {  // only the buffers the next call reads; it rewrites the other pair completely
-      EARHIP_HIP(hipMemsetAsync(r->tail[r->cur].p, 0, r->tail[r->cur].n * sizeof(float), r->ctx->stream));
-      EARHIP_HIP(hipMemsetAsync(r->dly[r->cur].p, 0, r->dly[r->cur].n * sizeof(float), r->ctx->stream));
-    }
+    r->fresh = true;  // the next call reads the all-zero state and rewrites its own pair completely
   });
 }
 
