@@ -52,9 +52,26 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // the segments itself and the descriptor pass is skipped; with long curves the 16-lanes-per-
   // object search of k_seg_prep is the faster one (measured both ways)
   const bool fused_prep = slots && (size_t)ps.zero_row <= (size_t)8 * M;
+  // f16x2 kernel: K0 also probes the level of the call's inputs (one float4 per object at the start
+  // and in the middle of the call; rows must allow 16-byte loads).  The two level words alternate between calls: this call's
+  // K0 raises word `li` (zero since the last f16x2 call cleared it), its K1 reads it and clears the other.
+  LevelProbe probe;
+  unsigned *level_cur = nullptr, *level_next = nullptr;
+  if (ml.bf3 && ml.h2 && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
+    if (!ctx->level.p) ctx->level.alloc_zero(2, ctx->stream);
+    level_cur = ctx->level.p + ctx->level_idx;
+    level_next = ctx->level.p + (ctx->level_idx ^ 1);
+    ctx->level_idx ^= 1;
+    probe.in = in_dev;
+    probe.in_stride = in_stride;
+    probe.nsamples = nsamples;
+    probe.every = std::max(1, (ml.ntiles + 1) / 2);  // two instants per object at most: every probe is a page walk
+                                                     // (2.5 ns each in K0; eight instants cost 20 us)
+    probe.level = level_cur;
+  }
   if (!fused_prep)
     hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
-                       ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc);
+                       ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
   sl.count = reinterpret_cast<int *>(sl.slots + (size_t)kTileSlots * M * ml.ntiles);
@@ -97,9 +114,11 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #define EARHIP_H2_CASE(NCT_)                                                                                        \
   if (cp.nct == NCT_) {                                                                                             \
     if (ml.tile() == 512)                                                                                           \
-      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, ps.zero_row, xs, gs);       \
+      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, ps.zero_row, xs, gs,       \
+                         level_cur, level_next);                                                                     \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs);       \
+      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs,       \
+                         level_cur, level_next);                                                                     \
   }
     EARHIP_H2_CASE(1) EARHIP_H2_CASE(2) EARHIP_H2_CASE(3)
 #undef EARHIP_H2_CASE
@@ -285,7 +304,7 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
     if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e);
     if (const char *e = getenv("EARHIP_XSCALE")) {  // f16x2 kernel: log2 of the input prescale
       const int v = atoi(e);
-      if (v >= -64 && v <= 64) c->x_scale_log2 = v;
+      if (v >= -64 && v <= 64) c->x_scale_log2 = v, c->x_scale_auto = false;
     }
     if (const char *e = getenv("EARHIP_WAVES")) {
       const int v = atoi(e);

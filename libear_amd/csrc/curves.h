@@ -198,7 +198,7 @@ class CurveSet {
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
   float gain_scale() const {
     if (!(gain_max_ < 1e30f)) return 0.0f;
-    if (gain_max_ < 1e-30f) return 1.0f;
+    if (gain_max_ < 1e-18f) return 1.0f;  // (nothing audible to scale)
     int e;
     std::frexp(gain_max_, &e);  // gain_max_ = f * 2^e, 0.5 <= f < 1
     return std::ldexp(1.0f, 14 - e);

@@ -11,8 +11,8 @@
 //     = 19 binades below the top of the f16 range; below that the error is 2^-25 ABSOLUTE
 //     in scaled units.  The prescale puts the operands at the top of the range: the gains
 //     by 2^14 / (largest |gain| of the curve set, rounded up to a power of two; known at
-//     commit), the inputs by the context's input scale (default 2^14: full-scale audio,
-//     |x| < 4, is exact to 2^-22 down to about -100 dBFS, and 2^-39 absolute below);
+//     commit), the inputs of a call by 2^7 / (the level K0 probes in them; EARHIP_XSCALE: a fixed
+//     scale);
 //   * of the four partial products the three of order >= 2^-11 are kept: xl*bh, xh*bl,
 //     xh*bh (relative error of the contraction on the headline scene: 7e-8, see
 //     tests/test_gpu_render.py and DESIGN.md section 4);
@@ -57,7 +57,8 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // work (and the gain rows' L2 traffic) when no curve point falls inside 512-sample tiles.
 template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
-k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
+k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const unsigned *level_cur,
+              unsigned *level_next) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kBf3Chunk;
   constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
   constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
@@ -66,6 +67,19 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
   const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
+  if (level_cur) {
+    // input scale of THIS call from the level K0 probed: the largest magnitude seen, in [2^E, 2^(E+1)),
+    // goes to [2^7, 2^8) — peaks up to 256x the probed maximum stay inside the f16 range (beyond:
+    // exact fallback below), and samples down to 2^-11 of it keep a normal low piece (2^-22 relative;
+    // below that 2^-33 of the maximum, absolute).  Nothing seen (silence), absurd or non-finite
+    // levels: clamped.
+    const unsigned lv = *level_cur;
+    if (lv) {
+      const int E = max(-60, min(20, (int)(lv >> 23) - 127));
+      x_scale = __uint_as_float((unsigned)(127 + 7 - E) << 23);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *level_next = 0;
+  }
   const int nparts = gridDim.y;
   const int part = blockIdx.y;
   const int m_lo = (int)(((int64_t)P.M * part) / nparts);
@@ -90,8 +104,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
   clear_totals();
 
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
-  // with k = {a, b} of ONE object (gain_bf3.h), accumulated into tot0 times sc
-  auto single_object = [&](int m, float sc) {
+  // with k = {a, b} of ONE object (gain_bf3.h), accumulated into tot0 in units of 1 / (sx sg)
+  // (the two scales are applied to the two operands: their product may not be a float)
+  auto single_object = [&](int m, float sx, float sg) {
     if (tile_len <= 0) return;
     const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
@@ -112,12 +127,12 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
           const float p = (float)(dk.d0 + s) * dk.scale;  // gain_interpolator.hpp:272
           float coef = ramp ? (is_b ? p : 1.0f - p) : (is_b ? 0.0f : 1.0f);
           coef = (slot0 && s >= cur && s < r1) ? coef : 0.0f;
-          a[r] = (x * coef) * sc;
+          a[r] = (x * coef) * sx;
         }
         const int grow = dk.row + ((ramp && is_b && slot0) ? 1 : 0);
         const float *gp = gain + (size_t)grow * rowlen + col0 + li;
 #pragma unroll
-        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16] * sg;
 #pragma unroll
         for (int r = 0; r < NRT; r++)
 #pragma unroll
@@ -132,8 +147,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
 
   const int nobj = m_hi - m_lo;
   const int nch = (P.vec_ok && nobj >= CH) ? (nobj + CH - 1) / CH : 0;
-  const float unit = x_scale * g_scale;
-  float inv = 1.0f / unit;  // exact: powers of two
+  float inv_x = 1.0f / x_scale, inv_g = 1.0f / g_scale;  // exact: powers of two
 
   if (nch > 0) {
     // (addressing, descriptor hand-over and load order: see the comments in gain_bf3.h)
@@ -338,7 +352,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
       while (multi) {
         const int j = __builtin_ctzll(multi);
         multi &= multi - 1;
-        single_object(m_lo + b0 + j, unit);
+        single_object(m_lo + b0 + j, x_scale, g_scale);
       }
     }
     // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the
@@ -352,12 +366,12 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
         for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
     if (__ballot(bad)) {
       clear_totals();
-      inv = 1.0f;
-      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f);
+      inv_x = inv_g = 1.0f;
+      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, 1.0f);
     }
   } else {
-    inv = 1.0f;
-    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f);  // unaligned rows
+    inv_x = inv_g = 1.0f;
+    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, 1.0f);  // unaligned rows
   }
 
   if (tile_len <= 0) return;
@@ -376,7 +390,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale) {
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < NRT; r++)
-        v[r] = __builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv;
+        v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_g;
       if (P.vec_ok && s + 3 < tile_len) {
         *reinterpret_cast<f32x4 *>(o + s) = v;
       } else {

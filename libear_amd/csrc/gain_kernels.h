@@ -104,12 +104,30 @@ __device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int ba
 // (the searches hit the same lines); the block transposes through LDS so that
 // the descriptors land TILE-MAJOR, desc[tile][M]: K1 walks the objects of one
 // tile and reads them as one contiguous stream.
+// Input level (f16x2 gain kernel): with `level` set, every thread of every `level_every`-th tile also
+// looks at four input samples of its object and tile; the largest magnitude seen (as float bits) is
+// left in *level.  The f16x2 kernel scales the inputs of the call by a power of two chosen from it.
+struct LevelProbe {
+  const float *in = nullptr;  // nullptr: no probing
+  size_t in_stride = 0;
+  int nsamples = 0;
+  int every = 1;              // probe tiles 0, every, 2 every, ...
+  unsigned *level = nullptr;  // zero before the launch
+};
 static __global__ void __launch_bounds__(256)
 k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end,
-           SegDesc *desc) {
+           SegDesc *desc, LevelProbe probe) {
   __shared__ SegDesc sh[16][17];
   const int ti = threadIdx.x & 15, oi = threadIdx.x >> 4;
   const int tile = blockIdx.x * 16 + ti, m = blockIdx.y * 16 + oi;
+  // the probe is requested first and looked at last: its latency (a TLB miss, typically) hides behind
+  // the segment search
+  float4 px = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (probe.in) {  // (wave-uniform branch)
+    const int s = tile * tile_samples + 4 * ((m + 5 * tile) & 15);
+    if (tile < ntiles && m < M && tile % probe.every == 0 && s + 3 < probe.nsamples)
+      px = *reinterpret_cast<const float4 *>(probe.in + (size_t)m * probe.in_stride + s);
+  }
   if (tile < ntiles && m < M) {
     const int base = ps.off[m], n = ps.off[m + 1] - base;
     const int64_t t0 = t_call + (int64_t)tile * tile_samples;
@@ -122,6 +140,16 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
   const int to = threadIdx.x >> 4, oo = threadIdx.x & 15;
   const int tile_o = blockIdx.x * 16 + to, m_o = blockIdx.y * 16 + oo;
   if (tile_o < ntiles && m_o < M) desc[(size_t)tile_o * M + m_o] = sh[to][oo];
+  if (probe.in) {
+    unsigned v = max(max(__float_as_uint(px.x) & 0x7fffffffu, __float_as_uint(px.y) & 0x7fffffffu),
+                     max(__float_as_uint(px.z) & 0x7fffffffu, __float_as_uint(px.w) & 0x7fffffffu));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
+    // one atomic per wave would serialise thousands of them on one address: look first — new maxima
+    // get rare quickly (a stale read only costs an unnecessary atomic)
+    if ((threadIdx.x & 63) == 0 && v != 0)  // (only the waves that probed something touch the word)
+      if (v > __atomic_load_n(probe.level, __ATOMIC_RELAXED)) atomicMax(probe.level, v);
+  }
 }
 
 // ---------------------------------------------------------------------------

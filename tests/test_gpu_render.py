@@ -440,11 +440,12 @@ def test_f16x2_kernel_both_tiles_vs_oracle(tile, m, layout):
     assert scenes.rel_rms(parts, want) <= 1e-6
 
 
-@pytest.mark.parametrize("amp,gamp", [(1e-4, 1.0), (300.0, 1.0), (1.0, 2000.0), (1.0, 3e-4), (1e-3, 50.0)])
+@pytest.mark.parametrize("amp,gamp", [(1e-4, 1.0), (300.0, 1.0), (1.0, 2000.0), (1.0, 3e-4), (1e-3, 50.0),
+                                      (1e-7, 1.0), (3e4, 1e-3), (1e-9, 1e-6)])
 def test_f16x2_kernel_operand_ranges(amp, gamp):
-    """The f16x2 kernel scales the gains by their own maximum and the inputs by a fixed 2^14: quiet
-    inputs keep 1e-6, inputs beyond the f16 range after the prescale (|x| >= 4) take the exact
-    in-kernel fallback, large and small gains are absorbed by the gain scale."""
+    """The f16x2 kernel scales the gains by their own maximum and the inputs by a power of two from the
+    level K0 probes in the call's inputs: 1e-6 holds at any level; inputs beyond the f16 range after the
+    prescale (peaks far above the probed level) take the exact in-kernel fallback."""
     layout, block, nblocks, m = "4+5+0", 512, 3, 64
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
@@ -456,6 +457,22 @@ def test_f16x2_kernel_operand_ranges(amp, gamp):
     got = run_hip(curves, x, n, block, dec, 255, [nblocks])
     assert np.isfinite(got).all()
     assert scenes.rel_rms(got, want) <= 1e-6
+
+
+def test_f16x2_kernel_peak_far_above_the_probed_level():
+    """a burst 10^4 above the rest of the call, in a sample the level probe does not see: the wave tiles
+    that hold it overflow the f16 range and are recomputed exactly"""
+    layout, block, nblocks, m = "4+5+0", 512, 3, 64
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = (scenes.audio(m, block * nblocks, seed=9) * np.float32(1e-3)).astype(np.float32)
+    x[:, 700:703] *= np.float32(1e4)   # (the probe reads samples 4 ((m + 5 tile) & 15) .. +3 of a tile)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    for tile in ("256", "512"):
+        got = _with_env({"EARHIP_H2_TILE": tile}, lambda: run_hip(curves, x, n, block, dec, 255, [nblocks]))
+        assert np.isfinite(got).all()
+        assert scenes.rel_rms(got, want) <= 1e-6
 
 
 def test_f16x2_kernel_non_finite_input_stays_local():
