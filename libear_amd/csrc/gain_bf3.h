@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
         // blocks 0 and 1, and only then are the next chunk's inputs requested; they are waited
         // for at the hand-over after the last block.  (With the inputs requested at the top,
         // the first use of a gain row waited for them too and serialised the prefetch.)
-        const bool conv0 = blk == 0, conv1 = blk == 1, copy = false;
+        const bool conv0 = blk == 0, conv1 = blk == 1;
         if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
         if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
         if (blk == (NBLK > 2 ? 2 : 1)) {
@@ -353,13 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_gain_mix_bf3(GainMixParams P, int ze
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
           }
-        } else if (copy && blk > 0) {
-#pragma unroll
-          for (int k = 0; k < 24; k++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          }
-        } else if (blk > 0 || copy) {
+        } else if (blk > 0) {
 #pragma unroll
           for (int k = 0; k < 24; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
