@@ -161,13 +161,16 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
     const int bfr1 = lane < 16 * NCT ? NCT * 2 : 2;
     auto chunk_base = [&](int c) { return min(m_lo + c * CH, m_hi - CH); };
 
-    auto load_x = [&](int c, f32x4 (&x)[8]) {
+    // inputs q0 .. q0 + n - 1 of chunk c
+    auto load_x_part = [&](int c, f32x4 (&x)[8], int q0, int n) {
       const char *bp = reinterpret_cast<const char *>(P.in + (size_t)chunk_base(c) * P.in_stride);
 #pragma unroll
       for (int q = 0; q < 8; q++)
-        x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
-            bp + (size_t)q * P.in_stride * sizeof(float) + xlane));
+        if (q >= q0 && q < q0 + n)
+          x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
+              bp + (size_t)q * P.in_stride * sizeof(float) + xlane));
     };
+    auto load_x = [&](int c, f32x4 (&x)[8]) { load_x_part(c, x, 0, 8); };
     // What this WAVE converts for chunk c: objects chunk_base + NQ w + q.  Their descriptors are
     // wave-uniform: scalar loads (requested one chunk ahead), scalar row arithmetic, and the
     // gain rows come in as (scalar row pointer) + (the lane's column).
@@ -288,7 +291,10 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
           al[rp][qp] = pack_f16(r0[0], r1[0]);
           al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
         }
-      load_x(min(c + 2, nch - 1), xc);  // (the last two chunks re-request the last one: never used)
+      // The inputs of chunk c+2 go into the registers just freed, a few requests per MFMA block:
+      // requested in one burst right here, by all the workgroup's waves at once, they queue up in the
+      // CU's address unit and the waves sit in their load instructions instead of issuing MFMAs.
+      constexpr int XB = 2 * NCT >= 4 ? 4 : 2 * NCT;  // blocks that carry input requests
       // 2*NCT blocks (column tile ct = blk >> 1, operand blk & 1: B0 / B1) of 12 MFMAs: three
       // partial products per operand pair, smallest first.  MFMA and VALU instructions do not
       // overlap except for one VALU instruction directly behind an MFMA
@@ -323,6 +329,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
 #pragma unroll
           for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[0], tot1[r][ct]);
         }
+        if (blk < XB) load_x_part(min(c + 2, nch - 1), xc, blk * (8 / XB), 8 / XB);  // (past the end: never used)
         const bool conv0 = blk == NBLK - 2, conv1 = blk == NBLK - 1;
         if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
         if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
@@ -333,6 +340,13 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
           for (int k = 0; k < 12; k++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+        } else if (blk < XB) {
+#pragma unroll
+          for (int k = 0; k < 8 / XB; k++) {  // MFMAs, then one request (address arithmetic + load)
+            __builtin_amdgcn_sched_group_barrier(0x008, 12 / (8 / XB), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
           }
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
