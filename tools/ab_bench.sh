@@ -7,6 +7,6 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cp $ROOT/libear_amd/lib/libearhip.so /tmp/libearhip_keep.so
 for round in 1 2 3; do for v in "$@"; do
   cp $ROOT/libear_amd/lib/$v.so $ROOT/libear_amd/lib/libearhip.so
-  echo "$v: $(timeout 200 python $ROOT/bench.py --steps 30 --warmup 5 --stream-only $ARGS 2>/dev/null | python $ROOT/tools/benchline.py)"
+  echo "$v: $(timeout 200 python $ROOT/bench.py --steps 100 --warmup 10 --stream-only $ARGS 2>/dev/null | python $ROOT/tools/benchline.py)"
 done; done
 cp /tmp/libearhip_keep.so $ROOT/libear_amd/lib/libearhip.so
