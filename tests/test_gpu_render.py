@@ -55,6 +55,21 @@ def run_oracle(curves, x, n_out, block, dec, delay):
     return o.process(x)
 
 
+def _with_env(env, fn):
+    keep = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        return fn()
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("m,n,block,nblocks", [(1, 6, 512, 3), (64, 10, 512, 4), (5, 3, 64, 9), (33, 24, 256, 5)])
 def test_gain_stage_strict_bit_exact(m, n, block, nblocks):
     """C1/C2-shaped: ramped gains only; strict mode reproduces the CPU path bit for bit."""
@@ -324,6 +339,50 @@ def test_random_scenes_vs_oracle(seed):
     assert scenes.rel_rms(got, want) <= 1e-6, (layout, block, nblocks, m, kind, calls)
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EARHIP_FUZZ_SEEDS", "16")))))
+def test_random_aligned_scenes_split_operand_kernels(seed):
+    """Randomised scenes the split-operand kernels take (no curve point inside a tile): points on a
+    256 or 512 grid with a random mix of ramps, constant stretches and steps (duplicate times), object
+    counts around the 32-object chunk, random call partitions (short calls split the objects over
+    workgroups), random signal and gain levels, both tiles of the f16x2 kernel."""
+    rng = np.random.default_rng(5000 + seed)
+    layout = ["0+5+0", "4+5+0", "9+10+3"][int(rng.integers(0, 3))]
+    n = len(LAYOUTS[layout])
+    block = int([256, 512, 1024][int(rng.integers(0, 3))])
+    nblocks = int(rng.integers(2, 9))
+    m = int(rng.choice([32, 33, 47, 63, 64, 65, 96, 100, 129, 200]))
+    total = block * nblocks
+    grid_step = int([256, 512][int(rng.integers(0, 2))])
+    grid = np.arange(0, total + grid_step, grid_step)
+    glevel = np.float32(10.0 ** rng.uniform(-3, 2))
+    curves = []
+    for i in range(m):
+        k = int(rng.integers(1, min(len(grid), 8) + 1))
+        t = np.sort(rng.choice(grid, size=k, replace=False)).astype(np.int64)
+        if k >= 3 and rng.random() < 0.3:
+            t[1] = t[0]  # a step
+        d = (rng.uniform(0, 1, (k, n)) * glevel).astype(np.float32)
+        f = (rng.uniform(0, 1, (k, n)) * glevel).astype(np.float32)
+        if k >= 2 and rng.random() < 0.4:
+            d[-1], f[-1] = d[-2], f[-2]  # a constant stretch
+        curves.append((t, d, f))
+    dec = decorrelators(layout)
+    if block < 512:
+        dec = dec[:, :block].copy()
+    x = (scenes.audio(m, total, seed=seed) * np.float32(10.0 ** rng.uniform(-5, 2))).astype(np.float32)
+    calls = []
+    left = nblocks
+    while left > 0:
+        c = int(rng.integers(1, left + 1))
+        calls.append(c)
+        left -= c
+    tile = ["256", "512", None][int(rng.integers(0, 3))]
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = _with_env({"EARHIP_H2_TILE": tile}, lambda: run_hip(curves, x, n, block, dec, 255, calls))
+    assert np.isfinite(got).all()
+    assert scenes.rel_rms(got, want) <= 1e-6, (layout, block, nblocks, m, grid_step, calls, tile)
+
+
 @pytest.mark.parametrize("seed", list(range(4)))
 def test_random_large_scenes_vs_oracle(seed):
     """Like test_random_scenes_vs_oracle at object counts and stream lengths where the kernels run
@@ -404,21 +463,6 @@ def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
     assert scenes.rel_rms(outs[0], want) <= 1e-6
     assert scenes.rel_rms(outs[1], want) <= 1e-6
     assert scenes.rel_rms(outs[0], outs[1]) <= 1e-6
-
-
-def _with_env(env, fn):
-    keep = {k: os.environ.get(k) for k in env}
-    try:
-        for k, v in env.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
-        return fn()
-    finally:
-        for k, v in keep.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
 
 
 @pytest.mark.parametrize("tile", ["256", "512"])
