@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--kernel-timing-every", type=int, default=8,
+                    help="record the per-kernel HIP events (roofline, kernels_ms) on every n-th timed step")
     ap.add_argument("--precondition-ms", type=float, default=40.0,
                     help="untimed steps of the same workload before the W warm-up steps, until this much wall time "
                          "has passed: an idle MI355X needs 10-20 ms of load to leave its low-power clocks "
@@ -189,7 +191,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    r.enable_timing(True)
+    # per-kernel HIP events on every TIME_EVERY-th step of the timed region (each timed step records six
+    # events = ~20 us of idle GPU; timing every step costs 4 % of the headline value)
+    time_every = max(1, min(args.kernel_timing_every, args.steps))
+    timed_steps = len(range(0, args.steps, time_every))
+    r.enable_timing(time_every)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -230,10 +236,10 @@ def main():
         gain_b, dec_b, dm_b = algorithmic_bytes(M, N, B, K)
         # a long call is cut into chunks (K1 of chunk c+1 overlaps K2 of chunk c): per-step sums for
         # the kernel table, per-launch figures for the roofline (what rocprofv3 averages)
-        k1_launches = max(timing["gain_mix_launches"], 1) / args.steps
-        k1_ms = timing["gain_mix_ms"] / args.steps
-        k2_ms = timing["decor_ms"] / args.steps
-        k0_ms = timing["prep_ms"] / args.steps
+        k1_launches = max(timing["gain_mix_launches"], 1) / timed_steps
+        k1_ms = timing["gain_mix_ms"] / timed_steps
+        k2_ms = timing["decor_ms"] / timed_steps
+        k0_ms = timing["prep_ms"] / timed_steps
         achieved = gain_b * T / (k1_ms * 1e-3) / 1e9
         whole = (gain_b + dec_b + dm_b) * T / t_step / 1e9
         traffic = None
@@ -270,6 +276,7 @@ def main():
             "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
             "exchange_check": None if exchange_err is None else
                               {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}")},
+            "kernel_timing": {"timed_steps": timed_steps, "every": time_every},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
             "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),

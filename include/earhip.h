@@ -237,7 +237,9 @@ int earhip_render_process_device(earhip_render *r, size_t nblocks,
 int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *in,
                           float *const *out);
 /* Kernel timing (HIP events on the context's stream around each launch).
- * enable != 0 starts collecting and zeroes the counters. */
+ * enable != 0 starts collecting and zeroes the counters; enable = n > 1 times
+ * every n-th process call only, starting with the next one (each timed call
+ * records six events, which costs the GPU about 20 us of idle time). */
 int earhip_render_enable_timing(earhip_render *r, int enable);
 /* Sums since enable: [0] gain_mix kernel ms, [1] its launches, [2] decorrelate/
  * delay/mix kernel ms, [3] its launches, [4] segment-prep kernel ms, [5] its

@@ -352,6 +352,7 @@ class Renderer:
                                                   C.c_size_t(out_stride)))
 
     def enable_timing(self, on=True):
+        """True / 1: time the kernels of every process call; n > 1: of every n-th call; False: stop"""
         check(load().earhip_render_enable_timing(self.h, int(on)))
 
     def get_timing(self):

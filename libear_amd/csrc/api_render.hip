@@ -118,6 +118,8 @@ struct earhip_render {
   PinBuf<float> p_in, p_out;
   // timing
   bool timing = false;
+  int timing_every = 1;      // time every n-th process call (the event records cost ~3 us of idle GPU each)
+  long timing_calls = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   struct Pending { hipEvent_t e[6]; bool has_k2; };
   std::vector<Pending> pending;
@@ -174,7 +176,8 @@ struct earhip_render {
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");
     Pending pd;
     hipEvent_t *evp = nullptr;
-    if (timing) {
+    const bool timed = timing && (timing_calls++ % timing_every) == 0;
+    if (timed) {
       for (int i = 0; i < 6; i++) pd.e[i] = get_event();
       pd.has_k2 = K == 2;
       evp = pd.e;
@@ -231,7 +234,7 @@ struct earhip_render {
       cur ^= 1;
       fresh = false;
     }
-    if (timing) pending.push_back(pd);
+    if (timed) pending.push_back(pd);
     t += nsamples;
   }
 };
@@ -447,6 +450,8 @@ int earhip_render_enable_timing(earhip_render *r, int enable) {
     r->ctx->use();
     if (r->timing) r->drain_timing();
     r->timing = enable != 0;
+    r->timing_every = enable > 1 ? enable : 1;
+    r->timing_calls = 0;
     for (int i = 0; i < 3; i++) r->acc_ms[i] = r->acc_n[i] = 0;
   });
 }
