@@ -271,6 +271,10 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->D = cfg->delay;
     r->T = cfg->max_blocks;
     r->L = 2 * r->B;
+    // workgroup decorrelator kernel: blocks per run.  Block 1024 (BASELINE config 5, 512 blocks x 24
+    // loudspeakers): 7 -> K2 0.113 ms, 5 -> 0.117, 11 -> 0.128, 15 -> 0.140 (two rounds of workgroups that fill
+    // the chip evenly beat one ragged round)
+    if (r->L == 2048) r->run_len = 7;
     if (const char *e = getenv("EARHIP_RUN")) {  // tuning knob: blocks per decorrelator run (odd)
       const int v = atoi(e);
       if (v >= 1 && v <= 255) r->run_len = v | 1, r->run_len_set = true;
