@@ -272,11 +272,12 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
           (ctx->use_mfma == 2 || ctx->use_mfma == 4 ||
            (ctx->use_mfma == 3 && aligned && (can_h2 || ramp_share >= 0.35)));
   L.h2 = L.bf3 && can_h2;
-  // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (four rounds of workgroups or more)
+  // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (two rounds of workgroups or more:
+  // 512 blocks of 512: K1 0.215 vs 0.236 ms; one round, 256 blocks: 0.127 vs 0.120)
   // (EARHIP_H2_TILE=256|512 forces one of them where the curves allow it: tests, tuning)
   const char *force_tile = getenv("EARHIP_H2_TILE");
   const int forced = force_tile ? atoi(force_tile) : 0;
-  L.wide = L.h2 && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 4 * ctx->num_cus);
+  L.wide = L.h2 && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
   if (L.mfma && !L.bf3 && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;
