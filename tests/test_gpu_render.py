@@ -490,6 +490,8 @@ def test_f16x2_kernel_operand_ranges(amp, gamp):
     """The f16x2 kernel scales the gains by their own maximum and the inputs by a power of two from the
     level K0 probes in the call's inputs: 1e-6 holds at any level; inputs beyond the f16 range after the
     prescale (peaks far above the probed level) take the exact in-kernel fallback."""
+    if os.environ.get("EARHIP_XSCALE") is not None and not 1e-5 <= amp <= 3.0:
+        pytest.skip("fixed input scale (EARHIP_XSCALE): levels far from full scale lose precision by design")
     layout, block, nblocks, m = "4+5+0", 512, 3, 64
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
