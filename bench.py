@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--layout", default="9+10+3")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
-    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving"), default="dense",
+    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed"), default="dense",
                     help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
                          "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -135,6 +135,11 @@ def main():
         curves = scenes.adm_curves(M, N, total, period=240, ramp=240, seed=12 + rank)
     elif args.scene == "static":  # one gain vector per object and bus, never changing
         curves = scenes.constant_curves(M, N, seed=8 + rank)
+    elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
+        curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
+        odd = scenes.adm_curves(max(M // 128, 1), N, total, seed=11 + rank)
+        for i, c in enumerate(odd):
+            curves[(128 * i + 7) % M] = c
     else:
         curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
     gen = torch.Generator(device=dev)

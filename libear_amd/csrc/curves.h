@@ -154,6 +154,38 @@ class CurveSet {
         g = b;
       }
     grid_ = g;
+    // The same per grid size of the split-operand kernels, tolerant of a few objects: an object is ON the
+    // grid G when all its points are congruent modulo G to the phase most objects share.  Objects off the
+    // grid only cost their own slow path in the tiles where their points fall.
+    const int grids[2] = {512, 256};
+    for (int gi = 0; gi < 2; gi++) {
+      const int64_t G = grids[gi];
+      std::vector<int64_t> phase(M_, -1);  // -1: the object's points do not share a phase
+      for (int m = 0; m < M_; m++) {
+        const auto &t = times_[m];
+        if (t.empty()) continue;
+        const int64_t p0 = ((t[0] % G) + G) % G;
+        bool same = true;
+        for (int64_t v : t) same = same && (((v % G) + G) % G) == p0;
+        if (same) phase[m] = p0;
+      }
+      std::vector<int64_t> sorted;
+      for (int m = 0; m < M_; m++)
+        if (phase[m] >= 0) sorted.push_back(phase[m]);
+      std::sort(sorted.begin(), sorted.end());
+      int64_t best = 0;
+      size_t best_n = 0;
+      for (size_t i = 0; i < sorted.size();) {
+        size_t j = i;
+        while (j < sorted.size() && sorted[j] == sorted[i]) j++;
+        if (j - i > best_n) best_n = j - i, best = sorted[i];
+        i = j;
+      }
+      grid_phase_[gi] = best;
+      int empty = 0;
+      for (int m = 0; m < M_; m++) empty += times_[m].empty() ? 1 : 0;
+      grid_off_[gi] = M_ - empty - (int)best_n;
+    }
     // share of the curves' time spans spent in ramps (the rest is constant)
     double span = 0, ramp = 0;
     const int allflat = (1 << nbus_) - 1;
@@ -189,7 +221,18 @@ class CurveSet {
   }
 
   // largest tile of the split-operand kernels (512, 256) with no curve point strictly inside; 0: none
-  int aligned_tile(int64_t t_call) const { return tiles_aligned(512, t_call) ? 512 : tiles_aligned(256, t_call) ? 256 : 0; }
+  // A few objects off the grid (at most M / 64) are tolerated: the split-operand kernels send an object
+  // with a point inside a tile through their exact slow path for that tile only (about the cost of a
+  // chunk of 32 objects each), which beats moving the whole scene to the slot kernel.
+  int aligned_tile(int64_t t_call) const {
+    const int grids[2] = {512, 256};
+    for (int gi = 0; gi < 2; gi++) {
+      const int64_t G = grids[gi];
+      if (tiles_aligned((int)G, t_call)) return (int)G;
+      if (grid_off_[gi] <= M_ / 64 && (((t_call - grid_phase_[gi]) % G) + G) % G == 0) return (int)G;
+    }
+    return 0;
+  }
 
   // fraction of the curves' time in ramps; 0 for static gains
   double ramp_share() const { return ramp_share_; }
@@ -229,6 +272,8 @@ class CurveSet {
   int npoints_ = 0;
   int64_t t_ref_ = 0;
   uint64_t grid_ = 0;
+  int64_t grid_phase_[2] = {0, 0};  // [512, 256]: the phase most objects' points share
+  int grid_off_[2] = {0, 0};        // objects whose points are not all on that phase
   double ramp_share_ = 0;
   float gain_max_ = 0;
   DevBuf<int32_t> d_off_;

@@ -539,6 +539,42 @@ def test_f16x2_kernel_non_finite_input_stays_local():
     assert (~np.isfinite(got[:, 3 * block:])).any()
 
 
+@pytest.mark.parametrize("tile", [None, "256", "512"])
+def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
+    """A few objects whose metadata ignores the block grid (2 of 128 here; up to M / 64) do not move the
+    scene to the slot kernel: they take the exact slow path in the tiles where their points fall."""
+    from libear_amd import capi
+    if os.environ.get("EARHIP_MFMA") not in (None, "3"):
+        pytest.skip("kernel forced by EARHIP_MFMA")
+    layout, block, nblocks, m = "4+5+0", 512, 6, 128
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    odd = scenes.adm_curves(2, n, total, period=700, ramp=150, seed=3)
+    curves[17], curves[90] = odd[0], odd[1]
+    x = scenes.audio(m, total, seed=21)
+    want = run_oracle(curves, x, n, block, dec, 255)
+
+    def render():
+        r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+        set_renderer_curves(r, curves, True)
+        out = r.process(x)
+        kind = r.gain_kernel()
+        r.close()
+        return out, kind
+
+    got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
+    assert kind == 3
+    assert scenes.rel_rms(got, want) <= 1e-6
+    # three such objects are more than M / 64: the slot kernel takes over
+    curves[5] = scenes.adm_curves(1, n, total, period=500, ramp=100, seed=4)[0]
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
+    assert kind == 1
+    assert scenes.rel_rms(got, want) <= 1e-6
+
+
 def test_gain_kernel_choice_follows_the_curves():
     """f16x2 kernel (3) for curves without points inside the tiles (block-aligned ramps, static gains),
     f32 slot kernel (1) for curves that ignore the tile grid, VALU kernel (0) in strict mode; small object counts never use (3); bf16x3 (2) only when forced."""
