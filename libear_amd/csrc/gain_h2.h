@@ -106,13 +106,21 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
   // with k = {a, b} of ONE object (gain_bf3.h), accumulated into tot0 in units of 1 / (sx sg)
   // (the two scales are applied to the two operands: their product may not be a float)
-  auto single_object = [&](int m, float sx, float sg) {
+  // khint >= 0: the segment index K0 found at the start of the WORKGROUP tile (the search then only
+  // walks on from there: a few steps instead of log2 n dependent loads per object and wave)
+  auto single_object = [&](int m, float sx, float sg, int khint = -1) {
     if (tile_len <= 0) return;
     const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;
-    int k = upper_bound_time(P.ps.time + base, n, tile_t0);
+    int k;
+    if (khint >= 0) {
+      k = min(khint, n);
+      while (k < n && P.ps.time[base + k] <= tile_t0) k++;
+    } else {
+      k = upper_bound_time(P.ps.time + base, n, tile_t0);
+    }
     int cur = 0;
     while (cur < tile_len) {
       const SegDesc dk = describe_segment(P.ps, base, n, k, tile_t0, tile_t1);
@@ -370,7 +378,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
       while (multi) {
         const int j = __builtin_ctzll(multi);
         multi &= multi - 1;
-        single_object(m_lo + b0 + j, x_scale, g_scale);
+        // (the k field of a descriptor is exact for these objects: the piece ends inside the tile)
+        single_object(m_lo + b0 + j, x_scale, g_scale, seg_k(__shfl(db.info, j)));
       }
     }
     // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the

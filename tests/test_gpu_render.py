@@ -541,7 +541,7 @@ def test_f16x2_kernel_non_finite_input_stays_local():
 
 @pytest.mark.parametrize("tile", [None, "256", "512"])
 def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
-    """A few objects whose metadata ignores the block grid (2 of 128 here; up to M / 64) do not move the
+    """A few objects whose metadata ignores the block grid (2 of 128 here; up to M / 32) do not move the
     scene to the slot kernel: they take the exact slow path in the tiles where their points fall."""
     from libear_amd import capi
     if os.environ.get("EARHIP_MFMA") not in (None, "3"):
@@ -567,8 +567,9 @@ def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
     got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
     assert kind == 3
     assert scenes.rel_rms(got, want) <= 1e-6
-    # three such objects are more than M / 64: the slot kernel takes over
-    curves[5] = scenes.adm_curves(1, n, total, period=500, ramp=100, seed=4)[0]
+    # five such objects are more than M / 32: the slot kernel takes over
+    more = scenes.adm_curves(3, n, total, period=500, ramp=100, seed=4)
+    curves[5], curves[40], curves[77] = more[0], more[1], more[2]
     want = run_oracle(curves, x, n, block, dec, 255)
     got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
     assert kind == 1
