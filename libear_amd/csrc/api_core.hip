@@ -69,9 +69,15 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
                                                      // (2.5 ns each in K0; eight instants cost 20 us)
     probe.level = level_cur;
   }
-  if (!fused_prep)
-    hipLaunchKernelGGL(k_seg_prep, dim3((ml.ntiles + 15) / 16, (M + 15) / 16), dim3(256), 0,
-                       ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
+  if (!fused_prep) {
+    const dim3 ogrid((M + 15) / 16);
+    if (ml.ntiles >= 2048)
+      hipLaunchKernelGGL(k_seg_prep<4>, dim3((ml.ntiles + 63) / 64, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
+    else
+      hipLaunchKernelGGL(k_seg_prep<2>, dim3((ml.ntiles + 31) / 32, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
+  }
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
   sl.count = reinterpret_cast<int *>(sl.slots + (size_t)kTileSlots * M * ml.ntiles);
