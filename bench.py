@@ -5,18 +5,21 @@
     24 decorrelators (512-tap FIR, FFT 1024), 255-sample compensation delay, mix-down.
 
 One "step" = one stream-mode pass of the hot path over T consecutive blocks (default 1024, i.e.
-10.9 s of audio) for 1024 objects per GPU, inputs and gain curves already resident in HBM.  Every
-block is a full-length ramp between dense uniform(0,1) gain vectors (worst case).
+10.9 s of audio), inputs and gain curves already resident in HBM.  Every block is a full-length ramp
+between dense uniform(0,1) gain vectors (worst case).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 
-Rank 0 prints ONE JSON line.  `value` = object-samples consumed per second over all GPUs
+`--config C2|C3|C4|C5` selects a BASELINE.json configuration (default C4 = the one the metric is quoted
+on: 1024 objects in total); `--objects/--layout/--block-size/--blocks/--buses/--hoa` override single
+fields.  Rank 0 prints ONE JSON line.  `value` = object-samples consumed per second over all GPUs
 (Msamples/s = M*B*T / t_step / 1e6); `rtf` = real-time factor (B*T/48000) / t_step.
-Multi-GPU: objects are sharded (1024 per rank, weak scaling; `--scaling strong` splits 1024 objects
-over the ranks instead), each rank renders its shard and the partial loudspeaker buses are summed by
-one RCCL reduce-scatter over the channel axis, overlapped with the next step's render.
+Multi-GPU: the scene's objects are sharded over the ranks (BASELINE config 4: strong scaling), each
+rank renders its shard and the partial loudspeaker buses are summed by one RCCL reduce-scatter over the
+channel axis, overlapped with the next step's render; the weak-scaling figure (--objects per rank) is
+reported in the same line under `weak_scaling`.
 """
 import argparse
 import json
@@ -30,14 +33,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3  # vector / f32-MFMA peak, same guide
-BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak, same guide
 SAMPLE_RATE = 48000.0
 
+PRESETS = {  # BASELINE.json `configs` (C2..C5)
+    "C2": dict(objects=64, hoa=0, layout="4+5+0", block_size=512, buses=1, blocks=1024),
+    "C3": dict(objects=256, hoa=0, layout="9+10+3", block_size=512, buses=2, blocks=1024),
+    "C4": dict(objects=1024, hoa=0, layout="9+10+3", block_size=512, buses=2, blocks=1024),
+    "C5": dict(objects=512, hoa=16, layout="9+10+3", block_size=1024, buses=2, blocks=512),
+}
 
-def algorithmic_bytes(m, n, b, k, ramp=True):
-    """bytes_gain, bytes_dec, bytes_delay_mix per block"""
-    e = 2 if ramp else 1
-    gain = 4 * (m * b + e * k * m * n + k * n * b)
+
+def algorithmic_bytes(m, n, b, k, m_static=0):
+    """bytes_gain, bytes_dec, bytes_delay_mix per block.  m ramped objects on k buses plus
+    m_static channels through a constant matrix on the direct bus (config 5's HOA bed: one gain row)."""
+    gain = 4 * (m * b + 2 * k * m * n + k * n * b)
+    if m_static:
+        gain += 4 * (m_static * b + m_static * n + n * b)
     p, d = 1, 255
     dec = n * (4 * b + 8 * p * (b + 1) + 2 * 8 * p * (b + 1) + 2 * 4 * b + 4 * b) if k == 2 else 0
     dm = n * (4 * b + 2 * 4 * d + 4 * b + 4 * b) if k == 2 else 0
@@ -46,6 +58,8 @@ def algorithmic_bytes(m, n, b, k, ramp=True):
 
 GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 2: "k_gain_mix_bf3 (bf16x3 MFMA)",
                 3: "k_gain_mix_h2 (f16x2 MFMA)"}
+GAIN_DTYPES = {0: "f32 (VALU, libear's exact arithmetic)", 1: "f32 (f32 MFMA, f32 accumulate)",
+               2: "f32 io / bf16x3-split MFMA, f32 accumulate", 3: "f32 io / f16x2-split MFMA, f32 accumulate"}
 
 
 def mfma_roofline(kind, macs_per_term, k1_ms):
@@ -61,33 +75,53 @@ def mfma_roofline(kind, macs_per_term, k1_ms):
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "note": "executed " + what}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(PRESETS), default="C4", help="BASELINE.json configuration")
+    ap.add_argument("--objects", type=int, default=None, help="objects of the scene (in total; --scaling weak: per GPU)")
+    ap.add_argument("--hoa", type=int, default=None, help="extra input channels through a constant decode matrix (config 5)")
+    ap.add_argument("--blocks", type=int, default=None, help="blocks per step (stream length T)")
+    ap.add_argument("--block-size", type=int, default=None)
+    ap.add_argument("--layout", default=None)
+    ap.add_argument("--buses", type=int, choices=(1, 2), default=None,
+                    help="1: ramped gains only (config 2); 2: direct + diffuse, decorrelators, delay, mix")
     ap.add_argument("--kernel-timing-every", type=int, default=8,
                     help="record the per-kernel HIP events (roofline, kernels_ms) on every n-th timed step")
     ap.add_argument("--precondition-ms", type=float, default=40.0,
                     help="untimed steps of the same workload before the W warm-up steps, until this much wall time "
                          "has passed: an idle MI355X needs 10-20 ms of load to leave its low-power clocks "
                          "(steps measured right after start-up are ~9 %% slower)")
-    ap.add_argument("--objects", type=int, default=1024, help="objects per GPU")
-    ap.add_argument("--blocks", type=int, default=1024, help="blocks per step (stream length T)")
-    ap.add_argument("--block-size", type=int, default=512)
-    ap.add_argument("--layout", default="9+10+3")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
     ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed"), default="dense",
                     help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
                          "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --objects per GPU (default); strong: --objects in total, split over the GPUs")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default, BASELINE config 4): --objects in total, split over the GPUs; "
+                         "weak: --objects per GPU")
     ap.add_argument("--row-pad", type=int, default=0,
                     help="floats of padding between the input rows (row stride = samples + pad; multiple of 4)")
     ap.add_argument("--stream-only", action="store_true",
                     help="only the timed stream-mode steps (no block-mode, parity or CPU legs): for PMC profiling passes")
     args = ap.parse_args()
+    cfg = dict(PRESETS[args.config])
+    for key, val in (("objects", args.objects), ("hoa", args.hoa), ("blocks", args.blocks),
+                     ("block_size", args.block_size), ("layout", args.layout), ("buses", args.buses)):
+        if val is not None:
+            cfg[key] = val
 
     import numpy as np
     import torch
@@ -113,174 +147,258 @@ def main():
     import scenes
     from layouts import LAYOUTS
     from libear_amd import capi
-    from libear_amd.distributed import exchange
+    from libear_amd.distributed import channel_range, exchange, padded_channels, shard_range
 
-    from libear_amd.distributed import shard_range
-    names = LAYOUTS[args.layout]
-    N, B, T, K = len(names), args.block_size, args.blocks, 2
-    if args.scaling == "strong":  # the scene has --objects in total; this rank renders its shard
-        lo, hi = shard_range(args.objects, rank, world)
-        M, M_total = hi - lo, args.objects
-    else:
-        M, M_total = args.objects, args.objects * world
+    names = LAYOUTS[cfg["layout"]]
+    N, B, T, K = len(names), cfg["block_size"], cfg["blocks"], cfg["buses"]
     total = B * T
-
-    # decorrelator FIRs: designed natively (libearhip group G, setup path)
-    dec = capi.design_decorrelators(names)
-
-    # ---- scene: resident in HBM before the timed region --------------------------------------
-    if args.scene == "adm":
-        curves = scenes.adm_curves(M, N, total, seed=11 + rank)
-    elif args.scene == "moving":  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
-        curves = scenes.adm_curves(M, N, total, period=240, ramp=240, seed=12 + rank)
-    elif args.scene == "static":  # one gain vector per object and bus, never changing
-        curves = scenes.constant_curves(M, N, seed=8 + rank)
-    elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
-        curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
-        odd = scenes.adm_curves(max(M // 128, 1), N, total, seed=11 + rank)
-        for i, c in enumerate(odd):
-            curves[(128 * i + 7) % M] = c
-    else:
-        curves = scenes.dense_curves(M, N, B, T, seed=7 + rank)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    in_stride = total + args.row_pad
-    x_full = torch.rand((M, in_stride), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
-    x = x_full[:, :total]  # planar rows, in_stride floats apart
-    outs = [torch.zeros((N, total), device=dev, dtype=torch.float32) for _ in range(2)]
-    owned = [torch.zeros((N // world, total), device=dev, dtype=torch.float32) for _ in range(2)] \
-        if world > 1 else None
+    dec = capi.design_decorrelators(names) if K == 2 else None  # designed natively (libearhip group G)
+    delay = capi.compensation_delay() if K == 2 else 0
+    n_pad = padded_channels(N, world)
 
     stream = torch.cuda.current_stream(dev)
     ctx = capi.Context(dev_index, stream.cuda_stream)
     ctx.set_strict(args.strict)
-    r = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=T)
-    for m, (t, d, f) in enumerate(curves):
-        r.set_object_points(m, t, d, f)
-    r.commit()
 
-    pending = [None, None]
+    class Workload:
+        """this rank's shard of a scene of `objects` objects (+ `hoa` bed channels on rank 0), resident
+        in HBM, with its renderer and double-buffered output / exchange buffers"""
 
-    def step(i, exchange_outputs=True):
-        buf = i % 2
-        if pending[buf] is not None:  # the exchange that last read this buffer must be done
-            pending[buf].wait()
-            pending[buf] = None
-        r.reset(0)
-        r.process_device(T, x.data_ptr(), in_stride, outs[buf].data_ptr(), total)
-        if world > 1 and exchange_outputs:
-            _, work = exchange(outs[buf], owned[buf], async_op=True)
-            pending[buf] = work
+        def __init__(self, objects, hoa, scaling, seed_base=0, context=None):
+            if scaling == "strong":  # the scene has `objects` in total; this rank renders its shard
+                lo, hi = shard_range(objects, rank, world)
+                self.M_obj, self.M_total = hi - lo, objects + hoa
+            else:
+                self.M_obj, self.M_total = objects, (objects + hoa) * world
+            self.M_hoa = hoa if (rank == 0 or scaling == "weak") else 0  # the bed goes to one rank (SURVEY 8e)
+            self.M = self.M_obj + self.M_hoa
+            m, seed = max(self.M_obj, 1), seed_base + rank
+            if args.scene == "adm":
+                curves = scenes.adm_curves(m, N, total, seed=11 + seed)
+            elif args.scene == "moving":  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
+                curves = scenes.adm_curves(m, N, total, period=240, ramp=240, seed=12 + seed)
+            elif args.scene == "static":  # one gain vector per object and bus, never changing
+                curves = scenes.constant_curves(m, N, seed=8 + seed)
+            elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
+                curves = scenes.dense_curves(m, N, B, T, seed=7 + seed)
+                odd = scenes.adm_curves(max(m // 128, 1), N, total, seed=11 + seed)
+                for i, c in enumerate(odd):
+                    curves[(128 * i + 7) % m] = c
+            else:
+                curves = scenes.dense_curves(m, N, B, T, seed=7 + seed)
+            curves = curves[:self.M_obj]
+            if self.M_hoa:  # constant decode matrix: one gain point on the direct bus, nothing on the diffuse bus
+                decode = np.random.default_rng(55).uniform(-0.5, 0.5, (self.M_hoa, N)).astype(np.float32)
+                curves = [(np.zeros(1, np.int64), decode[c:c + 1], np.zeros((1, N), np.float32))
+                          for c in range(self.M_hoa)] + curves
+            self.curves = curves
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1234 + seed)
+            self.in_stride = total + args.row_pad
+            rows = max(self.M, 1)
+            self.x_full = torch.rand((rows, self.in_stride), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+            self.x = self.x_full[:, :total]  # planar rows, in_stride floats apart
+            self.outs = [torch.zeros((n_pad, total), device=dev, dtype=torch.float32) for _ in range(2)]
+            self.owned = [torch.zeros((n_pad // world, total), device=dev, dtype=torch.float32) for _ in range(2)] \
+                if world > 1 else None
+            self.r = self.renderer(context or ctx)
+            self.pending = [None, None]
 
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        def renderer(self, context, max_blocks=None, npoints=None):
+            r = capi.Renderer(context, max(self.M, 1), N, B, dec, delay, max_blocks=max_blocks or T)
+            for m, (t, d, f) in enumerate(self.curves):
+                r.set_object_points(m, t[:npoints], d[:npoints], f[:npoints] if K == 2 else None)
+            r.commit()
+            return r
 
-    # bring the device out of its idle power state (setup, like the allocation above: not a step count)
-    pre_steps = 0
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-        step(pre_steps, exchange_outputs=False)  # wall-clock bounded: ranks may differ, so no collective here
-        pre_steps += 1
-        if pre_steps % 8 == 0:
+        def step(self, i, exchange_outputs=True, r=None):
+            buf = i % 2
+            if self.pending[buf] is not None:  # the exchange that last read this buffer must be done
+                self.pending[buf].wait()
+                self.pending[buf] = None
+            r = r or self.r
+            r.reset(0)
+            r.process_device(T, self.x.data_ptr(), self.in_stride, self.outs[buf].data_ptr(), total)
+            if world > 1 and exchange_outputs:
+                _, work = exchange(self.outs[buf], self.owned[buf], async_op=True)
+                self.pending[buf] = work
+
+        def drain(self):
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+
+        def timed(self, steps, warmup, precondition_ms=0.0, r=None, timing_every=0):
+            """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
+            returns (seconds, max over ranks)"""
+            pre_steps = 0
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < precondition_ms:
+                self.step(pre_steps, exchange_outputs=False, r=r)  # wall-clock bounded: ranks may differ, so no collective here
+                pre_steps += 1
+                if pre_steps % 8 == 0:
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            for i in range(warmup):
+                self.step(i, r=r)
+            self.drain()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            if timing_every:
+                (r or self.r).enable_timing(timing_every)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(i, r=r)
+            self.drain()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            return dt, pre_steps
+
+        def close(self):
+            self.r.close()
+
+    # ---- the measured workload ---------------------------------------------------------------------
+    wl = Workload(cfg["objects"], cfg["hoa"], args.scaling)
+    M, M_total = wl.M, wl.M_total
     # per-kernel HIP events on every TIME_EVERY-th step of the timed region (each timed step records six
     # events = ~20 us of idle GPU; timing every step costs 4 % of the headline value)
     time_every = max(1, min(args.kernel_timing_every, args.steps))
     timed_steps = len(range(0, args.steps, time_every))
-    r.enable_timing(time_every)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timing = r.get_timing()
-    gain_kernel = r.gain_kernel()
-    r.enable_timing(False)
+    dt, pre_steps = wl.timed(args.steps, args.warmup, args.precondition_ms, timing_every=time_every)
+    timing = wl.r.get_timing()
+    plan = wl.r.last_plan()
+    gain_kernel = plan["kernel"]
+    wl.r.enable_timing(False)
 
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     # multi-rank self-check (outside the timed region, all ranks take part): the slice this rank
     # owns after the reduce-scatter equals the sum of all ranks' partial outputs
     exchange_err = None
     if world > 1 and (backend == "nccl" or os.environ.get("EARHIP_BENCH_CHECK") == "force"):
-        from libear_amd.distributed import channel_range
         w = min(total, 4096)
         last = (args.steps - 1) % 2
-        ref = outs[last][:, :w].clone()
+        per = n_pad // world
+        if backend == "nccl":  # the reduce-scatter left the partial output in place
+            part = wl.outs[last][:, :w].clone()
+            got = wl.owned[last][:, :w]
+        else:  # (the all-reduce of the CPU backends sums `outs` in place: render the partial again)
+            wl.step(last, exchange_outputs=False)
+            torch.cuda.synchronize()
+            part = wl.outs[last][:, :w].clone()
+            _, work = exchange(wl.outs[last], None, async_op=True)
+            work.wait()
+            got = wl.outs[last][rank * per:(rank + 1) * per, :w]
+        ref = part.clone()
         dist.all_reduce(ref, op=dist.ReduceOp.SUM)
-        lo, hi = channel_range(N, rank, world)
-        got = owned[last][:, :w] if backend == "nccl" else outs[last][lo:hi, :w]
-        err = ((got - ref[lo:hi]).abs().max() / ref.abs().max().clamp_min(1e-30)).to(torch.float64).reshape(1)
+        err = ((got - ref[rank * per:(rank + 1) * per]).abs().max() / ref.abs().max().clamp_min(1e-30))
+        err = err.to(torch.float64).reshape(1)
         dist.all_reduce(err, op=dist.ReduceOp.MAX)
         exchange_err = float(err.item())
     t_step = dt / args.steps
     value = M_total * total / t_step / 1e6
     rtf = (total / SAMPLE_RATE) / t_step
 
+    # weak-scaling companion figure (N > 1): --objects per rank, short run, same line
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.stream_only:
+        ww = Workload(cfg["objects"], cfg["hoa"], "weak", seed_base=100)
+        wsteps = max(3, min(args.steps, 10))
+        wdt, _ = ww.timed(wsteps, 2)
+        weak = {"value": round(ww.M_total * total / (wdt / wsteps) / 1e6, 1), "unit": "Msamples/s",
+                "objects_per_gpu": ww.M, "objects_total": ww.M_total, "steps": wsteps,
+                "ms_per_step": round(wdt / wsteps * 1e3, 4), "scaling": "weak"}
+        ww.close()
+        del ww
+
     result = None
     if rank == 0:
-        gain_b, dec_b, dm_b = algorithmic_bytes(M, N, B, K)
-        # a long call is cut into chunks (K1 of chunk c+1 overlaps K2 of chunk c): per-step sums for
-        # the kernel table, per-launch figures for the roofline (what rocprofv3 averages)
+        gain_b, dec_b, dm_b = algorithmic_bytes(wl.M_obj, N, B, K, wl.M_hoa)
+        # a long call may be cut into several launches: per-step sums for the kernel table, per-launch
+        # figures for the roofline (what rocprofv3 averages)
         k1_launches = max(timing["gain_mix_launches"], 1) / timed_steps
         k1_ms = timing["gain_mix_ms"] / timed_steps
         k2_ms = timing["decor_ms"] / timed_steps
         k0_ms = timing["prep_ms"] / timed_steps
         achieved = gain_b * T / (k1_ms * 1e-3) / 1e9
         whole = (gain_b + dec_b + dm_b) * T / t_step / 1e9
-        traffic = None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the
+        # figure is attached only when profiles/traffic.json was measured (rocprofv3 --pmc passes,
+        # tools/profile_passes.sh) for exactly this kernel instantiation, shape and scene
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("objects") == M and tj.get("blocks") == T and tj.get("block_size") == B:
-                    # measured per step (all K1 launches of one pass over T blocks), reported per launch
+                same = (tj.get("objects") == M and tj.get("blocks") == T and tj.get("block_size") == B and
+                        tj.get("channels") == N and tj.get("buses", 2) == K and tj.get("gain_kernel") == gain_kernel and
+                        tj.get("tile") == plan["tile"] and tj.get("scene", "dense") == args.scene)
+                if same:
                     traffic = int(tj.get("gain_mix_hbm_bytes_per_step") / k1_launches)
+                    traffic_source = "profiles/traffic.json: " + tj.get("source", "")
             except Exception:
                 traffic = None
+        # what a kernel that only reads gets out of this box, measured in this run: the 100 % mark
+        peak_measured = None
+        try:
+            if total % 256 == 0 and wl.in_stride % 256 == 0 and M >= 32:
+                ms_lin, ms_rows = ctx.read_bandwidth(wl.x_full.data_ptr(), M, wl.in_stride, total, reps=5)
+                peak_measured = {"linear_read_GBps": round(M * wl.in_stride * 4 / ms_lin / 1e6, 1),
+                                 "row_pattern_read_GBps": round(M * total * 4 / ms_rows / 1e6, 1),
+                                 "bytes": M * total * 4,
+                                 "note": "read-only kernels over the input buffer of this run, HIP events, 5 launches each"}
+        except Exception as e:  # a probe must never cost the measurement
+            peak_measured = {"error": str(e)}
+        best_read = max(peak_measured.get("linear_read_GBps", 0), peak_measured.get("row_pattern_read_GBps", 0)) \
+            if peak_measured and "error" not in peak_measured else None
+
+        workload = (f"BASELINE config {args.config}: {wl.M_obj} objects"
+                    + (f" + {wl.M_hoa} bed channels (constant decode matrix)" if wl.M_hoa else "")
+                    + f"{'/GPU' if world > 1 else ''} -> {cfg['layout']} ({N} ch), block {B}, 48 kHz: "
+                    + ("ramped direct+diffuse gains, " + f"{N} decorrelators (512 taps), delay 255, mix" if K == 2
+                       else "ramped gains only (one bus, no decorrelator)")
+                    + f"; stream of {T} blocks per step")
+        gains_desc = {"dense": "dense uniform(0,1), full-length ramp every block",
+                      "adm": "dense uniform(0,1); metadata every 960 samples at a per-object phase, 240-sample ramp then constant",
+                      "moving": "dense uniform(0,1); a new target every 240 samples at a per-object phase, always ramping",
+                      "static": "dense uniform(0,1), one gain vector per object, never changing",
+                      "mixed": "the dense scene with 8 of every 1024 objects on ADM-like metadata off the block grid"}[args.scene]
         result = {
             "metric": "Msamples/s", "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preconditioning_steps": pre_steps,
             "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": GAIN_DTYPES.get(gain_kernel, "f32"), "data": "synthetic",
             "rtf": round(rtf, 1),
             "config": {
-                "workload": f"{M} objects/GPU -> {args.layout} ({N} ch), block {B}, 48 kHz: ramped direct+diffuse "
-                            f"gains, {N} decorrelators (512 taps), delay 255, mix; stream of {T} blocks per step",
+                "workload": workload, "baseline_config": args.config,
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
-                "blocks_per_step": T, "buses": K,
-                "gains": "dense uniform(0,1), full-length ramp every block" if args.scene == "dense" else
-                         "dense uniform(0,1); metadata every 960 samples at a per-object phase, 240-sample ramp then constant",
+                "blocks_per_step": T, "buses": K, "scene": args.scene, "gains": gains_desc,
                 "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels",
                 "strict": bool(args.strict)},
-            "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"), "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"),
+                         "plan": {"tile_samples": plan["tile"], "tiles": plan["ntiles"], "object_splits": plan["gsplit"]},
+                         "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "peak_measured": peak_measured,
+                         "frac_of_measured_read": round(achieved / best_read, 4) if best_read else None,
                          "launches_per_step": round(k1_launches, 2),
                          "algorithmic_bytes_per_launch": int(gain_b * T / k1_launches),
                          "avg_launch_ms": round(k1_ms / k1_launches, 4)},
             "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
             "exchange_check": None if exchange_err is None else
                               {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}")},
+            "weak_scaling": weak,
             "kernel_timing": {"timed_steps": timed_steps, "every": time_every},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
@@ -288,22 +406,60 @@ def main():
                            "gain_fp32_equivalent_tflops": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2)},
         }
 
-        # ---- block mode (the latency figure): ONE 512-sample block per call through the host-pointer
+        # ---- distribution over steps: each step between its own pair of events on the launch stream
+        # (the events cost the GPU a few us of idle time per step: these are not the headline figure)
+        if world == 1 and not args.stream_only:
+            n_ev = max(10, min(args.steps, 100))
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+            for i, (e0, e1) in enumerate(evs):
+                e0.record(stream)
+                wl.step(i)
+                e1.record(stream)
+            torch.cuda.synchronize()
+            ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+            result["step_ms"] = {"median": round(ms[len(ms) // 2], 4), "p95": round(ms[int(0.95 * (len(ms) - 1))], 4),
+                                 "min": round(ms[0], 4), "max": round(ms[-1], 4), "steps": n_ev,
+                                 "note": "per-step HIP events in a separate pass after the timed region"}
+
+        # ---- the same workload on the exact-f32 gain kernels (the default kernel splits f32 operands into
+        # two f16 pieces; these do not): f32 MFMA and strict VALU (libear's arithmetic, bit-identical)
+        if world == 1 and not args.stream_only and not args.strict:
+            keep = os.environ.get("EARHIP_MFMA")
+            os.environ["EARHIP_MFMA"] = "1"
+            try:
+                ctx1 = capi.Context(dev_index, stream.cuda_stream)  # (the knob is read when a context is created)
+            finally:
+                os.environ.pop("EARHIP_MFMA", None)
+                if keep is not None:
+                    os.environ["EARHIP_MFMA"] = keep
+            r1 = wl.renderer(ctx1)
+            n1 = max(3, min(args.steps, 10))
+            dt1, _ = wl.timed(n1, 2, r=r1)
+            k1 = r1.last_plan()["kernel"]
+            r1.close()
+            ctx1.set_strict(True)
+            r0 = wl.renderer(ctx1)
+            n0 = max(2, min(args.steps, 3))
+            dt0, _ = wl.timed(n0, 1, r=r0)
+            r0.close()
+            ctx1.close()
+            result["value_f32_exact"] = {"value": round(M_total * total / (dt1 / n1) / 1e6, 1), "unit": "Msamples/s",
+                                         "kernel": GAIN_KERNELS.get(k1, "?"), "steps": n1,
+                                         "ms_per_step": round(dt1 / n1 * 1e3, 4)}
+            result["value_strict"] = {"value": round(M_total * total / (dt0 / n0) / 1e6, 1), "unit": "Msamples/s",
+                                      "kernel": GAIN_KERNELS[0], "steps": n0, "ms_per_step": round(dt0 / n0 * 1e3, 4)}
+
+        # ---- block mode (the latency figure): ONE block per call through the host-pointer
         # entry point, i.e. including H2D of the inputs, K0/K1/K2 and D2H of the outputs.  Reported
         # beside the stream-mode value, never as `value`.
         if world == 1 and not args.stream_only:
-            rb = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=1)
-            for m, (t, d, f) in enumerate(curves):
-                rb.set_object_points(m, t[:34], d[:34], f[:34])
-            rb.commit()
+            rb = wl.renderer(ctx, max_blocks=1, npoints=34)
             import ctypes
-            xb = np.ascontiguousarray(x[:, :B].cpu().numpy())
+            xb = np.ascontiguousarray(wl.x[:, :B].cpu().numpy())
             ob = np.zeros((N, B), np.float32)
             ip, op = capi._chan_ptrs(xb), capi._chan_ptrs(ob)  # built once: not part of a call
             lib = capi.load()
-            for _ in range(3):
-                capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
-            for _ in range(20):
+            for _ in range(23):
                 capi.check(lib.earhip_render_process(rb.h, ctypes.c_size_t(1), ip, op))
             nb_calls = 200  # >= 200 timed blocks after 20 warm-up, median and p95
             lat = []
@@ -320,38 +476,59 @@ def main():
                                     "Msamples_per_s": round(M * B / bdt / 1e6, 1),
                                     "note": "one block per call from host channel pointers: staging copy, H2D, K0/K1/K2, D2H, sync"}
 
-        # ---- parity gate in the same run: first two blocks against the CPU oracle -------------
-        if not args.stream_only:
+        # ---- parity gate on the TIMED output: every step starts from reset(0), so the first blocks of
+        # the buffer the last timed step wrote are the first blocks of the stream, produced by the very
+        # launch plan that was timed; the CPU oracle renders the same blocks.  Per channel.
+        if not args.stream_only and (world == 1 or backend == "nccl"):
             import _oracle  # the checker; used only below (parity gate and cpu_baseline)
-            nb = 2
-            xs = x[:, :nb * B].cpu().numpy()
-            rr = capi.Renderer(ctx, M, N, B, dec, 255, max_blocks=nb)
-            for m, (t, d, f) in enumerate(curves):
-                rr.set_object_points(m, t[:nb + 1], d[:nb + 1], f[:nb + 1])
-            got = rr.process(xs)
-            rr.close()
-            o = _oracle.ObjectsRenderer(M, N, B, dec, 255)
-            for m, (t, d, f) in enumerate(curves):
-                o.set_points(m, 0, t[:nb + 1], d[:nb + 1])
-                o.set_points(m, 1, t[:nb + 1], f[:nb + 1])
+            nb = 4
+            last = (args.steps - 1) % 2
+            wl.step(last, exchange_outputs=False)  # the timed call again into the same buffer (the passes above reused it)
+            torch.cuda.synchronize()
+            parity_plan = wl.r.last_plan()
+            got = wl.outs[last][:N, :nb * B].cpu().numpy()
+            xs = wl.x[:, :nb * B].cpu().numpy()
+            win = scenes.window_curves(wl.curves, 0, nb * B)
+            if K == 2:
+                o = _oracle.ObjectsRenderer(max(M, 1), N, B, dec, delay)
+            else:
+                o = _oracle.ObjectsRenderer(max(M, 1), N, B, np.zeros((N, 1), np.float32), 0)
+            for m, (t, d, f) in enumerate(win):
+                o.set_points(m, 0, t, d)
+                o.set_points(m, 1, t, f if K == 2 else np.zeros_like(d))
             want = o.process(xs)
-            truth = scenes.render_f64([(t[:nb + 1], d[:nb + 1], f[:nb + 1]) for t, d, f in curves], xs, N, dec, 255)
-            result["parity"] = {"rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
+            truth = scenes.render_f64([(t, d, f if K == 2 else None) for t, d, f in win], xs, N, dec, delay)
+            result["parity"] = {"what": f"first {nb} blocks of the timed call's own output buffer",
+                                "kernel": GAIN_KERNELS.get(parity_plan["kernel"], "?"),
+                                "plan": {"tile_samples": parity_plan["tile"], "tiles": parity_plan["ntiles"],
+                                         "object_splits": parity_plan["gsplit"]},
+                                "same_plan_as_timed": parity_plan == plan,
+                                "rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
+                                "max_channel_rel_rms_vs_cpu": float(f"{scenes.rel_rms_per_channel(got, want):.3e}"),
                                 "gpu_rel_rms_vs_float64": float(f"{scenes.rel_rms(got, truth):.3e}"),
                                 "cpu_rel_rms_vs_float64": float(f"{scenes.rel_rms(want, truth):.3e}"),
+                                "max_channel_gpu_rel_rms_vs_float64": float(f"{scenes.rel_rms_per_channel(got, truth):.3e}"),
                                 "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
                                 "tolerance": 1e-6}
 
         # ---- CPU baseline: the scalar restatement on this host, bounded sample -----------------
         if world == 1 and args.cpu_blocks > 0 and not args.stream_only:
+            import _oracle
             cb = min(args.cpu_blocks, T)
-            xc = x[:, :cb * B].cpu().numpy()
+            xc = wl.x[:, :cb * B].cpu().numpy()
+            cwin = scenes.window_curves(wl.curves, 0, cb * B)
+            fir = dec if K == 2 else np.zeros((N, 1), np.float32)
+
+            def make(lo, hi, native):
+                oc = _oracle.ObjectsRenderer(hi - lo, N, B, fir, delay, native=native)
+                for j, m in enumerate(range(lo, hi)):
+                    t, d, f = cwin[m]
+                    oc.set_points(j, 0, t, d)
+                    oc.set_points(j, 1, t, f if K == 2 else np.zeros_like(d))
+                return oc
             res = {}
             for native in (False, True):
-                oc = _oracle.ObjectsRenderer(M, N, B, dec, 255, native=native)
-                for m, (t, d, f) in enumerate(curves):
-                    oc.set_points(m, 0, t[:cb + 1], d[:cb + 1])
-                    oc.set_points(m, 1, t[:cb + 1], f[:cb + 1])
+                oc = make(0, M, native)
                 c0 = time.perf_counter()
                 oc.process(xc)
                 cdt = time.perf_counter() - c0
@@ -362,14 +539,7 @@ def main():
             from concurrent.futures import ThreadPoolExecutor
             nthreads = max(1, min(os.cpu_count() or 1, 16, M // 32))  # >= 32 objects per shard: each shard also decorrelates
             bounds = [(M * i // nthreads, M * (i + 1) // nthreads) for i in range(nthreads)]
-            shards = []
-            for lo, hi in bounds:
-                oc = _oracle.ObjectsRenderer(hi - lo, N, B, dec, 255, native=True)
-                for j, m in enumerate(range(lo, hi)):
-                    t, d, f = curves[m]
-                    oc.set_points(j, 0, t[:cb + 1], d[:cb + 1])
-                    oc.set_points(j, 1, t[:cb + 1], f[:cb + 1])
-                shards.append((oc, np.ascontiguousarray(xc[lo:hi])))
+            shards = [(make(lo, hi, True), np.ascontiguousarray(xc[lo:hi])) for lo, hi in bounds]
             c0 = time.perf_counter()
             with ThreadPoolExecutor(nthreads) as ex:  # ctypes releases the GIL during the call
                 parts = list(ex.map(lambda s: s[0].process(s[1]), shards))
@@ -378,18 +548,40 @@ def main():
                 total_out = total_out + p_
             mt = M * cb * B / (time.perf_counter() - c0) / 1e6
             del shards
+            # the gain stage alone in libear's two forms: one GainInterpolator<LinearInterpVector> per object and
+            # bus + sum (docs/dsp.rst:54-56; what the composition above does) and the fused
+            # GainInterpolator<LinearInterpMatrix> per bus (gain_interpolator.hpp:250-278)
+            fb = min(cb, 32)
+            xf = np.ascontiguousarray(xc[:, :fb * B])
+            fwin = scenes.window_curves(wl.curves, 0, fb * B)
+            forms = {}
+            if args.scene == "dense" and not wl.M_hoa:  # (the fused form needs one common time axis)
+                tms = fwin[0][0]
+                vals = [np.stack([c[1 + b] for c in fwin], axis=1) for b in range(K)]  # [points][M][N]
+                c0 = time.perf_counter()
+                for b in range(K):
+                    _oracle.gain_interp("matrix", tms, vals[b], xf, [B] * fb)
+                forms["fused_matrix"] = round(M * fb * B / (time.perf_counter() - c0) / 1e6, 2)
+                c0 = time.perf_counter()
+                for b in range(K):
+                    acc = np.zeros((N, fb * B), np.float32)
+                    for m in range(M):
+                        acc += _oracle.gain_interp("vector", tms, vals[b][:, m:m + 1, :], xf[m:m + 1], [B] * fb)
+                forms["per_object_vector_plus_sum"] = round(M * fb * B / (time.perf_counter() - c0) / 1e6, 2)
+                forms["sample"] = f"first {fb} blocks, {K} bus(es), -O3 -DNDEBUG, 1 thread (the per-object form sums in numpy)"
             result["cpu_baseline"] = {
                 "value": round(res[False], 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                "sample": f"first {cb} blocks of the same scene ({M} objects -> {N} ch), scalar C++14 restatement "
-                          "of libear's per-object GainInterpolator<LinearInterpVector> + bus sum, BlockConvolver, "
-                          "DelayBuffer; -O3 -DNDEBUG (libear Release flags), 1 thread",
+                "sample": f"first {cb} blocks of the same scene ({M} inputs -> {N} ch), scalar C++14 restatement "
+                          "of libear's per-object GainInterpolator<LinearInterpVector> + bus sum"
+                          + (", BlockConvolver, DelayBuffer" if K == 2 else "") + "; -O3 -DNDEBUG (libear Release flags), 1 thread",
                 "rtf": round((B / SAMPLE_RATE) / (M * B / (res[False] * 1e6)), 3),
                 "value_march_native": round(res[True], 2),
                 "value_sharded_threads": round(mt, 1), "threads": nthreads,
-                "host_cpus": os.cpu_count()}
+                "gain_stage_forms_Msamples_per_s": forms or None,
+                "cpu_model": cpu_model(), "host_cpus": os.cpu_count()}
         print(json.dumps(result), flush=True)
 
-    r.close()
+    wl.close()
     ctx.close()
     if world > 1:
         dist.barrier()

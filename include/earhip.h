@@ -63,6 +63,13 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
 /* tuning aid: enqueue a 1-thread kernel that writes {shader-cycle counter,
  * constant-rate counter} (2 x uint64) to device memory */
 int earhip_debug_clock_probe(earhip_ctx *ctx, void *out_dev);
+/* measurement aid (bench.py's `roofline.peak_measured`): average duration in ms, over `reps`
+ * launches timed with HIP events on the context's stream, of two kernels that only READ
+ * in_dev [rows][stride]: ms[0] a linear stream over rows * stride floats, ms[1] the gain stage's
+ * access pattern (each workgroup a 1 KB piece of every row) over rows * nsamples floats.
+ * stride and nsamples: multiples of 256, nsamples <= stride; in_dev 16-byte aligned. */
+int earhip_debug_read_bandwidth(earhip_ctx *ctx, const float *in_dev, size_t rows, size_t stride,
+                                size_t nsamples, int reps, double ms[2]);
 
 /* ------------------------------------------------------------------------
  * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector
@@ -131,6 +138,10 @@ int earhip_conv_ctx_create(earhip_ctx *ctx, size_t block_size,
 int earhip_conv_ctx_destroy(earhip_conv_ctx *cctx);
 int earhip_conv_filter_create(earhip_conv_ctx *cctx, size_t n, const float *taps,
                               earhip_conv_filter **out);
+/* Drops the creator's reference.  A convolver keeps its own reference for every queue slot
+ * that points at the filter (libear's queue holds shared_ptrs,
+ * src/dsp/block_convolver_impl.hpp:154-167), so a filter may be destroyed while it is still
+ * in use or fading out; it is freed when the last slot lets go of it. */
 int earhip_conv_filter_destroy(earhip_conv_filter *filter);
 size_t earhip_conv_filter_num_blocks(const earhip_conv_filter *filter);
 /* filter may be NULL (then num_blocks must be > 0); num_blocks 0 = take the
@@ -184,6 +195,24 @@ int earhip_decorrelator_size(void);               /* 512 */
 int earhip_decorrelator_compensation_delay(void); /* 255 */
 int earhip_design_decorrelator_basic(int decorrelator_id, int size, double *out);
 int earhip_design_decorrelators(int n_channels, const char *const *channel_names, float *out);
+
+/* ------------------------------------------------------------------------
+ * (H) ITU-R BS.2051 loudspeaker layouts (setup path, host data) — replaces
+ * ear::loadLayouts / ear::getLayout (include/ear/bs2051.hpp:8-11, src/bs2051.cpp:11-22,
+ * table src/bs2051_layouts.cpp): what the render path needs of a Layout — channel
+ * names in layout order (decorrelator ids), nominal positions (the gain producers) and
+ * the LFE flags (zero-gain columns; Layout::withoutLfe, include/ear/layout.hpp).
+ * An unknown layout name is EARHIP_INVALID_ARGUMENT (libear throws unknown_layout).
+ * ---------------------------------------------------------------------- */
+int earhip_layout_count(void);
+const char *earhip_layout_name(int index); /* NULL when out of range */
+int earhip_layout_num_channels(const char *layout, int *n_channels);
+/* any output pointer may be NULL; *name points at static storage */
+int earhip_layout_channel(const char *layout, int index, const char **name, double *azimuth,
+                          double *elevation, int *is_lfe);
+/* designDecorrelators<float>(getLayout(layout)) — or of getLayout(layout).withoutLfe() —
+ * out: [channels kept][512] (include/ear/decorrelate.hpp:26-28) */
+int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, float *out);
 
 /* ------------------------------------------------------------------------
  * (F) Composed Objects render block — the chain libear documents but does not
@@ -249,6 +278,10 @@ int earhip_render_get_timing(earhip_render *r, double out[6]);
  * arithmetic (strict mode), 1 = f32 MFMA, 2 = bf16x3 MFMA, 3 = f16x2 MFMA (2, 3: all
  * curve points on tile boundaries); -1 before the first call. */
 int earhip_render_gain_kernel(const earhip_render *r, int *kind);
+/* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
+ * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
+ * For tests and benchmarks that must know which kernel instantiation they measured. */
+int earhip_render_last_plan(const earhip_render *r, int out[4]);
 
 #ifdef __cplusplus
 }

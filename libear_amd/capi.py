@@ -106,6 +106,13 @@ class Context:
     def synchronize(self):
         check(load().earhip_ctx_synchronize(self.h))
 
+    def read_bandwidth(self, dev_ptr, rows, stride, nsamples, reps=5):
+        """(ms linear stream over rows*stride floats, ms gain-stage row pattern over rows*nsamples floats)"""
+        ms = (C.c_double * 2)()
+        check(load().earhip_debug_read_bandwidth(self.h, C.c_void_p(dev_ptr), C.c_size_t(rows), C.c_size_t(stride),
+                                                 C.c_size_t(nsamples), int(reps), ms))
+        return ms[0], ms[1]
+
     def close(self):
         if self.h:
             load().earhip_ctx_destroy(self.h)
@@ -293,6 +300,32 @@ def design_decorrelators(names):
     return out
 
 
+def layout_names():
+    """(H) names of the BS.2051 layouts the library knows"""
+    lib = load()
+    lib.earhip_layout_name.restype = C.c_char_p
+    return [lib.earhip_layout_name(i).decode() for i in range(lib.earhip_layout_count())]
+
+
+def layout_channels(layout):
+    """(H) [(name, azimuth, elevation, is_lfe)] of a BS.2051 layout, in layout order"""
+    n = C.c_int(0)
+    check(load().earhip_layout_num_channels(layout.encode(), C.byref(n)))
+    out = []
+    for i in range(n.value):
+        name, az, el, lfe = C.c_char_p(), C.c_double(), C.c_double(), C.c_int()
+        check(load().earhip_layout_channel(layout.encode(), i, C.byref(name), C.byref(az), C.byref(el), C.byref(lfe)))
+        out.append((name.value.decode(), az.value, el.value, bool(lfe.value)))
+    return out
+
+
+def design_decorrelators_for_layout(layout, without_lfe=False):
+    chans = [c for c in layout_channels(layout) if not (without_lfe and c[3])]
+    out = np.empty((len(chans), load().earhip_decorrelator_size()), np.float32)
+    check(load().earhip_design_decorrelators_for_layout(layout.encode(), int(without_lfe), _ptr(out)))
+    return out
+
+
 def design_decorrelator_basic(dec_id, size=512):
     out = np.empty(size, np.float64)
     check(load().earhip_design_decorrelator_basic(dec_id, size, _ptr(out, C.POINTER(C.c_double))))
@@ -366,6 +399,12 @@ class Renderer:
         kind = C.c_int(-1)
         check(load().earhip_render_gain_kernel(self.h, C.byref(kind)))
         return kind.value
+
+    def last_plan(self):
+        """launch plan of the last call: gain kernel, samples per workgroup tile, tiles, object splits"""
+        out = (C.c_int * 4)()
+        check(load().earhip_render_last_plan(self.h, out))
+        return {"kernel": out[0], "tile": out[1], "ntiles": out[2], "gsplit": out[3]}
 
     def close(self):
         if self.h:

@@ -69,8 +69,26 @@ struct earhip_conv_filter {
   earhip_conv_ctx *cctx;
   int nblocks;
   DevBuf<cf> spec;  // [nblocks][B+1]
+  // One reference for the creator's handle (dropped by earhip_conv_filter_destroy) and one per
+  // convolver queue slot that points here: libear's queue holds shared_ptrs
+  // (src/dsp/block_convolver_impl.hpp:154-167), so a caller may let go of a Filter that is still
+  // fading out.  Not atomic: a filter and the convolvers using it belong to one thread, like libear's.
+  int refs = 1;
   const cf *block(int i) const { return spec.p + (size_t)i * (cctx->B + 1); }
 };
+
+static void filter_release(const earhip_conv_filter *f) {
+  if (!f) return;
+  earhip_conv_filter *m = const_cast<earhip_conv_filter *>(f);
+  if (--m->refs > 0) return;
+  (void)hipStreamSynchronize(m->cctx->ctx->stream);  // a queued kernel may still read the spectra
+  m->cctx->live--;
+  delete m;
+}
+static const earhip_conv_filter *filter_retain(const earhip_conv_filter *f) {
+  if (f) const_cast<earhip_conv_filter *>(f)->refs++;
+  return f;
+}
 
 struct earhip_conv {
   earhip_conv_ctx *cctx;
@@ -87,7 +105,14 @@ struct earhip_conv {
   DevBuf<float> d_in, d_out;
   PinBuf<float> p_io;
 
-  const earhip_conv_filter *&filt(int i) { return fq[(f_ofs + i) % (P + 1)]; }
+  const earhip_conv_filter *filt(int i) const { return fq[(f_ofs + i) % (P + 1)]; }
+  // queue slot i <- f; the slot owns a reference (retain before release: f may be what the slot holds)
+  void set_filt(int i, const earhip_conv_filter *f) {
+    const earhip_conv_filter *&q = fq[(f_ofs + i) % (P + 1)];
+    filter_retain(f);
+    filter_release(q);
+    q = f;
+  }
   int sidx(int i) const { return (s_ofs + i) % P; }
   cf *old_at(int i) { return sp_old.p + (size_t)sidx(i) * (cctx->B + 1); }
   cf *new_at(int i) { return sp_new.p + (size_t)sidx(i) * (cctx->B + 1); }
@@ -236,10 +261,7 @@ int earhip_conv_filter_create(earhip_conv_ctx *cctx, size_t n, const float *taps
 
 int earhip_conv_filter_destroy(earhip_conv_filter *filter) {
   return guarded([&] {
-    if (!filter) return;
-    (void)hipStreamSynchronize(filter->cctx->ctx->stream);
-    filter->cctx->live--;
-    delete filter;
+    filter_release(filter);  // the creator's reference; convolver queues may still hold theirs
   });
 }
 
@@ -276,7 +298,7 @@ int earhip_conv_create(earhip_conv_ctx *cctx, const earhip_conv_filter *filter, 
     c->p_io.reserve(2 * (size_t)B);
     if (filter) {
       c->check_filter(filter);
-      for (auto &q : c->fq) q = filter;  // set_filter
+      for (int i = 0; i <= c->P; i++) c->set_filt(i, filter);  // set_filter
     }
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     cctx->live++;
@@ -288,7 +310,9 @@ int earhip_conv_destroy(earhip_conv *conv) {
   return guarded([&] {
     if (!conv) return;
     (void)hipStreamSynchronize(conv->cctx->ctx->stream);
-    conv->cctx->live--;
+    earhip_conv_ctx *cctx = conv->cctx;
+    for (int i = 0; i <= conv->P; i++) conv->set_filt(i, nullptr);
+    cctx->live--;
     delete conv;
   });
 }
@@ -298,7 +322,7 @@ int earhip_conv_crossfade_filter(earhip_conv *conv, const earhip_conv_filter *fi
   return guarded([&] {
     require(conv != nullptr, "conv must not be NULL");
     conv->check_filter(filter);
-    conv->filt(0) = filter;
+    conv->set_filt(0, filter);
   });
 }
 
@@ -307,7 +331,7 @@ int earhip_conv_set_filter(earhip_conv *conv, const earhip_conv_filter *filter) 
   return guarded([&] {
     require(conv != nullptr, "conv must not be NULL");
     conv->check_filter(filter);
-    for (auto &q : conv->fq) q = filter;
+    for (int i = 0; i <= conv->P; i++) conv->set_filt(i, filter);
   });
 }
 
@@ -332,12 +356,14 @@ int earhip_conv_process(earhip_conv *c, const float *in, float *out) {
         }
     }
     const int i0 = c->sidx(0);
+    bool staged = false;  // an async copy out of p_io is in flight
     if (silent) {  // :156-159
       c->old_zero[i0] = 1;
       c->new_zero[i0] = 1;
     } else {
       std::memcpy(c->p_io.p, in, sizeof(float) * B);
       EARHIP_HIP(hipMemcpyAsync(c->d_in.p, c->p_io.p, sizeof(float) * B, hipMemcpyHostToDevice, s));
+      staged = true;
       const int fade = c->filt(1) != c->filt(0) ? 1 : 0;  // :162
 #define CALL(LL) conv_forward_t<LL>(c->d_in.p, fade, cc->tw.p, c->old_at(0), c->new_at(0), s)
       EARHIP_DISPATCH_L(L, CALL)
@@ -389,6 +415,8 @@ int earhip_conv_process(earhip_conv *c, const float *in, float *out) {
     } else {  // :231-234
       have_out = false;
       std::memset(out, 0, sizeof(float) * B);
+      // (input stored for a later filter, nothing produced: the staging buffer is the next call's too)
+      if (staged) EARHIP_HIP(hipStreamSynchronize(s));
     }
     if (have_out) {
       EARHIP_HIP(hipMemcpyAsync(c->p_io.p + B, c->d_out.p, sizeof(float) * B, hipMemcpyDeviceToHost, s));
@@ -399,7 +427,7 @@ int earhip_conv_process(earhip_conv *c, const float *in, float *out) {
     // rotate_queues (:114-122)
     c->s_ofs = (c->s_ofs + c->P - 1) % c->P;
     c->f_ofs = (c->f_ofs + c->P) % (c->P + 1);
-    c->filt(0) = c->filt(1);
+    c->set_filt(0, c->filt(1));  // (the slot rotated in held the oldest filter: released here)
   });
 }
 

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 
 #include "common.h"
 #include "curves.h"
@@ -242,7 +243,9 @@ struct PolicyCache {
   }
 };
 static std::vector<std::pair<earhip_ctx *, std::unique_ptr<PolicyCache>>> g_policy;
+static std::mutex g_policy_mutex;  // contexts are single-owner, the table of them is shared by all threads
 static PolicyCache *policy_cache(earhip_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_policy_mutex);
   for (auto &p : g_policy)
     if (p.first == ctx) return p.second.get();
   g_policy.emplace_back(ctx, std::unique_ptr<PolicyCache>(new PolicyCache));
@@ -254,7 +257,95 @@ static __global__ void k_clock_probe(unsigned long long *out) {
   out[1] = wall_clock64();  // constant-rate counter
 }
 
+// Read-bandwidth probes (earhip_debug_read_bandwidth): what this chip delivers to a kernel that does
+// nothing but read, (a) one linear stream, (b) the gain stage's pattern — every workgroup reads a 1 KB
+// piece of each of `rows` rows that lie `stride` floats apart, 32 rows in flight per wave.
+static __global__ void __launch_bounds__(256) k_read_linear(const f32x4 *in, float *out, size_t n4) {
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * 256;
+  for (; i + 3 * step < n4; i += 4 * step) {
+    const f32x4 a = __builtin_nontemporal_load(in + i), b = __builtin_nontemporal_load(in + i + step);
+    const f32x4 c = __builtin_nontemporal_load(in + i + 2 * step), d = __builtin_nontemporal_load(in + i + 3 * step);
+    acc += (a + b) + (c + d);
+  }
+  for (; i < n4; i += step) acc += __builtin_nontemporal_load(in + i);
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[0] = 1.0f;  // (keeps the loads alive)
+}
+static __global__ void __launch_bounds__(256) k_read_rows(const float *in, float *out, int rows, size_t stride) {
+  constexpr int DEPTH = 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, kg = lane >> 4;
+  const float *base = in + (size_t)blockIdx.x * 256 + w * 64 + li * 4;
+  auto row = [&](int r) { return base + (size_t)min(r, rows - 1) * stride; };
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 ring[DEPTH][8];
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      ring[d][q] = __builtin_nontemporal_load((const f32x4 *)row(d * 32 + kg * 8 + q));
+  for (int r0 = 0; r0 < rows; r0 += 32 * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) acc += ring[d][q];
+      const int rn = r0 + 32 * DEPTH + d * 32;
+      if (rn < rows)
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          ring[d][q] = __builtin_nontemporal_load((const f32x4 *)row(rn + kg * 8 + q));
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[0] = 1.0f;
+}
+
 extern "C" {
+
+// Measurement aid: time `reps` launches of the two read kernels above over in_dev [rows][stride]
+// (nsamples valid floats per row; 16-byte aligned, stride and nsamples multiples of 256) with HIP
+// events on the context's stream.  ms[0]: average of the linear read of rows * stride floats,
+// ms[1]: average of the row-pattern read of rows * nsamples floats.
+int earhip_debug_read_bandwidth(earhip_ctx *ctx, const float *in_dev, size_t rows, size_t stride,
+                                size_t nsamples, int reps, double ms[2]) {
+  return guarded([&] {
+    require(ctx != nullptr && in_dev != nullptr && ms != nullptr, "NULL argument");
+    require(rows >= 1 && rows < ((size_t)1 << 24) && reps >= 1 && reps <= 1000, "rows / reps out of range");
+    require(stride % 256 == 0 && nsamples % 256 == 0 && nsamples >= 256 && nsamples <= stride &&
+                ((uintptr_t)in_dev & 15) == 0,
+            "buffer must be 16-byte aligned with stride and nsamples multiples of 256");
+    ctx->use();
+    if (!ctx->level.p) ctx->level.alloc_zero(2, ctx->stream);
+    float *sink = reinterpret_cast<float *>(ctx->level.p);  // never written (the kernels' condition is never true)
+    hipEvent_t e[4];
+    for (auto &x : e) EARHIP_HIP(hipEventCreate(&x));
+    const size_t n4 = rows * stride / 4;
+    const unsigned lin_blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)ctx->num_cus * 32);
+    auto linear = [&] {
+      hipLaunchKernelGGL(k_read_linear, dim3(lin_blocks), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<const f32x4 *>(in_dev), sink, n4);
+    };
+    auto pattern = [&] {
+      hipLaunchKernelGGL(k_read_rows, dim3((unsigned)(nsamples / 256)), dim3(256), 0, ctx->stream, in_dev, sink,
+                         (int)rows, stride);
+    };
+    linear();  // (warm-up launch of each kernel outside its interval)
+    EARHIP_HIP(hipEventRecord(e[0], ctx->stream));
+    for (int i = 0; i < reps; i++) linear();
+    EARHIP_HIP(hipEventRecord(e[1], ctx->stream));
+    pattern();
+    EARHIP_HIP(hipEventRecord(e[2], ctx->stream));
+    for (int i = 0; i < reps; i++) pattern();
+    EARHIP_HIP(hipEventRecord(e[3], ctx->stream));
+    EARHIP_HIP(hipGetLastError());
+    EARHIP_HIP(hipEventSynchronize(e[3]));
+    float t = 0.0f;
+    EARHIP_HIP(hipEventElapsedTime(&t, e[0], e[1]));
+    ms[0] = (double)t / reps;
+    EARHIP_HIP(hipEventElapsedTime(&t, e[2], e[3]));
+    ms[1] = (double)t / reps;
+    for (auto &x : e) (void)hipEventDestroy(x);
+  });
+}
 
 // Tuning aid: enqueue a probe that samples the shader-cycle and the constant-rate
 // counters into device memory `out_dev[2]` (two probes bracket a region to get
@@ -333,11 +424,14 @@ int earhip_ctx_destroy(earhip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (size_t i = 0; i < g_policy.size(); i++)
-      if (g_policy[i].first == ctx) {
-        g_policy.erase(g_policy.begin() + i);
-        break;
-      }
+    {
+      std::lock_guard<std::mutex> lock(g_policy_mutex);
+      for (size_t i = 0; i < g_policy.size(); i++)
+        if (g_policy[i].first == ctx) {
+          g_policy.erase(g_policy.begin() + i);
+          break;
+        }
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
   });

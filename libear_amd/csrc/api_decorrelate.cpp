@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "layout_table.h"
 
 using namespace earhip;
 
@@ -51,9 +52,64 @@ std::vector<double> design_basic(int id, int size) {
   for (int i = 0; i < size; i++) h[i] = a[i].real() / size;
   return h;
 }
+// ear::getLayout (src/bs2051.cpp:13-22): unknown names are an error
+const LayoutEntry &find_layout(const char *name) {
+  require(name != nullptr, "layout name must not be NULL");
+  for (int i = 0; i < kNumLayouts; i++)
+    if (std::strcmp(kLayouts[i].name, name) == 0) return kLayouts[i];
+  fail_invalid(std::string("unknown layout ") + name);
+}
+
+void design_for_names(const std::vector<std::string> &names, float *out) {
+  for (size_t c = 0; c < names.size(); c++) {
+    int id = 0;
+    for (auto &n : names)
+      if (n < names[c]) id++;
+    const auto h = design_basic(id, kDecorrelatorSize);
+    for (int i = 0; i < kDecorrelatorSize; i++) out[c * kDecorrelatorSize + i] = (float)h[i];
+  }
+}
 }  // namespace
 
 extern "C" {
+
+int earhip_layout_count(void) { return kNumLayouts; }
+
+const char *earhip_layout_name(int index) {
+  return index >= 0 && index < kNumLayouts ? kLayouts[index].name : nullptr;
+}
+
+int earhip_layout_num_channels(const char *layout, int *n_channels) {
+  return guarded([&] {
+    require(n_channels != nullptr, "n_channels must not be NULL");
+    *n_channels = find_layout(layout).n;
+  });
+}
+
+int earhip_layout_channel(const char *layout, int index, const char **name, double *azimuth,
+                          double *elevation, int *is_lfe) {
+  return guarded([&] {
+    const LayoutEntry &L = find_layout(layout);
+    require(index >= 0 && index < L.n, "channel index out of range");
+    const LayoutChannel &c = L.channels[index];
+    if (name) *name = c.name;
+    if (azimuth) *azimuth = c.azimuth;
+    if (elevation) *elevation = c.elevation;
+    if (is_lfe) *is_lfe = c.is_lfe ? 1 : 0;
+  });
+}
+
+// designDecorrelators(getLayout(name)) / designDecorrelators(getLayout(name).withoutLfe())
+int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, float *out) {
+  return guarded([&] {
+    require(out != nullptr, "out must not be NULL");
+    const LayoutEntry &L = find_layout(layout);
+    std::vector<std::string> names;
+    for (int c = 0; c < L.n; c++)
+      if (!(without_lfe && L.channels[c].is_lfe)) names.push_back(L.channels[c].name);
+    design_for_names(names, out);
+  });
+}
 
 int earhip_decorrelator_size(void) { return kDecorrelatorSize; }
 
@@ -80,13 +136,7 @@ int earhip_design_decorrelators(int n_channels, const char *const *channel_names
       require(channel_names[c] != nullptr, "channel name must not be NULL");
       names[c] = channel_names[c];
     }
-    for (int c = 0; c < n_channels; c++) {
-      int id = 0;
-      for (auto &n : names)
-        if (n < names[c]) id++;
-      const auto h = design_basic(id, kDecorrelatorSize);
-      for (int i = 0; i < kDecorrelatorSize; i++) out[(size_t)c * kDecorrelatorSize + i] = (float)h[i];
-    }
+    design_for_names(names, out);
   });
 }
 

@@ -101,6 +101,7 @@ struct earhip_render {
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
+  int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 bf16x3 MFMA, 3 f16x2 MFMA
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
   bool run_len_set = false;  // EARHIP_RUN given: also fixes the run length of the wave kernel
@@ -173,7 +174,13 @@ struct earhip_render {
     last_kind = ml.bf3 ? (ml.h2 ? 3 : 2) : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
+    // the bus is sized for every plan plan_mix can make (earhip_render_create); should a tuning knob
+    // push a plan beyond it, fewer object splits are always a valid plan
+    while (ml.gsplit > 1 && part_stride * ml.gsplit > bus.n) ml.gsplit /= 2;
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");
+    last_plan[0] = ml.tile();
+    last_plan[1] = ml.ntiles;
+    last_plan[2] = ml.gsplit;
     Pending pd;
     hipEvent_t *evp = nullptr;
     const bool timed = timing && (timing_calls++ % timing_every) == 0;
@@ -285,17 +292,16 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
     const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
     r->desc.alloc(desc_units(r->M, max_tiles));
-    // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits
-    // (gsplit > 1) are only chosen for calls with few tiles: plan_mix keeps
-    // gsplit * ntiles < 4 * num_cus, so gsplit * nsamples < 4 * num_cus * 256.
+    // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits (gsplit > 1) are only
+    // chosen for calls with few tiles: plan_mix doubles gsplit while gsplit * (ntiles / tpw) stays below
+    // 2 * num_cus, so gsplit * ntiles < (4 * num_cus + gsplit) * tpw with tiles of at most 256 samples
+    // (tpw = 1) or 16 * nrt samples (f32 MFMA kernel, tpw adjacent tiles per workgroup).
     r->max_gsplit = 16;  // block mode: more splits make K2 sum more partial slabs than K1 gains
     if (const char *e = getenv("EARHIP_GSPLIT")) {  // tuning knob: grid-level splits of short calls
       const int v = atoi(e);
       if (v >= 1 && v <= 32) r->max_gsplit = v;
     }
-    const size_t pad_samples = (max_samples + 3) & ~(size_t)3;
-    const size_t split_samples = (size_t)4 * ctx->num_cus * 256 + 4 * r->max_gsplit;
-    r->bus.alloc_zero((size_t)r->K * r->N * std::max(pad_samples, split_samples), ctx->stream);
+    r->bus.alloc_zero((size_t)r->K * r->N * bus_samples_bound(ctx, max_samples, r->max_gsplit), ctx->stream);
     if (r->K == 2) {
       const auto tw = make_twiddles(r->L);
       r->tw.alloc(r->L);
@@ -475,6 +481,14 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind) {
   return guarded([&] {
     require(r != nullptr && kind != nullptr, "NULL argument");
     *kind = r->last_kind;
+  });
+}
+
+int earhip_render_last_plan(const earhip_render *r, int out[4]) {
+  return guarded([&] {
+    require(r != nullptr && out != nullptr, "NULL argument");
+    out[0] = r->last_kind;
+    for (int i = 0; i < 3; i++) out[1 + i] = r->last_plan[i];
   });
 }
 

@@ -358,6 +358,18 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   return L;
 }
 
+// Samples per bus column that hold [gsplit][pad4(nsamples)] for every plan plan_mix can make for calls
+// of up to max_samples samples: it doubles gsplit only while gsplit * (ntiles / tpw) < 2 * num_cus, so
+// gsplit * ntiles < (4 * num_cus + gsplit) * tpw, with tiles of at most 512 samples (split-operand
+// kernels, tpw = 1), 256 (VALU) or 16 * nrt (f32 MFMA kernel, tpw adjacent tiles per workgroup).
+inline size_t bus_samples_bound(const earhip_ctx *ctx, size_t max_samples, int max_gsplit) {
+  const size_t pad = (max_samples + 3) & ~(size_t)3;
+  const size_t tpw_max = (size_t)std::max(1, std::min(ctx->tiles_per_wg, ctx->max_waves));
+  const size_t split_tiles = (size_t)4 * ctx->num_cus + max_gsplit;
+  const size_t split = std::max(split_tiles * 512, split_tiles * tpw_max * 16 * (size_t)ctx->nrt) + 4 * (size_t)max_gsplit;
+  return std::max(pad, std::min(pad * (size_t)max_gsplit, split));
+}
+
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml);
 
 // Enqueue K0 + K1.  out: [gsplit][ncols][out_stride] (part_stride floats apart)

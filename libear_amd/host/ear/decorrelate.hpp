@@ -21,6 +21,21 @@ namespace ear {
       out[i].assign(flat.begin() + (size_t)i * taps, flat.begin() + (size_t)(i + 1) * taps);
     return out;
   }
+  /// designDecorrelators(getLayout(name)) — or of getLayout(name).withoutLfe() — by BS.2051 layout
+  /// name (the native side holds the channel-name table, src/bs2051_layouts.cpp)
+  inline std::vector<std::vector<float>> designDecorrelators(const char *layout_name,
+                                                             bool without_lfe = false) {
+    int n = 0;
+    hip::check(earhip_layout_num_channels(layout_name, &n));
+    std::vector<std::string> names;
+    for (int i = 0; i < n; i++) {
+      const char *name = nullptr;
+      int lfe = 0;
+      hip::check(earhip_layout_channel(layout_name, i, &name, nullptr, nullptr, &lfe));
+      if (!(without_lfe && lfe)) names.push_back(name);
+    }
+    return designDecorrelators(names);
+  }
   inline std::vector<double> designDecorrelatorBasic(int decorrelatorId, int size) {
     std::vector<double> out(size);
     hip::check(earhip_design_decorrelator_basic(decorrelatorId, size, out.data()));

@@ -67,7 +67,6 @@ namespace ear {
         BlockConvolver(const Context &ctx, const Filter &filter, size_t num_blocks = 0)
             : ctx_(ctx.impl) {
           hip::check(earhip_conv_create(ctx_->h, filter.impl->h, num_blocks, &h_));
-          for (auto &f : live_) f = filter.impl;
         }
         ~BlockConvolver() { earhip_conv_destroy(h_); }
         BlockConvolver(const BlockConvolver &) = delete;
@@ -77,25 +76,19 @@ namespace ear {
         void process(const float *in, float *out) { hip::check(earhip_conv_process(h_, in, out)); }
         void crossfade_filter(const Filter &filter) {
           hip::check(earhip_conv_crossfade_filter(h_, filter.impl->h));
-          keep(filter.impl);
         }
         void fade_down() { hip::check(earhip_conv_crossfade_filter(h_, nullptr)); }
         void set_filter(const Filter &filter) {
           hip::check(earhip_conv_set_filter(h_, filter.impl->h));
-          keep(filter.impl);
         }
         void unset_filter() { hip::check(earhip_conv_set_filter(h_, nullptr)); }
 
        private:
-        // libear holds shared_ptrs to the filters in its queue; keep the most
-        // recent ones alive in the same spirit (a filter must outlive its use)
-        void keep(const std::shared_ptr<detail::FilterHandle> &f) {
-          live_[next_++ % 4] = f;
-        }
+        // (the convolver's queue holds its own references to the filters it uses, like libear's
+        // shared_ptr queue, src/dsp/block_convolver_impl.hpp:154-167: a Filter may be destroyed while
+        // it is still fading out)
         std::shared_ptr<detail::CtxHandle> ctx_;
         earhip_conv *h_ = nullptr;
-        std::shared_ptr<detail::FilterHandle> live_[4];
-        size_t next_ = 0;
       };
     }  // namespace block_convolver
   }  // namespace dsp

@@ -16,7 +16,7 @@ namespace ear {
       ObjectsRenderer(size_t n_objects, size_t n_out, size_t block_size,
                       const std::vector<std::vector<float>> &decorrelators, int delay,
                       size_t max_blocks = 1, hip::Context &ctx = hip::default_context())
-          : n_objects_(n_objects), n_out_(n_out), block_size_(block_size) {
+          : n_objects_(n_objects), n_out_(n_out), block_size_(block_size), two_buses_(!decorrelators.empty()) {
         earhip_render_config cfg;
         cfg.n_objects = (int)n_objects;
         cfg.n_out = (int)n_out;
@@ -46,9 +46,19 @@ namespace ear {
       void set_object_points(size_t object, const std::vector<int64_t> &times,
                              const std::vector<std::vector<float>> &direct,
                              const std::vector<std::vector<float>> &diffuse) {
+        if (direct.size() != times.size()) throw invalid_argument("one direct gain vector per time");
+        if (two_buses_ ? diffuse.size() != times.size() : !diffuse.empty())
+          throw invalid_argument(two_buses_ ? "one diffuse gain vector per time"
+                                            : "diffuse gains given to a renderer without a diffuse bus");
         std::vector<float> d, f;
-        for (auto &p : direct) d.insert(d.end(), p.begin(), p.end());
-        for (auto &p : diffuse) f.insert(f.end(), p.begin(), p.end());
+        for (auto &p : direct) {
+          if (p.size() != n_out_) throw invalid_argument("gain vector length != number of outputs");
+          d.insert(d.end(), p.begin(), p.end());
+        }
+        for (auto &p : diffuse) {
+          if (p.size() != n_out_) throw invalid_argument("gain vector length != number of outputs");
+          f.insert(f.end(), p.begin(), p.end());
+        }
         hip::check(earhip_render_set_object_points(h_, (int)object, (int)times.size(), times.data(),
                                                    d.data(), f.empty() ? nullptr : f.data()));
       }
@@ -70,6 +80,7 @@ namespace ear {
 
      private:
       size_t n_objects_, n_out_, block_size_;
+      bool two_buses_;
       earhip_render *h_ = nullptr;
     };
   }  // namespace dsp

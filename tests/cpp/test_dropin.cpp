@@ -184,6 +184,9 @@ struct ConvCase {
   std::vector<int> ir_for_block;
   bool null_for_zeros;
   Vec input;
+  // every Filter handed to the convolver is a temporary that dies right after the call, as libear
+  // allows (its queue holds shared_ptrs, src/dsp/block_convolver_impl.hpp:154-167)
+  bool temporaries = false;
 };
 
 static void run_conv_case(const char *name, ConvCase c) {
@@ -218,13 +221,18 @@ static void run_conv_case(const char *name, ConvCase c) {
     max_blocks = std::max(max_blocks, filters.back().num_blocks());
   }
   BlockConvolver conv(ctx, max_blocks);
-  if (c.initial >= 0) conv.set_filter(filters[c.initial]);
+  if (c.initial >= 0) {
+    if (c.temporaries) conv.set_filter(Filter(ctx, c.irs[c.initial].size(), c.irs[c.initial].data()));
+    else conv.set_filter(filters[c.initial]);
+  }
+  if (c.temporaries) filters.clear();
   Vec out(len, 0.0f);
   for (size_t blk = 0; blk < c.nblocks; blk++) {
     const int cur = c.ir_for_block[blk], last = blk == 0 ? c.initial : c.ir_for_block[blk - 1];
     if (cur != last) {
-      if (cur >= 0) conv.crossfade_filter(filters[cur]);
-      else conv.fade_down();
+      if (cur < 0) conv.fade_down();
+      else if (c.temporaries) conv.crossfade_filter(Filter(ctx, c.irs[cur].size(), c.irs[cur].data()));
+      else conv.crossfade_filter(filters[cur]);
     }
     bool zero = true;
     for (size_t j = 0; j < c.B; j++) zero = zero && c.input[blk * c.B + j] == 0.0f;
@@ -264,6 +272,17 @@ static void test_block_convolver() {
                 {512, 9, {sparse_random(1024, 20, 1), sparse_random(1536, 20, 2), sparse_random(512, 20, 3),
                           sparse_random(2048, 20, 4)},
                  0, {0, 1, 2, 3, 3, 2, 2, 1, 0}, false, sparse_random(512 * 9, 500, 0)});
+  {
+    // a filter change on EVERY block with 6 partitions, each Filter a temporary: the old filters are
+    // still queued (fading out over 6 blocks) long after their handles are gone
+    ConvCase c{256, 14, {}, 0, {}, false, sparse_random(256 * 14, 400, 0)};
+    for (int i = 0; i < 7; i++) c.irs.push_back(sparse_random(256 * 6 - 17 * i, 25, 10 + i));
+    for (int b = 0; b < 14; b++) c.ir_for_block.push_back((b + 1) % 7);
+    c.temporaries = true;
+    run_conv_case("temporary_filters_every_block", c);
+    c.ir_for_block[5] = -1;  // ... one of them a fade to silence and back
+    run_conv_case("temporary_filters_with_silence", c);
+  }
   {
     Context c512(512, get_fft_hip()), c256(256, get_fft_hip());
     BlockConvolver conv(c512, 1);
@@ -431,8 +450,107 @@ static void test_objects_renderer() {
   CHECK(err <= 1e-6);
 }
 
+// ---- PtrAdapter (reference include/ear/dsp/ptr_adapter.hpp:10-40; used by every reference DSP test) ----
+// a minimal column-major matrix with the two members set_eigen needs (cols(), col(c).data())
+struct ColMajor {
+  size_t rows_, cols_;
+  Vec data_;
+  ColMajor(size_t r, size_t c) : rows_(r), cols_(c), data_(r * c, 0.0f) {}
+  struct Col {
+    float *p;
+    float *data() const { return p; }
+  };
+  struct ConstCol {
+    const float *p;
+    const float *data() const { return p; }
+  };
+  size_t cols() const { return cols_; }
+  Col col(size_t c) { return Col{data_.data() + c * rows_}; }
+  ConstCol col(size_t c) const { return ConstCol{data_.data() + c * rows_}; }
+  float &at(size_t r, size_t c) { return data_[c * rows_ + r]; }
+};
+
+static void test_ptr_adapter() {
+  const size_t n = 300, nch = 3, delay = 40;
+  ColMajor in(n, nch), out(n, nch);
+  for (size_t c = 0; c < nch; c++)
+    for (size_t i = 0; i < n; i++) in.at(i, c) = (float)(c * 1000 + i);
+  PtrAdapterConst in_p(nch);
+  PtrAdapter out_p(nch);
+  CHECK(in_p.size() == nch);
+  // the reference's idiom (tests/delay_buffer_tests.cpp:17-24): re-point the adapters at an offset
+  // for every call, process in pieces
+  DelayBuffer db(nch, delay);
+  size_t ofs = 0;
+  for (size_t len : {100u, 7u, 193u}) {
+    const ColMajor &cin = in;
+    in_p.set_eigen(cin, ofs);
+    out_p.set_eigen(out, ofs);
+    CHECK(in_p.ptrs()[1] == in.data_.data() + n + ofs);
+    db.process(len, in_p.ptrs(), out_p.ptrs());
+    ofs += len;
+  }
+  bool ok = true;
+  for (size_t c = 0; c < nch; c++)
+    for (size_t i = 0; i < n; i++) ok = ok && out.at(i, c) == (i < delay ? 0.0f : in.at(i - delay, c));
+  CHECK(ok);
+  // wrong channel count: ear_assert -> internal_error (ptr_adapter.hpp:19-20)
+  bool threw = false;
+  try {
+    ColMajor two(n, 2);
+    out_p.set_eigen(two);
+  } catch (const ear::internal_error &) {
+    threw = true;
+  }
+  CHECK(threw);
+  // the Eigen-free spelling gives the same pointers
+  PtrAdapter planar(nch);
+  planar.set_planar(out.data_.data(), n, 5);
+  out_p.set_eigen(out, 5);
+  for (size_t c = 0; c < nch; c++) CHECK(planar.ptrs()[c] == out_p.ptrs()[c]);
+  // GainInterpolator driven through adapters (reference tests/gain_interpolator_tests.cpp:42-52)
+  GainInterpolator<LinearInterpVector> interp;
+  interp.interp_points.emplace_back(0, std::vector<float>{1.0f, 0.0f, 0.5f});
+  interp.interp_points.emplace_back(100, std::vector<float>{0.0f, 1.0f, 0.5f});
+  ColMajor x(200, 1), y(200, nch);
+  for (size_t i = 0; i < 200; i++) x.at(i, 0) = 1.0f;
+  PtrAdapterConst xp(1);
+  PtrAdapter yp(nch);
+  const ColMajor &cx = x;
+  xp.set_eigen(cx);
+  yp.set_eigen(y);
+  interp.process(0, 200, xp.ptrs(), yp.ptrs());
+  ok = true;
+  for (size_t i = 0; i < 200; i++) {
+    const float p = i < 100 ? (float)i * (1.0f / 100.0f) : 1.0f;
+    ok = ok && y.at(i, 0) == (i < 100 ? (1.0f - p) * 1.0f + p * 0.0f : 0.0f) && y.at(i, 2) == 0.5f;
+  }
+  CHECK(ok);
+}
+
+static void test_layout_names() {
+  // "decorrelators for 4+5+0 without LFE": M+030 gets filter id 1 (reference
+  // tests/decorrelate_tests.cpp:35-44), the caller never spells a channel name
+  const auto f = designDecorrelators("4+5+0", true);
+  CHECK(f.size() == 9);
+  const auto basic = designDecorrelatorBasic(1, 512);
+  bool ok = f.size() == 9 && f[0].size() == 512;
+  for (size_t i = 0; ok && i < 512; i++) ok = f[0][i] == (float)basic[i];
+  CHECK(ok);
+  CHECK(designDecorrelators("9+10+3").size() == 24);
+  bool threw = false;
+  try {
+    designDecorrelators("1+2+3");
+  } catch (const ear::invalid_argument &) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
 int main() {
   try {
+    test_ptr_adapter();
+    test_layout_names();
     test_gain_interpolator();
     test_block_convolver();
     test_delay_and_adapter();

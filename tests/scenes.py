@@ -148,3 +148,59 @@ def render_f64(curves, x, n_out, decorrelators=None, delay=0):
         dl = np.concatenate([np.zeros(delay), direct[c]])[:total]
         out[c] = dec + dl
     return out
+
+
+def rel_rms_per_channel(a, b):
+    """largest per-channel relative RMS error: max_c |a_c - b_c| / |b_c| (a silent reference channel
+    must be matched exactly: inf otherwise)"""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    num = np.linalg.norm(a - b, axis=1)
+    den = np.linalg.norm(b, axis=1)
+    worst = 0.0
+    for n_, d_ in zip(num, den):
+        if d_ == 0.0:
+            worst = max(worst, 0.0 if n_ == 0.0 else np.inf)
+        else:
+            worst = max(worst, n_ / d_)
+    return float(worst)
+
+
+def window_curves(curves, t_lo, t_hi):
+    """the curves restricted to what [t_lo, t_hi) can see (the points inside plus one on each side),
+    with times relative to t_lo: rendering them from time 0 equals rendering the originals from t_lo"""
+    out = []
+    for t, d, f in curves:
+        t = np.asarray(t, np.int64)
+        lo = max(int(np.searchsorted(t, t_lo, side="right")) - 1, 0)
+        hi = min(int(np.searchsorted(t, t_hi, side="left")) + 1, len(t))
+        hi = max(hi, lo + 1)
+        out.append((t[lo:hi] - t_lo, d[lo:hi], None if f is None else f[lo:hi]))
+    return out
+
+
+def mixed_level_sparse(n_obj, n_out, block, n_blocks, lfe=(), span_db=100.0, seed=21):
+    """Realistic panning (3 loudspeakers per object, unit power, sqrt(1-d)/sqrt(d) split, zero LFE
+    columns) with object LEVELS spread over 0 .. -span_db: the loud objects (above -40 dB) only feed the
+    first half of the loudspeakers, so the second half carries quiet objects alone.  Returns
+    (curves, levels); the levels are meant for the signals or the gains, as the test chooses."""
+    rng = np.random.default_rng(seed)
+    times = block * np.arange(n_blocks + 1, dtype=np.int64)
+    speakers = [c for c in range(n_out) if c not in lfe]
+    first, second = speakers[:len(speakers) // 2], speakers[len(speakers) // 2:]
+    levels = (10.0 ** (-rng.uniform(0.0, span_db, n_obj) / 20.0)).astype(np.float32)
+    levels[0] = 1.0
+    curves = []
+    for m in range(n_obj):
+        pool = first if levels[m] > 1e-2 else second
+        d = np.zeros((n_blocks + 1, n_out), np.float32)
+        f = np.zeros((n_blocks + 1, n_out), np.float32)
+        for k in range(n_blocks + 1):
+            idx = rng.choice(pool, min(3, len(pool)), replace=False)
+            g = rng.uniform(0.1, 1.0, len(idx))
+            g /= np.sqrt(np.sum(g * g))
+            diff = rng.choice([0.0, 0.5, 1.0])
+            d[k, idx] = (g * np.sqrt(1.0 - diff)).astype(np.float32)
+            f[k, idx] = (g * np.sqrt(diff)).astype(np.float32)
+        curves.append((times, d, f))
+    return curves, levels

@@ -105,3 +105,13 @@ def test_segment_search_on_cpu(tmp_path):
                     src, "-o", str(exe)], check=True)
     res = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
     assert res.returncode == 0, res.stdout
+
+
+def test_launch_plans_fit_the_bus_buffer_on_cpu(tmp_path):
+    """libear_amd/csrc/curves.h: every plan plan_mix makes fits bus_samples_bound() (host code, hipcc)"""
+    exe = tmp_path / "test_plan_bounds"
+    src = os.path.join(ROOT, "tests", "cpp", "test_plan_bounds.cpp")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I",
+                    os.path.join(ROOT, "libear_amd", "csrc"), src, "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+    assert res.returncode == 0, res.stdout

@@ -1,12 +1,18 @@
-"""Native decorrelator design (libearhip group G, host code) vs the reference's known answers
-(reference tests/decorrelate_tests.cpp:19-44) and vs the CPU oracle."""
+"""Native decorrelator design and BS.2051 channel table (libearhip groups G and H, host code) vs the
+reference's known answers (reference tests/decorrelate_tests.cpp:19-44), the layout data of
+tests/layouts.py and the CPU oracle.  Host code: runs in the CPU suite AND in the GPU suite (the driver's
+`-m gpu` run loads the same library on the GPU box)."""
 import numpy as np
+import pytest
 
 import _oracle
 from layouts import LAYOUTS, without_lfe
 
+both = pytest.mark.parametrize("where", ["cpu", pytest.param("gpu", marks=pytest.mark.gpu)])
 
-def test_known_answers():
+
+@both
+def test_known_answers(where):
     from libear_amd import capi
     dec = capi.design_decorrelator_basic(7, 512)
     kat = {0: -0.1124280906086625, 1: -0.00944671630601479, 255: 0.057714955000898516,
@@ -15,7 +21,8 @@ def test_known_answers():
         assert abs(dec[i] - v) < 1e-12
 
 
-def test_matches_oracle_and_id_rule():
+@both
+def test_matches_oracle_and_id_rule(where):
     from libear_amd import capi
     assert capi.compensation_delay() == 255
     for layout in ("0+5+0", "4+5+0", "9+10+3"):
@@ -27,3 +34,29 @@ def test_matches_oracle_and_id_rule():
     names = without_lfe(LAYOUTS["4+5+0"])
     f = capi.design_decorrelators(names)
     assert np.array_equal(f[names.index("M+030")], capi.design_decorrelator_basic(1, 512).astype(np.float32))
+
+
+@both
+def test_native_layout_table(where):
+    """every BS.2051 layout: channel names, order and LFE flags as in the reference's table; the
+    decorrelators "for 4+5+0 without LFE" give M+030 filter id 1 (reference
+    tests/decorrelate_tests.cpp:35-44) without the caller knowing any channel name"""
+    from libear_amd import capi
+    assert sorted(capi.layout_names()) == sorted(LAYOUTS)
+    for layout, names in LAYOUTS.items():
+        chans = capi.layout_channels(layout)
+        assert [c[0] for c in chans] == names
+        assert [c[3] for c in chans] == [n.startswith("LFE") for n in names]
+        for name, az, el, lfe in chans:
+            if not lfe and name[1:].lstrip("H")[1:].isdigit():  # e.g. M+030, U-110, UH+180: azimuth in the name
+                sign = -1.0 if name.lstrip("MUHTB")[0] == "-" else 1.0
+                assert az == sign * float(name[-3:])
+                assert el == {"M": 0.0, "U": 30.0, "B": -30.0, "T": 90.0}[name[0]] or name.startswith("UH")
+    assert capi.layout_channels("9+10+3")[15] == ("T+000", 0.0, 90.0, False)
+    with pytest.raises(capi.InvalidArgument):
+        capi.layout_channels("1+2+3")
+    f = capi.design_decorrelators_for_layout("4+5+0", without_lfe=True)
+    names = without_lfe(LAYOUTS["4+5+0"])
+    assert f.shape == (len(names), 512)
+    assert np.array_equal(f[names.index("M+030")], capi.design_decorrelator_basic(1, 512).astype(np.float32))
+    assert np.array_equal(capi.design_decorrelators_for_layout("9+10+3"), capi.design_decorrelators(LAYOUTS["9+10+3"]))

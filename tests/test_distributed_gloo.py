@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -34,7 +35,7 @@ def _worker(rank, world, port, tmp):
     import _oracle
     import scenes
     from layouts import LAYOUTS
-    from libear_amd.distributed import channel_range, exchange, shard_range
+    from libear_amd.distributed import channel_range, exchange, padded_channels, shard_range
 
     names = LAYOUTS["4+5+0"]
     m, n, block, nblocks = 24, len(names), 512, 3
@@ -46,12 +47,16 @@ def _worker(rank, world, port, tmp):
     for i, (t, d, f) in enumerate(curves[lo:hi]):
         o.set_points(i, 0, t, d)
         o.set_points(i, 1, t, f)
-    partial = torch.from_numpy(o.process(x[lo:hi]))
+    # exchange buffers hold the channel count rounded up to a multiple of the ranks (10 channels, 3 ranks:
+    # 12 rows, the last rank owns 2 real channels)
+    partial = torch.zeros((padded_channels(n, world), block * nblocks), dtype=torch.float32)
+    partial[:n] = torch.from_numpy(o.process(x[lo:hi]))
     owned, work = exchange(partial, async_op=True)
     work.wait()
     clo, chi = channel_range(n, rank, world)
-    assert owned.shape[0] == chi - clo
-    np.save(os.path.join(tmp, f"owned_{rank}.npy"), owned.numpy())
+    assert owned.shape[0] == padded_channels(n, world) // world
+    assert not owned[chi - clo:].any()  # padding rows stay zero
+    np.save(os.path.join(tmp, f"owned_{rank}.npy"), owned[:chi - clo].numpy())
     if rank == 0:
         full = _oracle.ObjectsRenderer(m, n, block, dec, 255)
         for i, (t, d, f) in enumerate(curves):
@@ -62,8 +67,8 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_shard_and_exchange_world_size_2(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_and_exchange(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     full = np.load(tmp_path / "full.npy")
     got = np.concatenate([np.load(tmp_path / f"owned_{r}.npy") for r in range(world)], axis=0)
@@ -82,9 +87,11 @@ def test_shard_ranges_cover_everything():
                 lo, hi = shard_range(m, r, world)
                 cover.extend(range(lo, hi))
             assert cover == list(range(m))
-    for world in (1, 2, 4, 8):
-        cover = []
-        for r in range(world):
-            lo, hi = channel_range(24, r, world)
-            cover.extend(range(lo, hi))
-        assert cover == list(range(24))
+    for n in (24, 10, 6, 2):  # 9+10+3, 4+5+0, 0+5+0, 0+2+0: ragged ownership where the ranks do not divide n
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = channel_range(n, r, world)
+                assert 0 <= hi - lo <= -(-n // world)
+                cover.extend(range(lo, hi))
+            assert cover == list(range(n))

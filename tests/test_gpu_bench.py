@@ -1,0 +1,70 @@
+"""bench.py itself, at reduced stream lengths: every BASELINE configuration produces a complete line
+(roofline + cpu_baseline + parity on the timed output, per channel), and the multi-rank control flow
+(object sharding, ragged channel ownership, the exchange, the self-check) runs with several ranks
+sharing the one GPU of the box over gloo.  Each run is a fresh child process (torchrun for N > 1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_bench(args, nproc=1, env=None):
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port())]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    e = dict(os.environ)
+    e.update(env or {})
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=e, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5"])
+def test_every_baseline_config_gives_a_complete_parity_checked_line(config):
+    line = run_bench(["--config", config, "--blocks", "64", "--steps", "4", "--warmup", "1", "--cpu-blocks", "4"])
+    assert line["metric"] == "Msamples/s" and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["baseline_config"] == config
+    assert line["dtype"].startswith("f32")
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1.0 and r["peak"] == 8000.0
+    assert r["traffic"] is None or r["traffic_source"]
+    assert r["peak_measured"] and "error" not in r["peak_measured"]
+    p = line["parity"]
+    assert p["same_plan_as_timed"]
+    assert p["rel_rms_vs_cpu"] <= 1e-6 and p["max_channel_rel_rms_vs_cpu"] <= 1e-6
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["cpu_model"]
+    assert line["value_f32_exact"]["value"] > 0 and line["value_strict"]["value"] > 0
+    assert line["step_ms"]["median"] > 0 and line["block_mode"]["ms_per_block"] > 0
+
+
+@pytest.mark.parametrize("nproc,layout", [(2, "9+10+3"), (3, "4+5+0")])
+def test_multi_rank_control_flow_on_one_gpu_over_gloo(nproc, layout):
+    """ranks share cuda:0, the collective runs over gloo: sharding, ragged channel ownership (10 channels
+    over 3 ranks), the asynchronous exchange and its self-check (owned slice == all-reduce of the partials)"""
+    line = run_bench(["--objects", "96", "--layout", layout, "--blocks", "32", "--steps", "3", "--warmup", "1",
+                      "--cpu-blocks", "0"], nproc=nproc,
+                     env={"EARHIP_BENCH_BACKEND": "gloo", "EARHIP_BENCH_CHECK": "force"})
+    assert line["n_gpus"] == nproc and line["scaling"] == "strong"
+    assert line["config"]["objects_total"] == 96 and line["config"]["objects_per_gpu"] == 96 // nproc
+    assert line["exchange_check"]["max_rel_err_owned_slice_vs_all_reduce"] <= 1e-6
+    assert line["weak_scaling"]["objects_total"] == 96 * nproc and line["weak_scaling"]["value"] > 0

@@ -23,7 +23,10 @@ pytestmark = pytest.mark.gpu
 
 
 def decorrelators(layout):
-    return _oracle.design_decorrelators(LAYOUTS[layout])
+    """the FIRs come from the product's native design (libearhip group G), as a caller's would; they equal
+    the oracle's (tests/test_decorrelate_native.py, test_gpu_render_full.py)"""
+    from libear_amd import capi
+    return capi.design_decorrelators(LAYOUTS[layout])
 
 
 def run_hip(curves, x, n_out, block, dec, delay, calls, strict=False):

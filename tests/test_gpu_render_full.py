@@ -1,0 +1,198 @@
+"""The composed render at BASELINE.json's FULL sizes, through the device entry point, against the CPU
+oracle on windows of the stream, PER CHANNEL.
+
+The oracle renders a window [b0, b0 + nb) of a long stream from block b0 - 1 on (zero state there):
+with a one-partition decorrelator (512 taps <= one block) and a 255-sample delay, block t of the
+output depends on blocks t - 1 and t of the buses only, so everything from b0 on is exact.
+
+  * the headline call itself: 1024 objects -> 9+10+3, block 512, 1024 blocks in ONE call (the launch
+    plan bench.py times: gain kernel on 512-sample tiles), windows at the start, middle and end;
+  * BASELINE config 5 at full size: 16 HOA channels (constant decode matrix) + 512 objects, block 1024;
+  * config 2 (64 objects -> 4+5+0, ramped gains only, one bus) and config 3 (256 -> 9+10+3);
+  * objects at levels spread over 100 dB with realistic 3-loudspeaker panning: every loudspeaker within
+    1e-6 of the oracle, also those that carry quiet objects only;
+  * call lengths between block mode and stream mode with metadata that ignores the block grid (object
+    splits across workgroups: the bus buffer must hold every plan).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle
+import scenes
+from _hip import ctx
+from layouts import LAYOUTS
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6  # north_star: relative RMS vs the reference CPU path
+
+
+def decorrelators(layout):
+    from libear_amd import capi
+    return capi.design_decorrelators(LAYOUTS[layout])
+
+
+def oracle_window(curves, x_win, n_out, block, dec, delay, t_lo, two_bus=True):
+    """x_win: the inputs from absolute time t_lo on (whole blocks); output for the same samples, exact
+    from the second block on when t_lo > 0"""
+    nb = x_win.shape[1] // block
+    win = scenes.window_curves(curves, t_lo, t_lo + nb * block)
+    if two_bus:
+        o = _oracle.ObjectsRenderer(x_win.shape[0], n_out, block, dec, delay)
+    else:
+        o = _oracle.ObjectsRenderer(x_win.shape[0], n_out, block, np.zeros((n_out, 1), np.float32), 0)
+    for m, (t, d, f) in enumerate(win):
+        o.set_points(m, 0, t, d)
+        o.set_points(m, 1, t, f if (two_bus and f is not None) else np.zeros_like(d))
+    return o.process(x_win)
+
+
+def render_device(curves, x_dev, n_out, block, dec, delay, calls, t0=0):
+    """x_dev: torch [M][total] on the GPU; returns (out_dev, plan of the last call)"""
+    import torch
+    from libear_amd import capi
+    m, total = x_dev.shape
+    r = capi.Renderer(ctx(), m, n_out, block, dec, delay, max_blocks=max(calls))
+    for i, (t, d, f) in enumerate(curves):
+        r.set_object_points(i, t, d, f if dec is not None else None)
+    r.reset(t0)
+    out = torch.zeros((n_out, total), device=x_dev.device, dtype=torch.float32)
+    torch.cuda.synchronize()
+    ofs = 0
+    for nb in calls:
+        r.process_device(nb, x_dev.data_ptr() + 4 * ofs, total, out.data_ptr() + 4 * ofs, total)
+        ofs += nb * block
+    ctx().synchronize()
+    plan = r.last_plan()
+    r.close()
+    return out, plan
+
+
+def check_windows(curves, x_dev, out_dev, n_out, block, dec, delay, windows, two_bus=True, tol=TOL):
+    worst = 0.0
+    for b0, nb in windows:
+        lead = 1 if b0 > 0 else 0
+        lo, hi = (b0 - lead) * block, (b0 + nb) * block
+        xw = x_dev[:, lo:hi].cpu().numpy()
+        want = oracle_window(curves, xw, n_out, block, dec, delay, lo, two_bus)[:, lead * block:]
+        got = out_dev[:, b0 * block:hi].cpu().numpy()
+        assert np.isfinite(got).all()
+        e_all = scenes.rel_rms(got, want)
+        e_ch = scenes.rel_rms_per_channel(got, want)
+        assert e_all <= tol and e_ch <= tol, (b0, nb, e_all, e_ch)
+        worst = max(worst, e_ch)
+    return worst
+
+
+def device_audio(m, total, seed, scale=None):
+    import torch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    x = torch.rand((m, total), generator=gen, device="cuda", dtype=torch.float32) * 2.0 - 1.0
+    if scale is not None:
+        x *= torch.as_tensor(scale, device="cuda", dtype=torch.float32)[:, None]
+    return x
+
+
+def test_headline_call_at_its_own_size_vs_oracle_windows():
+    """BASELINE config 4 at G = 1 exactly as bench.py runs it: ONE call of 1024 blocks, 1024 objects."""
+    layout, m, block, nblocks = "9+10+3", 1024, 512, 1024
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = device_audio(m, block * nblocks, 1234)
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    if os.environ.get("EARHIP_MFMA") in (None, "3") and os.environ.get("EARHIP_H2_TILE") is None:
+        assert plan["kernel"] == 3 and plan["tile"] == 512 and plan["gsplit"] == 1, plan
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (511, 2), (1021, 3)])
+    print(f"headline call: worst per-channel rel RMS vs oracle {worst:.3e}, plan {plan}")
+
+
+def test_config5_full_size_hoa_bed_plus_512_objects_block_1024():
+    """BASELINE config 5: 16 HOA channels through a constant 16 x 24 decode matrix + 512 ramped objects,
+    block 1024 (FFT 2048), a 256-block stream in one call."""
+    layout, block, nblocks, n_hoa, n_obj = "9+10+3", 1024, 256, 16, 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    rng = np.random.default_rng(55)
+    decode = rng.uniform(-0.5, 0.5, (n_hoa, n)).astype(np.float32)
+    curves = [(np.zeros(1, np.int64), decode[c:c + 1], np.zeros((1, n), np.float32)) for c in range(n_hoa)]
+    curves += scenes.dense_curves(n_obj, n, block, nblocks)
+    x = device_audio(n_hoa + n_obj, block * nblocks, 77)
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 2), (100, 2), (254, 2)])
+    print(f"config 5: worst per-channel rel RMS vs oracle {worst:.3e}, plan {plan}")
+    # the same stream in uneven calls (state carried across calls)
+    out2, _ = render_device(curves, x, n, block, dec, 255, [1, 99, 156])
+    check_windows(curves, x, out2, n, block, dec, 255, [(0, 2), (99, 3), (254, 2)])
+
+
+@pytest.mark.parametrize("m,layout,two_bus,nblocks", [(64, "4+5+0", False, 1024), (256, "9+10+3", True, 1024)])
+def test_config2_and_config3_full_streams(m, layout, two_bus, nblocks):
+    """BASELINE configs 2 (ramped gains only: one bus, no decorrelator) and 3, 1024-block streams."""
+    block = 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout) if two_bus else None
+    curves = scenes.dense_curves(m, n, block, nblocks, seed=m)
+    x = device_audio(m, block * nblocks, m)
+    out, plan = render_device(curves, x, n, block, dec, 255 if two_bus else 0, [nblocks])
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (500, 3), (1021, 3)], two_bus=two_bus)
+    print(f"{m} objects -> {layout}: worst per-channel rel RMS vs oracle {worst:.3e}, plan {plan}")
+
+
+@pytest.mark.parametrize("what", ["signals", "gains"])
+@pytest.mark.parametrize("m,nblocks", [(256, 64), (1024, 512)])
+def test_levels_spread_over_100_db_every_channel_within_tolerance(what, m, nblocks):
+    """Objects at 0 .. -100 dB, 3 loudspeakers each; the loudspeakers of the second half of the layout
+    carry only objects below -40 dB.  Whole-output RMS would hide them: every channel is checked."""
+    layout, block = "9+10+3", 512
+    names = LAYOUTS[layout]
+    n = len(names)
+    dec = decorrelators(layout)
+    lfe = [i for i, nm in enumerate(names) if nm.startswith("LFE")]
+    curves, levels = scenes.mixed_level_sparse(m, n, block, nblocks, lfe, seed=m)
+    if what == "gains":
+        curves = [(t, (d * lv).astype(np.float32), (f * lv).astype(np.float32)) for (t, d, f), lv in zip(curves, levels)]
+        x = device_audio(m, block * nblocks, 5)
+    else:
+        x = device_audio(m, block * nblocks, 5, scale=levels)
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    mid = nblocks // 2
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (mid, 2), (nblocks - 2, 2)])
+    print(f"levels over 100 dB ({what}, {m} objects): worst per-channel rel RMS {worst:.3e}, plan {plan}")
+
+
+@pytest.mark.parametrize("nblocks", [1, 2, 7, 33, 40, 63, 64])
+def test_call_lengths_between_block_and_stream_mode_off_grid_metadata(nblocks):
+    """ADM-like metadata (f32 slot kernel) at 256 objects with max_blocks = 64: calls of 33..63 blocks
+    split the objects over workgroups (partial bus slabs) — every plan must fit the bus buffer."""
+    layout, m, block, cap = "9+10+3", 256, 512, 64
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, seed=nblocks)
+    x = device_audio(m, total, nblocks)
+    import torch
+    from libear_amd import capi
+    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=cap)
+    for i, (t, d, f) in enumerate(curves):
+        r.set_object_points(i, t, d, f)
+    out = torch.zeros((n, total), device="cuda", dtype=torch.float32)
+    r.process_device(nblocks, x.data_ptr(), total, out.data_ptr(), total)
+    ctx().synchronize()
+    plan = r.last_plan()
+    r.close()
+    wins = [(0, min(2, nblocks))] + ([(nblocks - 2, 2)] if nblocks > 3 else [])
+    check_windows(curves, x, out, n, block, dec, 255, wins)
+    print(plan)
+
+
+def test_native_decorrelators_equal_the_oracles():
+    """the FIRs every GPU render test uses come from the native design (libearhip group G); they are the
+    oracle's (both restate src/decorrelate.cpp:31-97 in double and cast to float; the doubles agree to
+    ~1e-16, so a float may differ in its last bit)"""
+    for layout in ("0+5+0", "4+5+0", "9+10+3"):
+        got, want = decorrelators(layout), _oracle.design_decorrelators(LAYOUTS[layout])
+        assert np.max(np.abs(got - want)) <= 2e-9
