@@ -56,17 +56,15 @@ def algorithmic_bytes(m, n, b, k, m_static=0):
     return gain, dec, dm
 
 
-GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 2: "k_gain_mix_bf3 (bf16x3 MFMA)",
-                3: "k_gain_mix_h2 (f16x2 MFMA)"}
+GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 3: "k_gain_mix_h2 (f16x2 MFMA)",
+                4: "k_gain_mix_p2 (f16x2 MFMA over piece lists)"}
 GAIN_DTYPES = {0: "f32 (VALU, libear's exact arithmetic)", 1: "f32 (f32 MFMA, f32 accumulate)",
-               2: "f32 io / bf16x3-split MFMA, f32 accumulate", 3: "f32 io / f16x2-split MFMA, f32 accumulate"}
+               3: "f32 io / f16x2-split MFMA, f32 accumulate", 4: "f32 io / f16x2-split MFMA, f32 accumulate"}
 
 
 def mfma_roofline(kind, macs_per_term, k1_ms):
     """The gain kernel against the matrix pipe it runs on (secondary to the HBM roofline)."""
-    if kind == 2:   # 2 operands (B0, B1) x 6 bf16 partial products per object, column and sample
-        flops, peak, what = 24.0 * macs_per_term, BF16_PEAK_TFLOPS, "bf16 MFMA flops: 6 partial products x {gain at tile start, slope}"
-    elif kind == 3:  # 2 operands (B0, B1) x 3 f16 partial products per object, column and sample
+    if kind in (3, 4):  # 2 operands (B0, B1) x 3 f16 partial products per object, column and sample
         flops, peak, what = 12.0 * macs_per_term, BF16_PEAK_TFLOPS, "f16 MFMA flops: 3 partial products x {gain at tile start, slope}"
     else:           # 2 f32 MACs (start, end gain row) per object, column and sample
         flops, peak, what = 4.0 * macs_per_term, FP32_PEAK_TFLOPS, "f32 flops: 2 MACs per object, column and sample for a ramp"
@@ -156,7 +154,12 @@ def main():
     delay = capi.compensation_delay() if K == 2 else 0
     n_pad = padded_channels(N, world)
 
-    stream = torch.cuda.current_stream(dev)
+    # ONE stream for everything: the renderer's launches, torch's ops, the events below, and the stream
+    # RCCL orders its collectives against (a context given no stream creates its own non-blocking one,
+    # which torch's default stream knows nothing about)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx = capi.Context(dev_index, stream.cuda_stream)
     ctx.set_strict(args.strict)
 

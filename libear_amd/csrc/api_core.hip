@@ -9,18 +9,18 @@
 #include "curves.h"
 #include "gain_kernels.h"
 #include "gain_mfma.h"
-#include "gain_bf3.h"
 #include "gain_h2.h"
+#include "gain_p2.h"
 
 namespace earhip {
 
-static_assert(kBf3Tile == 256, "MixLaunch::tile() and tiles_aligned(256, ...) assume the bf16x3 tile");
+static_assert(kSplitTile == 256, "MixLaunch::tile() and tiles_aligned(256, ...) assume the 4-wave tile");
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml) {
-  if (ml.wsplit <= 1 || ml.bf3) return 0;
+  if (ml.wsplit <= 1 || ml.split || ml.pieces) return 0;
   if (ml.mfma) return (size_t)cp.mgroups * ml.tpw * cp.nct * 16 * ml.tile() * sizeof(float);
   return (size_t)cp.ngroups * cp.nout * ml.tile() * sizeof(float);
 }
@@ -44,7 +44,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const ColumnPlan &cp = cs.plan();
   const PointStore ps = cs.device();
   const int M = cs.M();
-  const bool slots = ml.mfma && !ml.bf3;
+  const bool slots = ml.mfma && !ml.split && !ml.pieces;
   if (slots && M > kMaxSlotObjects) fail_internal("slot lists address objects with 16 bits");
   if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
   // K0: segment descriptors; for the f32 MFMA kernel K0s then turns them into the
@@ -58,7 +58,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // K0 raises word `li` (zero since the last f16x2 call cleared it), its K1 reads it and clears the other.
   LevelProbe probe;
   unsigned *level_cur = nullptr, *level_next = nullptr;
-  if (ml.bf3 && ml.h2 && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
+  if ((ml.split || ml.pieces) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
     if (!ctx->level.p) ctx->level.alloc_zero(2, ctx->stream);
     level_cur = ctx->level.p + ctx->level_idx;
     level_next = ctx->level.p + (ctx->level_idx ^ 1);
@@ -87,6 +87,17 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (slots)
     hipLaunchKernelGGL(k_slot_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
+  // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
+  PieceLists pl;
+  pl.pieces = reinterpret_cast<Piece *>(desc + (size_t)M * ml.ntiles);
+  pl.M = M;
+  pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
+  pl.ovf = pl.count + (size_t)8 * ml.ntiles;
+  if (ml.pieces) {
+    if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
+    hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(), t_call,
+                       t_call + nsamples, desc, pl);
+  }
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
   P.sl = sl;
@@ -115,7 +126,23 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const size_t lds = mix_lds_bytes(cp, ml);
   if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
   bool launched = false;
-  if (ml.bf3 && ml.h2) {
+  if (ml.pieces) {
+    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+    // (gains at 2^12: a ramp piece that starts inside its tile is extended back to the tile start, gain_p2.h)
+    const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale() * 0.25f;
+#define EARHIP_P2_CASE(NCT_)                                                                                        \
+  if (cp.nct == NCT_) {                                                                                             \
+    if (ml.pw == 4)                                                                                                 \
+      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
+                         level_next);                                                                                \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 2>), bgrid, dim3(128), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
+                         level_next);                                                                                \
+  }
+    EARHIP_P2_CASE(1) EARHIP_P2_CASE(2) EARHIP_P2_CASE(3)
+#undef EARHIP_P2_CASE
+    launched = true;
+  } else if (ml.split) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale();
 #define EARHIP_H2_CASE(NCT_)                                                                                        \
@@ -130,12 +157,6 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     EARHIP_H2_CASE(1) EARHIP_H2_CASE(2) EARHIP_H2_CASE(3)
 #undef EARHIP_H2_CASE
     launched = true;
-  } else if (ml.bf3) {
-    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
-    if (cp.nct == 1) hipLaunchKernelGGL(k_gain_mix_bf3<1>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
-    if (cp.nct == 2) hipLaunchKernelGGL(k_gain_mix_bf3<2>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
-    if (cp.nct == 3) hipLaunchKernelGGL(k_gain_mix_bf3<3>, bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row);
-    launched = true;
   }
 #define EARHIP_MIX_CASE(NOUT_, SPL_, STRICT_)                                   \
   if (cp.nout == NOUT_ && ml.spl == SPL_ && strict == STRICT_) {                 \
@@ -143,7 +164,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     launched = true;                                                             \
   }
 #define EARHIP_MFMA_CASE(NCT_, NRT_)                                            \
-  if (ml.mfma && !ml.bf3 && cp.nct == NCT_ && ml.nrt == NRT_) {                             \
+  if (ml.mfma && !ml.split && cp.nct == NCT_ && ml.nrt == NRT_) {                             \
     launch_mfma_t<NCT_, NRT_>(P, grid, block, lds, ctx->stream);                 \
     launched = true;                                                             \
   }
@@ -183,8 +204,8 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
-                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale());
-    desc.reserve(desc_units(n_in, ml.ntiles));
+                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density());
+    desc.reserve(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,
                       out_stride, 0, desc.p, nullptr);

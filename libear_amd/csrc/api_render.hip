@@ -102,7 +102,7 @@ struct earhip_render {
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
-  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 bf16x3 MFMA, 3 f16x2 MFMA
+  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
   bool run_len_set = false;  // EARHIP_RUN given: also fixes the run length of the wave kernel
 
@@ -170,8 +170,8 @@ struct earhip_render {
     curves->commit(ctx);
     const bool strict = ctx->strict;
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit,
-                            curves->aligned_tile(t), curves->ramp_share(), curves->gain_scale());
-    last_kind = ml.bf3 ? (ml.h2 ? 3 : 2) : ml.mfma ? 1 : 0;
+                            curves->aligned_tile(t), curves->ramp_share(), curves->gain_scale(), curves->point_density());
+    last_kind = ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
     // the bus is sized for every plan plan_mix can make (earhip_render_create); should a tuning knob
@@ -291,7 +291,7 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // smallest tile any gain kernel of this context uses (f32 MFMA: 16 * nrt samples)
     const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
     const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
-    r->desc.alloc(desc_units(r->M, max_tiles));
+    r->desc.alloc(std::max(desc_units(r->M, max_tiles), piece_units(r->M, (max_samples + 127) / 128)));
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits (gsplit > 1) are only
     // chosen for calls with few tiles: plan_mix doubles gsplit while gsplit * (ntiles / tpw) stays below
     // 2 * num_cus, so gsplit * ntiles < (4 * num_cus + gsplit) * tpw with tiles of at most 256 samples

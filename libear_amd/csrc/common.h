@@ -118,7 +118,7 @@ struct earhip_ctx {
   bool own_stream = false;
   bool strict = false;
   int spl = 4;  // samples per lane of the VALU gain_mix kernel (2 or 4)
-  int use_mfma = 3;  // non-strict gain stage: 0 VALU, 1 f32 MFMA, 2 bf16x3 MFMA, 4 f16x2 MFMA, 3 (default) f16x2
+  int use_mfma = 3;  // non-strict gain stage: 0 VALU, 1 f32 MFMA, 4 f16x2 MFMA, 3 (default) f16x2
                      // when all curve points lie on tile boundaries, else f32 MFMA
   int x_scale_log2 = 14;  // f16x2 kernel: inputs are scaled by 2^x_scale_log2 before the split (gain_h2.h) ...
   bool x_scale_auto = true;  // ... unless a level estimate of the call's inputs is available (default: K0 probes them)

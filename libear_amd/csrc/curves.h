@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "gain_kernels.h"
+#include "gain_p2.h"
 
 namespace earhip {
 
@@ -138,7 +139,7 @@ class CurveSet {
       at += n;
     }
     h_off_.p[M_] = (int32_t)at;
-    std::memset(h_gain_.p + P * row, 0, row * sizeof(float));  // the all-zero row (k_gain_mix_bf3)
+    std::memset(h_gain_.p + P * row, 0, row * sizeof(float));  // the all-zero row (split-operand kernels)
     npoints_ = (int)P;
     // common grid of all point times: every time is t_ref_ + k * grid_ (grid_ = 0: all equal)
     t_ref_ = P ? times_[0][0] : 0;
@@ -197,6 +198,11 @@ class CurveSet {
       }
     }
     ramp_share_ = span > 0 ? ramp / span : 0.0;
+    // curve points per sample and object over the time the curves span (the piece kernel picks its tile from it)
+    double npts = 0;
+    for (int m = 0; m < M_; m++)
+      if (times_[m].size() > 1) npts += (double)(times_[m].size() - 1);
+    point_density_ = span > 0 ? npts / span : 0.0;
     // largest |gain| (k_gain_mix_h2 scales the gains to the top of the f16 range); NaN / inf count as huge
     float gmax = 0.0f;
     for (size_t i = 0; i < P * row; i++) {
@@ -236,6 +242,8 @@ class CurveSet {
 
   // fraction of the curves' time in ramps; 0 for static gains
   double ramp_share() const { return ramp_share_; }
+  // curve points per sample and object (0 for static gains)
+  double point_density() const { return point_density_; }
 
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
@@ -275,6 +283,7 @@ class CurveSet {
   int64_t grid_phase_[2] = {0, 0};  // [512, 256]: the phase most objects' points share
   int grid_off_[2] = {0, 0};        // objects whose points are not all on that phase
   double ramp_share_ = 0;
+  double point_density_ = 0;
   float gain_max_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
@@ -290,45 +299,52 @@ class CurveSet {
 // How K1 is spread over the chip for one call.
 struct MixLaunch {
   bool mfma;                   // matrix-core kernel (default) or VALU kernel (strict mode)
-  bool bf3 = false;            // matrix-core kernel on split operands (gain_bf3.h / gain_h2.h); tile = 256 samples
-  bool h2 = false;             // with bf3: the f16x2 kernel (gain_h2.h) instead of the bf16x3 one
-  bool wide = false;           // with h2: 8 waves on 512-sample tiles
+  bool split = false;          // matrix-core kernel on f16x2 split operands (gain_h2.h); tile = 256 samples
+  bool wide = false;           // with split: 8 waves on 512-sample tiles
+  bool pieces = false;         // matrix-core kernel on f16x2 split operands over per-tile piece lists (gain_p2.h)
+  int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
   int tpw = 1;                 // MFMA: adjacent tiles per workgroup
-  int tile() const { return bf3 ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
+  int tile() const { return pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
-                          float gain_scale = 0.0f) {
+                          float gain_scale = 0.0f, double point_density = 0.0) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
-  // Split-operand kernels (tile = 256 or 512 samples, no curve point inside a tile): f16x2 by default
-  // (3; 4 forces it) when the gains can be scaled into f16 range — its cost does not depend on the
-  // curves and is below the f32 slot kernel's even for static gains; bf16x3 when forced (2), or as the
-  // fallback for non-finite gains when the curves are mostly ramps (the slot lists of the f32 kernel
-  // make constant pieces half as expensive as ramps: break-even with bf16x3 at about one third of the
-  // time in ramps).
-  const bool can_h2 = gain_scale > 0.0f && ctx->use_mfma != 2;
-  L.bf3 = L.mfma && M >= 32 &&
-          (ctx->use_mfma == 2 || ctx->use_mfma == 4 ||
-           (ctx->use_mfma == 3 && aligned && (can_h2 || ramp_share >= 0.35)));
-  L.h2 = L.bf3 && can_h2;
+  // Split-operand kernel (tile = 256 or 512 samples, no curve point inside a tile; 4 forces it where the
+  // gains allow): f16x2 when the gains can be scaled into f16 range — its cost does not depend on the
+  // curves and is below the f32 slot kernel's even for static gains.  Curve sets with non-finite gains
+  // stay on the f32 slot kernel.
+  L.split = L.mfma && M >= 32 && gain_scale > 0.0f && ctx->use_mfma != 5 &&
+            (ctx->use_mfma == 4 || (ctx->use_mfma == 3 && aligned));
   // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (two rounds of workgroups or more:
   // 512 blocks of 512: K1 0.215 vs 0.236 ms; one round, 256 blocks: 0.127 vs 0.120)
   // (EARHIP_H2_TILE=256|512 forces one of them where the curves allow it: tests, tuning)
   const char *force_tile = getenv("EARHIP_H2_TILE");
   const int forced = force_tile ? atoi(force_tile) : 0;
-  L.wide = L.h2 && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
+  // Piece-list kernel: everything else the f16x2 operands can represent — metadata that ignores the tile
+  // grid costs its curve points, not a different kernel (5 forces it for aligned curves as well).  Its
+  // tile: 256 samples while a tile rarely holds a curve point of an object, else 128 (EARHIP_P2_TILE).
+  L.pieces = L.mfma && !L.split && M >= 32 && M <= kMaxPieceObjects && gain_scale > 0.0f &&
+             (ctx->use_mfma == 3 || ctx->use_mfma == 5);
+  if (ctx->use_mfma == 5 && L.pieces) L.split = false;
+  if (L.pieces) {
+    const char *pt = getenv("EARHIP_P2_TILE");
+    const int ptile = pt ? atoi(pt) : 0;
+    L.pw = ptile == 256 ? 4 : ptile == 128 ? 2 : (point_density * 256.0 <= 0.3 ? 4 : 2);
+  }
+  L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
-  if (L.mfma && !L.bf3 && M > kMaxSlotObjects) L.mfma = false;
+  if (L.mfma && !L.split && !L.pieces && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
-  if (L.bf3) {
+  if (L.split || L.pieces) {
     // one workgroup = 4 adjacent 64-sample tiles x all objects of its grid-level
     // split; few tiles (block mode): split the objects across workgroups
     L.wsplit = 1;

@@ -1,10 +1,20 @@
 // gain_h2.h — K1 on the f16 matrix cores with every fp32 operand split into TWO f16
-// pieces after an exact power-of-two prescale ("f16x2"): the same bus-forming contraction
-// and the same tiling as gain_bf3.h,
+// pieces after an exact power-of-two prescale ("f16x2").  The bus-forming contraction of
+// gain_mfma.h,
 //
-//     bus[col][s] = sum_m x_m(s) * (B0_m,col + (s - s0) * B1_m,col)      (gain_bf3.h, top)
+//     bus[col][s] = sum_m x_m(s) * g_m,col(s),      g linear in s on a curve segment,
 //
-// with HALF the matrix instructions and half the operand-splitting arithmetic:
+// with the ramp moved to the gain side.  For a workgroup tile starting at sample s0
+//
+//     g(s) = B0 + (s - s0) * B1,   B0 = (1-p0)*S + p0*E  (libear's gain AT s0,
+//                                  gain_interpolator.hpp:272-274),
+//                                  B1 = scale * (E - S)  (slope per sample)
+//
+// so  bus = sum_m x*B0 + (s - s0) * sum_m x*B1 : two plain products with the SAME left
+// operand x, and (s - s0) is applied to the accumulator rows.  x is split once per sample
+// and object; B0/B1 are split once per workgroup tile and object and shared by the
+// workgroup's waves through LDS.  The f32-in MFMA runs at the vector rate (157 TFLOP/s:
+// 0.70 ms for the headline scene, above its HBM floor of 0.33 ms); the f16 MFMA at 16x that:
 //
 //   * v * 2^k = h + l with f16 pieces (11 + 11 significand bits, RNE, residual exact in
 //     fp32) is good to 2^-22 relative as long as l is a normal f16, i.e. over 2^16 / 2^-3
@@ -25,14 +35,31 @@
 //     recomputes its tile with the exact f32 MFMA path, unscaled.  Correct for any input,
 //     fast for audio.
 //
-// Fragment layouts: as gain_bf3.h (v_mfma_f32_16x16x32_f16 has the bf16 instruction's).
+// Fragment layout of v_mfma_f32_16x16x32_f16 (8 f16 = 4 VGPRs per operand):
+//   A: lane l holds row l&15, k = 8*(l>>4) .. +7     B: column l&15, same k
+//   D: lane l holds column l&15, rows 4*(l>>4) + e, e = 0..3
+// k = the 32 objects of a chunk; row i of row tile r = sample 4*i + r of the wave's
+// 64-sample tile (a lane's 4 inputs of one object are one 16-byte load and the D fragments
+// of the 4 row tiles interleave into float4 stores); column j of column tile c = bus column
+// col0 + 16*c + j.
+//
+// Objects with a curve point inside the workgroup tile, unaligned buffers and partial tiles
+// use the exact f32 MFMA on the same accumulators (slow path, same arithmetic as
+// gain_mfma.h).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
-#include "gain_bf3.h"
+#include "gain_kernels.h"
+#include "gain_mfma.h"
 
 namespace earhip {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSplitTile = 256;   // samples per workgroup tile of the 4-wave kernel (descriptor tile)
+constexpr int kSplitChunk = 32;   // objects per MFMA (k)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -50,7 +77,7 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
                                                 0, 0, 0);
 }
 
-// P.ntiles / P.desc refer to WORKGROUP tiles of kBf3Tile samples.  x_scale, g_scale: exact
+// P.ntiles / P.desc refer to WORKGROUP tiles of kSplitTile samples.  x_scale, g_scale: exact
 // powers of two (see above); zero_row: index of an all-zero gain row.
 // NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
 // conversion of a chunk's gains is shared by the whole workgroup, so the 512-sample tile halves that
@@ -59,7 +86,7 @@ template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const unsigned *level_cur,
               unsigned *level_next) {
-  constexpr int NRT = 4, TS = 16 * NRT, CH = kBf3Chunk;
+  constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
   constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
   __shared__ u32x4 bfrag[2][NFRAG + 4][64];  // + 4 never-read fragments: the lanes without a column write there
@@ -104,7 +131,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   clear_totals();
 
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
-  // with k = {a, b} of ONE object (gain_bf3.h), accumulated into tot0 in units of 1 / (sx sg)
+  // with k = {a, b} of ONE object (k slots 2, 3 idle), accumulated into tot0 in units of 1 / (sx sg)
   // (the two scales are applied to the two operands: their product may not be a float)
   // khint >= 0: the segment index K0 found at the start of the WORKGROUP tile (the search then only
   // walks on from there: a few steps instead of log2 n dependent loads per object and wave)
@@ -158,7 +185,10 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   float inv_x = 1.0f / x_scale, inv_g = 1.0f / g_scale;  // exact: powers of two
 
   if (nch > 0) {
-    // (addressing, descriptor hand-over and load order: see the comments in gain_bf3.h)
+    // lane-constant part of the input address: byte offset of this lane's float4 (lanes past the
+    // end of the call re-read the last vector; never stored).  All loads below are (wave-uniform
+    // 64-bit base) + (32-bit lane offset).  The last chunk is moved back to end at m_hi (its objects
+    // that the previous chunk already covered get the zero row).
     const int nvec = (P.nsamples + 3) & ~3;
     const unsigned xs = (unsigned)min(tile_s0 + li * NRT, nvec - 4);
     const unsigned xlane = ((unsigned)(kg * 8) * (unsigned)P.in_stride + xs) * 4u;

@@ -299,7 +299,7 @@ def test_render_errors():
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("EARHIP_FUZZ_SEEDS", "16")))))
 def test_random_scenes_vs_oracle(seed):
-    """Randomised shapes: object count (odd, below/above the 32-object chunk of the bf16x3 kernel),
+    """Randomised shapes: object count (odd, below/above the 32-object chunk of the split-operand kernels),
     layout, block size, call partition, curve families (aligned ramps, ADM-like, ragged, static) and
     call start times; every output within 1e-6 relative RMS of the oracle."""
     rng = np.random.default_rng(1000 + seed)
@@ -570,18 +570,20 @@ def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
     got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
     assert kind == 3
     assert scenes.rel_rms(got, want) <= 1e-6
-    # five such objects are more than M / 32: the slot kernel takes over
+    # five such objects are more than M / 32: the piece-list kernel takes over (cost proportional to the
+    # curve points, whatever their times)
     more = scenes.adm_curves(3, n, total, period=500, ramp=100, seed=4)
     curves[5], curves[40], curves[77] = more[0], more[1], more[2]
     want = run_oracle(curves, x, n, block, dec, 255)
     got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
-    assert kind == 1
+    assert kind == 4
     assert scenes.rel_rms(got, want) <= 1e-6
 
 
 def test_gain_kernel_choice_follows_the_curves():
     """f16x2 kernel (3) for curves without points inside the tiles (block-aligned ramps, static gains),
-    f32 slot kernel (1) for curves that ignore the tile grid, VALU kernel (0) in strict mode; small object counts never use (3); bf16x3 (2) only when forced."""
+    f16x2 piece-list kernel (4) for curves that ignore the tile grid, VALU kernel (0) in strict mode; fewer than
+    32 objects: f32 slot kernel (1)."""
     from libear_amd import capi
     layout, block, nblocks = "0+5+0", 512, 4
     n = len(LAYOUTS[layout])
@@ -606,8 +608,59 @@ def test_gain_kernel_choice_follows_the_curves():
         pytest.skip("kernel forced by EARHIP_MFMA")
     dense = scenes.dense_curves(64, n, block, nblocks)
     assert kernel_for(64, dense) == 3
-    assert kernel_for(64, dense, t0=17) == 1          # same curves, call grid shifted off the points
+    assert kernel_for(64, dense, t0=17) == 4          # same curves, call grid shifted off the points
     assert kernel_for(64, dense, strict=True) == 0
     assert kernel_for(16, scenes.dense_curves(16, n, block, nblocks)) == 1   # fewer than 32 objects
-    assert kernel_for(64, scenes.adm_curves(64, n, total, seed=1)) == 1
+    assert kernel_for(64, scenes.adm_curves(64, n, total, seed=1)) == 4
+    assert kernel_for(20, scenes.adm_curves(20, n, total, seed=1)) == 1
     assert kernel_for(64, scenes.constant_curves(64, n)) == 3   # static gains: no point inside any tile
+
+
+@pytest.mark.parametrize("tile", ["256", None])
+@pytest.mark.parametrize("kind,m,layout,block,nblocks,calls",
+                         [("adm", 64, "9+10+3", 512, 8, [8]), ("adm", 200, "4+5+0", 512, 6, [1, 2, 3]),
+                          ("ragged", 100, "9+10+3", 256, 9, [9]), ("dense", 96, "9+10+3", 512, 5, [5]),
+                          ("constant", 130, "0+5+0", 1024, 3, [3]), ("short", 64, "9+10+3", 512, 4, [4]),
+                          ("adm", 1100, "9+10+3", 512, 12, [5, 7])])
+def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, calls):
+    """k_gain_mix_p2 forced for every curve family (EARHIP_MFMA=5): metadata that ignores the tile grid,
+    irregular curves with steps and dense points, block-aligned ramps, static gains, ramps so short that
+    their extension back to the tile start leaves the f16 range (exact path), per channel."""
+    from libear_amd import capi
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    if kind == "adm":
+        curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
+    elif kind == "ragged":
+        curves = scenes.ragged_curves(m, n, total, seed=m)
+    elif kind == "dense":
+        curves = scenes.dense_curves(m, n, block, nblocks, seed=m)
+    elif kind == "constant":
+        curves = scenes.constant_curves(m, n, seed=m)
+    else:  # 9-sample ramps at arbitrary times
+        curves = scenes.adm_curves(m, n, total, period=333, ramp=9, seed=m)
+    x = scenes.audio(m, total, seed=m)
+    want = run_oracle(curves, x, n, block, dec, 255)
+
+    def render():
+        c = capi.Context(0)  # (the kernel choice is read when a context is created)
+        try:
+            r = capi.Renderer(c, m, n, block, dec, 255, max_blocks=max(calls))
+            set_renderer_curves(r, curves, True)
+            out = np.zeros((n, total), np.float32)
+            ofs = 0
+            for nb in calls:
+                out[:, ofs:ofs + nb * block] = r.process(x[:, ofs:ofs + nb * block])
+                ofs += nb * block
+            plan = r.last_plan()
+            r.close()
+        finally:
+            c.close()
+        return out, plan
+
+    got, plan = _with_env({"EARHIP_MFMA": "5", "EARHIP_P2_TILE": tile}, render)
+    assert plan["kernel"] == 4, plan
+    assert np.isfinite(got).all()
+    assert scenes.rel_rms(got, want) <= 1e-6, (scenes.rel_rms(got, want), plan)
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6, (scenes.rel_rms_per_channel(got, want), plan)
