@@ -93,10 +93,27 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   pl.M = M;
   pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
   pl.ovf = pl.count + (size_t)8 * ml.ntiles;
+  pl.cw = pl.ovf + (size_t)M * ml.ntiles;
   if (ml.pieces) {
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(), t_call,
                        t_call + nsamples, desc, pl);
+    if (getenv("EARHIP_DEBUG_P2")) {  // debug aid: the lists as K0p wrote them
+      EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+      std::vector<int> cnt((size_t)8 * ml.ntiles);
+      EARHIP_HIP(hipMemcpy(cnt.data(), pl.count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+      std::vector<Piece> pc((size_t)pl.cap());
+      for (int t = 0; t < ml.ntiles; t++) {
+        fprintf(stderr, "tile %d: counts %d %d %d %d ovf %d\n", t, cnt[t * 8], cnt[t * 8 + 1], cnt[t * 8 + 2], cnt[t * 8 + 3], cnt[t * 8 + 4]);
+        EARHIP_HIP(hipMemcpy(pc.data(), pl.pieces + (size_t)t * pl.cap(), pc.size() * sizeof(Piece), hipMemcpyDeviceToHost));
+        for (int l = 0, at = 0; l < 4; at += 32 * cnt[t * 8 + l], l++)
+          for (int i = 0; i < std::min(32 * cnt[t * 8 + l], 3); i++) {
+            const Piece &q = pc[at + i];
+            fprintf(stderr, "   list %d [%d]: m %u r0 %u r1 %u row %d p0 %g scale %g\n", l, i, q.mr & 0xffff, (q.mr >> 16) & 0xff,
+                    (q.mr >> 24) + 1, q.row, q.p0, q.scale);
+          }
+      }
+    }
   }
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
@@ -164,7 +181,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     launched = true;                                                             \
   }
 #define EARHIP_MFMA_CASE(NCT_, NRT_)                                            \
-  if (ml.mfma && !ml.split && cp.nct == NCT_ && ml.nrt == NRT_) {                             \
+  if (slots && cp.nct == NCT_ && ml.nrt == NRT_) {                                          \
     launch_mfma_t<NCT_, NRT_>(P, grid, block, lds, ctx->stream);                 \
     launched = true;                                                             \
   }

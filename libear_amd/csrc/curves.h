@@ -336,7 +336,10 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   if (L.pieces) {
     const char *pt = getenv("EARHIP_P2_TILE");
     const int ptile = pt ? atoi(pt) : 0;
-    L.pw = ptile == 256 ? 4 : ptile == 128 ? 2 : (point_density * 256.0 <= 0.3 ? 4 : 2);
+    // (the 2-wave variant converts 16 pieces per wave and chunk and does not fit the register file: 4 waves
+    // on 256 samples unless asked for)
+    L.pw = ptile == 128 ? 2 : 4;
+    (void)point_density;
   }
   L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
   // the slot lists of the f32 MFMA kernel address objects with 16 bits

@@ -44,48 +44,46 @@ struct Piece {
 static_assert(sizeof(Piece) == 16, "Piece is loaded as one dwordx4");
 
 constexpr int kPieceLists = 4;            // 2 * ramp + ranged
-constexpr int kPieceRanged = 3;           // capacity of the ranged lists: pieces per object and tile on average
-constexpr int kPieceMaxPerObject = 64;    // ranged pieces of ONE object in one tile; beyond: exact path
+constexpr int kPieceCapPerObject = 8;     // capacity of a tile's lists: pieces per object on average (+ padding)
+constexpr int kPieceMaxPerObject = 32;    // ranged pieces of ONE object in one tile; beyond: exact path
 constexpr float kPieceMaxP0 = 7.0f;       // see above
 constexpr int kPieceMaxTile = 256;        // r0, r1 - 1 are 8-bit fields
 constexpr int kMaxPieceObjects = 1 << 16;
 
 struct PieceLists {
-  Piece *pieces;  // [ntiles][cap()]: the four lists at list_off(0..3)
-  int *count;     // [ntiles][8]: entries of list 0..3 (padded to a multiple of 32 with null pieces), [4] exact-path objects
+  Piece *pieces;  // [ntiles][cap()]: the four lists back to back, each padded to a multiple of 32 with null pieces
+  int *count;     // [ntiles][8]: CHUNKS (32 pieces) of list 0..3, [4] exact-path objects
   int *ovf;       // [ntiles][M]: objects that take the exact per-object path
+  int *cw;        // [ntiles][M]: scratch of k_piece_list (piece counts per object)
   int M;
-  __host__ __device__ int cap_plain() const { return (M + 31) & ~31; }
-  __host__ __device__ int cap_ranged() const { return (kPieceRanged * M + 31) & ~31; }
-  __host__ __device__ int list_off(int l) const {
-    return (l & 1 ? cap_plain() : 0) + (l & 2 ? cap_plain() + cap_ranged() : 0);
-  }
-  __host__ __device__ int list_cap(int l) const { return l & 1 ? cap_ranged() : cap_plain(); }
-  __host__ __device__ int cap() const { return 2 * (cap_plain() + cap_ranged()); }
+  __host__ __device__ int cap() const { return kPieceCapPerObject * M + 4 * 32; }
 };
 // 16-byte units of a buffer holding the descriptors (SegDesc[ntiles][M]) and, behind them, the piece lists
 __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
   PieceLists pl;
   pl.M = (int)M;
-  return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
+  return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 8 * M * ntiles + 15) / 16 + 1;
 }
 
-// K0p: one workgroup per tile, threads over objects, behind k_seg_prep: turns the tile's descriptors
-// (coalesced reads, no searching) into its piece lists.  Offsets come from ordered scans over the
-// objects, so the lists are deterministic.
+// K0p: one workgroup per tile, behind k_seg_prep: turns the tile's descriptors (coalesced reads, no
+// searching) into its piece lists, threads over objects.  A first pass counts the pieces of every
+// object and list, which fixes where each list starts (they lie back to back, each padded to whole
+// chunks); a second pass writes them at offsets from ordered scans over the objects: the lists are in
+// object order, deterministic.
 static __global__ void __launch_bounds__(256)
 k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end, const SegDesc *desc,
              PieceLists pl) {
   __shared__ unsigned wsum[3][4];
-  __shared__ int base[kPieceLists], base_o;
+  __shared__ int tot[kPieceLists], lbase[kPieceLists], run[kPieceLists], run_o, all_exact;
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t t0 = t_call + (int64_t)tile * tile_samples;
   int64_t t_end = t0 + tile_samples;
   if (t_end > t_call_end) t_end = t_call_end;
   Piece *lists = pl.pieces + (size_t)tile * pl.cap();
   int *ovf = pl.ovf + (size_t)tile * M;
-  if (tid < kPieceLists) base[tid] = 0;
-  if (tid == 0) base_o = 0;
+  const SegDesc *dtile = desc + (size_t)tile * M;
+  if (tid < kPieceLists) tot[tid] = 0, run[tid] = 0;
+  if (tid == 0) run_o = 0;
   __syncthreads();
   Piece null_piece;
   null_piece.mr = 1u << 16;  // object 0, empty range [1, 1)
@@ -93,18 +91,17 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
   null_piece.p0 = 0.0f;
   null_piece.scale = 0.0f;
 
-  // the pieces of object m inside the tile, first one described by d (k_seg_prep), the others found by
+  // the pieces of object m inside the tile, first one described by dk (k_seg_prep), the others found by
   // walking on (GainInterpolator::process, gain_interpolator.hpp:58-86).  out == nullptr: count only.
-  // nx[0..1]: descriptors of the 2nd and 3rd segment, kept in registers between the counting and the
-  // writing pass.  Returns false when the object needs the exact path (a piece too steep to extend back
-  // to the tile start, or too many pieces).
-  auto walk = [&](int m, SegDesc dk, Piece *const *out, int (&cnt)[kPieceLists], SegDesc (&nx)[2], bool fill) {
+  // Returns false when the object needs the exact path (a piece too steep to extend back to the tile
+  // start, or too many pieces).
+  auto walk = [&](int m, SegDesc dk, Piece *const *out, int (&cnt)[kPieceLists]) {
     int pbase = 0, n = 0;
     if (dk.info & kSegMulti) {
       pbase = ps.off[m];
       n = ps.off[m + 1] - pbase;
     }
-    int k = seg_k(dk.info), cur = 0, step = 0;
+    int k = seg_k(dk.info), cur = 0;
     bool ok = true;
 #pragma unroll
     for (int l = 0; l < kPieceLists; l++) cnt[l] = 0;
@@ -125,22 +122,16 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
         cur = r1;
       }
       if (!(dk.info & kSegMulti)) break;
-      k++;
-      if (step < 2 && !fill) {
-        dk = nx[step];
-      } else {
-        dk = describe_segment(ps, pbase, n, k, t0, t_end);
-        if (step < 2) nx[step] = dk;
-      }
-      step++;
       if (cnt[1] + cnt[3] > kPieceMaxPerObject) {
         ok = false;
         break;
       }
+      k++;
+      dk = describe_segment(ps, pbase, n, k, t0, t_end);
     }
     return ok;
   };
-  // inclusive scan over the 256 threads of up to three packed counters; totals through `total`
+  // inclusive scan over the 256 threads of three packed counters; totals through `total`
   auto block_scan = [&](unsigned (&v)[3], unsigned (&total)[3]) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -154,84 +145,120 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      unsigned pre = 0, tot = 0;
+      unsigned pre = 0, t = 0;
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         const unsigned x = wsum[j][w];
         if (w < wv) pre += x;
-        tot += x;
+        t += x;
       }
-      total[j] = tot;
+      total[j] = t;
       v[j] += pre;
     }
     __syncthreads();
   };
+  // ---- pass 1: the piece counts of every object (kept for pass 2 in the tile's count words) and of every list
+  int *cw = pl.cw + (size_t)tile * M;
+  {
+    int mine[kPieceLists] = {0, 0, 0, 0};
+    for (int mb = 0; mb < M; mb += 256) {
+      const int m = mb + tid;
+      if (m < M) {
+        int cnt[kPieceLists];
+        const bool exact = !walk(m, dtile[m], nullptr, cnt);
+        // plain counts <= 1, ranged ones <= kPieceMaxPerObject + 1
+        cw[m] = exact ? -1 : (cnt[0] | (cnt[2] << 1) | (cnt[1] << 2) | (cnt[3] << 12));
+        if (!exact)
+#pragma unroll
+          for (int l = 0; l < kPieceLists; l++) mine[l] += cnt[l];
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < kPieceLists; l++) {
+      int v = mine[l];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0 && v) atomicAdd(&tot[l], v);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int at = 0;
+    for (int l = 0; l < kPieceLists; l++) {
+      lbase[l] = at;
+      at += (tot[l] + 31) & ~31;
+    }
+    // a tile with more pieces than its lists hold (more than kPieceCapPerObject per object on average):
+    // only the whole-tile pieces are listed, every object with a curve point inside takes the exact path
+    all_exact = at > pl.cap() ? 1 : 0;
+    if (all_exact) {
+      lbase[0] = 0;
+      lbase[1] = lbase[2] = (tot[0] + 31) & ~31;
+      lbase[3] = lbase[2] + ((tot[2] + 31) & ~31);
+      tot[1] = tot[3] = 0;
+    }
+  }
+  __syncthreads();
+  const bool tile_over = all_exact != 0;
+
+  // ---- pass 2: offsets from ordered scans of the counts, then the segment walk again, writing
   for (int mb = 0; mb < M; mb += 256) {
     const int m = mb + tid;
-    SegDesc d, nx[2];
-    d.info = 0;
     int cnt[kPieceLists] = {0, 0, 0, 0};
     bool exact = false;
+    SegDesc d;
+    d.info = 0;
     if (m < M) {
-      d = desc[(size_t)tile * M + m];
-      exact = !walk(m, d, nullptr, cnt, nx, true);
-      // the ranged lists are bounded: an object whose pieces do not fit takes the exact path (its
-      // slots stay reserved and are filled with null pieces: no gaps, offsets of the others unchanged)
+      const int w = cw[m];
+      d = dtile[m];
+      exact = w < 0;
+      if (!exact) {
+        cnt[0] = w & 1;
+        cnt[2] = (w >> 1) & 1;
+        cnt[1] = (w >> 2) & 1023;
+        cnt[3] = (w >> 12) & 1023;
+        if (tile_over && cnt[1] + cnt[3] > 0) {
+          exact = true;
+          cnt[1] = cnt[3] = 0;
+        }
+      }
     }
-    if (exact) cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
-    // plain counts <= 1 per object, ranged ones <= 65: (10 + 10 bits) and (16 + 16 bits) per 256 objects
-    unsigned v[3] = {(unsigned)cnt[0] | ((unsigned)cnt[2] << 10), (unsigned)cnt[1] | ((unsigned)cnt[3] << 16), 0u};
+    unsigned v[3] = {(unsigned)cnt[0] | ((unsigned)cnt[2] << 16), (unsigned)cnt[1] | ((unsigned)cnt[3] << 16), exact ? 1u : 0u};
+    const unsigned own[3] = {v[0], v[1], v[2]};
     unsigned last[3];
-    {
-      // first scan: list offsets
-      unsigned t[3] = {v[0], v[1], 0u};
-      block_scan(t, last);
-      v[0] = t[0];
-      v[1] = t[1];
-    }
-    int off[kPieceLists];
-    off[0] = base[0] + (int)(v[0] & 1023u) - cnt[0];
-    off[2] = base[2] + (int)(v[0] >> 10) - cnt[2];
-    off[1] = base[1] + (int)(v[1] & 0xffffu) - cnt[1];
-    off[3] = base[3] + (int)(v[1] >> 16) - cnt[3];
-    const bool spill = !exact && (off[1] + cnt[1] > pl.cap_ranged() || off[3] + cnt[3] > pl.cap_ranged());
-    unsigned ov[3] = {(exact || spill) ? 1u : 0u, 0u, 0u}, olast[3];
-    block_scan(ov, olast);
+    block_scan(v, last);
     if (m < M) {
-      Piece *out[kPieceLists];
-#pragma unroll
-      for (int l = 0; l < kPieceLists; l++) out[l] = lists + pl.list_off(l) + off[l];
-      if (exact || spill) {
-        ovf[base_o + (int)ov[0] - 1] = m;
-        if (spill)  // its reserved slots, as far as they lie inside the lists
-#pragma unroll
-          for (int l = 0; l < kPieceLists; l++)
-            for (int i = 0; i < cnt[l]; i++)
-              if (off[l] + i < pl.list_cap(l)) out[l][i] = null_piece;
-      } else if (cnt[0] + cnt[1] + cnt[2] + cnt[3] > 0) {
+      if (exact) {
+        ovf[run_o + (int)(v[2] - own[2])] = m;
+      } else {
+        Piece *out[kPieceLists];
+        out[0] = lists + lbase[0] + run[0] + (int)((v[0] - own[0]) & 0xffffu);
+        out[2] = lists + lbase[2] + run[2] + (int)((v[0] - own[0]) >> 16);
+        out[1] = lists + lbase[1] + run[1] + (int)((v[1] - own[1]) & 0xffffu);
+        out[3] = lists + lbase[3] + run[3] + (int)((v[1] - own[1]) >> 16);
         int c2[kPieceLists];
-        walk(m, d, out, c2, nx, false);
+        walk(m, d, out, c2);
       }
     }
     __syncthreads();
     if (tid == 0) {
-      base[0] += (int)(last[0] & 1023u);
-      base[2] += (int)(last[0] >> 10);
-      base[1] += (int)(last[1] & 0xffffu);
-      base[3] += (int)(last[1] >> 16);
-      base_o += (int)olast[0];
+      run[0] += (int)(last[0] & 0xffffu);
+      run[2] += (int)(last[0] >> 16);
+      run[1] += (int)(last[1] & 0xffffu);
+      run[3] += (int)(last[1] >> 16);
+      run_o += (int)last[2];
     }
     __syncthreads();
   }
-  // pad every list to a multiple of 32 with null pieces; publish the counts
+  // pad every list to whole chunks with null pieces; publish the chunk counts
 #pragma unroll
   for (int l = 0; l < kPieceLists; l++) {
-    const int n = min(base[l], pl.list_cap(l));
+    const int n = tot[l];
     const int padded = (n + 31) & ~31;
-    if (n + tid < padded) lists[pl.list_off(l) + n + tid] = null_piece;
-    if (tid == 0) pl.count[tile * 8 + l] = padded;
+    if (n + tid < padded) lists[lbase[l] + n + tid] = null_piece;
+    if (tid == 0) pl.count[tile * 8 + l] = padded >> 5;
   }
-  if (tid == 0) pl.count[tile * 8 + 4] = base_o;
+  if (tid == 0) pl.count[tile * 8 + 4] = run_o;
 }
 
 // K1p.  grid = (workgroup tiles, grid-level splits of the chunk schedule, column super-groups),
@@ -357,21 +384,12 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   if (P.vec_ok) {
     // ---- the chunk schedule of this workgroup: the four lists back to back, 32 pieces per chunk
     const Piece *lbase = pl.pieces + (size_t)wgtile * pl.cap();
-    const int n0 = cnt[0] >> 5, n1 = cnt[1] >> 5, n2 = cnt[2] >> 5, n3 = cnt[3] >> 5;
+    const int n0 = cnt[0], n1 = cnt[1], n2 = cnt[2], n3 = cnt[3];
     const int total = n0 + n1 + n2 + n3;
     const int c_lo = (int)(((int64_t)total * part) / nparts), c_hi = (int)(((int64_t)total * (part + 1)) / nparts);
     const int first_ramp = n0 + n1;
     // first piece of chunk c (clamped: requests past the schedule re-read its last chunk)
-    auto chunk_ptr = [&](int c) -> const Piece * {
-      int i = min(c, total - 1);
-      if (i < n0) return lbase + pl.list_off(0) + 32 * i;
-      i -= n0;
-      if (i < n1) return lbase + pl.list_off(1) + 32 * i;
-      i -= n1;
-      if (i < n2) return lbase + pl.list_off(2) + 32 * i;
-      i -= n2;
-      return lbase + pl.list_off(3) + 32 * i;
-    };
+    auto chunk_ptr = [&](int c) -> const Piece * { return lbase + 32 * min(c, total - 1); };
     auto is_ranged = [&](int c) { return (c >= n0 && c < first_ramp) || c >= first_ramp + n2; };
 
     if (c_hi > c_lo) {
@@ -395,15 +413,24 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       // the lane's piece words q0 .. q0 + N - 1 of chunk c (read where they are used: no registers held)
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
-      // inputs q0 .. q0 + n - 1 (n even) of chunk c
+      // inputs q0 .. q0 + n - 1 (n even) of chunk c.  A piece whose range misses this wave's 64 samples
+      // contributes nothing here (its input scale is 0 for every lane): its request goes to object 0's
+      // row instead — one line the L1 already holds, not another trip to L2 (a quarter of all input
+      // requests on metadata that ignores the block grid).
       auto load_x_part = [&](int c, f32x4 (&x)[8], int q0, int n) {
         const char *bp = reinterpret_cast<const char *>(P.in) + xlane;
+        const bool ranged = is_ranged(c);  // (wave-uniform)
 #pragma unroll
         for (int q = 0; q < 8; q += 2)
           if (q >= q0 && q < q0 + n) {
             const u32x2 mw = lane_word2(c, q);
-            x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)(mw[0] & 0xffffu) * rstride));
-            x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)(mw[1] & 0xffffu) * rstride));
+            uint32_t o0 = mw[0] & 0xffffu, o1 = mw[1] & 0xffffu;
+            if (ranged) {
+              o0 = (((mw[0] >> 16) & 0xffu) < (unsigned)(wave_s0 + TS) && (mw[0] >> 24) >= (unsigned)wave_s0) ? o0 : 0u;
+              o1 = (((mw[1] >> 16) & 0xffu) < (unsigned)(wave_s0 + TS) && (mw[1] >> 24) >= (unsigned)wave_s0) ? o1 : 0u;
+            }
+            x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)o0 * rstride));
+            x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)o1 * rstride));
           }
       };
       // What this WAVE converts for chunk c: pieces NQ w + q.  Wave-uniform: scalar loads (requested one

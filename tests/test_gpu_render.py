@@ -629,6 +629,8 @@ def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, call
     from libear_amd import capi
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
+    if block < 512:
+        dec = dec[:, :block].copy()  # fused render supports FIRs up to one block
     total = block * nblocks
     if kind == "adm":
         curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
