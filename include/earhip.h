@@ -215,6 +215,35 @@ int earhip_layout_channel(const char *layout, int index, const char **name, doub
 int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, float *out);
 
 /* ------------------------------------------------------------------------
+ * (I) Gain-vector producer for Objects content — replaces ear::GainCalculatorObjects
+ * (include/ear/gain_calculators.hpp:45-56, src/object_based/gain_calculator_objects.cpp:24-57)
+ * for point sources: the polar point-source panner (src/common/point_source_panner.cpp:
+ * triplets, quads, virtual n-gons, extra height loudspeakers and their downmix, the 0+2+0
+ * stereo downmix), zero gains on the LFE channels, gain, and the sqrt(1 - diffuse) /
+ * sqrt(diffuse) split into the direct and diffuse vectors that feed (F).  A BATCH of
+ * positions per call (one device thread each, double precision): what a renderer needs
+ * per (object, metadata block).  Not implemented, as in libear's own calculate() or beyond
+ * it: Cartesian positions, divergence, channel lock, zone exclusion, screen scaling,
+ * extent (width / height / depth != 0).
+ * layout: an ITU-R BS.2051 name (group H).  Positions are polar: azimuth, elevation in
+ * degrees (ADM convention), distance; distance / gain / diffuse may be NULL (1, 1, 0).
+ * direct, diffuse_out: [npos][n_channels] float, LFE columns zero.
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_panner earhip_panner;
+int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **out);
+int earhip_panner_destroy(earhip_panner *p);
+int earhip_panner_num_channels(const earhip_panner *p, int *n_channels);
+/* host pointers: H2D, kernel, D2H, synchronise */
+int earhip_panner_calculate(earhip_panner *p, size_t npos, const double *azimuth,
+                            const double *elevation, const double *distance, const double *gain,
+                            const double *diffuse, float *direct, float *diffuse_out);
+/* device pointers: enqueues on the context's stream, does not synchronise */
+int earhip_panner_calculate_device(earhip_panner *p, size_t npos, const double *azimuth,
+                                   const double *elevation, const double *distance,
+                                   const double *gain, const double *diffuse, float *direct,
+                                   float *diffuse_out);
+
+/* ------------------------------------------------------------------------
  * (F) Composed Objects render block — the chain libear documents but does not
  * implement (docs/dsp.rst:40-71, include/ear/gain_calculators.hpp:45-56):
  *   per object: interpolated direct and diffuse gain vectors (a

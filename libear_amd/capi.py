@@ -336,6 +336,38 @@ def compensation_delay():
     return load().earhip_decorrelator_compensation_delay()
 
 
+class Panner:
+    """(I) gain-vector producer for Objects content (point-source pan, LFE mask, diffuse split), batched."""
+
+    def __init__(self, ctx, layout):
+        self.h = C.c_void_p()
+        check(load().earhip_panner_create(ctx.h, layout.encode(), C.byref(self.h)))
+        n = C.c_int(0)
+        check(load().earhip_panner_num_channels(self.h, C.byref(n)))
+        self.n_out = n.value
+
+    def calculate(self, az, el, dist=None, gain=None, diffuse=None):
+        """arrays [n] (degrees) -> (direct, diffuse) float32 [n][n_out]"""
+        f64 = C.POINTER(C.c_double)
+        az = np.ascontiguousarray(np.atleast_1d(az), np.float64)
+        n = az.size
+
+        def arr(v):
+            return None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (n,)))
+        el, dist, gain, diffuse = arr(el), arr(dist), arr(gain), arr(diffuse)
+        d = np.empty((n, self.n_out), np.float32)
+        f = np.empty((n, self.n_out), np.float32)
+        check(load().earhip_panner_calculate(
+            self.h, C.c_size_t(n), _ptr(az, f64), _ptr(el, f64), None if dist is None else _ptr(dist, f64),
+            None if gain is None else _ptr(gain, f64), None if diffuse is None else _ptr(diffuse, f64), _ptr(d), _ptr(f)))
+        return d, f
+
+    def close(self):
+        if self.h:
+            load().earhip_panner_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Renderer:
     """(F) composed Objects render block."""
 

@@ -1,0 +1,512 @@
+// api_panner.hip — (I) the gain-vector producer for Objects content of include/earhip.h: libear's
+// GainCalculatorObjects (src/object_based/gain_calculator_objects.cpp:24-57) for point sources — the polar
+// point-source panner of src/common/point_source_panner.cpp (triplets, quads, virtual n-gons, the extra
+// height loudspeakers and their downmix, the 0+2+0 stereo downmix), the LFE mask and the
+// sqrt(1 - diffuse) / sqrt(diffuse) split — as a BATCH kernel: one thread per (object, metadata block).
+//
+// At 10^4 x real time a scene of 1024 objects with an ADM block every 20 ms needs 5 * 10^8 gain vectors
+// per wall-clock second; the reference computes them one at a time on the host (virtual dispatch over
+// region objects, Eigen temporaries).  Here the layout's regions are flattened once, on the host and in
+// double precision, into a table of plain records (set-up: cold), and the per-position work — a walk over
+// at most ~45 regions with 3x3 products, one or two square roots — runs on the device in double
+// precision.  The arithmetic of a region test follows the reference's operation for operation
+// (point_source_panner.cpp:43-51, :86-101, :118-136, :157-190), so results agree to the last bits of a
+// double and are identical after the cast to float in all but rounding-boundary cases.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "layout_table.h"
+
+namespace earhip {
+
+constexpr int kMaxNgon = 16;   // real loudspeakers around one virtual loudspeaker
+constexpr int kMaxPanOut = 32; // loudspeakers of a layout (without LFE)
+
+struct PanRegion {
+  int kind;                // 0 triplet, 1 quad, 2 virtual n-gon
+  int n;                   // vertices
+  int out[kMaxNgon];       // REAL channel (without LFE) each vertex's gain is mixed into (extra height
+                           // loudspeakers are mixed into the loudspeaker below / above them)
+  // triplet: basis[0]; n-gon: basis[i] of the triplet (tri[i][0], tri[i][1], virtual centre)
+  double basis[kMaxNgon][9];
+  int tri[kMaxNgon][2];
+  double centre_downmix[kMaxNgon];
+  // quad
+  int order[4];
+  double poly_x[9], poly_y[9], pos[4][3];
+};
+
+struct PanTable {
+  int n_regions;
+  int n_real;  // loudspeakers without LFE
+  const PanRegion *regions;
+};
+
+struct Vec3 {
+  double x, y, z;
+};
+__host__ __device__ inline Vec3 vsub(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__host__ __device__ inline Vec3 vadd(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__host__ __device__ inline double vdot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ inline Vec3 vcross(Vec3 a, Vec3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// libear's polar convention (src/common/geom.cpp:82-87): azimuth anticlockwise from the front, degrees
+__host__ __device__ inline Vec3 polar_to_cart(double az, double el, double dist) {
+  const double pi = 3.14159265358979323846264338327950288;
+  const double a = -az * pi / 180.0, e = el * pi / 180.0;
+  return {sin(a) * cos(e) * dist, cos(a) * cos(e) * dist, sin(e) * dist};
+}
+
+// position^T * basis of a triplet; true when inside (all coordinates >= -1e-11), pv normalised and
+// clamped to [0, 1] (point_source_panner.cpp:43-51)
+__device__ inline bool triplet_gains(const double *b, Vec3 p, double (&pv)[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) pv[j] = p.x * b[j] + p.y * b[3 + j] + p.z * b[6 + j];
+  const double eps = -1e-11;
+  if (!(pv[0] >= eps && pv[1] >= eps && pv[2] >= eps)) return false;
+  const double n = sqrt(pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2]);
+#pragma unroll
+  for (int j = 0; j < 3; j++) pv[j] = fmin(fmax(pv[j] / n, 0.0), 1.0);
+  return true;
+}
+
+// first real root in (-1e-10, 1 + 1e-10) of poly . position, clamped (point_source_panner.cpp:157-190)
+__device__ inline bool quad_pan(const double *poly, Vec3 p, double &out) {
+  const double a = poly[0] * p.x + poly[1] * p.y + poly[2] * p.z;
+  const double b = poly[3] * p.x + poly[4] * p.y + poly[5] * p.z;
+  const double c = poly[6] * p.x + poly[7] * p.y + poly[8] * p.z;
+  const double eps = 1e-10;
+  double roots[2];
+  int nr = 0;
+  if (fabs(c) < eps) {
+    roots[nr++] = 0.0;
+  } else if (fabs(a) < eps) {
+    roots[nr++] = -c / b;
+  } else {
+    const double det = b * b - 4.0 * a * c;
+    if (det > eps) {
+      roots[nr++] = (-b + sqrt(det)) / (2.0 * a);
+      roots[nr++] = (-b - sqrt(det)) / (2.0 * a);
+    } else if (det > -eps) {
+      roots[nr++] = -b / (2.0 * a);
+    }
+  }
+  for (int i = 0; i < nr; i++)
+    if (-eps < roots[i] && roots[i] < 1.0 + eps) {
+      out = fmin(fmax(roots[i], 0.0), 1.0);
+      return true;
+    }
+  return false;
+}
+
+// Gains of the real loudspeakers (without LFE) for one direction: the first region that takes the
+// position (PolarPointSourcePanner::handle, :208-217), the extra loudspeakers mixed down and the result
+// power-normalised (PointSourcePannerDownmix::handle, :239-250).  false: no region took it.
+__device__ inline bool pan_full(const PanTable &T, Vec3 p, double (&real)[kMaxPanOut]) {
+  for (int c = 0; c < T.n_real; c++) real[c] = 0.0;
+  bool found = false;
+  for (int ri = 0; ri < T.n_regions && !found; ri++) {
+    const PanRegion &R = T.regions[ri];
+    if (R.kind == 0) {
+      double pv[3];
+      if (triplet_gains(R.basis[0], p, pv)) {
+        found = true;
+        for (int k = 0; k < 3; k++) real[R.out[k]] += pv[k];
+      }
+    } else if (R.kind == 1) {
+      double x, y;
+      if (quad_pan(R.poly_x, p, x) && quad_pan(R.poly_y, p, y)) {
+        double pvs[4];
+        pvs[R.order[0]] = (1 - x) * (1 - y);
+        pvs[R.order[1]] = x * (1 - y);
+        pvs[R.order[2]] = x * y;
+        pvs[R.order[3]] = (1 - x) * y;
+        Vec3 vel = {0.0, 0.0, 0.0};
+        for (int k = 0; k < 4; k++) {
+          vel.x += pvs[k] * R.pos[k][0];
+          vel.y += pvs[k] * R.pos[k][1];
+          vel.z += pvs[k] * R.pos[k][2];
+        }
+        if (vdot(vel, p) > 0) {
+          found = true;
+          const double n = sqrt(pvs[0] * pvs[0] + pvs[1] * pvs[1] + pvs[2] * pvs[2] + pvs[3] * pvs[3]);
+          for (int k = 0; k < 4; k++) real[R.out[k]] += pvs[k] / n;
+        }
+      }
+    } else {
+      for (int t = 0; t < R.n && !found; t++) {
+        double pv[3];
+        if (triplet_gains(R.basis[t], p, pv)) {
+          found = true;
+          // the virtual centre's gain is distributed to the real loudspeakers, then the n-gon's
+          // gains are normalised (:86-101)
+          double g[kMaxNgon];
+          double n2 = 0.0;
+          for (int k = 0; k < R.n; k++) {
+            double v = 0.0;
+            if (k == R.tri[t][0]) v = pv[0];
+            if (k == R.tri[t][1]) v = pv[1];
+            g[k] = v + R.centre_downmix[k] * pv[2];
+            n2 += g[k] * g[k];
+          }
+          const double n = sqrt(n2);
+          for (int k = 0; k < R.n; k++) real[R.out[k]] += g[k] / n;
+        }
+      }
+    }
+  }
+  if (!found) return false;
+  double n2 = 0.0;
+  for (int c = 0; c < T.n_real; c++) n2 += real[c] * real[c];
+  const double n = sqrt(n2);
+  for (int c = 0; c < T.n_real; c++) real[c] /= n;
+  return true;
+}
+
+struct PanParams {
+  PanTable table;      // the layout's regions; stereo: those of 0+5+0
+  int stereo;          // 0+2+0: pan with 0+5+0, downmix (point_source_panner.cpp:374-398)
+  int n_full;          // loudspeakers of the layout incl. LFE
+  int full_index[kMaxPanOut];  // real loudspeaker (without LFE) -> index in the full layout
+  int stereo_index[2];         // 0+2+0: M+030, M-030
+};
+
+// one thread per position: direct / diffuse [npos][n_full] float; *missed counts positions no region took
+static __global__ void __launch_bounds__(128)
+k_pan_objects(PanParams P, size_t npos, const double *az, const double *el, const double *dist, const double *gain,
+              const double *diffuse, float *direct, float *diff, unsigned *missed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npos) return;
+  const Vec3 p = polar_to_cart(az[i], el[i], dist ? dist[i] : 1.0);
+  double real[kMaxPanOut];
+  double pv[kMaxPanOut];
+  int n_pv;
+  const bool ok = pan_full(P.table, p, real);
+  float *d = direct + i * P.n_full, *f = diff + i * P.n_full;
+  for (int c = 0; c < P.n_full; c++) d[c] = f[c] = 0.0f;
+  if (!ok) {
+    atomicAdd(missed, 1u);
+    return;
+  }
+  if (P.stereo) {
+    const double s3 = sqrt(3.0) / 3.0, s5 = sqrt(0.5);
+    double l = real[0] + s3 * real[2] + s5 * real[3];
+    double r = real[1] + s3 * real[2] + s5 * real[4];
+    const double n = sqrt(l * l + r * r);
+    const double front = fmax(real[0], fmax(real[1], real[2])), back = fmax(real[3], real[4]);
+    const double lev = pow(0.5, 0.5 * back / (front + back));  // 0 dB at the front to -3 dB at the back
+    pv[0] = l / n * lev;
+    pv[1] = r / n * lev;
+    n_pv = 2;
+  } else {
+    n_pv = P.table.n_real;
+    for (int c = 0; c < n_pv; c++) pv[c] = real[c];
+  }
+  const double g = gain ? gain[i] : 1.0, df = diffuse ? diffuse[i] : 0.0;
+  const double sd = sqrt(1.0 - df), sf = sqrt(df);
+  for (int c = 0; c < n_pv; c++) {
+    // PolarExtent at zero extent: sqrt(pv^2) (src/object_based/polar_extent.cpp:247-277); gain; split (:47-56)
+    const double v = sqrt(pv[c] * pv[c]) * g;
+    const int o = P.stereo ? P.stereo_index[c] : P.full_index[c];
+    d[o] = (float)(v * sd);
+    f[o] = (float)(v * sf);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Set-up (host, double): flatten the regions of a layout
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct SetupChannel {
+  std::string name;
+  double az, el;
+};
+
+void invert3(const Vec3 (&rows)[3], double (&inv)[9]) {
+  const double m[3][3] = {{rows[0].x, rows[0].y, rows[0].z}, {rows[1].x, rows[1].y, rows[1].z}, {rows[2].x, rows[2].y, rows[2].z}};
+  double cof[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      cof[i][j] = m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+    }
+  const double inv_det = 1.0 / (m[0][0] * cof[0][0] + m[0][1] * cof[0][1] + m[0][2] * cof[0][2]);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) inv[i * 3 + j] = cof[j][i] * inv_det;  // adjugate / determinant
+}
+
+// order of the vertices around their centre (src/common/geom.cpp:37-70)
+std::vector<int> vertex_order(const std::vector<Vec3> &v) {
+  Vec3 c = {0, 0, 0};
+  for (auto &p : v) c = vadd(c, p);
+  c = {c.x / v.size(), c.y / v.size(), c.z / v.size()};
+  const Vec3 a = vsub(v[0], c);
+  Vec3 b = {0, 0, 0};
+  double best = 1e300;
+  for (size_t i = 1; i < v.size(); i++) {
+    const Vec3 r = vsub(v[i], c);
+    const double col = std::fabs(vdot(r, a));
+    if (col < best) best = col, b = r;
+  }
+  std::vector<double> ang(v.size());
+  for (size_t i = 0; i < v.size(); i++) {
+    const Vec3 r = vsub(v[i], c);
+    ang[i] = std::atan2(vdot(r, a), vdot(r, b));
+  }
+  std::vector<int> idx(v.size());
+  for (size_t i = 0; i < v.size(); i++) idx[i] = (int)i;
+  std::sort(idx.begin(), idx.end(), [&](int x, int y) { return ang[x] < ang[y]; });
+  return idx;
+}
+
+void poly_basis(const Vec3 (&q)[4], double (&rows)[9]) {  // point_source_panner.cpp:138-155
+  const Vec3 a = q[0], b = q[1], c = q[2], d = q[3];
+  const Vec3 r0 = vcross(vsub(b, a), vsub(c, d));
+  const Vec3 r1 = vadd(vcross(a, vsub(c, d)), vcross(vsub(b, a), d));
+  const Vec3 r2 = vcross(a, d);
+  const Vec3 r[3] = {r0, r1, r2};
+  for (int i = 0; i < 3; i++) rows[3 * i] = r[i].x, rows[3 * i + 1] = r[i].y, rows[3 * i + 2] = r[i].z;
+}
+
+const LayoutEntry &layout_entry(const char *name) {
+  require(name != nullptr, "layout name must not be NULL");
+  for (int i = 0; i < kNumLayouts; i++)
+    if (std::strcmp(kLayouts[i].name, name) == 0) return kLayouts[i];
+  fail_invalid(std::string("unknown layout ") + name);
+}
+
+// the regions of a layout with precomputed hull facets (configureFullPolarPanner, :478-561)
+std::vector<PanRegion> build_regions(const LayoutEntry &L, int &n_real) {
+  require(L.facets != nullptr, "layout has no facet table");
+  std::vector<SetupChannel> real;
+  for (int c = 0; c < L.n; c++)
+    if (!L.channels[c].is_lfe) real.push_back({L.channels[c].name, L.channels[c].azimuth, L.channels[c].elevation});
+  n_real = (int)real.size();
+  require(n_real <= kMaxPanOut, "too many loudspeakers");
+  // extra loudspeakers above / below the mid-layer ones where a layer has none in that direction,
+  // each mixed into its mid-layer loudspeaker (extraPosVerticalNominal, :256-349)
+  std::vector<Vec3> verts;
+  std::vector<int> mix_to;  // augmented vertex -> real loudspeaker
+  for (int c = 0; c < n_real; c++) verts.push_back(polar_to_cart(real[c].az, real[c].el, 1.0)), mix_to.push_back(c);
+  const double layers[2][3] = {{-30.0, -70.0, -10.0}, {30.0, 10.0, 70.0}};
+  for (auto &layer : layers) {
+    double az_range = -1.0, el_sum = 0.0;
+    int in_layer = 0;
+    for (auto &ch : real)
+      if (layer[1] <= ch.el && ch.el <= layer[2]) az_range = std::max(az_range, std::fabs(ch.az)), el_sum += ch.el, in_layer++;
+    const double az_limit = in_layer ? az_range + 40.0 : 0.0;
+    const double layer_el = in_layer ? el_sum / in_layer : layer[0];
+    for (int c = 0; c < n_real; c++)
+      if (-10 <= real[c].el && real[c].el <= 10 && std::fabs(real[c].az) >= az_limit - 1e-5) {
+        verts.push_back(polar_to_cart(real[c].az, layer_el, 1.0));
+        mix_to.push_back(c);
+      }
+  }
+  // virtual loudspeakers below and (unless the layout has one overhead) above (:442-455)
+  std::vector<int> virt;
+  bool overhead = false;
+  for (auto &ch : real) overhead = overhead || ch.name == "T+000" || ch.name == "UH+180";
+  virt.push_back((int)verts.size());
+  verts.push_back({0.0, 0.0, -1.0});
+  if (!overhead) {
+    virt.push_back((int)verts.size());
+    verts.push_back({0.0, 0.0, 1.0});
+  }
+  auto is_virtual = [&](int v) { return std::find(virt.begin(), virt.end(), v) != virt.end(); };
+  std::vector<std::vector<int>> facets;
+  for (const int *f = L.facets; *f; f += 1 + *f) facets.emplace_back(f + 1, f + 1 + *f);
+  std::vector<PanRegion> regions;
+  // n-gons around the virtual loudspeakers first (:497-527)
+  for (int vv : virt) {
+    std::vector<int> ring;  // ascending, like the reference's std::set
+    for (auto &f : facets)
+      if (std::find(f.begin(), f.end(), vv) != f.end())
+        for (int v : f)
+          if (v != vv && std::find(ring.begin(), ring.end(), v) == ring.end()) ring.push_back(v);
+    std::sort(ring.begin(), ring.end());
+    require((int)ring.size() <= kMaxNgon && ring.size() >= 3, "unsupported n-gon size");
+    for (int v : ring) require(!is_virtual(v), "invalid triangulation");
+    PanRegion R;
+    std::memset(&R, 0, sizeof(R));
+    R.kind = 2;
+    R.n = (int)ring.size();
+    std::vector<Vec3> pos;
+    for (int k = 0; k < R.n; k++) {
+      R.out[k] = mix_to[ring[k]];
+      R.centre_downmix[k] = 1.0 / std::sqrt((double)R.n);
+      pos.push_back(verts[ring[k]]);
+    }
+    const std::vector<int> order = vertex_order(pos);
+    for (int t = 0; t < R.n; t++) {
+      const int a = order[t], b = order[(t + 1) % R.n];
+      R.tri[t][0] = a;
+      R.tri[t][1] = b;
+      const Vec3 rows[3] = {pos[a], pos[b], verts[vv]};
+      invert3(rows, R.basis[t]);
+    }
+    regions.push_back(R);
+  }
+  // every other facet: a triplet or a quad (:528-559)
+  for (auto &f : facets) {
+    bool touches = false;
+    for (int v : f) touches = touches || is_virtual(v);
+    if (touches) continue;
+    PanRegion R;
+    std::memset(&R, 0, sizeof(R));
+    R.n = (int)f.size();
+    for (int k = 0; k < R.n; k++) R.out[k] = mix_to[f[k]];
+    if (f.size() == 3) {
+      R.kind = 0;
+      const Vec3 rows[3] = {verts[f[0]], verts[f[1]], verts[f[2]]};
+      invert3(rows, R.basis[0]);
+    } else if (f.size() == 4) {
+      R.kind = 1;
+      std::vector<Vec3> pos;
+      for (int k = 0; k < 4; k++) {
+        pos.push_back(verts[f[k]]);
+        R.pos[k][0] = verts[f[k]].x, R.pos[k][1] = verts[f[k]].y, R.pos[k][2] = verts[f[k]].z;
+      }
+      const std::vector<int> order = vertex_order(pos);
+      Vec3 q[4], qs[4];
+      for (int k = 0; k < 4; k++) R.order[k] = order[k], q[k] = pos[order[k]];
+      for (int k = 0; k < 4; k++) qs[k] = q[(k + 1) % 4];
+      poly_basis(q, R.poly_x);
+      poly_basis(qs, R.poly_y);
+    } else {
+      fail_internal("facets with more than 4 vertices are not supported");
+    }
+    regions.push_back(R);
+  }
+  return regions;
+}
+
+}  // namespace
+}  // namespace earhip
+
+using namespace earhip;
+
+struct earhip_panner {
+  earhip_ctx *ctx;
+  PanParams P;
+  DevBuf<PanRegion> regions;
+  DevBuf<unsigned> missed;
+  // staging of the host-pointer entry point (grown at first use)
+  DevBuf<double> d_in;
+  DevBuf<float> d_out;
+  PinBuf<double> p_in;
+  PinBuf<float> p_out;
+  PinBuf<unsigned> p_missed;
+};
+
+extern "C" {
+
+int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **out) {
+  return guarded([&] {
+    require(ctx != nullptr && out != nullptr, "NULL argument");
+    const LayoutEntry &L = layout_entry(layout);
+    ctx->use();
+    std::unique_ptr<earhip_panner> p(new earhip_panner);
+    p->ctx = ctx;
+    std::memset(&p->P, 0, sizeof(p->P));
+    p->P.n_full = L.n;
+    int n_real = 0;
+    std::vector<PanRegion> regions;
+    if (std::strcmp(L.name, "0+2+0") == 0) {  // configureStereoPolarPanner (:406-429)
+      regions = build_regions(layout_entry("0+5+0"), n_real);
+      p->P.stereo = 1;
+      for (int c = 0; c < L.n; c++) {
+        if (std::strcmp(L.channels[c].name, "M+030") == 0) p->P.stereo_index[0] = c;
+        if (std::strcmp(L.channels[c].name, "M-030") == 0) p->P.stereo_index[1] = c;
+      }
+    } else {
+      regions = build_regions(L, n_real);
+      int k = 0;
+      for (int c = 0; c < L.n; c++)
+        if (!L.channels[c].is_lfe) p->P.full_index[k++] = c;
+    }
+    p->regions.alloc(regions.size());
+    EARHIP_HIP(hipMemcpy(p->regions.p, regions.data(), sizeof(PanRegion) * regions.size(), hipMemcpyHostToDevice));
+    p->P.table.n_regions = (int)regions.size();
+    p->P.table.n_real = n_real;
+    p->P.table.regions = p->regions.p;
+    p->missed.alloc_zero(1, ctx->stream);
+    p->p_missed.reserve(1);
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    *out = p.release();
+  });
+}
+
+int earhip_panner_destroy(earhip_panner *p) {
+  return guarded([&] {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    delete p;
+  });
+}
+
+int earhip_panner_num_channels(const earhip_panner *p, int *n_channels) {
+  return guarded([&] {
+    require(p != nullptr && n_channels != nullptr, "NULL argument");
+    *n_channels = p->P.n_full;
+  });
+}
+
+int earhip_panner_calculate_device(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
+                                   const double *distance, const double *gain, const double *diffuse, float *direct,
+                                   float *diffuse_out) {
+  return guarded([&] {
+    require(p != nullptr, "panner must not be NULL");
+    require(azimuth && elevation && direct && diffuse_out, "azimuth, elevation and the outputs must not be NULL");
+    if (npos == 0) return;
+    p->ctx->use();
+    hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, p->ctx->stream, p->P, npos,
+                       azimuth, elevation, distance, gain, diffuse, direct, diffuse_out, p->missed.p);
+    EARHIP_HIP(hipGetLastError());
+  });
+}
+
+int earhip_panner_calculate(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
+                            const double *distance, const double *gain, const double *diffuse, float *direct,
+                            float *diffuse_out) {
+  return guarded([&] {
+    require(p != nullptr, "panner must not be NULL");
+    require(azimuth && elevation && direct && diffuse_out, "azimuth, elevation and the outputs must not be NULL");
+    require(npos < ((size_t)1 << 28), "too many positions");
+    if (npos == 0) return;
+    earhip_ctx *ctx = p->ctx;
+    ctx->use();
+    const size_t N = (size_t)p->P.n_full;
+    p->p_in.reserve(5 * npos);
+    p->d_in.reserve(5 * npos);
+    p->p_out.reserve(2 * npos * N);
+    p->d_out.reserve(2 * npos * N);
+    const double *src[5] = {azimuth, elevation, distance, gain, diffuse};
+    for (int k = 0; k < 5; k++)
+      if (src[k]) std::memcpy(p->p_in.p + k * npos, src[k], sizeof(double) * npos);
+    EARHIP_HIP(hipMemcpyAsync(p->d_in.p, p->p_in.p, sizeof(double) * 5 * npos, hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemsetAsync(p->missed.p, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, ctx->stream, p->P, npos, p->d_in.p,
+                       p->d_in.p + npos, distance ? p->d_in.p + 2 * npos : nullptr, gain ? p->d_in.p + 3 * npos : nullptr,
+                       diffuse ? p->d_in.p + 4 * npos : nullptr, p->d_out.p, p->d_out.p + npos * N, p->missed.p);
+    EARHIP_HIP(hipGetLastError());
+    EARHIP_HIP(hipMemcpyAsync(p->p_out.p, p->d_out.p, sizeof(float) * 2 * npos * N, hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(p->p_missed.p, p->missed.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(direct, p->p_out.p, sizeof(float) * npos * N);
+    std::memcpy(diffuse_out, p->p_out.p + npos * N, sizeof(float) * npos * N);
+    // (the reference dereferences an empty optional when no region takes a position: undefined there,
+    // an error here)
+    if (*p->p_missed.p != 0) fail_internal("point source panner: a position was not handled by any region");
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// ear/gain_calculators.hpp — GainCalculatorObjects with libear's interface
+// (include/ear/gain_calculators.hpp:45-56) over the device batch panner (earhip group I), plus the batched
+// call a renderer wants: all metadata blocks of all objects in one launch.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "hip.hpp"
+#include "metadata.hpp"
+
+namespace ear {
+  class GainCalculatorObjects {
+   public:
+    /// layout: an ITU-R BS.2051 layout (getLayout), with or without its LFE channels
+    explicit GainCalculatorObjects(const Layout &layout, hip::Context &ctx = hip::default_context()) {
+      const Layout full = getLayout(layout.name());
+      // which channels of the full layout the caller's layout keeps (Layout::withoutLfe drops the LFEs)
+      for (auto &c : layout.channels()) {
+        const int i = full.indexForName(c.name());
+        if (i < 0) throw invalid_argument("channel " + c.name() + " is not part of layout " + layout.name());
+        const PolarPosition a = c.polarPosition(), b = full.channels()[i].polarPosition();
+        if (a.azimuth != b.azimuth || a.elevation != b.elevation)
+          throw not_implemented("loudspeaker positions other than the nominal ones");
+        keep_.push_back(i);
+      }
+      n_full_ = full.channels().size();
+      hip::check(earhip_panner_create(ctx.get(), layout.name().c_str(), &h_));
+    }
+    ~GainCalculatorObjects() { earhip_panner_destroy(h_); }
+    GainCalculatorObjects(const GainCalculatorObjects &) = delete;
+    GainCalculatorObjects &operator=(const GainCalculatorObjects &) = delete;
+
+    /// one metadata block -> direct and diffuse gain vectors (resized to the layout's channel count)
+    template <typename T>
+    void calculate(const ObjectsTypeMetadata &metadata, std::vector<T> &directGains, std::vector<T> &diffuseGains) {
+      std::vector<std::vector<T>> d, f;
+      calculate(std::vector<ObjectsTypeMetadata>(1, metadata), d, f);
+      directGains = d[0];
+      diffuseGains = f[0];
+    }
+    /// a batch of metadata blocks in one device launch
+    template <typename T>
+    void calculate(const std::vector<ObjectsTypeMetadata> &metadata, std::vector<std::vector<T>> &directGains,
+                   std::vector<std::vector<T>> &diffuseGains) {
+      const size_t n = metadata.size();
+      std::vector<double> az(n), el(n), dist(n), gain(n), diffuse(n);
+      for (size_t i = 0; i < n; i++) {
+        const ObjectsTypeMetadata &m = metadata[i];
+        // libear's own refusals (src/object_based/gain_calculator_objects.cpp:37-44) ...
+        if (m.cartesian || m.position.isCartesian) throw not_implemented("cartesian");
+        if (m.objectDivergence.divergence != 0.0) throw not_implemented("divergence");
+        if (m.channelLock.flag) throw not_implemented("channelLock");
+        if (m.zoneExclusion.zones.size()) throw not_implemented("zoneExclusion");
+        if (m.screenRef) throw not_implemented("screenRef");
+        // ... and one more: extent panning is not part of the device path
+        if (m.width != 0.0 || m.height != 0.0 || m.depth != 0.0) throw not_implemented("extent");
+        az[i] = m.position.polar.azimuth;
+        el[i] = m.position.polar.elevation;
+        dist[i] = m.position.polar.distance;
+        gain[i] = m.gain;
+        diffuse[i] = m.diffuse;
+      }
+      std::vector<float> d(n * n_full_), f(n * n_full_);
+      hip::check(earhip_panner_calculate(h_, n, az.data(), el.data(), dist.data(), gain.data(), diffuse.data(), d.data(),
+                                         f.data()));
+      directGains.assign(n, std::vector<T>(keep_.size()));
+      diffuseGains.assign(n, std::vector<T>(keep_.size()));
+      for (size_t i = 0; i < n; i++)
+        for (size_t c = 0; c < keep_.size(); c++) {
+          directGains[i][c] = (T)d[i * n_full_ + keep_[c]];
+          diffuseGains[i][c] = (T)f[i * n_full_ + keep_[c]];
+        }
+    }
+
+   private:
+    earhip_panner *h_ = nullptr;
+    std::vector<int> keep_;
+    size_t n_full_ = 0;
+  };
+}  // namespace ear

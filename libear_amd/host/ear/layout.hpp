@@ -1,0 +1,89 @@
+// ear/layout.hpp — what the render path needs of libear's Layout / Channel (include/ear/layout.hpp:12-95)
+// and of ear::loadLayouts / ear::getLayout (include/ear/bs2051.hpp:8-11): the ITU-R BS.2051 layouts from
+// the native table (earhip group H).  Same class and accessor names; positions are the nominal ones.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "hip.hpp"
+
+namespace ear {
+  struct PolarPosition {
+    PolarPosition(double az = 0.0, double el = 0.0, double dist = 1.0) : azimuth(az), elevation(el), distance(dist) {}
+    double azimuth, elevation, distance;
+  };
+  struct CartesianPosition {
+    CartesianPosition(double X = 0.0, double Y = 0.0, double Z = 0.0) : X(X), Y(Y), Z(Z) {}
+    double X, Y, Z;
+  };
+
+  class Channel {
+   public:
+    Channel() = default;
+    Channel(const std::string &name, PolarPosition pos, bool isLfe = false) : name_(name), pos_(pos), lfe_(isLfe) {}
+    const std::string &name() const { return name_; }
+    PolarPosition polarPosition() const { return pos_; }
+    PolarPosition polarPositionNominal() const { return pos_; }
+    bool isLfe() const { return lfe_; }
+
+   private:
+    std::string name_;
+    PolarPosition pos_;
+    bool lfe_ = false;
+  };
+
+  class Layout {
+   public:
+    Layout(std::string name = "", std::vector<Channel> channels = std::vector<Channel>())
+        : name_(std::move(name)), channels_(std::move(channels)) {}
+    std::string name() const { return name_; }
+    const std::vector<Channel> &channels() const { return channels_; }
+    Layout withoutLfe() const {
+      Layout l(name_);
+      for (auto &c : channels_)
+        if (!c.isLfe()) l.channels_.push_back(c);
+      return l;
+    }
+    std::vector<bool> isLfe() const {
+      std::vector<bool> v;
+      for (auto &c : channels_) v.push_back(c.isLfe());
+      return v;
+    }
+    std::vector<std::string> channelNames() const {
+      std::vector<std::string> v;
+      for (auto &c : channels_) v.push_back(c.name());
+      return v;
+    }
+    /// index of the channel with this name, or -1 (libear: boost::optional<int>)
+    int indexForName(const std::string &name) const {
+      for (size_t i = 0; i < channels_.size(); i++)
+        if (channels_[i].name() == name) return (int)i;
+      return -1;
+    }
+
+   private:
+    std::string name_;
+    std::vector<Channel> channels_;
+  };
+
+  /// Get a layout given its ITU-R BS.2051 name (e.g. `4+5+0`); unknown names throw (libear: unknown_layout).
+  inline Layout getLayout(const std::string &name) {
+    int n = 0;
+    hip::check(earhip_layout_num_channels(name.c_str(), &n));
+    std::vector<Channel> ch;
+    for (int i = 0; i < n; i++) {
+      const char *cn = nullptr;
+      double az = 0, el = 0;
+      int lfe = 0;
+      hip::check(earhip_layout_channel(name.c_str(), i, &cn, &az, &el, &lfe));
+      ch.emplace_back(cn, PolarPosition(az, el, 1.0), lfe != 0);
+    }
+    return Layout(name, ch);
+  }
+  /// Get all ITU-R BS.2051 layouts.
+  inline std::vector<Layout> loadLayouts() {
+    std::vector<Layout> v;
+    for (int i = 0; i < earhip_layout_count(); i++) v.push_back(getLayout(earhip_layout_name(i)));
+    return v;
+  }
+}  // namespace ear

@@ -259,3 +259,95 @@ int oracle_render_process(ObjectsRenderer *r, size_t n_obj, size_t n_out,
 }
 
 }  // extern "C"
+
+// ---- Objects gain producer (panner_oracle.hpp) -------------------------------------------------
+#include "panner_oracle.hpp"
+
+extern "C" {
+
+void *oracle_panner_create(const char *layout) {
+  void *out = nullptr;
+  guarded([&] { out = new panner_oracle::GainCalculatorObjects(layout); });
+  return out;
+}
+void oracle_panner_destroy(void *p) { delete static_cast<panner_oracle::GainCalculatorObjects *>(p); }
+int oracle_panner_n_out(void *p) { return static_cast<panner_oracle::GainCalculatorObjects *>(p)->n_out(); }
+// n positions: az, el, dist, gain, diffuse [n] -> direct, diffuse [n][n_out]; returns the number of
+// positions no region handled (their rows are left untouched)
+int oracle_panner_calculate(void *p, size_t n, const double *az, const double *el, const double *dist,
+                            const double *gain, const double *diffuse, float *direct, float *diff) {
+  auto *g = static_cast<panner_oracle::GainCalculatorObjects *>(p);
+  const size_t no = (size_t)g->n_out();
+  int missed = 0;
+  for (size_t i = 0; i < n; i++)
+    if (!g->calculate(az[i], el[i], dist[i], gain[i], diffuse[i], direct + i * no, diff + i * no)) missed++;
+  return missed;
+}
+// the inner point source panner (layout without LFE): pv [n][n_out_without_lfe] in double
+int oracle_psp_n_out(void *p) { return static_cast<panner_oracle::GainCalculatorObjects *>(p)->psp->n_out(); }
+int oracle_psp_handle(void *p, size_t n, const double *xyz, double *pv) {
+  auto *g = static_cast<panner_oracle::GainCalculatorObjects *>(p);
+  const size_t no = (size_t)g->psp->n_out();
+  int missed = 0;
+  for (size_t i = 0; i < n; i++) {
+    const panner_oracle::Opt o = g->psp->handle({xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+    if (!o.ok) {
+      missed++;
+      continue;
+    }
+    for (size_t c = 0; c < no; c++) pv[i * no + c] = o.v[c];
+  }
+  return missed;
+}
+// extraPosVerticalNominal of a layout without LFE: returns the number of extra channels; az / el [<= 32];
+// downmix_index [<= 32]: the real channel each extra one is mixed into
+int oracle_extra_pos_vertical_nominal(const char *layout, double *az, double *el, int *downmix_index) {
+  int n = -1;
+  guarded([&] {
+    const auto chans = panner_oracle::layout_without_lfe(layout);
+    std::vector<panner_oracle::ExtraChan> extra;
+    std::vector<panner_oracle::Vec> dm;
+    panner_oracle::extra_pos_vertical_nominal(chans, extra, dm);
+    for (size_t i = 0; i < extra.size(); i++) {
+      az[i] = extra[i].az;
+      el[i] = extra[i].el_real;
+      downmix_index[i] = -1;
+      for (size_t c = 0; c < chans.size(); c++)
+        if (dm[chans.size() + i][c] == 1.0) downmix_index[i] = (int)c;
+    }
+    n = (int)extra.size();
+  });
+  return n;
+}
+// single regions for the reference's region-level tests: kind 0 Triplet, 1 QuadRegion, 2 VirtualNgon
+// (positions [n][3]; VirtualNgon: centre [3], downmix [n]); pv [n]; returns 1 when handled
+int oracle_region_handle(int kind, int n, const double *positions, const double *centre, const double *downmix,
+                         const double *xyz, double *pv) {
+  int ok = 0;
+  guarded([&] {
+    std::vector<int> ch(n);
+    std::vector<panner_oracle::V3> pos(n);
+    for (int i = 0; i < n; i++) ch[i] = i, pos[i] = {positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]};
+    std::unique_ptr<panner_oracle::RegionHandler> r;
+    if (kind == 0) r.reset(new panner_oracle::Triplet(ch, pos));
+    else if (kind == 1) r.reset(new panner_oracle::QuadRegion(ch, pos));
+    else r.reset(new panner_oracle::VirtualNgon(ch, pos, {centre[0], centre[1], centre[2]}, panner_oracle::Vec(downmix, downmix + n)));
+    const panner_oracle::Opt o = r->handle({xyz[0], xyz[1], xyz[2]});
+    if (o.ok) {
+      ok = 1;
+      for (int i = 0; i < n; i++) pv[i] = o.v[i];
+    }
+  });
+  return ok;
+}
+int oracle_stereo_downmix_handle(const double *xyz, double *pv2) {
+  int ok = 0;
+  guarded([&] {
+    panner_oracle::StereoPannerDownmix s({0, 1}, {panner_oracle::cart(30, 0, 1), panner_oracle::cart(-30, 0, 1)});
+    const panner_oracle::Opt o = s.handle({xyz[0], xyz[1], xyz[2]});
+    if (o.ok) ok = 1, pv2[0] = o.v[0], pv2[1] = o.v[1];
+  });
+  return ok;
+}
+
+}  // extern "C"

@@ -26,7 +26,7 @@ def load(native=False):
     path = os.path.join(ODIR, "_build", name)
     src_newer = (not os.path.exists(path)) or any(
         os.path.getmtime(os.path.join(ODIR, f)) > os.path.getmtime(path)
-        for f in ("ear_oracle.hpp", "oracle_capi.cpp"))
+        for f in ("ear_oracle.hpp", "oracle_capi.cpp", "panner_oracle.hpp", "bs2051_data.h"))
     if src_newer:
         _build()
     lib = C.CDLL(path)
@@ -265,3 +265,76 @@ class ObjectsRenderer:
             self.lib.oracle_render_destroy(self.h)
         except Exception:
             pass
+
+
+def cart(az, el, dist=1.0):
+    """libear's polar -> Cartesian convention (src/common/geom.cpp:82-87)"""
+    az, el = np.radians(-np.asarray(az, np.float64)), np.radians(np.asarray(el, np.float64))
+    return np.stack([np.sin(az) * np.cos(el) * dist, np.cos(az) * np.cos(el) * dist, np.sin(el) * dist + 0 * az], axis=-1)
+
+
+class GainCalculatorObjects:
+    """Objects gain producer (oracle/panner_oracle.hpp): point-source pan + LFE mask + diffuse split."""
+
+    def __init__(self, layout):
+        lib().oracle_panner_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().oracle_panner_create(layout.encode()))
+        if not self.h:
+            raise OracleError(1, lib().oracle_last_error().decode())
+        self.n_out = lib().oracle_panner_n_out(self.h)
+        self.n_psp = lib().oracle_psp_n_out(self.h)
+
+    def calculate(self, az, el, dist=None, gain=None, diffuse=None):
+        """arrays [n] -> (direct, diffuse) float32 [n][n_out]"""
+        az = np.ascontiguousarray(np.atleast_1d(az), np.float64)
+        n = az.size
+        el = np.ascontiguousarray(np.broadcast_to(np.asarray(el, np.float64), (n,)))
+        dist = np.ascontiguousarray(np.broadcast_to(np.asarray(1.0 if dist is None else dist, np.float64), (n,)))
+        gain = np.ascontiguousarray(np.broadcast_to(np.asarray(1.0 if gain is None else gain, np.float64), (n,)))
+        diffuse = np.ascontiguousarray(np.broadcast_to(np.asarray(0.0 if diffuse is None else diffuse, np.float64), (n,)))
+        d = np.zeros((n, self.n_out), np.float32)
+        f = np.zeros((n, self.n_out), np.float32)
+        missed = lib().oracle_panner_calculate(self.h, C.c_size_t(n), ptr(az, f64p), ptr(el, f64p), ptr(dist, f64p),
+                                               ptr(gain, f64p), ptr(diffuse, f64p), ptr(d), ptr(f))
+        assert missed == 0, f"{missed} positions not handled by any region"
+        return d, f
+
+    def psp(self, xyz):
+        """the inner point source panner on Cartesian positions [n][3] -> (pv [n][channels without LFE], missed)"""
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        pv = np.zeros((xyz.shape[0], self.n_psp), np.float64)
+        missed = lib().oracle_psp_handle(self.h, C.c_size_t(xyz.shape[0]), ptr(xyz, f64p), ptr(pv, f64p))
+        return pv, missed
+
+    def __del__(self):
+        try:
+            lib().oracle_panner_destroy(self.h)
+        except Exception:
+            pass
+
+
+def extra_pos_vertical_nominal(layout):
+    az, el = np.zeros(32), np.zeros(32)
+    idx = np.zeros(32, np.int32)
+    n = lib().oracle_extra_pos_vertical_nominal(layout.encode(), ptr(az, f64p), ptr(el, f64p), idx.ctypes.data_as(C.POINTER(C.c_int)))
+    assert n >= 0, lib().oracle_last_error().decode()
+    return list(zip(az[:n], el[:n])), list(idx[:n])
+
+
+def region_handle(kind, positions, xyz, centre=None, downmix=None):
+    """kind: 'triplet' | 'quad' | 'ngon'; returns pv [n] or None"""
+    positions = np.ascontiguousarray(positions, np.float64)
+    n = positions.shape[0]
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    centre = np.ascontiguousarray(np.zeros(3) if centre is None else centre, np.float64)
+    downmix = np.ascontiguousarray(np.zeros(n) if downmix is None else downmix, np.float64)
+    pv = np.zeros(n, np.float64)
+    ok = lib().oracle_region_handle({"triplet": 0, "quad": 1, "ngon": 2}[kind], n, ptr(positions, f64p), ptr(centre, f64p),
+                                    ptr(downmix, f64p), ptr(xyz, f64p), ptr(pv, f64p))
+    return pv if ok else None
+
+
+def stereo_downmix_handle(xyz):
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    pv = np.zeros(2, np.float64)
+    return pv if lib().oracle_stereo_downmix_handle(ptr(xyz, f64p), ptr(pv, f64p)) else None

@@ -15,6 +15,7 @@
 
 #include "ear/decorrelate.hpp"
 #include "ear/dsp/dsp.hpp"
+#include "ear/gain_calculators.hpp"
 
 using namespace ear;
 using namespace ear::dsp;
@@ -547,8 +548,88 @@ static void test_layout_names() {
   CHECK(threw);
 }
 
+// ---- GainCalculatorObjects (reference tests/gain_calculator_objects_tests.cpp:74-160) ----------------
+static void test_gain_calculator_objects() {
+  const Layout layout = getLayout("4+7+0").withoutLfe();
+  CHECK(layout.channels().size() == 11);
+  GainCalculatorObjects calc(layout);
+  auto only = [&](const std::vector<float> &g, const char *name, double value) {
+    bool ok = g.size() == layout.channels().size();
+    for (size_t i = 0; ok && i < g.size(); i++)
+      ok = std::fabs(g[i] - (layout.channels()[i].name() == name ? value : 0.0)) < 1e-6;
+    return ok;
+  };
+  std::vector<float> direct, diffuse;
+  ObjectsTypeMetadata otm;
+  otm.position = PolarPosition(0.0, 0.0, 1.0);
+  calc.calculate(otm, direct, diffuse);
+  CHECK(only(direct, "M+000", 1.0) && only(diffuse, "", 0.0));
+  otm.position = PolarPosition(30.0, 0.0, 1.0);
+  calc.calculate(otm, direct, diffuse);
+  CHECK(only(direct, "M+030", 1.0));
+  otm.position = PolarPosition(45.0, 30.0, 1.0);
+  calc.calculate(otm, direct, diffuse);
+  CHECK(only(direct, "U+045", 1.0));
+  otm.position = PolarPosition(0.0, 0.0, 1.0);
+  otm.diffuse = 0.5;
+  calc.calculate(otm, direct, diffuse);
+  CHECK(only(direct, "M+000", std::sqrt(0.5)) && only(diffuse, "M+000", std::sqrt(0.5)));
+  otm.diffuse = 1.0;
+  calc.calculate(otm, direct, diffuse);
+  CHECK(only(direct, "", 0.0) && only(diffuse, "M+000", 1.0));
+  otm.diffuse = 0.0;
+  otm.gain = 0.5;
+  calc.calculate(otm, direct, diffuse);
+  CHECK(only(direct, "M+000", 0.5));
+  // "not implemented" (:134-160)
+  auto refuses = [&](ObjectsTypeMetadata m) {
+    try {
+      calc.calculate(m, direct, diffuse);
+    } catch (const ear::not_implemented &) {
+      return true;
+    }
+    return false;
+  };
+  ObjectsTypeMetadata base;
+  ObjectsTypeMetadata m = base;
+  m.cartesian = true;
+  CHECK(refuses(m));
+  m = base;
+  m.position = CartesianPosition(0.0, 1.0, 0.0);
+  CHECK(refuses(m));
+  m = base;
+  m.objectDivergence = ObjectDivergence(0.5);
+  CHECK(refuses(m));
+  m = base;
+  m.channelLock.flag = true;
+  CHECK(refuses(m));
+  m = base;
+  m.zoneExclusion.zones.push_back(ExclusionZone());
+  CHECK(refuses(m));
+  m = base;
+  m.screenRef = true;
+  CHECK(refuses(m));
+  m = base;
+  m.width = 20.0;
+  CHECK(refuses(m));
+  CHECK(!refuses(base));
+  // with the LFE channel kept, its column is zero (gain_calculator_objects.cpp:50-52); a batch in one launch
+  GainCalculatorObjects full(getLayout("4+7+0"));
+  std::vector<ObjectsTypeMetadata> batch(3);
+  batch[1].position = PolarPosition(-30.0, 0.0, 1.0);
+  batch[2].position = PolarPosition(110.0, 20.0, 2.0);
+  batch[2].diffuse = 0.3;
+  std::vector<std::vector<float>> bd, bf;
+  full.calculate(batch, bd, bf);
+  CHECK(bd.size() == 3 && bd[0].size() == 12 && bd[0][3] == 0.0f && bd[2][3] == 0.0f);
+  double power = 0;
+  for (size_t c = 0; c < 12; c++) power += (double)bd[2][c] * bd[2][c] + (double)bf[2][c] * bf[2][c];
+  CHECK(std::fabs(power - 1.0) < 1e-6);
+}
+
 int main() {
   try {
+    test_gain_calculator_objects();
     test_ptr_adapter();
     test_layout_names();
     test_gain_interpolator();

@@ -204,3 +204,29 @@ def mixed_level_sparse(n_obj, n_out, block, n_blocks, lfe=(), span_db=100.0, see
             f[k, idx] = (g * np.sqrt(diff)).astype(np.float32)
         curves.append((times, d, f))
     return curves, levels
+
+
+def moving_sources(n_obj, total, period=960, seed=31):
+    """ADM-like trajectories: every `period` samples, at a per-object phase, an object gets a new position
+    (a random walk in azimuth / elevation) and diffuseness, reached over a quarter of the period and then
+    held.  Returns per object (azimuth, elevation, diffuse, times) arrays of its curve points: the values
+    feed a gain producer, the result is a gain curve like adm_curves()."""
+    rng = np.random.default_rng(seed)
+    az, el, df, times = [], [], [], []
+    ramp = max(period // 4, 1)
+    for m in range(n_obj):
+        phase = int(rng.integers(0, period))
+        starts = np.arange(phase - period, total + period, period, dtype=np.int64)
+        k = len(starts) + 1
+        a = np.cumsum(rng.normal(0.0, 25.0, k)) + rng.uniform(-180, 180)
+        a = (a + 180.0) % 360.0 - 180.0
+        e = np.clip(np.cumsum(rng.normal(0.0, 10.0, k)) + rng.uniform(-30, 60), -90, 90)
+        d = rng.choice([0.0, 0.0, 0.3, 1.0], k)
+        t = np.empty(2 * len(starts), np.int64)
+        t[0::2] = starts
+        t[1::2] = starts + ramp
+        idx = np.empty(2 * len(starts), np.int64)
+        idx[0::2] = np.arange(len(starts))      # block start: still the previous target
+        idx[1::2] = np.arange(len(starts)) + 1  # end of the ramp: the new target
+        az.append(a[idx]); el.append(e[idx]); df.append(d[idx]); times.append(t)
+    return az, el, df, times

@@ -1,0 +1,116 @@
+"""The device batch panner (libearhip group I, k_pan_objects) against the oracle's restatement of libear's
+GainCalculatorObjects / point source panner (oracle/panner_oracle.hpp, pinned by the reference's own tests
+in tests/test_oracle_panner.py): every BS.2051 layout, dense random directions and distances, a fine grid
+around the loudspeakers and region borders, gain and diffuseness — float32 outputs equal to the last bit
+(both sides compute in double and cast), plus the reference's known answers through the C ABI."""
+import numpy as np
+import pytest
+
+import _oracle
+from _hip import ctx
+from layouts import LAYOUTS
+
+pytestmark = pytest.mark.gpu
+
+ULP = 1.2e-7  # one float32 ulp at 1.0: the double results may differ in their last bits before the cast
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+def test_batch_panner_equals_oracle(layout):
+    from libear_amd import capi
+    rng = np.random.default_rng(len(layout) * 7 + sum(map(ord, layout)))
+    n = 20000
+    az = rng.uniform(-180.0, 180.0, n)
+    el = np.degrees(np.arcsin(rng.uniform(-1.0, 1.0, n)))
+    # the loudspeaker directions themselves and their neighbourhoods (region borders: the first region wins)
+    chans = capi.layout_channels(layout)
+    for i, (_, caz, cel, _) in enumerate(chans):
+        k = 40 * i
+        az[k:k + 40] = caz + np.r_[0.0, rng.normal(0, 0.5, 39)]
+        el[k:k + 40] = np.clip(cel + np.r_[0.0, rng.normal(0, 0.5, 39)], -90, 90)
+    az[-500:] = np.round(az[-500:] / 15.0) * 15.0  # directions on the 15 degree grid (exactly on many borders)
+    el[-500:] = np.round(el[-500:] / 15.0) * 15.0
+    dist = rng.uniform(0.1, 2.0, n)
+    gain = rng.uniform(0.0, 2.0, n)
+    diffuse = rng.choice([0.0, 0.25, 0.5, 1.0], n)
+    p = capi.Panner(ctx(), layout)
+    assert p.n_out == len(LAYOUTS[layout])
+    d, f = p.calculate(az, el, dist, gain, diffuse)
+    p.close()
+    o = _oracle.GainCalculatorObjects(layout)
+    wd, wf = o.calculate(az, el, dist, gain, diffuse)
+    assert np.max(np.abs(d - wd)) <= 2 * ULP and np.max(np.abs(f - wf)) <= 2 * ULP
+    assert np.mean(d == wd) > 0.999 and np.mean(f == wf) > 0.999  # (identical apart from rounding-boundary cases)
+    lfe = [i for i, nm in enumerate(LAYOUTS[layout]) if nm.startswith("LFE")]
+    assert not d[:, lfe].any() and not f[:, lfe].any()
+    # 3-sparse in practice: at most 4 loudspeakers carry a point source (quads), except under / above the
+    # layout where a virtual n-gon spreads it
+    nz = (d != 0).sum(axis=1) + 0
+    assert np.median(nz[diffuse < 1.0]) <= 4
+
+
+def test_reference_known_answers_through_the_c_abi():
+    """tests/gain_calculator_objects_tests.cpp:74-132 (4+7+0) and point_source_panner_tests.cpp:420-446 (0+5+0)"""
+    from libear_amd import capi
+    names = LAYOUTS["4+7+0"]
+    p = capi.Panner(ctx(), "4+7+0")
+
+    def nonzero(v):
+        return {names[i]: float(x) for i, x in enumerate(v) if abs(x) >= 1e-6}
+
+    for (az, el), ch in (((0.0, 0.0), "M+000"), ((30.0, 0.0), "M+030"), ((45.0, 30.0), "U+045")):
+        d, f = p.calculate(az, el)
+        assert nonzero(d[0]) == {ch: pytest.approx(1.0)} and nonzero(f[0]) == {}
+    d, f = p.calculate(0.0, 0.0, diffuse=0.5)
+    assert nonzero(d[0]) == {"M+000": pytest.approx(np.sqrt(0.5))} and nonzero(f[0]) == {"M+000": pytest.approx(np.sqrt(0.5))}
+    d, f = p.calculate(0.0, 0.0, diffuse=1.0)
+    assert nonzero(d[0]) == {} and nonzero(f[0]) == {"M+000": pytest.approx(1.0)}
+    d, f = p.calculate(0.0, 0.0, gain=0.5)
+    assert nonzero(d[0]) == {"M+000": pytest.approx(0.5)}
+    p.close()
+    p = capi.Panner(ctx(), "0+5+0")
+    d, _ = p.calculate([15.0, -15.0], [0.0, 0.0])
+    n5 = LAYOUTS["0+5+0"]
+    assert d[0][n5.index("M+030")] == pytest.approx(np.sqrt(0.5)) and d[0][n5.index("M+000")] == pytest.approx(np.sqrt(0.5))
+    assert d[1][n5.index("M-030")] == pytest.approx(np.sqrt(0.5)) and d[1][n5.index("M+000")] == pytest.approx(np.sqrt(0.5))
+    p.close()
+    p = capi.Panner(ctx(), "0+2+0")  # stereo: 0 dB at the front to -3 dB at the back (point_source_panner_tests.cpp:80-101)
+    d, _ = p.calculate([0.0, -30.0, -110.0, -180.0], [0.0] * 4)
+    assert np.allclose(d, [[np.sqrt(0.5)] * 2, [0.0, 1.0], [0.0, np.sqrt(0.5)], [0.5, 0.5]], atol=1e-6)
+    p.close()
+    with pytest.raises(capi.InvalidArgument):
+        capi.Panner(ctx(), "7+7+7")
+
+
+def test_panned_scene_renders_within_tolerance():
+    """moving point sources: gains from the device panner feed the renderer; the oracle renders the same
+    scene from the ORACLE's gains — producer and render path checked end to end, per channel"""
+    import scenes
+    from libear_amd import capi
+    layout, m, block, nblocks = "9+10+3", 96, 512, 6
+    names = LAYOUTS[layout]
+    n = len(names)
+    total = block * nblocks
+    dec = capi.design_decorrelators(names)
+    az, el, diffuse, times = scenes.moving_sources(m, total, period=700, seed=5)
+    p = capi.Panner(ctx(), layout)
+    o = _oracle.GainCalculatorObjects(layout)
+    curves, wcurves = [], []
+    for i in range(m):
+        d, f = p.calculate(az[i], el[i], None, None, diffuse[i])
+        curves.append((times[i], d, f))
+        wcurves.append((times[i],) + o.calculate(az[i], el[i], None, None, diffuse[i]))
+    p.close()
+    x = scenes.audio(m, total, seed=9)
+    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+    for i, (t, d, f) in enumerate(curves):
+        r.set_object_points(i, t, d, f)
+    got = r.process(x)
+    r.close()
+    w = _oracle.ObjectsRenderer(m, n, block, dec, 255)
+    for i, (t, d, f) in enumerate(wcurves):
+        w.set_points(i, 0, t, d)
+        w.set_points(i, 1, t, f)
+    want = w.process(x)
+    assert scenes.rel_rms(got, want) <= 1e-6
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
