@@ -104,9 +104,12 @@ def main():
                          "(steps measured right after start-up are ~9 %% slower)")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
-    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed"), default="dense",
+    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed", "panned", "panned-adm"), default="dense",
                     help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
-                         "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned)")
+                         "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned); "
+                         "panned / panned-adm: moving point sources through the device gain producer (libearhip group "
+                         "I: real 3-sparse VBAP gains, sqrt(1-d)/sqrt(d) split, zero LFE columns), a new position every "
+                         "block / every 960 samples at a per-object phase")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE config 4): --objects in total, split over the GPUs; "
                          "weak: --objects per GPU")
@@ -187,6 +190,21 @@ def main():
                 odd = scenes.adm_curves(max(m // 128, 1), N, total, seed=11 + seed)
                 for i, c in enumerate(odd):
                     curves[(128 * i + 7) % m] = c
+            elif args.scene in ("panned", "panned-adm"):
+                # moving point sources: positions -> gain vectors by the device batch panner (earhip group I)
+                if args.scene == "panned":  # a new position at every block boundary, reached over the whole block
+                    az, el, df, tms = scenes.moving_sources(m, total, period=B, seed=31 + seed, phase=0, ramp=B)
+                else:
+                    az, el, df, tms = scenes.moving_sources(m, total, period=960, seed=31 + seed)
+                pan = capi.Panner(context or ctx, cfg["layout"])
+                cat = lambda v: np.concatenate(v)
+                d_all, f_all = pan.calculate(cat(az), cat(el), None, None, cat(df))
+                pan.close()
+                curves, at = [], 0
+                for i in range(m):
+                    k = len(tms[i])
+                    curves.append((tms[i], d_all[at:at + k], f_all[at:at + k]))
+                    at += k
             else:
                 curves = scenes.dense_curves(m, N, B, T, seed=7 + seed)
             curves = curves[:self.M_obj]
@@ -375,7 +393,11 @@ def main():
                       "adm": "dense uniform(0,1); metadata every 960 samples at a per-object phase, 240-sample ramp then constant",
                       "moving": "dense uniform(0,1); a new target every 240 samples at a per-object phase, always ramping",
                       "static": "dense uniform(0,1), one gain vector per object, never changing",
-                      "mixed": "the dense scene with 8 of every 1024 objects on ADM-like metadata off the block grid"}[args.scene]
+                      "mixed": "the dense scene with 8 of every 1024 objects on ADM-like metadata off the block grid",
+                      "panned": "moving point sources, a new position every block: gains from the device panner "
+                                "(3-sparse VBAP gains, diffuse split, zero LFE columns)",
+                      "panned-adm": "moving point sources, a new position every 960 samples at a per-object phase: "
+                                    "gains from the device panner"}[args.scene]
         result = {
             "metric": "Msamples/s", "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preconditioning_steps": pre_steps,
@@ -558,7 +580,7 @@ def main():
             xf = np.ascontiguousarray(xc[:, :fb * B])
             fwin = scenes.window_curves(wl.curves, 0, fb * B)
             forms = {}
-            if args.scene == "dense" and not wl.M_hoa:  # (the fused form needs one common time axis)
+            if args.scene in ("dense", "panned") and not wl.M_hoa:  # (the fused form needs one common time axis)
                 tms = fwin[0][0]
                 vals = [np.stack([c[1 + b] for c in fwin], axis=1) for b in range(K)]  # [points][M][N]
                 c0 = time.perf_counter()

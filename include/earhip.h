@@ -243,6 +243,17 @@ int earhip_panner_calculate_device(earhip_panner *p, size_t npos, const double *
                                    const double *gain, const double *diffuse, float *direct,
                                    float *diffuse_out);
 
+/* (I, HOA) Decode matrix for scene-based (HOA) content — replaces ear::GainCalculatorHOA
+ * (include/ear/gain_calculators.hpp:58-70, src/hoa/gain_calculator_hoa.cpp:8-72,
+ * src/hoa/hoa.hpp:16-182): the AllRAD design over the layout's point source panner.  One
+ * (order, degree) pair per input channel; normalization "SN3D", "N3D" or "FuMa" (an unknown
+ * one is EARHIP_INVALID_ARGUMENT: libear throws adm_error); out: [n_channels][n_coef],
+ * rows of LFE channels zero.  It is constant over time: feed its COLUMNS to (F) or (A')
+ * as single-point gain curves (docs/dsp.rst:73-89).  screenRef and nfcRefDist are ignored
+ * by libear (with a warning) and are not parameters here. */
+int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, const int *orders,
+                             const int *degrees, const char *normalization, float *out);
+
 /* ------------------------------------------------------------------------
  * (F) Composed Objects render block — the chain libear documents but does not
  * implement (docs/dsp.rst:40-71, include/ear/gain_calculators.hpp:45-56):

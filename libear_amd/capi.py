@@ -368,6 +368,20 @@ class Panner:
             self.h = C.c_void_p()
 
 
+def hoa_decode_matrix(ctx, layout, orders, degrees, normalization="SN3D"):
+    """(I, HOA) AllRAD decode matrix [n_channels][n_coef] float32"""
+    o = np.ascontiguousarray(orders, np.int32)
+    d = np.ascontiguousarray(degrees, np.int32)
+    if len(o) != len(d):
+        raise InvalidArgument(INVALID_ARGUMENT, "orders and degrees must be the same size")
+    n = len(layout_channels(layout))
+    out = np.zeros((n, max(len(o), 1)), np.float32)
+    ip = C.POINTER(C.c_int)
+    check(load().earhip_hoa_decode_matrix(ctx.h, layout.encode(), len(o), o.ctypes.data_as(ip), d.ctypes.data_as(ip),
+                                          normalization.encode(), _ptr(out)))
+    return out[:, :len(o)]
+
+
 class Renderer:
     """(F) composed Objects render block."""
 

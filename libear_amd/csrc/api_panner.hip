@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "layout_table.h"
+#include "tdesign_5200.h"
 
 namespace earhip {
 
@@ -220,6 +221,32 @@ k_pan_objects(PanParams P, size_t npos, const double *az, const double *el, cons
   }
 }
 
+// HOA decoder design: panning values of unit vectors in double, [npos][n_pv] (2 for 0+2+0)
+static __global__ void __launch_bounds__(128)
+k_pan_points(PanParams P, size_t npos, const double *xyz, double *pv_out, unsigned *missed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npos) return;
+  const Vec3 p = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  double real[kMaxPanOut];
+  const int n_pv = P.stereo ? 2 : P.table.n_real;
+  if (!pan_full(P.table, p, real)) {
+    atomicAdd(missed, 1u);
+    for (int c = 0; c < n_pv; c++) pv_out[i * n_pv + c] = 0.0;
+    return;
+  }
+  if (P.stereo) {
+    const double s3 = sqrt(3.0) / 3.0, s5 = sqrt(0.5);
+    const double l = real[0] + s3 * real[2] + s5 * real[3], r = real[1] + s3 * real[2] + s5 * real[4];
+    const double n = sqrt(l * l + r * r);
+    const double front = fmax(real[0], fmax(real[1], real[2])), back = fmax(real[3], real[4]);
+    const double lev = pow(0.5, 0.5 * back / (front + back));
+    pv_out[2 * i] = l / n * lev;
+    pv_out[2 * i + 1] = r / n * lev;
+  } else {
+    for (int c = 0; c < n_pv; c++) pv_out[i * n_pv + c] = real[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Set-up (host, double): flatten the regions of a layout
 // ------------------------------------------------------------------------------------------------
@@ -388,6 +415,41 @@ std::vector<PanRegion> build_regions(const LayoutEntry &L, int &n_real) {
   return regions;
 }
 
+// ---- spherical harmonics (src/hoa/hoa.hpp:16-112; Boost.Math's Legendre functions and factorials from
+// their definitions)
+double factorial_d(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; i++) f *= i;
+  return f;
+}
+// associated Legendre function P_n^m(x) without the Condon-Shortley phase, upward recurrence in n
+double legendre_nm(int n, int m, double x) {
+  const double root = std::sqrt((1.0 - x) * (1.0 + x));
+  double p0 = 1.0;
+  for (int i = 1; i <= m; i++) p0 *= (2.0 * i - 1.0) * root;  // P_m^m
+  if (n == m) return p0;
+  double p1 = x * (2.0 * m + 1.0) * p0;                         // P_(m+1)^m
+  for (int l = m + 2; l <= n; l++) {
+    const double p2 = (x * (2.0 * l - 1.0) * p1 - (l + m - 1.0) * p0) / (l - m);
+    p0 = p1;
+    p1 = p2;
+  }
+  return p1;
+}
+enum HoaNorm { kN3D, kSN3D, kFuMa };
+double hoa_norm(HoaNorm t, int n, int am) {
+  const double sn3d = std::sqrt(factorial_d(n - am) / factorial_d(n + am));
+  if (t == kSN3D) return sn3d;
+  if (t == kN3D) return std::sqrt(2.0 * n + 1.0) * sn3d;
+  // FuMa: defined up to order 3 (hoa.hpp:56-72)
+  static const double f[4][4] = {{0.70710678118654752440, 0, 0, 0},
+                                 {1.0, 1.0, 0, 0},
+                                 {1.0, 1.15470053837925152902, 1.15470053837925152902, 0},
+                                 {1.0, 1.18585412256314232322, 1.34164078649987381784, 1.26491106406735172760}};
+  if (n > 3) fail_invalid("FuMa normalisation is defined up to order 3");
+  return f[n][am] * sn3d;
+}
+
 }  // namespace
 }  // namespace earhip
 
@@ -457,6 +519,95 @@ int earhip_panner_num_channels(const earhip_panner *p, int *n_channels) {
   return guarded([&] {
     require(p != nullptr && n_channels != nullptr, "NULL argument");
     *n_channels = p->P.n_full;
+  });
+}
+
+// GainCalculatorHOAImpl (src/hoa/gain_calculator_hoa.cpp:8-72): AllRAD — the point source panner sampled
+// at the 5200 directions of a spherical t-design (device, one thread per direction), times the N3D
+// spherical harmonics at those directions (host, double: a cold 24 x 5200 x n_coef product), power
+// normalised and converted to the requested normalisation.
+int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, const int *orders, const int *degrees,
+                             const char *normalization, float *out) {
+  return guarded([&] {
+    require(ctx != nullptr && out != nullptr, "NULL argument");
+    require(n_coef >= 1 && orders != nullptr && degrees != nullptr, "orders and degrees must be the same size");
+    require(n_coef <= 4096, "too many coefficients");
+    for (int i = 0; i < n_coef; i++) {
+      require(orders[i] >= 0, "orders must not be negative");
+      require(std::abs(degrees[i]) <= orders[i], "magnitude of degree must not be greater than order");
+      require(orders[i] <= 64, "order too high");
+    }
+    require(normalization != nullptr, "normalization must not be NULL");
+    HoaNorm norm;
+    if (std::strcmp(normalization, "N3D") == 0) norm = kN3D;
+    else if (std::strcmp(normalization, "SN3D") == 0) norm = kSN3D;
+    else if (std::strcmp(normalization, "FuMa") == 0) norm = kFuMa;
+    else fail_invalid(std::string("ADM error: unknown normalization type: '") + normalization + "'");
+    earhip_panner *pn = nullptr;
+    if (earhip_panner_create(ctx, layout, &pn) != EARHIP_OK) throw Error{EARHIP_INVALID_ARGUMENT, earhip_last_error()};
+    std::unique_ptr<earhip_panner, int (*)(earhip_panner *)> guard(pn, earhip_panner_destroy);
+    const size_t P = (size_t)kTDesignPoints, C = (size_t)n_coef;
+    const size_t S = pn->P.stereo ? 2 : (size_t)pn->P.table.n_real;
+    // the design's directions (src/hoa/hoa.cpp:4-14)
+    std::vector<double> xyz(3 * P);
+    for (size_t i = 0; i < P; i++) {
+      const double phi = kTDesign[i][0], theta = kTDesign[i][1];
+      xyz[3 * i] = std::sin(theta) * std::cos(phi);
+      xyz[3 * i + 1] = std::sin(theta) * std::sin(phi);
+      xyz[3 * i + 2] = std::cos(theta);
+    }
+    // G_virt [P][S] on the device
+    DevBuf<double> d_xyz, d_pv;
+    d_xyz.alloc(3 * P);
+    d_pv.alloc(P * S);
+    EARHIP_HIP(hipMemcpyAsync(d_xyz.p, xyz.data(), sizeof(double) * 3 * P, hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemsetAsync(pn->missed.p, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(k_pan_points, dim3((unsigned)((P + 127) / 128)), dim3(128), 0, ctx->stream, pn->P, P, d_xyz.p, d_pv.p,
+                       pn->missed.p);
+    EARHIP_HIP(hipGetLastError());
+    std::vector<double> G(P * S);
+    unsigned missed = 0;
+    EARHIP_HIP(hipMemcpyAsync(G.data(), d_pv.p, sizeof(double) * P * S, hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(&missed, pn->missed.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    if (missed) fail_internal("point source panner: a design direction was not handled by any region");
+    // Y_virt [C][P], N3D (hoa.hpp:115-133)
+    std::vector<double> Y(C * P);
+    for (size_t i = 0; i < P; i++) {
+      const double az = -std::atan2(xyz[3 * i], xyz[3 * i + 1]);
+      const double el = std::atan2(xyz[3 * i + 2], std::hypot(xyz[3 * i], xyz[3 * i + 1]));
+      for (size_t c = 0; c < C; c++) {
+        const int n = orders[c], m = degrees[c], am = std::abs(m);
+        const double trig = m > 0 ? std::sqrt(2.0) * std::cos(m * az) : m < 0 ? -std::sqrt(2.0) * std::sin(m * az) : 1.0;
+        Y[c * P + i] = hoa_norm(kN3D, n, am) * legendre_nm(n, am, std::sin(el)) * trig;
+      }
+    }
+    // D = G_virt (Y_virt^T / P), then |D Y_virt|_F = sqrt(P), then N3D -> norm (gain_calculator_hoa.cpp:56-63)
+    std::vector<double> D(S * C, 0.0);
+    for (size_t sp = 0; sp < S; sp++)
+      for (size_t c = 0; c < C; c++) {
+        double acc = 0.0;
+        for (size_t i = 0; i < P; i++) acc += G[i * S + sp] * (Y[c * P + i] / (double)P);
+        D[sp * C + c] = acc;
+      }
+    double fro = 0.0;
+    for (size_t sp = 0; sp < S; sp++)
+      for (size_t i = 0; i < P; i++) {
+        double v = 0.0;
+        for (size_t c = 0; c < C; c++) v += D[sp * C + c] * Y[c * P + i];
+        fro += v * v;
+      }
+    const double k = std::sqrt((double)P) / std::sqrt(fro);
+    const int n_full = pn->P.n_full;
+    for (size_t i = 0; i < (size_t)n_full * C; i++) out[i] = 0.0f;
+    for (size_t sp = 0; sp < S; sp++) {
+      const int row = pn->P.stereo ? pn->P.stereo_index[sp] : pn->P.full_index[sp];
+      for (size_t c = 0; c < C; c++) {
+        const int am = std::abs(degrees[c]);
+        const double conv = hoa_norm(kN3D, orders[c], am) / hoa_norm(norm, orders[c], am);
+        out[(size_t)row * C + c] = (float)(D[sp * C + c] * k * conv);
+      }
+    }
   });
 }
 

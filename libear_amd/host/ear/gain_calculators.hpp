@@ -3,6 +3,7 @@
 // call a renderer wants: all metadata blocks of all objects in one launch.
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "hip.hpp"
@@ -74,6 +75,51 @@ namespace ear {
 
    private:
     earhip_panner *h_ = nullptr;
+    std::vector<int> keep_;
+    size_t n_full_ = 0;
+  };
+
+  /// libear: include/ear/metadata.hpp:162-171
+  struct HOATypeMetadata {
+    std::vector<int> orders;
+    std::vector<int> degrees;
+    std::string normalization = std::string("SN3D");
+    double nfcRefDist = 0.0;  ///< ignored, as in libear (which warns)
+    bool screenRef = false;   ///< ignored, as in libear (which warns)
+  };
+
+  /// libear: include/ear/gain_calculators.hpp:58-70
+  class GainCalculatorHOA {
+   public:
+    explicit GainCalculatorHOA(const Layout &layout, hip::Context &ctx = hip::default_context())
+        : name_(layout.name()), ctx_(ctx) {
+      const Layout full = getLayout(layout.name());
+      for (auto &c : layout.channels()) {
+        const int i = full.indexForName(c.name());
+        if (i < 0) throw invalid_argument("channel " + c.name() + " is not part of layout " + layout.name());
+        keep_.push_back(i);
+      }
+      n_full_ = full.channels().size();
+    }
+    /// gains[coefficient][loudspeaker] (libear's column-major vector of vectors): must have that shape
+    template <typename T>
+    void calculate(const HOATypeMetadata &metadata, std::vector<std::vector<T>> &gains) {
+      if (metadata.orders.size() != metadata.degrees.size())
+        throw invalid_argument("orders and degrees must be the same size");
+      const size_t C = metadata.orders.size();
+      if (gains.size() != C) throw invalid_argument("incorrect number of cols in output matrix");
+      for (auto &col : gains)
+        if (col.size() != keep_.size()) throw invalid_argument("incorrect number of rows in output matrix column");
+      std::vector<float> D(n_full_ * (C ? C : 1));
+      hip::check(earhip_hoa_decode_matrix(ctx_.get(), name_.c_str(), (int)C, metadata.orders.data(), metadata.degrees.data(),
+                                          metadata.normalization.c_str(), D.data()));
+      for (size_t c = 0; c < C; c++)
+        for (size_t r = 0; r < keep_.size(); r++) gains[c][r] = (T)D[(size_t)keep_[r] * C + c];
+    }
+
+   private:
+    std::string name_;
+    hip::Context &ctx_;
     std::vector<int> keep_;
     size_t n_full_ = 0;
   };

@@ -351,3 +351,33 @@ int oracle_stereo_downmix_handle(const double *xyz, double *pv2) {
 }
 
 }  // extern "C"
+
+// ---- HOA decode matrix (hoa_oracle) -----------------------------------------------------------------
+extern "C" {
+// out [n_channels][n_coef] double; returns 0, or 1 (invalid argument) / 3 (other) with oracle_last_error()
+int oracle_hoa_decode_matrix(const char *layout, int n_coef, const int *orders, const int *degrees, const char *norm,
+                             double *out, int *n_channels) {
+  try {
+    std::vector<double> D;
+    int nc = 0;
+    hoa_oracle::decode_matrix(layout, std::vector<int>(orders, orders + n_coef), std::vector<int>(degrees, degrees + n_coef),
+                              norm, D, nc);
+    std::memcpy(out, D.data(), sizeof(double) * D.size());
+    *n_channels = nc;
+    return 0;
+  } catch (const std::invalid_argument &e) {
+    g_err = e.what();
+    return 1;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 3;
+  }
+}
+double oracle_sph_harm(int n, int m, double az, double el, const char *norm) {
+  return hoa_oracle::sph_harm(n, m, az, el, hoa_oracle::get_norm(norm));
+}
+void oracle_tdesign_points(double *xyz) {
+  const auto p = hoa_oracle::load_points();
+  for (size_t i = 0; i < p.size(); i++) xyz[3 * i] = p[i].x, xyz[3 * i + 1] = p[i].y, xyz[3 * i + 2] = p[i].z;
+}
+}  // extern "C"

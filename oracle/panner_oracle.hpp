@@ -474,3 +474,130 @@ struct GainCalculatorObjects {
 };
 
 }  // namespace panner_oracle
+
+// ------------------------------------------------------------------------------------------------
+// HOA decode matrix (AllRAD): src/hoa/hoa.hpp:16-182, src/hoa/hoa.cpp:4-14,
+// src/hoa/gain_calculator_hoa.cpp:8-72.  Associated Legendre functions and factorials (Boost.Math in the
+// reference) restated from their definitions.
+// ------------------------------------------------------------------------------------------------
+#include "tdesign_5200.h"
+
+namespace hoa_oracle {
+
+using panner_oracle::V3;
+using panner_oracle::Vec;
+
+inline double factorial(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; i++) f *= i;
+  return f;
+}
+// P_n^m(x) WITHOUT the Condon-Shortley phase (hoa.hpp:18-22: (-1)^m * boost::math::legendre_p, which has it):
+// (1 - x^2)^(m/2) d^m/dx^m P_n(x), by the standard upward recurrence in n
+inline double alegendre(int n, int m, double x) {
+  double pmm = 1.0;
+  const double somx2 = std::sqrt((1.0 - x) * (1.0 + x));
+  for (int i = 1; i <= m; i++) pmm *= (2.0 * i - 1.0) * somx2;
+  if (n == m) return pmm;
+  double pmmp1 = x * (2.0 * m + 1.0) * pmm;
+  if (n == m + 1) return pmmp1;
+  double pll = 0.0;
+  for (int ll = m + 2; ll <= n; ll++) {
+    pll = (x * (2.0 * ll - 1.0) * pmmp1 - (ll + m - 1.0) * pmm) / (ll - m);
+    pmm = pmmp1;
+    pmmp1 = pll;
+  }
+  return pll;
+}
+// hoa.hpp:44-76
+inline double norm_N3D(int n, int am) { return std::sqrt((2.0 * n + 1.0) * factorial(n - am) / factorial(n + am)); }
+inline double norm_SN3D(int n, int am) { return std::sqrt(factorial(n - am) / factorial(n + am)); }
+inline double norm_FuMa(int n, int am) {
+  const double f[4][4] = {{1.0 / std::sqrt(2.0), 0, 0, 0},
+                          {1.0, 1.0, 0, 0},
+                          {1.0, 2.0 / std::sqrt(3.0), 2.0 / std::sqrt(3.0), 0},
+                          {1.0, std::sqrt(45.0 / 32.0), 3.0 / std::sqrt(5.0), std::sqrt(8.0 / 5.0)}};
+  if (n > 3) throw std::out_of_range("FuMa is defined up to order 3");
+  return f[n][am] * norm_SN3D(n, am);
+}
+typedef double (*norm_f)(int, int);
+inline norm_f get_norm(const std::string &name) {
+  if (name == "N3D") return norm_N3D;
+  if (name == "SN3D") return norm_SN3D;
+  if (name == "FuMa") return norm_FuMa;
+  throw std::invalid_argument("ADM error: unknown normalization type: '" + name + "'");
+}
+// hoa.hpp:99-112
+inline double sph_harm(int n, int m, double az, double el, norm_f norm) {
+  double scale = 1.0;
+  if (m > 0) scale = std::sqrt(2.0) * std::cos(m * az);
+  else if (m < 0) scale = -std::sqrt(2.0) * std::sin(m * az);
+  return norm(n, std::abs(m)) * alegendre(n, std::abs(m), std::sin(el)) * scale;
+}
+// hoa.cpp:4-14
+inline std::vector<V3> load_points() {
+  std::vector<V3> p(ear_oracle_data::kTDesignPoints);
+  for (int i = 0; i < ear_oracle_data::kTDesignPoints; i++) {
+    const double phi = ear_oracle_data::kTDesign[i][0], theta = ear_oracle_data::kTDesign[i][1];
+    p[i] = {std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta)};
+  }
+  return p;
+}
+// gain_calculator_hoa.cpp:25-71; out: D_full [n_channels][n_coef] row-major (LFE rows zero)
+inline void decode_matrix(const std::string &layout, const std::vector<int> &orders, const std::vector<int> &degrees,
+                          const std::string &normalization, std::vector<double> &out, int &n_channels) {
+  if (orders.size() != degrees.size()) throw std::invalid_argument("orders and degrees must be the same size");
+  for (size_t i = 0; i < orders.size(); i++) {
+    if (orders[i] < 0) throw std::invalid_argument("orders must not be negative");
+    if (std::abs(degrees[i]) > orders[i]) throw std::invalid_argument("magnitude of degree must not be greater than order");
+  }
+  const norm_f norm = get_norm(normalization);
+  std::vector<bool> is_lfe;
+  panner_oracle::layout_without_lfe(layout, &is_lfe);
+  const auto psp = panner_oracle::configure_polar_panner(layout);
+  const std::vector<V3> points = load_points();
+  const size_t P = points.size(), C = orders.size(), S = (size_t)psp->n_out();
+  // Y_virt [C][P] (N3D), G_virt [S][P]
+  std::vector<double> Y(C * P), G(S * P);
+  for (size_t pi = 0; pi < P; pi++) {
+    const double az = -std::atan2(points[pi].x, points[pi].y);
+    const double el = std::atan2(points[pi].z, std::hypot(points[pi].x, points[pi].y));
+    for (size_t c = 0; c < C; c++) Y[c * P + pi] = sph_harm(orders[c], degrees[c], az, el, norm_N3D);
+    const panner_oracle::Opt pv = psp->handle(points[pi]);
+    if (!pv.ok) throw std::runtime_error("point not handled by the panner");
+    for (size_t s = 0; s < S; s++) G[s * P + pi] = pv.v[s];
+  }
+  // D = G_virt * (Y_virt^T / P)
+  std::vector<double> D(S * C, 0.0);
+  for (size_t s = 0; s < S; s++)
+    for (size_t c = 0; c < C; c++) {
+      double acc = 0.0;
+      for (size_t pi = 0; pi < P; pi++) acc += G[s * P + pi] * (Y[c * P + pi] / (double)P);
+      D[s * C + c] = acc;
+    }
+  // normalize_decode_matrix: D *= sqrt(P) / |D Y_virt|_F   (hoa.hpp:140-143)
+  double fro = 0.0;
+  for (size_t s = 0; s < S; s++)
+    for (size_t pi = 0; pi < P; pi++) {
+      double v = 0.0;
+      for (size_t c = 0; c < C; c++) v += D[s * C + c] * Y[c * P + pi];
+      fro += v * v;
+    }
+  const double k = std::sqrt((double)P) / std::sqrt(fro);
+  for (auto &v : D) v *= k;
+  // D *= diag(norm_N3D / norm)   (normalisation_conversion(n, m, norm_N3D, norm), hoa.hpp:147-160)
+  for (size_t c = 0; c < C; c++) {
+    const double conv = norm_N3D(orders[c], std::abs(degrees[c])) / norm(orders[c], std::abs(degrees[c]));
+    for (size_t s = 0; s < S; s++) D[s * C + c] *= conv;
+  }
+  n_channels = (int)is_lfe.size();
+  out.assign((size_t)n_channels * C, 0.0);
+  size_t s = 0;
+  for (size_t ch = 0; ch < is_lfe.size(); ch++) {
+    if (is_lfe[ch]) continue;
+    for (size_t c = 0; c < C; c++) out[ch * C + c] = D[s * C + c];
+    s++;
+  }
+}
+
+}  // namespace hoa_oracle

@@ -338,3 +338,31 @@ def stereo_downmix_handle(xyz):
     xyz = np.ascontiguousarray(xyz, np.float64)
     pv = np.zeros(2, np.float64)
     return pv if lib().oracle_stereo_downmix_handle(ptr(xyz, f64p), ptr(pv, f64p)) else None
+
+
+def hoa_decode_matrix(layout, orders, degrees, normalization="SN3D"):
+    """AllRAD decode matrix of libear's GainCalculatorHOA (oracle/panner_oracle.hpp, hoa_oracle):
+    [n_channels][n_coef] float64, LFE rows zero"""
+    o = np.ascontiguousarray(orders, np.int32)
+    d = np.ascontiguousarray(degrees, np.int32)
+    if len(o) != len(d):
+        raise OracleError(1, "orders and degrees must be the same size")
+    out = np.zeros((64, max(len(o), 1)), np.float64)
+    nch = C.c_int(0)
+    ip = C.POINTER(C.c_int)
+    rc = lib().oracle_hoa_decode_matrix(layout.encode(), len(o), o.ctypes.data_as(ip), d.ctypes.data_as(ip),
+                                        normalization.encode(), ptr(out, f64p), C.byref(nch))
+    if rc:
+        raise OracleError(rc, lib().oracle_last_error().decode())
+    return out.reshape(-1)[:nch.value * len(o)].reshape(nch.value, len(o)).copy()
+
+
+def sph_harm(n, m, az, el, norm="N3D"):
+    lib().oracle_sph_harm.restype = C.c_double
+    return lib().oracle_sph_harm(int(n), int(m), C.c_double(az), C.c_double(el), norm.encode())
+
+
+def tdesign_points():
+    xyz = np.zeros((5200, 3), np.float64)
+    lib().oracle_tdesign_points(ptr(xyz, f64p))
+    return xyz

@@ -627,8 +627,51 @@ static void test_gain_calculator_objects() {
   CHECK(std::fabs(power - 1.0) < 1e-6);
 }
 
+// ---- GainCalculatorHOA (reference tests/gain_calculator_hoa_tests.cpp:39-80) ----------------------------
+static void test_gain_calculator_hoa() {
+  GainCalculatorHOA gc(getLayout("0+5+0"));
+  HOATypeMetadata tm;
+  tm.orders = {0, 1, 1, 1};
+  tm.degrees = {0, -1, 0, 1};
+  std::vector<std::vector<double>> gains(4, std::vector<double>(6));
+  gc.calculate(tm, gains);
+  bool lfe_zero = true;
+  double w_sum = 0;
+  for (int c = 0; c < 4; c++) lfe_zero = lfe_zero && gains[c][3] == 0.0;
+  for (int s = 0; s < 6; s++) w_sum += gains[0][s];
+  CHECK(lfe_zero);
+  CHECK(w_sum > 0.5);  // the omnidirectional component feeds every loudspeaker with the same sign
+  CHECK(gains[3][0] > 0.0 && gains[3][1] > 0.0 && gains[3][4] < 0.0);  // X (front-back): front positive, rear negative
+  CHECK(gains[1][0] > 0.0 && gains[1][1] < 0.0);                        // Y (left-right): left positive, right negative
+  auto throws_invalid = [&](HOATypeMetadata m) {
+    try {
+      gc.calculate(m, gains);
+    } catch (const ear::invalid_argument &) {
+      return true;
+    }
+    return false;
+  };
+  HOATypeMetadata m = tm;
+  m.degrees.pop_back();
+  CHECK(throws_invalid(m));
+  m = tm;
+  m.orders[0] = -1;
+  CHECK(throws_invalid(m));
+  m = tm;
+  m.degrees[3] = 2;
+  CHECK(throws_invalid(m));
+  m = tm;
+  m.degrees[3] = -2;
+  CHECK(throws_invalid(m));
+  m = tm;
+  m.normalization = "foo";
+  CHECK(throws_invalid(m));
+  CHECK(!throws_invalid(tm));
+}
+
 int main() {
   try {
+    test_gain_calculator_hoa();
     test_gain_calculator_objects();
     test_ptr_adapter();
     test_layout_names();

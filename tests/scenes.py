@@ -206,17 +206,17 @@ def mixed_level_sparse(n_obj, n_out, block, n_blocks, lfe=(), span_db=100.0, see
     return curves, levels
 
 
-def moving_sources(n_obj, total, period=960, seed=31):
+def moving_sources(n_obj, total, period=960, seed=31, phase=None, ramp=None):
     """ADM-like trajectories: every `period` samples, at a per-object phase, an object gets a new position
     (a random walk in azimuth / elevation) and diffuseness, reached over a quarter of the period and then
     held.  Returns per object (azimuth, elevation, diffuse, times) arrays of its curve points: the values
     feed a gain producer, the result is a gain curve like adm_curves()."""
     rng = np.random.default_rng(seed)
     az, el, df, times = [], [], [], []
-    ramp = max(period // 4, 1)
+    ramp = max(period // 4, 1) if ramp is None else ramp
     for m in range(n_obj):
-        phase = int(rng.integers(0, period))
-        starts = np.arange(phase - period, total + period, period, dtype=np.int64)
+        ph = int(rng.integers(0, period)) if phase is None else phase
+        starts = np.arange(ph - period, total + period, period, dtype=np.int64)
         k = len(starts) + 1
         a = np.cumsum(rng.normal(0.0, 25.0, k)) + rng.uniform(-180, 180)
         a = (a + 180.0) % 360.0 - 180.0

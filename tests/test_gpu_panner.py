@@ -114,3 +114,67 @@ def test_panned_scene_renders_within_tolerance():
     want = w.process(x)
     assert scenes.rel_rms(got, want) <= 1e-6
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6
+
+
+@pytest.mark.parametrize("layout,order,norm", [("0+5+0", 1, "SN3D"), ("9+10+3", 3, "SN3D"), ("4+5+0", 3, "N3D"),
+                                               ("4+7+0", 3, "FuMa"), ("0+2+0", 2, "SN3D"), ("9+10+3", 5, "N3D")])
+def test_hoa_decode_matrix_equals_oracle(layout, order, norm):
+    """earhip_hoa_decode_matrix (AllRAD: the point source panner sampled on the device at the 5200 design
+    directions) vs the oracle's restatement of GainCalculatorHOA: float32 values within 1e-6"""
+    from libear_amd import capi
+    idx = [(n, m) for n in range(order + 1) for m in range(-n, n + 1)]
+    orders, degrees = [n for n, _ in idx], [m for _, m in idx]
+    got = capi.hoa_decode_matrix(ctx(), layout, orders, degrees, norm)
+    want = _oracle.hoa_decode_matrix(layout, orders, degrees, norm)
+    assert got.shape == want.shape == (len(LAYOUTS[layout]), len(idx))
+    assert np.max(np.abs(got - want)) <= 1e-6 * max(1.0, np.max(np.abs(want)))
+    lfe = [i for i, nm in enumerate(LAYOUTS[layout]) if nm.startswith("LFE")]
+    assert not got[lfe].any()
+
+
+def test_hoa_exceptions():
+    """tests/gain_calculator_hoa_tests.cpp:39-80"""
+    from libear_amd import capi
+    for orders, degrees in (([0, 1, 1, 1], [0, -1, 0]), ([-1, 1, 1, 1], [0, -1, 0, 1]), ([0, 1, 1, 1], [0, -1, 0, 2]),
+                            ([0, 1, 1, 1], [0, -1, 0, -2])):
+        with pytest.raises(capi.InvalidArgument):
+            capi.hoa_decode_matrix(ctx(), "0+5+0", orders, degrees)
+    with pytest.raises(capi.InvalidArgument) as e:
+        capi.hoa_decode_matrix(ctx(), "0+5+0", [0], [0], "foo")
+    assert "unknown normalization" in str(e.value)
+
+
+def test_hoa_bed_through_the_renderer_with_the_real_decode_matrix():
+    """BASELINE config 5's shape with libear's actual decode matrix: an order-3 bed (16 channels, constant
+    gains = the columns of the AllRAD matrix) + objects panned by the device producer, block 1024"""
+    import scenes
+    from libear_amd import capi
+    layout, block, nblocks, n_obj = "9+10+3", 1024, 3, 48
+    names = LAYOUTS[layout]
+    n = len(names)
+    idx = [(a, b) for a in range(4) for b in range(-a, a + 1)]
+    D = capi.hoa_decode_matrix(ctx(), layout, [a for a, _ in idx], [b for _, b in idx], "SN3D")
+    Dw = _oracle.hoa_decode_matrix(layout, [a for a, _ in idx], [b for _, b in idx], "SN3D").astype(np.float32)
+    total = block * nblocks
+    dec = capi.design_decorrelators(names)
+    az, el, df, tms = scenes.moving_sources(n_obj, total, period=1024, seed=2, phase=0, ramp=1024)
+    p = capi.Panner(ctx(), layout)
+    o = _oracle.GainCalculatorObjects(layout)
+    curves = [(np.zeros(1, np.int64), D[:, c][None, :].copy(), np.zeros((1, n), np.float32)) for c in range(16)]
+    wcurves = [(np.zeros(1, np.int64), Dw[:, c][None, :].copy(), np.zeros((1, n), np.float32)) for c in range(16)]
+    for i in range(n_obj):
+        curves.append((tms[i],) + p.calculate(az[i], el[i], None, None, df[i]))
+        wcurves.append((tms[i],) + o.calculate(az[i], el[i], None, None, df[i]))
+    p.close()
+    x = scenes.audio(16 + n_obj, total, seed=3)
+    r = capi.Renderer(ctx(), 16 + n_obj, n, block, dec, 255, max_blocks=nblocks)
+    for i, (t, d, f) in enumerate(curves):
+        r.set_object_points(i, t, d, f)
+    got = r.process(x)
+    r.close()
+    w = _oracle.ObjectsRenderer(16 + n_obj, n, block, dec, 255)
+    for i, (t, d, f) in enumerate(wcurves):
+        w.set_points(i, 0, t, d)
+        w.set_points(i, 1, t, f)
+    want = w.process(x)
+    assert scenes.rel_rms(got, want) <= 1e-6 and scenes.rel_rms_per_channel(got, want) <= 1e-6
