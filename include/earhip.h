@@ -323,6 +323,39 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind);
  * For tests and benchmarks that must know which kernel instantiation they measured. */
 int earhip_render_last_plan(const earhip_render *r, int out[4]);
 
+/* ------------------------------------------------------------------------
+ * (J) Multi-GPU exchange — no libear counterpart (libear is single-device).  Objects are
+ * sharded over the GPUs of one node, one process and one earhip_ctx per GPU; every rank
+ * renders its shard completely with (F) — everything after the buses is linear and per
+ * channel — and the partial outputs are summed by ONE RCCL reduce-scatter over the
+ * channel axis on the context's stream (xGMI): rank r ends up owning rows
+ * [r * per, (r + 1) * per) of the shared bus.
+ *   earhip_comm_unique_id: rank 0 makes the 128-byte id; the caller hands it to every
+ *     rank by its own means (MPI, torch.distributed, a socket, a file);
+ *   earhip_comm_create: collective over all ranks (ncclCommInitRank);
+ *   earhip_comm_channel_range: rows of the exchange buffers (n_out rounded up to a
+ *     multiple of the ranks; the rows past n_out must be zero) and the channels [lo, hi)
+ *     rank `rank` owns — ragged when the ranks do not divide n_out (10 channels on 4
+ *     ranks: 3, 3, 3, 1);
+ *   earhip_render_exchange_device: partial_dev [padded_rows][row_stride] ->
+ *     owned_dev [rows_per_rank][row_stride].  Ordered behind everything enqueued on the
+ *     context's stream so far (the render that wrote partial_dev) but run on the
+ *     communicator's own stream, so that it overlaps the next render; does not
+ *     synchronise the host.  slot (0 or 1) names one of two exchanges in flight
+ *     (double-buffered outputs);
+ *   earhip_comm_wait(slot): work enqueued on the context's stream after this call runs
+ *     after the last exchange issued with that slot — call it before rendering into that
+ *     slot's partial buffer again and before reading its owned buffer.
+ * ---------------------------------------------------------------------- */
+typedef struct earhip_comm earhip_comm;
+int earhip_comm_unique_id(void *id128);
+int earhip_comm_create(earhip_ctx *ctx, int rank, int world, const void *id128, earhip_comm **out);
+int earhip_comm_destroy(earhip_comm *comm);
+int earhip_comm_channel_range(int n_out, int rank, int world, int *padded_rows, int *lo, int *hi);
+int earhip_render_exchange_device(earhip_comm *comm, int slot, const float *partial_dev,
+                                  float *owned_dev, size_t rows_per_rank, size_t row_stride);
+int earhip_comm_wait(earhip_comm *comm, int slot);
+
 #ifdef __cplusplus
 }
 #endif

@@ -368,6 +368,41 @@ class Panner:
             self.h = C.c_void_p()
 
 
+class Comm:
+    """(J) RCCL communicator of the multi-GPU exchange: one per rank, made from rank 0's 128-byte id"""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(load().earhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def channel_range(n_out, rank, world):
+        pad, lo, hi = C.c_int(), C.c_int(), C.c_int()
+        check(load().earhip_comm_channel_range(n_out, rank, world, C.byref(pad), C.byref(lo), C.byref(hi)))
+        return pad.value, lo.value, hi.value
+
+    def __init__(self, ctx, rank, world, uid):
+        assert len(uid) == 128
+        self.rank, self.world = rank, world
+        self.h = C.c_void_p()
+        check(load().earhip_comm_create(ctx.h, rank, world, uid, C.byref(self.h)))
+
+    def exchange_device(self, slot, partial_ptr, owned_ptr, rows_per_rank, row_stride):
+        check(load().earhip_render_exchange_device(self.h, int(slot), C.c_void_p(partial_ptr), C.c_void_p(owned_ptr),
+                                                   C.c_size_t(rows_per_rank), C.c_size_t(row_stride)))
+
+    def wait(self, slot):
+        """orders the context's stream behind the last exchange issued with this slot"""
+        check(load().earhip_comm_wait(self.h, int(slot)))
+
+    def close(self):
+        if self.h:
+            load().earhip_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def hoa_decode_matrix(ctx, layout, orders, degrees, normalization="SN3D"):
     """(I, HOA) AllRAD decode matrix [n_channels][n_coef] float32"""
     o = np.ascontiguousarray(orders, np.int32)

@@ -1,0 +1,120 @@
+// api_comm.hip — (J) the one exchange step of the multi-GPU render of include/earhip.h: objects are
+// sharded over the GPUs of a node, every GPU renders its shard COMPLETELY (the chain after the buses is
+// linear and per channel), and the partial loudspeaker outputs are summed by one RCCL reduce-scatter
+// over the channel axis on the context's stream: every rank ends up owning a slice of the channels of the
+// shared bus.  libear has no such step (it is single-threaded, single-device): nothing to cite.  The
+// process-group part (who is rank r, how the 128-byte id reaches every rank) stays with the caller —
+// MPI, torch.distributed, a file: this library only needs the id.
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+
+#include "common.h"
+
+using namespace earhip;
+
+#define EARHIP_NCCL(expr)                                                                       \
+  do {                                                                                          \
+    ncclResult_t r_ = (expr);                                                                   \
+    if (r_ != ncclSuccess)                                                                      \
+      throw ::earhip::Error{EARHIP_DEVICE_ERROR,                                                \
+                            std::string("internal error: RCCL: ") + ncclGetErrorString(r_) + " in " #expr}; \
+  } while (0)
+
+struct earhip_comm {
+  earhip_ctx *ctx;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  // the collective runs on its own stream, ordered against the context's stream by events, so that it
+  // overlaps the next render: ready (render of this buffer done), done[slot] (exchange of slot done)
+  hipStream_t xstream = nullptr;
+  hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
+  bool issued[2] = {false, false};
+};
+
+extern "C" {
+
+int earhip_comm_unique_id(void *id128) {
+  return guarded([&] {
+    require(id128 != nullptr, "id must not be NULL");
+    static_assert(sizeof(ncclUniqueId) == 128, "the C ABI hands the id around as 128 bytes");
+    ncclUniqueId id;
+    EARHIP_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+  });
+}
+
+int earhip_comm_create(earhip_ctx *ctx, int rank, int world, const void *id128, earhip_comm **out) {
+  return guarded([&] {
+    require(ctx != nullptr && id128 != nullptr && out != nullptr, "NULL argument");
+    require(world >= 1 && rank >= 0 && rank < world, "rank / world out of range");
+    ctx->use();
+    std::unique_ptr<earhip_comm> c(new earhip_comm);
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    EARHIP_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    EARHIP_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    EARHIP_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    for (auto &e : c->done) EARHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = c.release();
+  });
+}
+
+int earhip_comm_destroy(earhip_comm *c) {
+  return guarded([&] {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    for (auto e : c->done)
+      if (e) (void)hipEventDestroy(e);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    delete c;
+  });
+}
+
+// rows of the exchange buffers: n_out rounded up to a multiple of the ranks; rank r owns the channels
+// [lo, hi) = rows [r * per, (r + 1) * per) clipped to n_out (ragged when the ranks do not divide n_out)
+int earhip_comm_channel_range(int n_out, int rank, int world, int *padded_rows, int *lo, int *hi) {
+  return guarded([&] {
+    require(n_out >= 1 && world >= 1 && rank >= 0 && rank < world, "arguments out of range");
+    const int per = (n_out + world - 1) / world;
+    if (padded_rows) *padded_rows = per * world;
+    if (lo) *lo = std::min(rank * per, n_out);
+    if (hi) *hi = std::min((rank + 1) * per, n_out);
+  });
+}
+
+int earhip_render_exchange_device(earhip_comm *c, int slot, const float *partial_dev, float *owned_dev,
+                                  size_t rows_per_rank, size_t row_stride) {
+  return guarded([&] {
+    require(c != nullptr && partial_dev != nullptr && owned_dev != nullptr, "NULL argument");
+    require(slot == 0 || slot == 1, "slot must be 0 or 1");
+    require(rows_per_rank >= 1 && row_stride >= 1, "empty exchange");
+    c->ctx->use();
+    // behind everything enqueued on the context's stream so far (the render that wrote partial_dev) ...
+    EARHIP_HIP(hipEventRecord(c->ready, c->ctx->stream));
+    EARHIP_HIP(hipStreamWaitEvent(c->xstream, c->ready, 0));
+    EARHIP_NCCL(ncclReduceScatter(partial_dev, owned_dev, rows_per_rank * row_stride, ncclFloat, ncclSum, c->comm, c->xstream));
+    // ... and ahead of whatever the caller orders behind earhip_comm_wait(slot)
+    EARHIP_HIP(hipEventRecord(c->done[slot], c->xstream));
+    c->issued[slot] = true;
+  });
+}
+
+int earhip_comm_wait(earhip_comm *c, int slot) {
+  return guarded([&] {
+    require(c != nullptr, "comm must not be NULL");
+    require(slot == 0 || slot == 1, "slot must be 0 or 1");
+    if (!c->issued[slot]) return;
+    EARHIP_HIP(hipStreamWaitEvent(c->ctx->stream, c->done[slot], 0));
+  });
+}
+
+}  // extern "C"

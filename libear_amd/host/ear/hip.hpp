@@ -36,6 +36,47 @@ namespace ear {
       earhip_ctx *ctx_ = nullptr;
     };
 
+    /// The exchange step of the multi-GPU render (earhip group J): one Communicator per rank, created
+    /// collectively from the 128-byte id rank 0 makes with unique_id() and the caller distributes.
+    class Communicator {
+     public:
+      struct Id {
+        char bytes[128];
+      };
+      static Id unique_id() {
+        Id id;
+        check(earhip_comm_unique_id(id.bytes));
+        return id;
+      }
+      Communicator(Context &ctx, int rank, int world, const Id &id) : rank_(rank), world_(world) {
+        check(earhip_comm_create(ctx.get(), rank, world, id.bytes, &comm_));
+      }
+      ~Communicator() { earhip_comm_destroy(comm_); }
+      Communicator(const Communicator &) = delete;
+      Communicator &operator=(const Communicator &) = delete;
+      /// rows of the exchange buffers for n_out channels
+      int padded_rows(int n_out) const {
+        int rows = 0;
+        check(earhip_comm_channel_range(n_out, rank_, world_, &rows, nullptr, nullptr));
+        return rows;
+      }
+      /// channels [lo, hi) of the shared bus this rank owns after the exchange
+      void channel_range(int n_out, int &lo, int &hi) const {
+        check(earhip_comm_channel_range(n_out, rank_, world_, nullptr, &lo, &hi));
+      }
+      /// sum the ranks' partial outputs (device buffers, [padded_rows][row_stride] -> [padded_rows / world][row_stride])
+      void exchange(int slot, const float *partial_dev, float *owned_dev, int n_out, size_t row_stride) {
+        check(earhip_render_exchange_device(comm_, slot, partial_dev, owned_dev, (size_t)(padded_rows(n_out) / world_), row_stride));
+      }
+      void wait(int slot) { check(earhip_comm_wait(comm_, slot)); }
+      int rank() const { return rank_; }
+      int world() const { return world_; }
+
+     private:
+      earhip_comm *comm_ = nullptr;
+      int rank_, world_;
+    };
+
     /// Context used by the drop-in classes whose libear signature has no place
     /// for one.  Device from $EARHIP_DEVICE (default 0).  Throws
     /// ear::internal_error when no GPU is present: there is no CPU fallback.
