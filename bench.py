@@ -166,6 +166,14 @@ def main():
     ctx = capi.Context(dev_index, stream.cuda_stream)
     ctx.set_strict(args.strict)
 
+    # the exchange step: torch.distributed's reduce_scatter_tensor (default) or the library's own RCCL
+    # communicator (EARHIP_BENCH_EXCHANGE=native: what a C++ caller of libearhip uses, earhip group J)
+    native_comm = None
+    if world > 1 and backend == "nccl" and os.environ.get("EARHIP_BENCH_EXCHANGE") == "native":
+        box = [capi.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        native_comm = capi.Comm(ctx, rank, world, box[0])
+
     class Workload:
         """this rank's shard of a scene of `objects` objects (+ `hoa` bed channels on rank 0), resident
         in HBM, with its renderer and double-buffered output / exchange buffers"""
@@ -237,18 +245,25 @@ def main():
             if self.pending[buf] is not None:  # the exchange that last read this buffer must be done
                 self.pending[buf].wait()
                 self.pending[buf] = None
+            if native_comm is not None:
+                native_comm.wait(buf)
             r = r or self.r
             r.reset(0)
             r.process_device(T, self.x.data_ptr(), self.in_stride, self.outs[buf].data_ptr(), total)
             if world > 1 and exchange_outputs:
-                _, work = exchange(self.outs[buf], self.owned[buf], async_op=True)
-                self.pending[buf] = work
+                if native_comm is not None:
+                    native_comm.exchange_device(buf, self.outs[buf].data_ptr(), self.owned[buf].data_ptr(), n_pad // world, total)
+                else:
+                    _, work = exchange(self.outs[buf], self.owned[buf], async_op=True)
+                    self.pending[buf] = work
 
         def drain(self):
             for b in range(2):
                 if self.pending[b] is not None:
                     self.pending[b].wait()
                     self.pending[b] = None
+                if native_comm is not None:
+                    native_comm.wait(b)
 
         def timed(self, steps, warmup, precondition_ms=0.0, r=None, timing_every=0):
             """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
@@ -408,7 +423,8 @@ def main():
                 "workload": workload, "baseline_config": args.config,
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
                 "blocks_per_step": T, "buses": K, "scene": args.scene, "gains": gains_desc,
-                "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels",
+                "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels"
+                               + (" (libearhip's own RCCL communicator)" if native_comm is not None else ""),
                 "strict": bool(args.strict)},
             "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"),
                          "plan": {"tile_samples": plan["tile"], "tiles": plan["ntiles"], "object_splits": plan["gsplit"]},
@@ -607,6 +623,8 @@ def main():
         print(json.dumps(result), flush=True)
 
     wl.close()
+    if native_comm is not None:
+        native_comm.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -210,6 +210,7 @@ struct GainStage {
   CurveSet curves;
   DevBuf<SegDesc> desc;
   DevBuf<float> parts;  // grid-level partial slabs
+  std::vector<float> rows;  // scratch of the policy entry points (two gain rows)
   bool force_ramp;
   GainStage(earhip_ctx *c, int ni, int no, bool ramp = false)
       : ctx(c), n_in(ni), n_out(no), curves(ni, no, 1, ramp), force_ramp(ramp) {}
@@ -515,7 +516,8 @@ int earhip_interp_apply_interp(earhip_ctx *ctx, int n_in, int n_out, const float
     // [start, end) and between equal points, like a direct call of apply_interp,
     // gain_interpolator.hpp:147-169)
     const int64_t t[2] = {start, end};
-    std::vector<float> rows(2 * (size_t)n_out);
+    std::vector<float> &rows = st->rows;
+    rows.resize(2 * (size_t)n_out);
     for (int m = 0; m < n_in; m++) {
       std::memcpy(rows.data(), start_point + (size_t)m * n_out, sizeof(float) * n_out);
       std::memcpy(rows.data() + n_out, end_point + (size_t)m * n_out, sizeof(float) * n_out);

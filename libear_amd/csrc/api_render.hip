@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -96,6 +98,69 @@ static int wave_run_len(int T, int N, int num_cus) {
   return best;
 }
 
+// Staging threads of the host-pointer entry point, started at the first long call and kept: a call
+// neither creates threads nor allocates.  A job = gather the channels of kGroups channel groups into
+// the pinned buffer, thread t taking every nthreads-th channel of a group; done[g] counts the threads
+// that have finished group g (the caller starts that group's transfer then).
+struct GatherPool {
+  static constexpr int kGroups = 8;
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable go, finished_cv;
+  uint64_t generation = 0;
+  int finished = 0;
+  bool quit = false;
+  // the job
+  const float *const *in = nullptr;
+  float *dst = nullptr;
+  size_t n = 0;
+  int M = 0;
+  std::atomic<int> done[kGroups];
+  int group_lo(int g) const { return (int)((int64_t)M * g / kGroups); }
+  int nthreads() const { return (int)threads.size(); }
+  void start(int count) {
+    for (int t = 0; t < count; t++)
+      threads.emplace_back([this, t] {
+        uint64_t seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            go.wait(lk, [&] { return quit || generation != seen; });
+            if (quit) return;
+            seen = generation;
+          }
+          const int nt = nthreads();
+          for (int g = 0; g < kGroups; g++) {
+            for (int m = group_lo(g) + t; m < group_lo(g + 1); m += nt) std::memcpy(dst + (size_t)m * n, in[m], sizeof(float) * n);
+            done[g].fetch_add(1, std::memory_order_release);
+          }
+          std::lock_guard<std::mutex> lk(mu);
+          if (++finished == nt) finished_cv.notify_one();
+        }
+      });
+  }
+  void submit(const float *const *in_, float *dst_, size_t n_, int M_) {
+    std::lock_guard<std::mutex> lk(mu);
+    in = in_, dst = dst_, n = n_, M = M_;
+    for (auto &d : done) d.store(0);
+    finished = 0;
+    generation++;
+    go.notify_all();
+  }
+  void wait_all() {
+    std::unique_lock<std::mutex> lk(mu);
+    finished_cv.wait(lk, [&] { return finished == nthreads(); });
+  }
+  ~GatherPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    go.notify_all();
+    for (auto &th : threads) th.join();
+  }
+};
+
 struct earhip_render {
   earhip_ctx *ctx = nullptr;
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
@@ -117,6 +182,7 @@ struct earhip_render {
   // host-pointer staging
   DevBuf<float> d_in, d_out;
   PinBuf<float> p_in, p_out;
+  std::unique_ptr<GatherPool> gather;  // staging threads of long host-pointer calls
   // timing
   bool timing = false;
   int timing_every = 1;      // time every n-th process call (the event records cost ~3 us of idle GPU each)
@@ -418,32 +484,24 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
       EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
-      // Long calls: the staging copy is what bounds the host-pointer path, so several
-      // threads gather the channels into the pinned buffer, group of channels by group,
-      // and each group's H2D transfer starts while the next group is being gathered.
-      const int G = 8;
-      const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-      std::atomic<int> done[G];
-      for (auto &d : done) d.store(0);
-      auto group_lo = [&](int g) { return (int)((int64_t)r->M * g / G); };
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthreads; t++)
-        pool.emplace_back([&, t] {
-          for (int g = 0; g < G; g++) {
-            for (int m = group_lo(g) + t; m < group_lo(g + 1); m += nthreads)
-              std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
-            done[g].fetch_add(1, std::memory_order_release);
-          }
-        });
+      // Long calls: the staging copy is what bounds the host-pointer path, so several (persistent)
+      // threads gather the channels into the pinned buffer, group of channels by group, and each
+      // group's H2D transfer starts while the next group is being gathered.
+      if (!r->gather) {
+        r->gather.reset(new GatherPool);
+        r->gather->start((int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+      }
+      GatherPool &gp = *r->gather;
+      gp.submit(in, r->p_in.p, n, r->M);
       hipError_t err = hipSuccess;
-      for (int g = 0; g < G; g++) {
-        while (done[g].load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
-        const size_t lo = (size_t)group_lo(g) * n, hi = (size_t)group_lo(g + 1) * n;
+      for (int g = 0; g < GatherPool::kGroups; g++) {
+        while (gp.done[g].load(std::memory_order_acquire) < gp.nthreads()) std::this_thread::yield();
+        const size_t lo = (size_t)gp.group_lo(g) * n, hi = (size_t)gp.group_lo(g + 1) * n;
         if (err == hipSuccess && hi > lo)
           err = hipMemcpyAsync(r->d_in.p + lo, r->p_in.p + lo, sizeof(float) * (hi - lo),
                                hipMemcpyHostToDevice, ctx->stream);
       }
-      for (auto &th : pool) th.join();
+      gp.wait_all();
       EARHIP_HIP(err);
     }
     r->process_device(nblocks, r->d_in.p, n, r->d_out.p, n);

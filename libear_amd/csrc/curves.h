@@ -161,7 +161,8 @@ class CurveSet {
     const int grids[2] = {512, 256};
     for (int gi = 0; gi < 2; gi++) {
       const int64_t G = grids[gi];
-      std::vector<int64_t> phase(M_, -1);  // -1: the object's points do not share a phase
+      std::vector<int64_t> &phase = scratch_phase_;  // (members: commit runs inside process calls of the policies)
+      phase.assign(M_, -1);  // -1: the object's points do not share a phase
       for (int m = 0; m < M_; m++) {
         const auto &t = times_[m];
         if (t.empty()) continue;
@@ -170,7 +171,8 @@ class CurveSet {
         for (int64_t v : t) same = same && (((v % G) + G) % G) == p0;
         if (same) phase[m] = p0;
       }
-      std::vector<int64_t> sorted;
+      std::vector<int64_t> &sorted = scratch_sorted_;
+      sorted.clear();
       for (int m = 0; m < M_; m++)
         if (phase[m] >= 0) sorted.push_back(phase[m]);
       std::sort(sorted.begin(), sorted.end());
@@ -294,6 +296,7 @@ class CurveSet {
   PinBuf<uint8_t> h_flat_;
   PinBuf<float> h_gain_;
   hipEvent_t staged_ = nullptr;
+  std::vector<int64_t> scratch_phase_, scratch_sorted_;
 };
 
 // How K1 is spread over the chip for one call.

@@ -114,9 +114,13 @@ namespace ear {
 
     /// M -> N; points hold one vector of per-output gains per input channel
     struct LinearInterpMatrix : public InterpType<std::vector<std::vector<float>>> {
-      static std::vector<float> flatten(const Point &p) {
+      /// dense row-major copy of a point in per-thread scratch `which` (grown once: no allocation in
+      /// process(), like libear — tests/gain_interpolator_tests.cpp:1,89,96)
+      static const std::vector<float> &flatten(const Point &p, int which) {
+        static thread_local std::vector<float> scratch[2];
+        std::vector<float> &flat = scratch[which];
         const size_t n_out = p.empty() ? 0 : p[0].size();
-        std::vector<float> flat(p.size() * n_out);
+        flat.resize(p.size() * n_out);
         for (size_t i = 0; i < p.size(); i++) {
           ear_assert(p[i].size() == n_out, "ragged gain matrix");
           std::copy(p[i].begin(), p[i].end(), flat.begin() + i * n_out);
@@ -127,7 +131,7 @@ namespace ear {
                                SampleIndex range_end, SampleIndex block_start, SampleIndex start,
                                SampleIndex end, const Point &start_point, const Point &end_point) {
         if (start_point.empty() || start_point[0].empty()) return;
-        const std::vector<float> s = flatten(start_point), e = flatten(end_point);
+        const std::vector<float> &s = flatten(start_point, 0), &e = flatten(end_point, 1);
         ear_assert(s.size() == e.size(), "points differ in size");
         hip::check(earhip_interp_apply_interp(hip::default_context().get(), (int)start_point.size(),
                                               (int)start_point[0].size(), in, out, range_start,
@@ -137,7 +141,7 @@ namespace ear {
       static void apply_constant(const float *const *in, float *const *out, SampleIndex range_start,
                                  SampleIndex range_end, const Point &point) {
         if (point.empty() || point[0].empty()) return;
-        const std::vector<float> p = flatten(point);
+        const std::vector<float> &p = flatten(point, 0);
         hip::check(earhip_interp_apply_constant(hip::default_context().get(), (int)point.size(),
                                                 (int)point[0].size(), in, out, range_start,
                                                 range_end, p.data()));

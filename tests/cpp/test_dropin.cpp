@@ -6,10 +6,15 @@
 // double precision, so this program needs nothing but libearhip.so and a GPU.
 // Build (one line): g++ -std=c++14 -Iinclude -Ilibear_amd/host tests/cpp/test_dropin.cpp
 //            -Llibear_amd/lib -learhip -Wl,-rpath,$PWD/libear_amd/lib -o test_dropin
+#include <dlfcn.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <new>
 #include <random>
 #include <vector>
 
@@ -19,6 +24,38 @@
 
 using namespace ear;
 using namespace ear::dsp;
+
+// ---- heap watch: while armed, every operator new issued from this program (the mirror headers are
+// header-only, so their allocations are here) or from libearhip.so is counted; the HIP runtime's own
+// allocations are not ours to judge.  libear enforces the same for its process() calls with
+// EIGEN_RUNTIME_NO_MALLOC (reference tests/gain_interpolator_tests.cpp:1,89,96).
+static std::atomic<bool> g_heap_armed{false};
+static std::atomic<long> g_heap_count{0};
+static void note_allocation(void *caller) {
+  if (!g_heap_armed.load(std::memory_order_relaxed)) return;
+  g_heap_armed.store(false);  // (dladdr may allocate)
+  Dl_info info;
+  if (dladdr(caller, &info) && info.dli_fname &&
+      (std::strstr(info.dli_fname, "libearhip") || std::strstr(info.dli_fname, "test_dropin")))
+    g_heap_count++;
+  g_heap_armed.store(true);
+}
+void *operator new(std::size_t n) {
+  note_allocation(__builtin_return_address(0));
+  void *p = std::malloc(n ? n : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void *operator new[](std::size_t n) {
+  note_allocation(__builtin_return_address(0));
+  void *p = std::malloc(n ? n : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
 
 static int g_failed = 0, g_checks = 0;
 #define CHECK(cond)                                                         \
@@ -669,8 +706,65 @@ static void test_gain_calculator_hoa() {
   CHECK(!throws_invalid(tm));
 }
 
+// ---- no heap allocation in any process() call once warmed up (the reference enforces it for
+// GainInterpolator in tests/gain_interpolator_tests.cpp:89-96) ------------------------------------------
+static void test_no_allocation_in_process() {
+  using namespace ear::dsp::block_convolver;
+  const size_t B = 512, n_in = 12, n_out = 6;
+  std::vector<Vec> in(n_in), out(n_out, Vec(B * 64));
+  for (size_t c = 0; c < n_in; c++) in[c] = random_vec(B * 64, 100 + (unsigned)c);
+  std::vector<const float *> ip(n_in);
+  std::vector<float *> op(n_out);
+  for (size_t c = 0; c < n_in; c++) ip[c] = in[c].data();
+  for (size_t c = 0; c < n_out; c++) op[c] = out[c].data();
+
+  GainInterpolator<LinearInterpVector> vec_interp;
+  vec_interp.interp_points.emplace_back(0, std::vector<float>(n_out, 0.25f));
+  vec_interp.interp_points.emplace_back(700, std::vector<float>(n_out, 0.75f));
+  GainInterpolator<LinearInterpMatrix> mat_interp;
+  mat_interp.interp_points.emplace_back(0, std::vector<std::vector<float>>(n_in, std::vector<float>(n_out, 0.1f)));
+  mat_interp.interp_points.emplace_back(900, std::vector<std::vector<float>>(n_in, std::vector<float>(n_out, 0.3f)));
+  Context cctx(B, get_fft_hip());
+  const Vec taps = random_vec(700, 5);
+  Filter filt(cctx, taps.size(), taps.data());
+  BlockConvolver conv(cctx, filt);
+  DelayBuffer delay(n_out, 255);
+  const auto dec = designDecorrelators("0+5+0");
+  ObjectsRenderer block_renderer(n_in, n_out, B, dec, 255, 1), stream_renderer(n_in, n_out, B, dec, 255, 64);
+  for (size_t m = 0; m < n_in; m++) {
+    const std::vector<std::vector<float>> g = {std::vector<float>(n_out, 0.1f), std::vector<float>(n_out, 0.2f)};
+    block_renderer.set_object_points(m, {0, 4096}, g, g);
+    stream_renderer.set_object_points(m, {0, 4096}, g, g);
+  }
+  VariableBlockSizeAdapter adapter(B, n_in, n_out,
+                                   [&](const float *const *i, float *const *o) { block_renderer.process(i, o); });
+  auto all = [&](long t) {
+    vec_interp.process(t, B, ip.data(), op.data());
+    mat_interp.process(t, B, ip.data(), op.data());
+    conv.process(in[0].data(), out[0].data());
+    delay.process(B, ip.data(), op.data());
+    block_renderer.process(ip.data(), op.data());
+    stream_renderer.process(64, ip.data(), op.data());
+    adapter.process(300, ip.data(), op.data());
+    adapter.process(700, ip.data(), op.data());
+  };
+  for (long t = 0; t < 3; t++) all(t * (long)B);  // warm-up: staging buffers grow here
+  g_heap_count = 0;
+  g_heap_armed = true;
+  for (long t = 3; t < 8; t++) all(t * (long)B);
+  g_heap_armed = false;
+  if (g_heap_count != 0) std::printf("  %ld heap allocations in steady-state process() calls\n", (long)g_heap_count);
+  CHECK(g_heap_count == 0);
+  // the watch itself works: an allocation of this program is seen
+  g_heap_armed = true;
+  { std::vector<int> v(1000); (void)v; }
+  g_heap_armed = false;
+  CHECK(g_heap_count >= 1);
+}
+
 int main() {
   try {
+    test_no_allocation_in_process();
     test_gain_calculator_hoa();
     test_gain_calculator_objects();
     test_ptr_adapter();

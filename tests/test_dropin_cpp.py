@@ -17,7 +17,7 @@ def build(tmp_path):
     libdir = os.path.join(ROOT, "libear_amd", "lib")
     cmd = ["g++", "-std=c++14", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "libear_amd", "host"), os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"),
-           "-L" + libdir, "-learhip", "-Wl,-rpath," + libdir, "-o", exe]
+           "-L" + libdir, "-learhip", "-ldl", "-Wl,-rpath," + libdir, "-o", exe]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout
     return exe
