@@ -37,8 +37,10 @@ BF16_PEAK_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak, same guide
 SAMPLE_RATE = 48000.0
 
 PRESETS = {  # BASELINE.json `configs` (C2..C5)
-    "C2": dict(objects=64, hoa=0, layout="4+5+0", block_size=512, buses=1, blocks=1024),
-    "C3": dict(objects=256, hoa=0, layout="9+10+3", block_size=512, buses=2, blocks=1024),
+    # (blocks per step: every configuration streams about the same number of object-blocks per step as the
+    # headline, 2^20 — a 64-object call of 1024 blocks is 40 us of GPU time, a fifth of it launch overhead)
+    "C2": dict(objects=64, hoa=0, layout="4+5+0", block_size=512, buses=1, blocks=8192),
+    "C3": dict(objects=256, hoa=0, layout="9+10+3", block_size=512, buses=2, blocks=4096),
     "C4": dict(objects=1024, hoa=0, layout="9+10+3", block_size=512, buses=2, blocks=1024),
     "C5": dict(objects=512, hoa=16, layout="9+10+3", block_size=1024, buses=2, blocks=512),
 }

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -478,9 +479,13 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     r->d_in.reserve(cap * r->M);
     r->d_out.reserve(cap * r->N);
     const size_t in_bytes = sizeof(float) * n * r->M;
+    const bool dbg = getenv("EARHIP_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = dbg ? now() : 0.0;
     if (in_bytes < ((size_t)16 << 20) || r->M < 16) {
-      // short calls (block mode): one gather, one transfer (splitting a 2 MB block into
-      // overlapped groups costs more in transfer calls than it hides)
+      // short calls (block mode): one gather, one transfer.  Splitting a 2 MB block into groups whose
+      // transfers overlap the gather was measured twice and loses (132 -> 150 us per call at the headline
+      // shape: four DMA start-ups cost more than the 30 us of gather they hide).
       for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
       EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
@@ -504,11 +509,17 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       gp.wait_all();
       EARHIP_HIP(err);
     }
+    const double t_b = dbg ? now() : 0.0;
     r->process_device(nblocks, r->d_in.p, n, r->d_out.p, n);
     EARHIP_HIP(hipMemcpyAsync(r->p_out.p, r->d_out.p, sizeof(float) * n * r->N,
                               hipMemcpyDeviceToHost, ctx->stream));
+    const double t_c = dbg ? now() : 0.0;
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    const double t_d = dbg ? now() : 0.0;
     for (int c = 0; c < r->N; c++) std::memcpy(out[c], r->p_out.p + c * n, sizeof(float) * n);
+    if (dbg)
+      fprintf(stderr, "render_process: gather+H2D enqueue %.1f us, launches %.1f us, wait %.1f us, scatter %.1f us\n", t_b - t_a,
+              t_c - t_b, t_d - t_c, now() - t_d);
   });
 }
 
