@@ -130,6 +130,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   };
   clear_totals();
 
+  // (objects the level probe found far below the call's level carry the same flag as objects with a
+  // curve point inside the tile — k_mark_quiet, gain_kernels.h — and take the same path)
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
   // with k = {a, b} of ONE object (k slots 2, 3 idle), accumulated into tot0 in units of 1 / (sx sg)
   // (the two scales are applied to the two operands: their product may not be a float)

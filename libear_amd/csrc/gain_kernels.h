@@ -113,7 +113,16 @@ struct LevelProbe {
   int nsamples = 0;
   int every = 1;              // probe tiles 0, every, 2 every, ...
   unsigned *level = nullptr;  // zero before the launch
+  unsigned *obj_level = nullptr;  // [M], zero before the launch: the same per object (largest magnitude probed)
 };
+// An object whose probed level lies this many binades below the call's is "quiet": the split-operand
+// kernels scale every input of a call by ONE power of two, which keeps 2^-22 relative precision over 11
+// binades (gain_h2.h); a quieter object, alone on a loudspeaker, would be off by more than 1e-6 there, so
+// it takes the exact f32 path of the kernel instead.  (Levels are float bits: biased exponents compare.)
+constexpr int kQuietBinades = 11;
+__host__ __device__ __forceinline__ bool level_is_quiet(unsigned obj_level, unsigned call_level) {
+  return obj_level != 0u && call_level != 0u && (int)(obj_level >> 23) < (int)(call_level >> 23) - kQuietBinades;
+}
 // kPrepRun consecutive tiles per thread: 2 for up to 2047 tiles (headline: K0 0.020 -> 0.018 ms), 4 beyond
 // (ADM scene, 4096 tiles of 128 samples: K0 + K0s 0.112 -> 0.092 ms)
 template <int kPrepRun>
@@ -166,13 +175,28 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
   if (probe.in) {
     unsigned v = max(max(__float_as_uint(px.x) & 0x7fffffffu, __float_as_uint(px.y) & 0x7fffffffu),
                      max(__float_as_uint(px.z) & 0x7fffffffu, __float_as_uint(px.w) & 0x7fffffffu));
+    // the 16 lanes of one object (its 16 runs of tiles) first: the object's own level
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
+    for (int d = 8; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
+    if (probe.obj_level && ti == 0 && m < M && v != 0) atomicMax(probe.obj_level + m, v);
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
     // one atomic per wave would serialise thousands of them on one address: look first — new maxima
     // get rare quickly (a stale read only costs an unnecessary atomic)
     if ((threadIdx.x & 63) == 0 && v != 0)  // (only the waves that probed something touch the word)
       if (v > __atomic_load_n(probe.level, __ATOMIC_RELAXED)) atomicMax(probe.level, v);
   }
+}
+
+// Behind k_seg_prep, ahead of k_gain_mix_h2: the descriptors of "quiet" objects (level_is_quiet) get the
+// flag of objects with a curve point inside the tile, which sends them through the kernel's exact path
+// in every tile.  A thread per (object, run of 64 tiles): nothing to do unless the object is quiet.
+static __global__ void __launch_bounds__(256)
+k_mark_quiet(SegDesc *desc, int M, int ntiles, const unsigned *obj_level, const unsigned *level_cur) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M || !level_is_quiet(obj_level[m], *level_cur)) return;
+  const int t0 = blockIdx.y * 64, t1 = min(t0 + 64, ntiles);
+  for (int t = t0; t < t1; t++) desc[(size_t)t * M + m].info |= kSegMulti;
 }
 
 // ---------------------------------------------------------------------------

@@ -196,3 +196,49 @@ def test_native_decorrelators_equal_the_oracles():
     for layout in ("0+5+0", "4+5+0", "9+10+3"):
         got, want = decorrelators(layout), _oracle.design_decorrelators(LAYOUTS[layout])
         assert np.max(np.abs(got - want)) <= 2e-9
+
+
+@pytest.mark.parametrize("kind", ["aligned", "adm"])
+@pytest.mark.parametrize("quiet_db", [-70.0, -100.0, -130.0])
+def test_quiet_objects_alone_on_their_loudspeakers(kind, quiet_db):
+    """Full-scale objects on one half of the loudspeakers, objects `quiet_db` below them on the other half,
+    interleaved in object order (every chunk of 32 holds both): the split-operand kernels scale a call's
+    inputs by one power of two, so an object more than ~66 dB below the call's level would be off by more
+    than 1e-6 on a loudspeaker it has to itself — the level probe sends such objects through the kernels'
+    exact f32 path.  Every channel within tolerance, block-aligned ramps (k_gain_mix_h2) and metadata
+    that ignores the block grid (k_gain_mix_p2)."""
+    layout, m, block, nblocks = "9+10+3", 128, 512, 16
+    names = LAYOUTS[layout]
+    n = len(names)
+    dec = decorrelators(layout)
+    total = block * nblocks
+    lfe = [i for i, nm in enumerate(names) if nm.startswith("LFE")]
+    spk = [c for c in range(n) if c not in lfe]
+    half = len(spk) // 2
+    rng = np.random.default_rng(int(-quiet_db))
+    if kind == "aligned":
+        times = [block * np.arange(nblocks + 1, dtype=np.int64)] * m
+    else:
+        base = scenes.adm_curves(m, n, total, seed=3)
+        times = [c[0] for c in base]
+    level = np.where(np.arange(m) % 4 == 1, 10.0 ** (quiet_db / 20.0), 1.0).astype(np.float32)
+    curves = []
+    for i in range(m):
+        k = len(times[i])
+        pool = spk[half:] if level[i] < 1.0 else spk[:half]
+        d = np.zeros((k, n), np.float32)
+        f = np.zeros((k, n), np.float32)
+        for j in range(k):
+            idx = rng.choice(pool, 3, replace=False)
+            g = rng.uniform(0.1, 1.0, 3)
+            g /= np.sqrt(np.sum(g * g))
+            diff = rng.choice([0.0, 0.5, 1.0])
+            d[j, idx] = g * np.sqrt(1.0 - diff)
+            f[j, idx] = g * np.sqrt(diff)
+        curves.append((times[i], d, f))
+    x = device_audio(m, total, 11, scale=level)
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    if os.environ.get("EARHIP_MFMA") in (None, "3"):
+        assert plan["kernel"] == (3 if kind == "aligned" else 4), plan
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (7, 2), (nblocks - 2, 2)])
+    print(f"quiet objects at {quiet_db} dB ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
