@@ -69,16 +69,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     probe.every = std::max(1, (ml.ntiles + 1) / 2);  // two instants per object at most: every probe is a page walk
                                                      // (2.5 ns each in K0; eight instants cost 20 us)
     probe.level = level_cur;
-    // per-object levels: zeroed, raised by K0, read by K0p / K1 (objects far below the call's level take
-    // the kernels' exact path)
+    // per-object levels: raised by K0; k_mark_quiet flags the quiet objects' descriptors and clears them
+    // again (all zero between calls)
     if (ctx->obj_level.n < (size_t)M) {
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      ctx->obj_level.alloc((size_t)M + M / 2 + 64);
+      ctx->obj_level.alloc_zero(2 * (size_t)M + 64, ctx->stream);
     }
-    EARHIP_HIP(hipMemsetAsync(ctx->obj_level.p, 0, sizeof(unsigned) * M, ctx->stream));
     probe.obj_level = ctx->obj_level.p;
   }
-  const unsigned *obj_level = probe.obj_level;
   if (!fused_prep) {
     const dim3 ogrid((M + 15) / 16);
     if (ml.ntiles >= 2048)
@@ -88,9 +86,6 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       hipLaunchKernelGGL(k_seg_prep<2>, dim3((ml.ntiles + 31) / 32, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
                          ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
   }
-  if (ml.split && obj_level)
-    hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256, (ml.ntiles + 63) / 64), dim3(256), 0, ctx->stream, desc, M,
-                       ml.ntiles, obj_level, level_cur);
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
   sl.count = reinterpret_cast<int *>(sl.slots + (size_t)kTileSlots * M * ml.ntiles);
@@ -99,6 +94,9 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (slots)
     hipLaunchKernelGGL(k_slot_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
+  if (probe.obj_level)
+    hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
+                       level_cur);
   // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
   PieceLists pl;
   pl.pieces = reinterpret_cast<Piece *>(desc + (size_t)M * ml.ntiles);
@@ -109,7 +107,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (ml.pieces) {
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(), t_call,
-                       t_call + nsamples, desc, pl, level_cur, obj_level);
+                       t_call + nsamples, desc, pl);
     if (getenv("EARHIP_DEBUG_P2")) {  // debug aid: the lists as K0p wrote them
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
       std::vector<int> cnt((size_t)8 * ml.ntiles);

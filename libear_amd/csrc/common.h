@@ -124,7 +124,7 @@ struct earhip_ctx {
   bool x_scale_auto = true;  // ... unless a level estimate of the call's inputs is available (default: K0 probes them)
   earhip::DevBuf<unsigned> level;  // [2] input level words (float bits), used alternately by successive calls
   int level_idx = 0;
-  earhip::DevBuf<unsigned> obj_level;  // [objects] per-object input level of the current call (float bits)
+  earhip::DevBuf<unsigned> obj_level;  // [objects] per-object input levels of the current call (float bits); all zero between calls
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
   int nrt = 8;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)

@@ -130,8 +130,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   };
   clear_totals();
 
-  // (objects the level probe found far below the call's level carry the same flag as objects with a
-  // curve point inside the tile — k_mark_quiet, gain_kernels.h — and take the same path)
+  // (objects the level probe found far below the call's level — kSegQuiet, set by k_mark_quiet
+  // — are treated like objects with a curve point inside the tile: zero row in the main loop,
+  // this path afterwards)
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
   // with k = {a, b} of ONE object (k slots 2, 3 idle), accumulated into tot0 in units of 1 / (sx sg)
   // (the two scales are applied to the two operands: their product may not be a float)
@@ -249,7 +250,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
         const SegDesc d = R.d[q];
         // objects the previous chunk already covered (last chunk moved back) and objects with
         // curve points inside the tile (slow path) get the all-zero row
-        const bool valid = m0 + q >= m_lo + cc * CH && !(d.info & kSegMulti);
+        const bool valid = m0 + q >= m_lo + cc * CH && !(d.info & (kSegMulti | kSegQuiet));
         const unsigned rs = (unsigned)(valid ? d.row : zero_row);
         const unsigned re = rs + ((valid && (d.info & kSegRamp)) ? 1u : 0u);
         D.p0[q] = (float)d.d0 * d.scale;  // gain_interpolator.hpp:272 at the tile start
@@ -406,7 +407,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
     // objects with curve points inside this workgroup tile (zero rows above)
     for (int b0 = 0; b0 < nobj; b0 += 64) {
       const SegDesc db = dtile[min(m_lo + b0 + lane, m_hi - 1)];
-      unsigned long long multi = __ballot((db.info & kSegMulti) && b0 + lane < nobj);
+      unsigned long long multi = __ballot((db.info & (kSegMulti | kSegQuiet)) && b0 + lane < nobj);
       while (multi) {
         const int j = __builtin_ctzll(multi);
         multi &= multi - 1;

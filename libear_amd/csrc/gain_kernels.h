@@ -58,6 +58,7 @@ static_assert(sizeof(SegDesc) == 16, "SegDesc is loaded as one dwordx4");
 
 constexpr int kSegRamp = 1;
 constexpr int kSegMulti = 2;
+constexpr int kSegQuiet = (int)0x80000000u;  // the object's input level is far below the call's (LevelProbe)
 constexpr int kMaxPointsPerObject = 1 << 18;
 __host__ __device__ __forceinline__ int seg_r1(int info) { return (info >> 4) & 0x1ff; }
 __host__ __device__ __forceinline__ int seg_k(int info) { return (info >> 13) & 0x3ffff; }
@@ -84,7 +85,9 @@ __device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int ba
   // (gain_interpolator.hpp:68-75)
   const bool ramp = ps.force_ramp || fb != allflat;
   const bool multi = !ps.force_ramp && k < n && ps.time[base + k] < t_end;
-  const int r1 = (int)((multi ? ps.time[base + k] : t_end) - t0);
+  // (9 bits: a piece that covers a whole 512-sample tile is stored as 511 — a piece that ends INSIDE a tile,
+  // the only kind whose end is ever read, is shorter — so that it cannot spill into the k field)
+  const int r1 = min((int)((multi ? ps.time[base + k] : t_end) - t0), 511);
   d.info = (k << 13) | (r1 << 4) | (fb << 2) | (multi ? kSegMulti : 0) | (ramp ? kSegRamp : 0);
   if (ramp) {
     const int64_t start = ps.time[base + k - 1], end = ps.time[base + k];
@@ -188,15 +191,20 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
   }
 }
 
-// Behind k_seg_prep, ahead of k_gain_mix_h2: the descriptors of "quiet" objects (level_is_quiet) get the
-// flag of objects with a curve point inside the tile, which sends them through the kernel's exact path
-// in every tile.  A thread per (object, run of 64 tiles): nothing to do unless the object is quiet.
+// Behind k_seg_prep (a kernel boundary: its descriptors and levels are complete and visible), ahead of the
+// split-operand gain kernels: the descriptors of "quiet" objects (level_is_quiet) get kSegQuiet in every
+// tile, which sends them through those kernels' exact path; the per-object levels are cleared for the
+// next call.  A thread per object: nothing to do unless the object is quiet.  (Doing this in
+// k_seg_prep's last workgroup instead needs a device-scope fence per workgroup — an L2 write-back on this
+// chip — and made K0 ten times slower.)
 static __global__ void __launch_bounds__(256)
-k_mark_quiet(SegDesc *desc, int M, int ntiles, const unsigned *obj_level, const unsigned *level_cur) {
+k_mark_quiet(SegDesc *desc, int M, int ntiles, unsigned *obj_level, const unsigned *level_cur) {
   const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M || !level_is_quiet(obj_level[m], *level_cur)) return;
-  const int t0 = blockIdx.y * 64, t1 = min(t0 + 64, ntiles);
-  for (int t = t0; t < t1; t++) desc[(size_t)t * M + m].info |= kSegMulti;
+  if (m >= M) return;
+  const unsigned lv = obj_level[m];
+  obj_level[m] = 0u;
+  if (!level_is_quiet(lv, *level_cur)) return;
+  for (int t = 0; t < ntiles; t++) desc[(size_t)t * M + m].info |= kSegQuiet;
 }
 
 // ---------------------------------------------------------------------------

@@ -72,7 +72,7 @@ __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
 // object order, deterministic.
 static __global__ void __launch_bounds__(256)
 k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end, const SegDesc *desc,
-             PieceLists pl, const unsigned *level_cur, const unsigned *obj_level) {
+             PieceLists pl) {
   __shared__ unsigned wsum[3][4];
   __shared__ int tot[kPieceLists], lbase[kPieceLists], run[kPieceLists], run_o, all_exact;
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -165,8 +165,9 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
       const int m = mb + tid;
       if (m < M) {
         int cnt[kPieceLists];
-        // (objects the level probe found far below the call's level take the exact path as well: gain_kernels.h)
-        const bool exact = !walk(m, dtile[m], nullptr, cnt) || (obj_level && level_is_quiet(obj_level[m], *level_cur));
+        // (objects the level probe found far below the call's level — kSegQuiet — take the exact path as well)
+        const SegDesc d0 = dtile[m];
+        const bool exact = !walk(m, d0, nullptr, cnt) || (d0.info & kSegQuiet);
         // plain counts <= 1, ranged ones <= kPieceMaxPerObject + 1
         cw[m] = exact ? -1 : (cnt[0] | (cnt[2] << 1) | (cnt[1] << 2) | (cnt[3] << 12));
         if (!exact)
