@@ -377,13 +377,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                same = (tj.get("objects") == M and tj.get("blocks") == T and tj.get("block_size") == B and
-                        tj.get("channels") == N and tj.get("buses", 2) == K and tj.get("gain_kernel") == gain_kernel and
-                        tj.get("tile") == plan["tile"] and tj.get("scene", "dense") == args.scene)
-                if same:
-                    traffic = int(tj.get("gain_mix_hbm_bytes_per_step") / k1_launches)
-                    traffic_source = "profiles/traffic.json: " + tj.get("source", "")
+                for tj in json.load(open(tpath)).get("entries", []):
+                    same = (tj.get("objects") == M and tj.get("blocks") == T and tj.get("block_size") == B and
+                            tj.get("channels") == N and tj.get("buses", 2) == K and tj.get("gain_kernel") == gain_kernel and
+                            tj.get("tile") == plan["tile"] and tj.get("scene", "dense") == args.scene)
+                    if same:
+                        traffic = int(tj.get("gain_mix_hbm_bytes_per_step") / k1_launches)
+                        traffic_source = "profiles/traffic.json: " + tj.get("kernel", "") + ", " + tj.get("source", "")
             except Exception:
                 traffic = None
         # what a kernel that only reads gets out of this box, measured in this run: the 100 % mark
