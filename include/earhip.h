@@ -275,7 +275,8 @@ typedef struct earhip_render_config {
   int n_buses;    /* 1: direct bus only, written straight to the output
                      2: direct + diffuse with decorrelation, delay and mix */
   /* n_buses == 2: decorrelator FIRs [n_out][n_taps] (designDecorrelators,
-   * include/ear/decorrelate.hpp:26-28); n_taps <= block_size */
+   * include/ear/decorrelate.hpp:26-28); FIRs longer than a block are partitioned like
+   * libear's Filter (src/dsp/block_convolver_impl.cpp:16-41), up to 64 partitions */
   const float *decorrelators;
   int n_taps;
   int delay;      /* compensation delay on the direct bus in samples

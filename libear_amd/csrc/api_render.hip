@@ -57,13 +57,13 @@ template <int L>
 static void launch_decor_t(const DecorParams &P, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((k_decorrelate_delay_mix<L>), grid, dim3(256), 0, s, P);
 }
-static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s) {
+static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s, bool force_wg = false) {
   switch (L) {
     case 128: launch_decor_t<128>(P, grid, s); break;
     case 256: launch_decor_t<256>(P, grid, s); break;
     case 512: launch_decor_t<512>(P, grid, s); break;
     case 1024:
-      if (getenv("EARHIP_K2_WG")) {  // the workgroup-per-run kernel (tuning / comparison)
+      if (force_wg || getenv("EARHIP_K2_WG")) {  // the workgroup-per-run kernel (FIRs of several partitions; tuning)
         launch_decor_t<1024>(P, grid, s);
       } else {  // one wave per run, kDecorWaves runs per workgroup
         hipLaunchKernelGGL(k_decorrelate_wave, dim3((grid.x + kDecorWaves - 1) / kDecorWaves, grid.y),
@@ -165,6 +165,7 @@ struct GatherPool {
 struct earhip_render {
   earhip_ctx *ctx = nullptr;
   int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
+  int NP = 1;  // partitions of the decorrelator FIRs (ceil(n_taps / B))
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
@@ -176,8 +177,8 @@ struct earhip_render {
   DevBuf<float> bus;  // [gsplit][K*N][bus_stride], strides chosen per call
   int max_gsplit = 1;
   DevBuf<cf> H, tw;
-  DevBuf<float> tail[2], dly[2];
-  DevBuf<float> ztail, zdly;  // all-zero state, never written: what the first call after a reset reads
+  DevBuf<float> tail[2], dly[2], hist[2];  // tails [NP][N][B]; diffuse-bus history [N][(NP-1) B]
+  DevBuf<float> ztail, zdly, zhist;  // all-zero state, never written: what the first call after a reset reads
   bool fresh = true;          // no call since create / reset: the state is zero
   int cur = 0;  // which state buffer holds the current state
   // host-pointer staging
@@ -277,7 +278,7 @@ struct earhip_render {
       P.bus_stride = bus_stride;
       P.part_stride = part_stride;
       P.nparts = ml.gsplit;
-      const bool wave_k2 = L == 1024 && !getenv("EARHIP_K2_WG");
+      const bool wave_k2 = L == 1024 && NP == 1 && !getenv("EARHIP_K2_WG");
       if (wave_k2 && ml.gsplit > 1) {
         // The wave kernel has one wave per run: summing the object splits there is a chain of
         // dependent loads on the call's critical path (block mode).  Sum them into slab 0 with the
@@ -290,10 +291,7 @@ struct earhip_render {
       }
       P.out = out_dev;
       P.out_stride = out_stride;
-      P.H = H.p;
       P.tw = tw.p;
-      P.tail_in = fresh ? ztail.p : tail[cur].p;
-      P.tail_out = tail[cur ^ 1].p;
       P.dly_in = fresh ? zdly.p : dly[cur].p;
       P.dly_out = dly[cur ^ 1].p;
       P.N = N;
@@ -301,9 +299,27 @@ struct earhip_render {
       const int R = wave_k2 && !run_len_set ? wave_run_len((int)nblocks, N, ctx->num_cus) : run_len;
       P.R = R;
       P.D = D;
+      P.hist_len = (NP - 1) * B;
+      P.hist_in = fresh ? zhist.p : hist[cur].p;
+      P.hist_out = hist[cur ^ 1].p;
       const dim3 grid((unsigned)((nblocks + R - 1) / R), N);
       if (evp && P.nparts == ml.gsplit) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
-      launch_decor(L, P, grid, ctx->stream);
+      // one launch per partition of the FIRs: partition 0 writes (decorrelated + delayed direct), the
+      // others add their share of the decorrelated signal (render_kernels.h)
+      for (int part = 0; part < NP; part++) {
+        P.H = H.p + (size_t)part * N * L;
+        P.tail_in = (fresh ? ztail.p : tail[cur].p) + (fresh ? 0 : (size_t)part * N * B);
+        P.tail_out = tail[cur ^ 1].p + (size_t)part * N * B;
+        P.shift = part * B;
+        P.accumulate = part > 0 ? 1 : 0;
+        if (wave_k2) {
+          hipLaunchKernelGGL(k_decorrelate_wave, dim3((grid.x + kDecorWaves - 1) / kDecorWaves, grid.y), dim3(64 * kDecorWaves),
+                             0, ctx->stream, P);
+          EARHIP_HIP(hipGetLastError());
+        } else {
+          launch_decor(L, P, grid, ctx->stream, NP > 1);
+        }
+      }
       if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
       cur ^= 1;
       fresh = false;
@@ -329,9 +345,9 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     if (cfg->n_buses == 2) {
       require(cfg->decorrelators != nullptr && cfg->n_taps >= 1,
               "n_buses == 2 needs decorrelator filters");
-      require(cfg->n_taps <= cfg->block_size,
-              "decorrelator filters longer than block_size are not supported by the fused "
-              "render (use BlockConvolver)");
+      require((cfg->n_taps + cfg->block_size - 1) / cfg->block_size <= 64,
+              "decorrelator filters of more than 64 blocks are not supported by the fused render "
+              "(use BlockConvolver)");
     } else {
       require(cfg->delay == 0, "delay needs n_buses == 2");
     }
@@ -373,30 +389,39 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
       const auto tw = make_twiddles(r->L);
       r->tw.alloc(r->L);
       EARHIP_HIP(hipMemcpy(r->tw.p, tw.data(), sizeof(cf) * r->L, hipMemcpyHostToDevice));
-      // H = DFT_L(zero-padded FIR), computed with the device transform, then made
-      // exactly Hermitian so that two real blocks separate cleanly
+      // H[p] = DFT_L(zero-padded partition p of the FIR: taps [p B, (p + 1) B), Filter::Filter,
+      // block_convolver_impl.cpp:16-41), computed with the device transform, then made exactly Hermitian so
+      // that two real blocks separate cleanly
+      r->NP = (cfg->n_taps + r->B - 1) / r->B;
+      const size_t rows = (size_t)r->NP * r->N;
+      std::vector<float> parts(rows * r->B, 0.0f);  // [NP][N][B]
+      for (int n = 0; n < r->N; n++)
+        for (int t = 0; t < cfg->n_taps; t++)
+          parts[((size_t)(t / r->B) * r->N + n) * r->B + t % r->B] = cfg->decorrelators[(size_t)n * cfg->n_taps + t];
       DevBuf<float> taps;
-      taps.alloc((size_t)r->N * cfg->n_taps);
-      EARHIP_HIP(hipMemcpy(taps.p, cfg->decorrelators, sizeof(float) * r->N * cfg->n_taps,
-                           hipMemcpyHostToDevice));
-      r->H.alloc((size_t)r->N * r->L);
-      launch_spectrum(r->L, taps.p, cfg->n_taps, cfg->n_taps, r->tw.p, r->H.p, r->N, ctx->stream);
+      taps.alloc(parts.size());
+      EARHIP_HIP(hipMemcpy(taps.p, parts.data(), sizeof(float) * parts.size(), hipMemcpyHostToDevice));
+      r->H.alloc(rows * r->L);
+      launch_spectrum(r->L, taps.p, r->B, r->B, r->tw.p, r->H.p, (int)rows, ctx->stream);
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      std::vector<cf> h((size_t)r->N * r->L);
+      std::vector<cf> h(rows * r->L);
       EARHIP_HIP(hipMemcpy(h.data(), r->H.p, sizeof(cf) * h.size(), hipMemcpyDeviceToHost));
-      for (int n = 0; n < r->N; n++) {
-        cf *hn = h.data() + (size_t)n * r->L;
+      for (size_t n = 0; n < rows; n++) {
+        cf *hn = h.data() + n * r->L;
         hn[0].y = 0.0f;
         hn[r->B].y = 0.0f;
         for (int k = 1; k < r->B; k++) hn[r->L - k] = cf_conj(hn[k]);
       }
       EARHIP_HIP(hipMemcpy(r->H.p, h.data(), sizeof(cf) * h.size(), hipMemcpyHostToDevice));
+      const size_t hist_n = (size_t)r->N * std::max((r->NP - 1) * r->B, 1);
       for (int i = 0; i < 2; i++) {
-        r->tail[i].alloc_zero((size_t)r->N * r->B, ctx->stream);
+        r->tail[i].alloc_zero(rows * r->B, ctx->stream);
         r->dly[i].alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
+        r->hist[i].alloc_zero(hist_n, ctx->stream);
         if (i == 0) {
           r->ztail.alloc_zero((size_t)r->N * r->B, ctx->stream);
           r->zdly.alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
+          r->zhist.alloc_zero(hist_n, ctx->stream);
         }
       }
     }

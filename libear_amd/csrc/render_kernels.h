@@ -2,8 +2,14 @@
 // Objects render block (libear docs/dsp.rst:40-71) that follows the bus-forming
 // gain stage, fused into one kernel:
 //
-//   diffuse bus --> BlockConvolver (P = 1 partition, static decorrelator FIR;
-//                   overlap-add exactly as block_convolver_impl.cpp:143-237)
+//   diffuse bus --> BlockConvolver (static decorrelator FIR; overlap-add exactly as
+//                   block_convolver_impl.cpp:143-237).  One launch handles ONE partition of the
+//                   FIR (<= B taps); a FIR longer than a block (blocks of 64..256 with the 512-tap
+//                   decorrelators) is P launches: partition p convolves the diffuse bus delayed by
+//                   p blocks (the previous call's last P - 1 blocks come from the history state)
+//                   with its own overlap-add tail and ADDS to the output — libear sums the
+//                   partitions' spectra before one inverse transform (:193-215), here their
+//                   time-domain results are summed; equal up to rounding
 //   direct bus  --> DelayBuffer(D)            (delay_buffer_impl.cpp:19-40)
 //   out = decorrelated + delayed              (docs/figures/objects.png)
 //
@@ -38,6 +44,12 @@ struct DecorParams {
   const float *dly_in;   // [N][D] last D direct-bus samples before the call
   float *dly_out;
   int N, T, R, D;
+  // partition pass (workgroup kernel only; the wave kernel handles single-partition FIRs)
+  int shift = 0;               // this partition's delay in samples (p * B)
+  int accumulate = 0;          // 1: out += decorrelated (no direct path, no delay-line update)
+  int hist_len = 0;            // (P - 1) * B: diffuse-bus samples kept from before the call
+  const float *hist_in = nullptr;  // [N][hist_len]
+  float *hist_out = nullptr;       // written by the pass with accumulate == 0
 };
 
 // radix-4 butterfly with the three twiddles given (already conjugated for DIR > 0 by
@@ -183,6 +195,12 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
     const int sd = s - P.D;
     return sd >= 0 ? bus_at(direct, sd) : P.dly_in[(size_t)n * P.D + (sd + P.D)];
   };
+  // diffuse bus delayed by this partition's shift: sample s of the call (s - shift may reach back into
+  // the history state)
+  auto diffuse_at = [&](int s) {
+    const int sd = s - P.shift;
+    return sd >= 0 ? bus_at(diffuse, sd) : P.hist_in[(size_t)n * P.hist_len + (sd + P.hist_len)];
+  };
   // this thread's input samples of the pair (tb, tb+1): real part block tb, imaginary tb+1
   auto load_pair = [&](int tb, cf (&z)[EPT]) {
     const bool have_re = tb >= 0 && tb < last, have_im = tb + 1 < last;
@@ -191,8 +209,8 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       const int i = tid + e * NT;
       z[e] = cf_make(0.0f, 0.0f);
       if (i < B) {
-        if (have_re) z[e].x = bus_at(diffuse, tb * B + i);
-        if (have_im) z[e].y = bus_at(diffuse, (tb + 1) * B + i);
+        if (have_re) z[e].x = diffuse_at(tb * B + i);
+        if (have_im) z[e].y = diffuse_at((tb + 1) * B + i);
       }
     }
   };
@@ -241,8 +259,8 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
       const int i = tid + e * NT;
-      dre[e] = (i < B && have_re && tb >= first) ? delayed(tb * B + i) : 0.0f;
-      dim[e] = (i < B && have_im) ? delayed((tb + 1) * B + i) : 0.0f;
+      dre[e] = (i < B && have_re && tb >= first && !P.accumulate) ? delayed(tb * B + i) : 0.0f;
+      dim[e] = (i < B && have_im && !P.accumulate) ? delayed((tb + 1) * B + i) : 0.0f;
     }
     cf *Z, *W;
     if constexpr (kTwInRegs) {
@@ -296,13 +314,13 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
       if (have_re) {
         if (tb >= first) {
           const float dec = (y_lo.x + tl) * norm;  // :223-226
-          out[tb * B + i] = dec + dre[e];
+          out[tb * B + i] = P.accumulate ? out[tb * B + i] + dec : dec + dre[e];
         }
         tl = y_hi.x;  // :224
       }
       if (have_im) {
         const float dec = (y_lo.y + tl) * norm;
-        out[(tb + 1) * B + i] = dec + dim[e];
+        out[(tb + 1) * B + i] = P.accumulate ? out[(tb + 1) * B + i] + dec : dec + dim[e];
         tl = y_hi.y;
       }
       tail[i] = tl;
@@ -342,7 +360,15 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
   if (last == P.T) {  // this workgroup owns the end of the call: publish the state
     for (int i = tid; i < B; i += NT) P.tail_out[(size_t)n * B + i] = tail[i];
     const int total = P.T * B;
-    for (int j = tid; j < P.D; j += NT) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+    if (!P.accumulate) {
+      for (int j = tid; j < P.D; j += NT) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+      // the last hist_len diffuse samples (history | this call) for the next call's later partitions
+      for (int j = tid; j < P.hist_len; j += NT) {
+        const int sd = total - P.hist_len + j;
+        P.hist_out[(size_t)n * P.hist_len + j] =
+            sd >= 0 ? bus_at(diffuse, sd) : P.hist_in[(size_t)n * P.hist_len + (sd + P.hist_len)];
+      }
+    }
   }
 }
 

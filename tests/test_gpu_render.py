@@ -105,8 +105,6 @@ def test_gain_stage_ragged_curves_strict_bit_exact():
 def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
-    if block < 512:
-        dec = dec[:, :block].copy()  # fused render supports FIRs up to one block
     total = block * nblocks
     if kind == "dense":
         curves = scenes.dense_curves(m, n, block, nblocks)
@@ -327,8 +325,6 @@ def test_random_scenes_vs_oracle(seed):
             t = np.sort(rng.choice(grid, size=k, replace=False)).astype(np.int64)
             curves.append((t, rng.uniform(0, 1, (k, n)).astype(np.float32), rng.uniform(0, 1, (k, n)).astype(np.float32)))
     dec = decorrelators(layout)
-    if block < 512:
-        dec = dec[:, :block].copy()
     x = scenes.audio(m, total, seed=seed)
     # random partition of the blocks into calls
     calls = []
@@ -370,8 +366,6 @@ def test_random_aligned_scenes_split_operand_kernels(seed):
             d[-1], f[-1] = d[-2], f[-2]  # a constant stretch
         curves.append((t, d, f))
     dec = decorrelators(layout)
-    if block < 512:
-        dec = dec[:, :block].copy()
     x = (scenes.audio(m, total, seed=seed) * np.float32(10.0 ** rng.uniform(-5, 2))).astype(np.float32)
     calls = []
     left = nblocks
@@ -422,8 +416,6 @@ def test_block_size_limits(block, nblocks, m):
     layout = "4+5+0"
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
-    if block < 512:
-        dec = dec[:, :block].copy()
     total = block * nblocks
     curves = scenes.adm_curves(m, n, total, period=777, ramp=100, seed=block)
     x = scenes.audio(m, total, seed=block)
@@ -629,8 +621,6 @@ def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, call
     from libear_amd import capi
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
-    if block < 512:
-        dec = dec[:, :block].copy()  # fused render supports FIRs up to one block
     total = block * nblocks
     if kind == "adm":
         curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
@@ -666,3 +656,27 @@ def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, call
     assert np.isfinite(got).all()
     assert scenes.rel_rms(got, want) <= 1e-6, (scenes.rel_rms(got, want), plan)
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6, (scenes.rel_rms_per_channel(got, want), plan)
+
+
+@pytest.mark.parametrize("block,n_taps,nblocks,calls", [(64, 512, 24, [24]), (128, 512, 10, [1, 2, 7]), (256, 512, 8, [3, 5]),
+                                                        (512, 1300, 6, [2, 4]), (1024, 1025, 4, [1, 3]), (256, 700, 9, [9])])
+def test_decorrelator_firs_longer_than_a_block(block, n_taps, nblocks, calls):
+    """FIRs of several partitions in the fused render (the 512-tap decorrelators at blocks of 64..256, longer
+    custom FIRs at any block size): one K2 launch per partition over the diffuse bus delayed by that many
+    blocks, history and per-partition overlap-add tails carried across calls — against the oracle's
+    partitioned BlockConvolver (block_convolver_impl.cpp:16-41,193-215)."""
+    layout, m = "4+5+0", 40
+    n = len(LAYOUTS[layout])
+    if n_taps == 512:
+        dec = decorrelators(layout)
+    else:
+        dec = (np.random.default_rng(n_taps).uniform(-1, 1, (n, n_taps)) * np.exp(-np.arange(n_taps) / 300.0)).astype(np.float32)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=500, ramp=120, seed=block)
+    x = scenes.audio(m, total, seed=n_taps)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, calls)
+    assert scenes.rel_rms(got, want) <= 1e-6
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
+    whole = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms(whole, want) <= 1e-6
