@@ -114,8 +114,10 @@ int earhip_gain_interp_process_device(earhip_gain_interp *gi, int64_t block_star
 /* ------------------------------------------------------------------------
  * (B) FFT plugin — an r2c/c2r transform with libear's FFTPlan contract
  * (include/ear/fft.hpp:27-50): forward n_fft reals -> n_fft/2+1 unpacked
- * complex bins; reverse the inverse; both un-normalised.  n_fft must be a
- * power of two in [64, 8192].  Host pointers.
+ * complex bins; reverse the inverse; both un-normalised.  Like libear's kissfft
+ * plan (src/fft_kiss.cpp:104-107) any even n_fft is taken — here up to 8192 with
+ * prime factors up to 97 (mixed radix 4/2/3/5 + a generic butterfly; the powers
+ * of two from 64 have their own kernels).  Host pointers.
  * ---------------------------------------------------------------------- */
 typedef struct earhip_fft_plan earhip_fft_plan;
 int earhip_fft_plan_create(earhip_ctx *ctx, size_t n_fft, earhip_fft_plan **out);
@@ -126,8 +128,8 @@ int earhip_fft_reverse(earhip_fft_plan *plan, const float *in_complex, float *ou
 /* ------------------------------------------------------------------------
  * (C) BlockConvolver — replaces ear::dsp::block_convolver::{Context, Filter,
  * BlockConvolver} (include/ear/dsp/block_convolver.hpp:28-112; behaviour of
- * src/dsp/block_convolver_impl.cpp:10-243).  block_size must be a power of two
- * in [32, 4096].
+ * src/dsp/block_convolver_impl.cpp:10-243).  block_size in [1, 4096] with prime
+ * factors up to 97 (480, 960, 1920 ... as well as the powers of two).
  * ---------------------------------------------------------------------- */
 typedef struct earhip_conv_ctx earhip_conv_ctx;
 typedef struct earhip_conv_filter earhip_conv_filter;
@@ -271,7 +273,8 @@ typedef struct earhip_render earhip_render;
 typedef struct earhip_render_config {
   int n_objects;  /* M: input channels handled by this instance (this GPU's shard) */
   int n_out;      /* N: loudspeakers */
-  int block_size; /* B: power of two in [64, 4096] */
+  int block_size; /* B in [16, 4096] with prime factors up to 97; the tuned kernels
+                     are the powers of two from 64 (512 and 1024 above all) */
   int n_buses;    /* 1: direct bus only, written straight to the output
                      2: direct + diffuse with decorrelation, delay and mix */
   /* n_buses == 2: decorrelator FIRs [n_out][n_taps] (designDecorrelators,

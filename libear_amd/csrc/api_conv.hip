@@ -29,7 +29,8 @@ static void conv_ifft_ola_t(const cf *Y, const cf *tw, float *tail, int use_tail
                      mode, out);
 }
 
-#define EARHIP_DISPATCH_L(L, CALL)                                              \
+// CALL(L) for the power-of-two sizes with their own instantiation, CALL_RT for every other size
+#define EARHIP_DISPATCH_L(L, CALL, CALL_RT)                                     \
   switch (L) {                                                                  \
     case 64: CALL(64); break;                                                   \
     case 128: CALL(128); break;                                                 \
@@ -39,8 +40,27 @@ static void conv_ifft_ola_t(const cf *Y, const cf *tw, float *tail, int use_tail
     case 2048: CALL(2048); break;                                               \
     case 4096: CALL(4096); break;                                               \
     case 8192: CALL(8192); break;                                               \
-    default: fail_invalid("FFT size must be a power of two in [64, 8192]");     \
+    default: CALL_RT; break;                                                    \
   }
+
+static FftShape shape_of(int L) {
+  FftShape S;
+  if (!fft_make_shape(L, &S)) fail_invalid("FFT size must be in [4, 8192] with prime factors up to 97");
+  return S;
+}
+static void ifft_real_rt(int L, const cf *in, const cf *tw, float *out, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(k_ifft_real_rt, dim3(rows), dim3(kFftThreads), fft_rt_lds(k_ifft_real_rt, L), s, shape_of(L),
+                     in, tw, out);
+}
+static void conv_forward_rt(int L, const float *x, int fade, const cf *tw, cf *Xo, cf *Xn, hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_forward_rt, dim3(1), dim3(kFftThreads), fft_rt_lds(k_conv_forward_rt, L), s,
+                     shape_of(L), x, fade, tw, Xo, Xn);
+}
+static void conv_ifft_ola_rt(int L, const cf *Y, const cf *tw, float *tail, int use_tail, int mode, float *out,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_ifft_ola_rt, dim3(1), dim3(kFftThreads), fft_rt_lds(k_conv_ifft_ola_rt, L), s,
+                     shape_of(L), Y, tw, tail, use_tail, mode, out);
+}
 }  // namespace earhip
 
 using namespace earhip;
@@ -145,8 +165,10 @@ extern "C" {
 int earhip_fft_plan_create(earhip_ctx *ctx, size_t n_fft, earhip_fft_plan **out) {
   return guarded([&] {
     require(ctx != nullptr && out != nullptr, "NULL argument");
-    require(is_pow2(n_fft) && n_fft >= 64 && n_fft <= 8192,
-            "n_fft must be a power of two in [64, 8192]");
+    // (kissfft's real transform needs an even length, submodules/kissfft/kiss_fftr.c; any factorisation)
+    FftShape shape;
+    require(n_fft % 2 == 0 && n_fft >= 2 && n_fft <= 8192 && fft_make_shape((int)n_fft, &shape),
+            "n_fft must be even, in [2, 8192], with prime factors up to 97");
     ctx->use();
     std::unique_ptr<earhip_fft_plan> p(new earhip_fft_plan);
     p->ctx = ctx;
@@ -189,7 +211,7 @@ int earhip_fft_reverse(earhip_fft_plan *p, const float *in_complex, float *out) 
     EARHIP_HIP(hipMemcpyAsync(p->spec.p, in_complex, sizeof(cf) * (p->L / 2 + 1),
                               hipMemcpyHostToDevice, ctx->stream));
 #define CALL(LL) ifft_real_t<LL>(p->spec.p, p->tw.p, p->td.p, 1, ctx->stream)
-    EARHIP_DISPATCH_L(p->L, CALL)
+    EARHIP_DISPATCH_L(p->L, CALL, ifft_real_rt(p->L, p->spec.p, p->tw.p, p->td.p, 1, ctx->stream))
 #undef CALL
     EARHIP_HIP(hipGetLastError());
     EARHIP_HIP(hipMemcpyAsync(out, p->td.p, sizeof(float) * p->L, hipMemcpyDeviceToHost, ctx->stream));
@@ -202,8 +224,9 @@ int earhip_fft_reverse(earhip_fft_plan *p, const float *in_complex, float *out) 
 int earhip_conv_ctx_create(earhip_ctx *ctx, size_t block_size, earhip_conv_ctx **out) {
   return guarded([&] {
     require(ctx != nullptr && out != nullptr, "NULL argument");
-    require(is_pow2(block_size) && block_size >= 32 && block_size <= 4096,
-            "block_size must be a power of two in [32, 4096]");
+    FftShape shape;
+    require(block_size >= 1 && block_size <= 4096 && fft_make_shape(2 * (int)block_size, &shape),
+            "block_size must be in [1, 4096] with prime factors up to 97");
     ctx->use();
     std::unique_ptr<earhip_conv_ctx> c(new earhip_conv_ctx);
     c->ctx = ctx;
@@ -366,7 +389,7 @@ int earhip_conv_process(earhip_conv *c, const float *in, float *out) {
       staged = true;
       const int fade = c->filt(1) != c->filt(0) ? 1 : 0;  // :162
 #define CALL(LL) conv_forward_t<LL>(c->d_in.p, fade, cc->tw.p, c->old_at(0), c->new_at(0), s)
-      EARHIP_DISPATCH_L(L, CALL)
+      EARHIP_DISPATCH_L(L, CALL, conv_forward_rt(L, c->d_in.p, fade, cc->tw.p, c->old_at(0), c->new_at(0), s))
 #undef CALL
       EARHIP_HIP(hipGetLastError());
       c->new_zero[i0] = 0;
@@ -402,13 +425,13 @@ int earhip_conv_process(earhip_conv *c, const float *in, float *out) {
     bool have_out = true;
     if (any) {  // :217-226
 #define CALL(LL) conv_ifft_ola_t<LL>(c->Y.p, cc->tw.p, c->tail.p, c->tail_zero ? 0 : 1, 0, c->d_out.p, s)
-      EARHIP_DISPATCH_L(L, CALL)
+      EARHIP_DISPATCH_L(L, CALL, conv_ifft_ola_rt(L, c->Y.p, cc->tw.p, c->tail.p, c->tail_zero ? 0 : 1, 0, c->d_out.p, s))
 #undef CALL
       EARHIP_HIP(hipGetLastError());
       c->tail_zero = false;
     } else if (!c->tail_zero) {  // :227-230
 #define CALL(LL) conv_ifft_ola_t<LL>(c->Y.p, cc->tw.p, c->tail.p, 1, 1, c->d_out.p, s)
-      EARHIP_DISPATCH_L(L, CALL)
+      EARHIP_DISPATCH_L(L, CALL, conv_ifft_ola_rt(L, c->Y.p, cc->tw.p, c->tail.p, 1, 1, c->d_out.p, s))
 #undef CALL
       EARHIP_HIP(hipGetLastError());
       c->tail_zero = true;  // tail contents are ignored while the flag is set

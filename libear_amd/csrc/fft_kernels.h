@@ -6,7 +6,9 @@
 //   k_conv_mac        Y = sum_t H_t (.) X_t over the partition queue (:193-209)
 //   k_conv_ifft_ola   inverse + overlap-add + tail update + 1/(2B) (:212-234)
 //   k_delay           DelayBuffer::process (delay_buffer_impl.cpp:19-40)
-// One 256-thread workgroup transforms one row entirely in LDS.
+// One 256-thread workgroup transforms one row entirely in LDS.  Every kernel comes as a template over a
+// power-of-two size and as an _rt twin for any other size (FftShape: mixed radix, dynamic LDS of 2 L
+// complex values) — libear's kissfft takes any block size (src/fft_kiss.cpp:104-107).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -125,6 +127,97 @@ k_conv_ifft_ola(const cf *Y, const cf *tw, float *tail, int use_tail, int mode, 
     tail[i] = y[B + i].x;
     out[i] = v * norm;
   }
+}
+
+
+// ---- run-time sizes (dynamic LDS: 2 L complex) ----------------------------------------
+static __global__ void __launch_bounds__(kFftThreads)
+k_spectrum_real_rt(FftShape S, const float *in, size_t in_stride, int n_valid, const cf *tw, cf *out) {
+  const int L = S.L;
+  cf *a = reinterpret_cast<cf *>(fft_dyn_lds), *b = a + L;
+  const int tid = threadIdx.x;
+  const float *x = in + (size_t)blockIdx.x * in_stride;
+  for (int i = tid; i < L; i += kFftThreads) a[i] = cf_make(i < n_valid ? x[i] : 0.0f, 0.0f);
+  cf *res = fft_run_shape<-1, kFftThreads>(a, b, tw, S, tid);
+  __syncthreads();
+  cf *o = out + (size_t)blockIdx.x * L;
+  for (int i = tid; i < L; i += kFftThreads) o[i] = res[i];
+}
+
+static __global__ void __launch_bounds__(kFftThreads)
+k_ifft_real_rt(FftShape S, const cf *in, const cf *tw, float *out) {
+  const int L = S.L;
+  cf *a = reinterpret_cast<cf *>(fft_dyn_lds), *b = a + L;
+  const int tid = threadIdx.x;
+  const cf *X = in + (size_t)blockIdx.x * (L / 2 + 1);
+  for (int i = tid; i < L; i += kFftThreads) a[i] = i <= L / 2 ? X[i] : cf_conj(X[L - i]);
+  cf *res = fft_run_shape<+1, kFftThreads>(a, b, tw, S, tid);
+  __syncthreads();
+  float *o = out + (size_t)blockIdx.x * L;
+  for (int i = tid; i < L; i += kFftThreads) o[i] = res[i].x;
+}
+
+static __global__ void __launch_bounds__(kFftThreads)
+k_conv_forward_rt(FftShape S, const float *x, int fade, const cf *tw, cf *X_old, cf *X_new) {
+  const int L = S.L, B = L / 2;
+  cf *a = reinterpret_cast<cf *>(fft_dyn_lds), *b = a + L;
+  const int tid = threadIdx.x;
+  const float i_scale = 1.0f / (float)B;  // block_convolver_impl.cpp:133
+  for (int i = tid; i < L; i += kFftThreads) {
+    cf v = cf_make(0.0f, 0.0f);
+    if (i < B) {
+      const float s = x[i];
+      if (fade) {
+        const float av = (float)i * i_scale, bv = 1.0f - av;  // :136-139
+        v = cf_make(bv * s, av * s);
+      } else {
+        v = cf_make(s, 0.0f);
+      }
+    }
+    a[i] = v;
+  }
+  cf *Z = fft_run_shape<-1, kFftThreads>(a, b, tw, S, tid);
+  __syncthreads();
+  for (int k = tid; k <= B; k += kFftThreads) {
+    const cf zk = Z[k], zc = cf_conj(Z[k == 0 ? 0 : L - k]);
+    if (fade) {
+      X_old[k] = cf_make(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+      X_new[k] = cf_make(0.5f * (zk.y - zc.y), -0.5f * (zk.x - zc.x));
+    } else {
+      X_new[k] = zk;
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(kFftThreads)
+k_conv_ifft_ola_rt(FftShape S, const cf *Y, const cf *tw, float *tail, int use_tail, int mode, float *out) {
+  const int L = S.L, B = L / 2;
+  const int tid = threadIdx.x;
+  const float norm = 1.0f / (float)(2 * B);  // block_convolver_impl.cpp:212
+  if (mode == 1) {
+    for (int i = tid; i < B; i += kFftThreads) out[i] = tail[i] * norm;
+    return;
+  }
+  cf *a = reinterpret_cast<cf *>(fft_dyn_lds), *b = a + L;
+  for (int i = tid; i < L; i += kFftThreads) a[i] = i <= B ? Y[i] : cf_conj(Y[L - i]);
+  cf *y = fft_run_shape<+1, kFftThreads>(a, b, tw, S, tid);
+  __syncthreads();
+  for (int i = tid; i < B; i += kFftThreads) {
+    float v = y[i].x;
+    if (use_tail) v = v + tail[i];
+    tail[i] = y[B + i].x;
+    out[i] = v * norm;
+  }
+}
+
+// dynamic LDS of an _rt kernel; above 64 KB the kernel has to be told once per process
+template <typename K>
+static size_t fft_rt_lds(K kernel, int L, size_t extra = 0) {
+  const size_t bytes = 2 * (size_t)L * sizeof(cf) + extra;
+  if (bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
+  return bytes;
 }
 
 // DelayBuffer: [mem; in] -> [out; mem'] per channel; mem double-buffered

@@ -1,4 +1,5 @@
-// fft_lds.h — power-of-two complex FFT passes for data held in LDS.
+// fft_lds.h — complex FFT passes for data held in LDS: compile-time power-of-two sizes (the hot
+// sizes) and run-time mixed-radix sizes (FftShape, any length whose prime factors are <= 97).
 //
 // Stockham auto-sort formulation: pass with radix R and Ns = product of the
 // radices of the previous passes maps butterfly j in [0, L/R) as
@@ -94,6 +95,115 @@ constexpr int fft_r4_passes(int L) { return fft_log2(L) / 2; }
 constexpr bool fft_has_r2(int L) { return fft_log2(L) % 2 == 1; }
 constexpr int fft_total_passes(int L) { return fft_r4_passes(L) + (fft_has_r2(L) ? 1 : 0); }
 
+
+// ---------------------------------------------------------------------------
+// Run-time sizes.  libear's FFT is kissfft (src/fft_kiss.cpp:104-107), which factorises ANY length
+// (radix 4, 2, 3, 5 butterflies, a generic one for other primes: submodules/kissfft/kissfft.hh:34-51),
+// so a BlockConvolver block size need not be a power of two (480 = 10 ms at 48 kHz, 960, 1920 ...).
+// Same Stockham formulation as above with the radix of every pass taken from a shape: radix-4 passes
+// first, then 2, 3, 5, then the remaining primes in ascending order through the generic butterfly
+// (O(p^2) per butterfly: inputs re-read from LDS instead of a register array of run-time size).
+struct FftShape {
+  int L;
+  int npass;
+  int radix[14];  // L <= 8192: at most 13 prime factors
+};
+constexpr int kFftMaxPrime = 97;
+
+// false: L has a prime factor above kFftMaxPrime (or is out of range)
+inline bool fft_make_shape(int L, FftShape *s) {
+  s->L = L;
+  s->npass = 0;
+  if (L < 2 || L > 8192) return false;
+  int rest = L;
+  while (rest % 4 == 0) s->radix[s->npass++] = 4, rest /= 4;
+  for (int p = 2; p <= kFftMaxPrime && rest > 1; p++)
+    while (rest % p == 0) {
+      if (s->npass == 14) return false;
+      s->radix[s->npass++] = p;
+      rest /= p;
+    }
+  return rest == 1;
+}
+
+// one radix-R butterfly of a pass over L points, j in [0, L / R)
+template <int DIR>
+EARHIP_HD void stockham_any(const cf *in, cf *out, const cf *tw, int L, int R, int Ns, int j) {
+  const int k = j % Ns;
+  const int M = L / R;              // butterflies of the pass = input stride
+  const int step = L / (Ns * R);    // W_{Ns R}^{k r} = tw[k r step]
+  const int base = (j - k) * R + k;
+  if (R == 4) {
+    cf v0 = in[j], v1 = in[j + M], v2 = in[j + 2 * M], v3 = in[j + 3 * M];
+    if (Ns > 1) {
+      v1 = cf_mul(v1, tw_load<DIR>(tw, k * step));
+      v2 = cf_mul(v2, tw_load<DIR>(tw, 2 * k * step));
+      v3 = cf_mul(v3, tw_load<DIR>(tw, 3 * k * step));
+    }
+    const cf a0 = cf_add(v0, v2), a1 = cf_sub(v0, v2);
+    const cf a2 = cf_add(v1, v3), a3 = cf_mul_i<DIR>(cf_sub(v1, v3));
+    out[base] = cf_add(a0, a2);
+    out[base + Ns] = cf_add(a1, a3);
+    out[base + 2 * Ns] = cf_sub(a0, a2);
+    out[base + 3 * Ns] = cf_sub(a1, a3);
+  } else if (R == 2) {
+    const cf v0 = in[j];
+    cf v1 = in[j + M];
+    if (Ns > 1) v1 = cf_mul(v1, tw_load<DIR>(tw, k * step));
+    out[base] = cf_add(v0, v1);
+    out[base + Ns] = cf_sub(v0, v1);
+  } else if (R == 3) {
+    const cf v0 = in[j];
+    cf v1 = in[j + M], v2 = in[j + 2 * M];
+    if (Ns > 1) {
+      v1 = cf_mul(v1, tw_load<DIR>(tw, k * step));
+      v2 = cf_mul(v2, tw_load<DIR>(tw, 2 * k * step));
+    }
+    // w = exp(DIR 2 pi i / 3) = -1/2 + DIR i sqrt(3)/2
+    const float h = 0.86602540378443865f;
+    const cf t = cf_add(v1, v2), d = cf_sub(v1, v2);
+    const cf m = cf_make(v0.x - 0.5f * t.x, v0.y - 0.5f * t.y);
+    const cf r = cf_mul_i<DIR>(cf_make(h * d.x, h * d.y));
+    out[base] = cf_add(v0, t);
+    out[base + Ns] = cf_add(m, r);
+    out[base + 2 * Ns] = cf_sub(m, r);
+  } else if (R == 5) {
+    const cf v0 = in[j];
+    cf v1 = in[j + M], v2 = in[j + 2 * M], v3 = in[j + 3 * M], v4 = in[j + 4 * M];
+    if (Ns > 1) {
+      v1 = cf_mul(v1, tw_load<DIR>(tw, k * step));
+      v2 = cf_mul(v2, tw_load<DIR>(tw, 2 * k * step));
+      v3 = cf_mul(v3, tw_load<DIR>(tw, 3 * k * step));
+      v4 = cf_mul(v4, tw_load<DIR>(tw, 4 * k * step));
+    }
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;  // cos(2 pi / 5), cos(4 pi / 5)
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;   // sin(2 pi / 5), sin(4 pi / 5)
+    const cf a1 = cf_add(v1, v4), a2 = cf_add(v2, v3), b1 = cf_sub(v1, v4), b2 = cf_sub(v2, v3);
+    const cf m1 = cf_make(v0.x + c1 * a1.x + c2 * a2.x, v0.y + c1 * a1.y + c2 * a2.y);
+    const cf m2 = cf_make(v0.x + c2 * a1.x + c1 * a2.x, v0.y + c2 * a1.y + c1 * a2.y);
+    const cf r1 = cf_mul_i<DIR>(cf_make(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+    const cf r2 = cf_mul_i<DIR>(cf_make(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+    out[base] = cf_add(v0, cf_add(a1, a2));
+    out[base + Ns] = cf_add(m1, r1);
+    out[base + 2 * Ns] = cf_add(m2, r2);
+    out[base + 3 * Ns] = cf_sub(m2, r2);
+    out[base + 4 * Ns] = cf_sub(m1, r1);
+  } else {  // any other prime: X_q = sum_r (in_r W_{Ns R}^{k r}) W_R^{r q},  W_R^{r q} = tw[(r q mod R) M]
+    for (int q = 0; q < R; q++) {
+      cf acc = in[j];
+      int rq = 0;
+      for (int r = 1; r < R; r++) {
+        rq += q;
+        if (rq >= R) rq -= R;
+        cf v = in[j + r * M];
+        if (Ns > 1) v = cf_mul(v, tw_load<DIR>(tw, r * k * step));
+        acc = cf_add(acc, cf_mul(v, tw_load<DIR>(tw, rq * M)));
+      }
+      out[base + q * Ns] = acc;
+    }
+  }
+}
+
 #if defined(__HIPCC__)
 // Runs passes [first, total) of an L-point transform on LDS buffers a -> b ->
 // a ...; `src` holds the input of pass `first`.  Every thread of the NT-thread
@@ -122,6 +232,25 @@ __device__ __forceinline__ cf *fft_run_passes(cf *src, cf *dst, const cf *tw,
     cf *t = src;
     src = dst;
     dst = t;
+  }
+  return src;
+}
+
+// the dynamic LDS of the run-time-size kernels (2 L complex, + what the kernel adds)
+extern __shared__ __attribute__((aligned(16))) unsigned char fft_dyn_lds[];
+
+// the same for a run-time shape (all passes)
+template <int DIR, int NT>
+__device__ __forceinline__ cf *fft_run_shape(cf *src, cf *dst, const cf *tw, const FftShape &S, int tid) {
+  int Ns = 1;
+  for (int p = 0; p < S.npass; ++p) {
+    const int R = S.radix[p];
+    __syncthreads();
+    for (int j = tid; j < S.L / R; j += NT) stockham_any<DIR>(src, dst, tw, S.L, R, Ns, j);
+    cf *t = src;
+    src = dst;
+    dst = t;
+    Ns *= R;
   }
   return src;
 }

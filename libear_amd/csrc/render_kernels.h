@@ -373,6 +373,89 @@ __global__ void __launch_bounds__(256) k_decorrelate_delay_mix(DecorParams P) {
 }
 
 // ---------------------------------------------------------------------------
+// K2 for block sizes without an instantiation above (anything that is not a power of two: 480, 960,
+// 1920 ...): the same run / pair / overlap-add structure as k_decorrelate_delay_mix with the transform
+// size taken from an FftShape (mixed radix, fft_lds.h), the spectral multiply as its own sweep and no
+// register staging — the general path, not a tuned one.  Dynamic LDS: 2 L complex + B floats.
+static __global__ void __launch_bounds__(256) k_decorrelate_delay_mix_rt(DecorParams P, FftShape S) {
+  constexpr int NT = 256;
+  const int L = S.L, B = L / 2;
+  cf *a = reinterpret_cast<cf *>(fft_dyn_lds), *b = a + L;
+  float *tail = reinterpret_cast<float *>(b + L);
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int first = blockIdx.x * P.R;
+  const int last = min(first + P.R, P.T);
+  const float norm = 1.0f / (float)(2 * B);  // block_convolver_impl.cpp:212
+  const cf *H = P.H + (size_t)n * L;
+  const float *direct = P.bus + (size_t)n * P.bus_stride;
+  const float *diffuse = P.bus + (size_t)(P.N + n) * P.bus_stride;
+  float *out = P.out + (size_t)n * P.out_stride;
+  auto bus_at = [&](const float *row, int s) {
+    const float *q = row + s;
+    float v = q[0];
+    for (int p = 1; p < P.nparts; p++) v += q[(size_t)p * P.part_stride];
+    return v;
+  };
+  auto delayed = [&](int s) {  // direct bus delayed by D (may reach back into the state)
+    const int sd = s - P.D;
+    return sd >= 0 ? bus_at(direct, sd) : P.dly_in[(size_t)n * P.D + (sd + P.D)];
+  };
+  auto diffuse_at = [&](int s) {  // diffuse bus delayed by this partition's shift
+    const int sd = s - P.shift;
+    return sd >= 0 ? bus_at(diffuse, sd) : P.hist_in[(size_t)n * P.hist_len + (sd + P.hist_len)];
+  };
+  for (int i = tid; i < B; i += NT) tail[i] = first == 0 ? P.tail_in[(size_t)n * B + i] : 0.0f;
+
+  // pairs of blocks through one complex transform: real part = block tb, imaginary part = block tb + 1
+  // (H is exactly Hermitian); the pair before `first` only rebuilds the overlap-add tail
+  for (int tb = first - 1; tb < last; tb += 2) {
+    const bool have_re = tb >= 0, have_im = tb + 1 < last;
+    __syncthreads();  // the previous pair's reads of a / b and tail are finished
+    for (int i = tid; i < B; i += NT) {
+      a[i] = cf_make(have_re ? diffuse_at(tb * B + i) : 0.0f, have_im ? diffuse_at((tb + 1) * B + i) : 0.0f);
+      a[i + B] = cf_make(0.0f, 0.0f);
+    }
+    cf *Z = fft_run_shape<-1, NT>(a, b, P.tw, S, tid);
+    __syncthreads();
+    for (int i = tid; i < L; i += NT) Z[i] = cf_mul(Z[i], H[i]);
+    cf *y = fft_run_shape<+1, NT>(Z, Z == a ? b : a, P.tw, S, tid);
+    __syncthreads();
+    for (int i = tid; i < B; i += NT) {
+      const cf y_lo = y[i], y_hi = y[B + i];
+      float tl = tail[i];
+      if (have_re) {
+        if (tb >= first) {
+          const float dec = (y_lo.x + tl) * norm;  // :223-226
+          out[tb * B + i] = P.accumulate ? out[tb * B + i] + dec : dec + delayed(tb * B + i);
+        }
+        tl = y_hi.x;  // :224
+      }
+      if (have_im) {
+        const float dec = (y_lo.y + tl) * norm;
+        out[(tb + 1) * B + i] = P.accumulate ? out[(tb + 1) * B + i] + dec : dec + delayed((tb + 1) * B + i);
+        tl = y_hi.y;
+      }
+      tail[i] = tl;
+    }
+  }
+
+  if (last == P.T) {  // this workgroup owns the end of the call: publish the state
+    __syncthreads();
+    for (int i = tid; i < B; i += NT) P.tail_out[(size_t)n * B + i] = tail[i];
+    const int total = P.T * B;
+    if (!P.accumulate) {
+      for (int j = tid; j < P.D; j += NT) P.dly_out[(size_t)n * P.D + j] = delayed(total + j);
+      for (int j = tid; j < P.hist_len; j += NT) {
+        const int sd = total - P.hist_len + j;
+        P.hist_out[(size_t)n * P.hist_len + j] =
+            sd >= 0 ? bus_at(diffuse, sd) : P.hist_in[(size_t)n * P.hist_len + (sd + P.hist_len)];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K2 for 512-sample blocks, one WAVE per (loudspeaker, run of blocks): the 1024-point
 // transforms are Stockham passes of radix 16, 16 and 4 with 16 values per lane (indices
 // lane + 64 m — the same layout on input and output, so forward, x H and inverse chain

@@ -225,9 +225,9 @@ class GainInterpolator {
 // ---------------------------------------------------------------------------
 // FFT — restatement of the vendored kissfft (submodules/kissfft/kissfft.hh,
 // BSD-3-Clause, Mark Borgerding) as used by src/fft_kiss.cpp.  Mixed-radix
-// decimation in time, radix 4 first then 2 (then odd radices, which the hot
-// path never hits for power-of-two blocks; 3 and 5 are provided, other primes
-// are rejected).  Written iteratively: digit-reversed load followed by the
+// decimation in time, radix 4 first then 2, then odd radices (3 and 5 with their
+// own butterflies, any other prime through the generic one — block sizes that
+// are not powers of two).  Written iteratively: digit-reversed load followed by the
 // butterfly passes deepest-first, which performs exactly the butterflies of
 // the recursive formulation (kissfft.hh:90-123) with identical operands.
 // ---------------------------------------------------------------------------
@@ -254,9 +254,6 @@ class KissLikeFFT {
       radix_.push_back(p);
       remain_.push_back(rem);
     } while (rem > 1);
-    for (size_t p_ : radix_)
-      if (p_ != 2 && p_ != 3 && p_ != 4 && p_ != 5)
-        throw invalid_argument("oracle FFT: unsupported radix");
     // digit-reversal: output slot sum(q_s * remain_s) reads input slot
     // sum(q_s * prod(radix_0..s-1))  (leaf copies of kissfft.hh:98-102)
     perm_.assign(n_, 0);
@@ -288,7 +285,8 @@ class KissLikeFFT {
           case 2: bfly2(f, fstride, m); break;
           case 3: bfly3(f, fstride, m); break;
           case 4: bfly4(f, fstride, m); break;
-          default: bfly5(f, fstride, m); break;
+          case 5: bfly5(f, fstride, m); break;
+          default: bfly_any(f, fstride, m, p); break;
         }
       }
     }
@@ -385,6 +383,25 @@ class KissLikeFFT {
                         d14.real() * yb.imag() - d23.real() * ya.imag());
       *f2 = c + d;
       *f3 = c - d;
+    }
+  }
+
+  // kissfft.hh:321-352: any other radix p, O(p^2) per butterfly; the twiddle index of output q1 walks
+  // in steps of fstride * (u + q1 m) modulo n
+  void bfly_any(cpx *f, size_t fstride, size_t m, size_t p) const {
+    std::vector<cpx> x(p);
+    for (size_t u = 0; u < m; ++u) {
+      for (size_t q1 = 0; q1 < p; ++q1) x[q1] = f[u + q1 * m];
+      for (size_t q1 = 0; q1 < p; ++q1) {
+        const size_t k = u + q1 * m;
+        size_t twidx = 0;
+        f[k] = x[0];
+        for (size_t q = 1; q < p; ++q) {
+          twidx += fstride * k;
+          if (twidx >= n_) twidx -= n_;
+          f[k] += x[q] * tw_[twidx];
+        }
+      }
     }
   }
 

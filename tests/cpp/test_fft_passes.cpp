@@ -52,6 +52,58 @@ double run_case(unsigned seed) {
   return std::sqrt(err / nrm);
 }
 
+// run-time shapes (mixed radix): the same check against a double DFT
+template <int DIR>
+double run_shape(int L, unsigned seed, bool *ok_shape) {
+  FftShape S;
+  *ok_shape = fft_make_shape(L, &S);
+  if (!*ok_shape) return 0.0;
+  std::vector<cf> a(L), b(L), tw(L);
+  for (int t = 0; t < L; t++) {
+    const double ang = -2.0 * M_PI * t / L;
+    tw[t] = cf_make((float)std::cos(ang), (float)std::sin(ang));
+  }
+  std::mt19937 g(seed);
+  std::uniform_real_distribution<float> u(-1, 1);
+  std::vector<std::complex<double>> x(L);
+  for (int i = 0; i < L; i++) {
+    a[i] = cf_make(u(g), u(g));
+    x[i] = {a[i].x, a[i].y};
+  }
+  cf *src = a.data(), *dst = b.data();
+  int Ns = 1;
+  for (int p = 0; p < S.npass; p++) {
+    const int R = S.radix[p];
+    for (int j = 0; j < L / R; j++) stockham_any<DIR>(src, dst, tw.data(), L, R, Ns, j);
+    std::swap(src, dst);
+    Ns *= R;
+  }
+  double err = 0, nrm = 0;
+  for (int k = 0; k < L; k++) {
+    std::complex<double> s = 0;
+    for (int n = 0; n < L; n++) {
+      const double ang = DIR * 2.0 * M_PI * (double)((long long)k * n % L) / L;
+      s += x[n] * std::complex<double>(std::cos(ang), std::sin(ang));
+    }
+    const std::complex<double> got(src[k].x, src[k].y);
+    err += std::norm(got - s);
+    nrm += std::norm(s);
+  }
+  return std::sqrt(err / nrm);
+}
+
+int check_shape(int L, bool expect_ok = true) {
+  bool s1, s2;
+  const double ef = run_shape<-1>(L, L, &s1), ei = run_shape<+1>(L, L + 1, &s2);
+  if (!expect_ok) {
+    std::printf("L=%5d (run-time) rejected: %s\n", L, !s1 ? "ok" : "FAIL");
+    return s1 ? 1 : 0;
+  }
+  const bool ok = s1 && s2 && ef < 6e-7 && ei < 6e-7;
+  std::printf("L=%5d (run-time) fwd_relerr=%.3g inv_relerr=%.3g %s\n", L, ef, ei, ok ? "ok" : "FAIL");
+  return ok ? 0 : 1;
+}
+
 template <int L>
 int check() {
   const double ef = run_case<L, -1>(L), ei = run_case<L, +1>(L + 1);
@@ -71,5 +123,10 @@ int main() {
   bad += check<2048>();
   bad += check<4096>();
   bad += check<8192>();
+  // 2 x block sizes that are not powers of two: 3- and 5-smooth, other primes, powers of two again
+  for (int L : {6, 10, 18, 30, 90, 96, 240, 882, 960, 1000, 1024, 1920, 2 * 1155, 3840, 6000, 2 * 97 * 31, 8192, 2 * 3 * 343})
+    bad += check_shape(L);
+  bad += check_shape(2 * 101, false);    // prime factor above kFftMaxPrime
+  bad += check_shape(2 * 4093, false);
   return bad;
 }

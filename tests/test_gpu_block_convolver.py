@@ -35,9 +35,10 @@ def test_scenario(sc):
     assert np.max(np.abs(got - ref)) < 1e-6
 
 
-@pytest.mark.parametrize("block", [32, 64, 256, 1024, 2048])
+@pytest.mark.parametrize("block", [32, 64, 256, 1024, 2048, 1, 2, 3, 16, 45, 100, 441, 480, 960, 1920, 3000, 4096])
 def test_other_block_sizes_dense_input(block):
-    """full-scale dense input (not sparse impulses), 3 partitions, one crossfade"""
+    """full-scale dense input (not sparse impulses), 3 partitions, one crossfade; block sizes that are not
+    powers of two take the mixed-radix transforms (kissfft factorises any length, kissfft.hh:34-51)"""
     ConvCtx, ConvFilter, BlockConvolver = _hip_classes()
     rng = np.random.default_rng(block)
     nblk = 6
@@ -113,4 +114,8 @@ def test_errors():
         conv.crossfade_filter(ConvFilter(c512, np.ones(513, np.float32)))
     assert "too many blocks" in str(e.value)
     with pytest.raises(capi.InvalidArgument):
-        ConvCtx(ctx(), 500)
+        ConvCtx(ctx(), 4093)  # a prime factor above 97
+    with pytest.raises(capi.InvalidArgument):
+        ConvCtx(ctx(), 0)
+    with pytest.raises(capi.InvalidArgument):
+        ConvCtx(ctx(), 8192)

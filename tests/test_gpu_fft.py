@@ -28,6 +28,26 @@ def test_forward_and_reverse(n_fft):
     plan.close()
 
 
+@pytest.mark.parametrize("n_fft", [4, 6, 30, 90, 96, 882, 960, 1000, 1920, 2 * 1155, 3840, 6000, 2 * 97 * 31])
+def test_sizes_that_are_not_powers_of_two(n_fft):
+    """kissfft takes any even real length (src/fft_kiss.cpp:104-107): mixed-radix plans (4, 2, 3, 5 and the
+    generic butterfly for other primes up to 97) against the oracle's restatement of the same factorisations"""
+    from libear_amd import capi
+    plan = capi.FFTPlan(ctx(), n_fft)
+    rng = np.random.default_rng(n_fft)
+    x = rng.uniform(-1, 1, n_fft).astype(np.float32)
+    X = plan.forward(x)
+    want = _oracle.rfft(x)
+    ref = np.fft.rfft(x.astype(np.float64))
+    assert np.linalg.norm(X - want) / np.linalg.norm(want) < 6e-7
+    assert np.linalg.norm(X - ref) / np.linalg.norm(ref) < 6e-7
+    y = plan.reverse(want)
+    want_y = _oracle.irfft_unnorm(want, n_fft)
+    assert np.linalg.norm(y - want_y) / np.linalg.norm(want_y) < 6e-7
+    assert np.max(np.abs(y / n_fft - x)) < 3e-6
+    plan.close()
+
+
 def test_golden_vectors():
     """the committed kissfft vectors (tests/golden) through the device transform"""
     import os
@@ -49,4 +69,8 @@ def test_golden_vectors():
 def test_bad_size_is_invalid_argument():
     from libear_amd import capi
     with pytest.raises(capi.InvalidArgument):
-        capi.FFTPlan(ctx(), 1000)
+        capi.FFTPlan(ctx(), 1001)  # odd (kiss_fftr needs an even length)
+    with pytest.raises(capi.InvalidArgument):
+        capi.FFTPlan(ctx(), 2 * 101)  # a prime factor above 97
+    with pytest.raises(capi.InvalidArgument):
+        capi.FFTPlan(ctx(), 16384)

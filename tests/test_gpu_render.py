@@ -284,7 +284,9 @@ def test_render_errors():
     from libear_amd import capi
     dec = decorrelators("0+5+0")
     with pytest.raises(capi.InvalidArgument):
-        capi.Renderer(ctx(), 4, 6, 500, dec, 255)  # block size not a power of two
+        capi.Renderer(ctx(), 4, 6, 4093, dec, 255)  # a prime above 97 in the block size
+    with pytest.raises(capi.InvalidArgument):
+        capi.Renderer(ctx(), 4, 6, 8192, dec, 255)  # too large
     r = capi.Renderer(ctx(), 4, 6, 512, dec, 255, max_blocks=2)
     with pytest.raises(capi.InvalidArgument):
         r.process(np.zeros((4, 512 * 3), np.float32))  # more blocks than max_blocks
@@ -424,6 +426,31 @@ def test_block_size_limits(block, nblocks, m):
     assert scenes.rel_rms(got, want) <= 1e-6
     step = run_hip(curves, x, n, block, dec, 255, [1] * nblocks)
     assert scenes.rel_rms(step, want) <= 1e-6
+
+
+@pytest.mark.parametrize("block,nblocks,calls,m", [(480, 9, [9], 40), (480, 9, [1, 2, 6], 40), (960, 5, [2, 3], 33), (1920, 3, [3], 24),
+                                                   (96, 15, [4, 11], 40), (120, 12, [12], 70), (45, 20, [7, 13], 12),
+                                                   (441, 6, [1, 5], 20), (1000, 4, [4], 64), (3000, 2, [1, 1], 24)])
+def test_block_sizes_that_are_not_powers_of_two(block, nblocks, calls, m):
+    """libear's kissfft factorises any length (submodules/kissfft/kissfft.hh:34-51: radix 4, 2, 3, 5, generic),
+    so the renderer's block size need not be a power of two: 10 ms at 48 kHz (480) and its multiples, odd sizes
+    (45, 441 = 3^2 7^2 through the generic butterfly).  The mixed-radix K2 kernel and the gain kernels on a block
+    grid that no tile size divides, against the oracle; the 512-tap decorrelators span several partitions at the
+    small sizes."""
+    layout = "4+5+0"
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=700, ramp=min(block // 3 + 5, 300), seed=block)
+    x = scenes.audio(m, total, seed=block)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, calls)
+    assert scenes.rel_rms(got, want) <= 1e-6
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
+    aligned = scenes.dense_curves(m, n, block, nblocks, seed=block + 1)  # a new gain vector every block
+    want = run_oracle(aligned, x, n, block, dec, 255)
+    got = run_hip(aligned, x, n, block, dec, 255, calls)
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
 
 
 @pytest.mark.parametrize("m,nblocks,calls,run", [(24, 37, [37], None), (24, 37, [1, 20, 3, 13], "3"),

@@ -49,7 +49,9 @@ def test_cfft64_matches_golden_bit_exact():
     assert same_bits(got, GOLD["cfft64_n512_inv1_out"])
 
 
-@pytest.mark.parametrize("n,inv", [(64, 0), (128, 1), (480, 0), (960, 1), (1024, 0), (4096, 1)])
+@pytest.mark.parametrize("n,inv", [(64, 0), (128, 1), (480, 0), (960, 1), (1024, 0), (4096, 1),
+                                   # radices beyond 2..5 (kissfft's generic butterfly): 7, 7*7, 11, 13*3, 97
+                                   (14, 0), (441, 1), (2 * 11 * 5, 0), (39 * 4, 1), (97 * 8, 0), (1155, 1)])
 def test_cfft_live_against_compiled_reference(n, inv):
     ref = _oracle.load_ref()
     if ref is None:
