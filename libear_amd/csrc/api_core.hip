@@ -114,13 +114,12 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       EARHIP_HIP(hipMemcpy(cnt.data(), pl.count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
       std::vector<Piece> pc((size_t)pl.cap());
       for (int t = 0; t < ml.ntiles; t++) {
-        fprintf(stderr, "tile %d: counts %d %d %d %d ovf %d\n", t, cnt[t * 8], cnt[t * 8 + 1], cnt[t * 8 + 2], cnt[t * 8 + 3], cnt[t * 8 + 4]);
+        fprintf(stderr, "tile %d: base chunks %d delta chunks %d exact objects %d\n", t, cnt[t * 8], cnt[t * 8 + 1], cnt[t * 8 + 4]);
         EARHIP_HIP(hipMemcpy(pc.data(), pl.pieces + (size_t)t * pl.cap(), pc.size() * sizeof(Piece), hipMemcpyDeviceToHost));
-        for (int l = 0, at = 0; l < 4; at += 32 * cnt[t * 8 + l], l++)
+        for (int l = 0, at = 0; l < 2; at += 32 * cnt[t * 8 + l], l++)
           for (int i = 0; i < std::min(32 * cnt[t * 8 + l], 3); i++) {
             const Piece &q = pc[at + i];
-            fprintf(stderr, "   list %d [%d]: m %u r0 %u r1 %u row %d p0 %g scale %g\n", l, i, q.mr & 0xffff, (q.mr >> 16) & 0xff,
-                    (q.mr >> 24) + 1, q.row, q.p0, q.scale);
+            fprintf(stderr, "   list %d [%d]: m %u row %d p0 %g scale %g\n", l, i, q.m, q.row, q.p0, q.scale);
           }
       }
     }
@@ -155,15 +154,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   bool launched = false;
   if (ml.pieces) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
-    // (gains at 2^12: a ramp piece that starts inside its tile is extended back to the tile start, gain_p2.h)
-    const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale() * 0.25f;
+    const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale();
 #define EARHIP_P2_CASE(NCT_)                                                                                        \
   if (cp.nct == NCT_) {                                                                                             \
     if (ml.pw == 4)                                                                                                 \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
                          level_next);                                                                                \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 2>), bgrid, dim3(128), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
+      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
                          level_next);                                                                                \
   }
     EARHIP_P2_CASE(1) EARHIP_P2_CASE(2) EARHIP_P2_CASE(3)

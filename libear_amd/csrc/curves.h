@@ -115,14 +115,14 @@ class CurveSet {
     for (int m = 0; m < M_; m++) P += times_[m].size();
     const size_t row = (size_t)plan_.row;
     if (staged_) EARHIP_HIP(hipEventSynchronize(staged_));  // staging buffers free again
-    if (M_ + 1 > (int)h_off_.n || P > h_time_.n || (P + 1) * row > h_gain_.n) {
+    if (M_ + 1 > (int)h_off_.n || P > h_time_.n || (P + 2) * row > h_gain_.n) {
       const size_t cap = P + P / 2 + 16;  // grow with headroom: appending points stays cheap
       h_off_.reserve(M_ + 1);
       h_time_.reserve(cap);
       h_flat_.reserve(cap);
-      h_gain_.reserve((cap + 1) * row);
+      h_gain_.reserve((cap + 2) * row);
     }
-    if (P > d_time_.n || (P + 1) * row > d_gain_.n || (size_t)M_ + 1 > d_off_.n) {
+    if (P > d_time_.n || (P + 2) * row > d_gain_.n || (size_t)M_ + 1 > d_off_.n) {
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // the old image may still be in use
       d_off_.reserve(M_ + 1);
       d_time_.reserve(h_time_.n);
@@ -139,7 +139,9 @@ class CurveSet {
       at += n;
     }
     h_off_.p[M_] = (int32_t)at;
-    std::memset(h_gain_.p + P * row, 0, row * sizeof(float));  // the all-zero row (split-operand kernels)
+    // two all-zero rows (split-operand kernels: the row objects to skip point at, and the row behind it that a
+    // null RAMP piece of the piece-list kernel reads as its end point)
+    std::memset(h_gain_.p + P * row, 0, 2 * row * sizeof(float));
     npoints_ = (int)P;
     // common grid of all point times: every time is t_ref_ + k * grid_ (grid_ = 0: all equal)
     t_ref_ = P ? times_[0][0] : 0;
@@ -215,7 +217,7 @@ class CurveSet {
     EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, (M_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, P * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, P, hipMemcpyHostToDevice, ctx->stream));
-    EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, (P + 1) * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, (P + 2) * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (!staged_) EARHIP_HIP(hipEventCreateWithFlags(&staged_, hipEventDisableTiming));
     EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
     dirty_ = false;
@@ -331,18 +333,18 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   const char *force_tile = getenv("EARHIP_H2_TILE");
   const int forced = force_tile ? atoi(force_tile) : 0;
   // Piece-list kernel: everything else the f16x2 operands can represent — metadata that ignores the tile
-  // grid costs its curve points, not a different kernel (5 forces it for aligned curves as well).  Its
-  // tile: 256 samples while a tile rarely holds a curve point of an object, else 128 (EARHIP_P2_TILE).
+  // grid costs its curve points, not a different kernel (5 forces it for aligned curves as well).
   L.pieces = L.mfma && !L.split && M >= 32 && M <= kMaxPieceObjects && gain_scale > 0.0f &&
              (ctx->use_mfma == 3 || ctx->use_mfma == 5);
   if (ctx->use_mfma == 5 && L.pieces) L.split = false;
   if (L.pieces) {
     const char *pt = getenv("EARHIP_P2_TILE");
     const int ptile = pt ? atoi(pt) : 0;
-    // (the 2-wave variant converts 16 pieces per wave and chunk and does not fit the register file: 4 waves
-    // on 256 samples unless asked for)
-    L.pw = ptile == 128 ? 2 : 4;
-    (void)point_density;
+    // 8 waves on 512 samples halve the gain conversions and the list building per sample but keep every ramp's
+    // delta piece alive over twice the samples: right while a tile holds about one curve point per object
+    // (ADM-like metadata, 2 points per 960 samples: whole step 0.74 -> 0.71 ms), wrong for curves that turn
+    // every 240 samples (1.35 -> 1.48 ms).  EARHIP_P2_TILE=256|512 forces.
+    L.pw = ptile == 512 ? 8 : ptile == 256 ? 4 : (point_density * 512.0 < 1.5 && nsamples / 512 >= 2 * ctx->num_cus) ? 8 : 4;
   }
   L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
   // the slot lists of the f32 MFMA kernel address objects with 16 bits

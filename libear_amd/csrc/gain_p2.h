@@ -1,32 +1,44 @@
-// gain_p2.h — K1 on the f16 matrix cores over per-tile PIECE lists ("f16x2 pieces"): the split-operand
-// formulation of gain_h2.h,
+// gain_p2.h — K1 on the f16 matrix cores over per-tile PIECE lists ("f16x2 pieces"), for gain curves whose
+// points ignore the tile grid (ADM blocks at arbitrary times).
 //
-//     bus[col][s] = sum_k x_m(k)(s) [r0_k <= s < r1_k] * (B0_k,col + (s - s0) * B1_k,col),
+// A gain curve is continuous and piecewise linear through its points (libear: GainInterpolator::process,
+// include/ear/dsp/gain_interpolator.hpp:58-86; constant before the first and after the last point, :68-75).
+// Inside a tile that starts at sample s0 it is therefore its value at the tile start plus what every ramp
+// that overlaps the tile has added so far:
 //
-// with the k dimension of the MFMA running over the PIECES of the workgroup tile instead of its objects: a
-// piece is one linear stretch (object, curve segment, sample range) of a gain curve inside the tile —
-// what one iteration of libear's segment walk handles (GainInterpolator::process,
-// include/ear/dsp/gain_interpolator.hpp:58-86).  An object whose segment covers the whole tile is one
-// piece; every curve point inside the tile adds one.  The range of a piece is applied to the INPUT (a
-// per-sample scale of 0 or 2^k folded into the prescale the operand split needs anyway); B0 / B1 of a
-// piece are its line extended to the tile start s0, so all pieces share the accumulator-side factor
-// (s - s0).  Four lists per tile, written by k_piece_list in object order (deterministic):
+//     g(s) = S_base + sum_k clamp(p_k(s), 0, 1) * (E_k - S_k),     p_k(s) = p0_k + (s - s0) * scale_k
 //
-//     constant pieces covering the whole tile | constant pieces with a range |
-//     ramp pieces covering the whole tile     | ramp pieces with a range
+// with S_base the START row of the segment the tile starts in (its own ramp, if it is one, is the first
+// term of the sum: p0 >= 0), p_k libear's ramp position (:272) of segment k with (S_k, E_k) its two gain
+// rows, and the clamp holding a ramp at 0 before it starts and at 1 after it ends — flat segments add
+// nothing.  Two equal times with different gains (a step) are a ramp of length one: p = s - (r - 1).
+// So the contraction over a tile runs over PIECES, the k dimension of the MFMA:
 //
-// Constant pieces have B1 = 0, so their chunks issue only the B0 half of the MFMAs (36 instead of 72
-// per 32 pieces, 64 samples and 48 columns) and convert half the gains; pieces with a range pay the range
-// test on their inputs.  The cost of a call is therefore proportional to its pieces: block-aligned ramps
-// cost what they cost in gain_h2.h, static gains half of that, and metadata that ignores the block grid
-// (ADM blocks at arbitrary times) pays for the curve points it actually has — there is no alignment rule
-// and no cliff.
+//     bus[col][s] = sum_{base pieces}  x_m(s)             * S_row,col
+//                 + sum_{delta pieces} x_m(s) clamp(p(s)) * (E - S)_row,col
 //
-// A ramp piece that starts inside the tile is extended BACK to s0: |B0| <= (1 + 2 |p0|) gmax with
-// p0 = (s0 - start) / length.  The gains are prescaled to 2^12 (not 2^14 as in gain_h2.h), which keeps
-// |p0| <= 7 inside the f16 range; objects with a steeper piece (a ramp shorter than a seventh of its
-// offset into the tile) are listed separately and take the exact per-object path, like objects whose
-// pieces do not fit the lists.
+// one base piece per object and one delta piece per (object, ramp overlapping the tile) — no sample ranges,
+// no alignment rule, no cliff: a call costs what its curve points cost.  The position factor is not linear
+// in s (the clamp), so it goes to the INPUT side: a delta chunk scales its inputs by clamp(p) before the
+// operand split; both kinds of chunk are then the same 36 MFMAs per 32 pieces, 64 samples and 48 columns on
+// one set of accumulators.  (gain_h2.h keeps the ramp on the gain side and needs a second set; it is the
+// kernel for curves ON the tile grid, where it has half the pieces.)  Block-aligned ramps cost a base and a
+// delta piece per object here, static gains one, ADM-like metadata (interpolate 5 ms, then hold) 1 + the
+// fraction of tiles a ramp touches.
+//
+// ONE list per tile, written by k_piece_list in object order (deterministic): every object's base piece
+// followed by its delta pieces, padded to whole chunks of 32 with null pieces (object 0, the all-zero gain
+// row).  The pieces of an object are neighbours in k, so its input row is requested from memory once (the
+// repeats hit in the cache): a call reads its inputs once however many curve points it has.  All pieces
+// go through the same arithmetic — a base piece is a delta piece with p = 1 (p0 = 1, scale = 0) whose gain
+// operand is S - 0 instead of E - S — so there are no chunk kinds and no branches in the loop; a tile
+// without any delta piece (static gains) skips the position factor altogether.  Objects with more than
+// kPieceMaxPerObject ramps in one tile, objects the level probe found far below the call's level
+// (kSegQuiet) and, in a tile whose list would overflow, every object with a delta piece take the exact
+// per-object path.
+//
+// Operand scaling and splitting as in gain_h2.h (x by the probed power of two, gains by 2^14 / the curve
+// set's largest gain: |E - S| <= 2^15 stays inside the f16 range).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,25 +48,24 @@
 namespace earhip {
 
 struct Piece {
-  uint32_t mr;  // object m | r0 << 16 | (r1 - 1) << 24   (range [r0, r1) relative to the tile start)
-  int32_t row;  // gain row of the segment's start point (ramp: end point = row + 1)
-  float p0;     // ramp: libear's p at the tile start, (float)(s0 - start) * scale (gain_interpolator.hpp:272); else 0
-  float scale;  // ramp: 1.0f / (float)(end - start); else 0
+  uint32_t m;   // object | kPieceDelta
+  int32_t row;  // base: the gain row; delta: the start row S of the ramp (end row E = row + 1)
+  float p0;     // delta: libear's p at the tile start, (float)(s0 - start) * scale (gain_interpolator.hpp:272); base: 1
+  float scale;  // delta: 1.0f / (float)(end - start); base: 0
 };
+constexpr uint32_t kPieceDelta = 1u << 31;
 static_assert(sizeof(Piece) == 16, "Piece is loaded as one dwordx4");
 
-constexpr int kPieceLists = 4;            // 2 * ramp + ranged
 constexpr int kPieceCapPerObject = 8;     // capacity of a tile's lists: pieces per object on average (+ padding)
-constexpr int kPieceMaxPerObject = 32;    // ranged pieces of ONE object in one tile; beyond: exact path
-constexpr float kPieceMaxP0 = 7.0f;       // see above
-constexpr int kPieceMaxTile = 256;        // r0, r1 - 1 are 8-bit fields
+constexpr int kPieceMaxPerObject = 32;    // delta pieces of ONE object in one tile; beyond: exact path
+constexpr int kPieceMaxTile = 512;
 constexpr int kMaxPieceObjects = 1 << 16;
 
 struct PieceLists {
-  Piece *pieces;  // [ntiles][cap()]: the four lists back to back, each padded to a multiple of 32 with null pieces
-  int *count;     // [ntiles][8]: CHUNKS (32 pieces) of list 0..3, [4] exact-path objects
+  Piece *pieces;  // [ntiles][cap()]: the tile's pieces in object order, padded to a multiple of 32 with null pieces
+  int *count;     // [ntiles][8]: [0] CHUNKS (32 pieces) of the list, [1] delta pieces in it, [4] exact-path objects
   int *ovf;       // [ntiles][M]: objects that take the exact per-object path
-  int *cw;        // [ntiles][M]: scratch of k_piece_list (piece counts per object)
+  int *cw;        // [ntiles][M]: scratch of k_piece_list (delta pieces per object)
   int M;
   __host__ __device__ int cap() const { return kPieceCapPerObject * M + 4 * 32; }
 };
@@ -66,72 +77,67 @@ __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
 }
 
 // K0p: one workgroup per tile, behind k_seg_prep: turns the tile's descriptors (coalesced reads, no
-// searching) into its piece lists, threads over objects.  A first pass counts the pieces of every
-// object and list, which fixes where each list starts (they lie back to back, each padded to whole
-// chunks); a second pass writes them at offsets from ordered scans over the objects: the lists are in
-// object order, deterministic.
+// searching) into its piece list, threads over objects.  A first pass counts the delta pieces of every
+// object; a second pass writes the pieces at offsets from an ordered scan over the objects.
 static __global__ void __launch_bounds__(256)
 k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end, const SegDesc *desc,
              PieceLists pl) {
   __shared__ unsigned wsum[3][4];
-  __shared__ int tot[kPieceLists], lbase[kPieceLists], run[kPieceLists], run_o, all_exact;
+  __shared__ int tot_p, run_p, run_d, run_o, all_exact;
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t t0 = t_call + (int64_t)tile * tile_samples;
   int64_t t_end = t0 + tile_samples;
   if (t_end > t_call_end) t_end = t_call_end;
-  Piece *lists = pl.pieces + (size_t)tile * pl.cap();
+  Piece *list = pl.pieces + (size_t)tile * pl.cap();
   int *ovf = pl.ovf + (size_t)tile * M;
   const SegDesc *dtile = desc + (size_t)tile * M;
-  if (tid < kPieceLists) tot[tid] = 0, run[tid] = 0;
-  if (tid == 0) run_o = 0;
+  if (tid == 0) tot_p = run_p = run_d = run_o = 0;
   __syncthreads();
   Piece null_piece;
-  null_piece.mr = 1u << 16;  // object 0, empty range [1, 1)
+  null_piece.m = 0u;
   null_piece.row = ps.zero_row;
-  null_piece.p0 = 0.0f;
+  null_piece.p0 = 1.0f;
   null_piece.scale = 0.0f;
 
-  // the pieces of object m inside the tile, first one described by dk (k_seg_prep), the others found by
-  // walking on (GainInterpolator::process, gain_interpolator.hpp:58-86).  out == nullptr: count only.
-  // Returns false when the object needs the exact path (a piece too steep to extend back to the tile
-  // start, or too many pieces).
-  auto walk = [&](int m, SegDesc dk, Piece *const *out, int (&cnt)[kPieceLists]) {
+  // the delta pieces of object m inside the tile: the segment the tile starts in is described by dk
+  // (k_seg_prep), the others are found by walking on (GainInterpolator::process, gain_interpolator.hpp:58-86).
+  // out == nullptr: count only.  Returns their number, -1 for too many.
+  auto walk = [&](int m, SegDesc dk, Piece *out) {
     int pbase = 0, n = 0;
     if (dk.info & kSegMulti) {
       pbase = ps.off[m];
       n = ps.off[m + 1] - pbase;
     }
-    int k = seg_k(dk.info), cur = 0;
-    bool ok = true;
-#pragma unroll
-    for (int l = 0; l < kPieceLists; l++) cnt[l] = 0;
+    int k = seg_k(dk.info), cur = 0, nd = 0;
     for (;;) {
       const int r1 = seg_r1(dk.info);
-      if (r1 > cur) {  // duplicate times make empty segments (steps)
-        const bool ramp = dk.info & kSegRamp;
-        const bool whole = cur == 0 && r1 == tile_samples;
+      if (dk.info & kSegRamp) {
         Piece a;
-        a.mr = (uint32_t)m | ((uint32_t)cur << 16) | ((uint32_t)(r1 - 1) << 24);
+        a.m = (uint32_t)m | kPieceDelta;
         a.row = dk.row;
-        a.p0 = ramp ? (float)dk.d0 * dk.scale : 0.0f;  // p(s) = (float)(d0 + s) * scale, :272
-        a.scale = ramp ? dk.scale : 0.0f;
-        ok = ok && !(__builtin_fabsf(a.p0) > kPieceMaxP0);
-        const int l = (ramp ? 2 : 0) + (whole ? 0 : 1);
-        if (out) out[l][cnt[l]] = a;
-        cnt[l]++;
-        cur = r1;
+        bool emit = true;
+        if (r1 > cur) {  // a ramp over [cur, r1) of the tile (and beyond): its own line, clamped
+          a.p0 = (float)dk.d0 * dk.scale;  // p(s) = (float)(d0 + s) * scale, :272
+          a.scale = dk.scale;
+        } else {  // two equal times with different gains: a step at cur = a ramp from cur - 1 to cur
+          a.p0 = (float)(1 - cur);
+          a.scale = 1.0f;
+          emit = cur > 0;  // (at the tile start the base piece already has the value after the step)
+        }
+        if (emit) {
+          if (out) out[nd] = a;
+          nd++;
+        }
       }
+      if (r1 > cur) cur = r1;
       if (!(dk.info & kSegMulti)) break;
-      if (cnt[1] + cnt[3] > kPieceMaxPerObject) {
-        ok = false;
-        break;
-      }
+      if (nd > kPieceMaxPerObject) return -1;
       k++;
       dk = describe_segment(ps, pbase, n, k, t0, t_end);
     }
-    return ok;
+    return nd;
   };
-  // inclusive scan over the 256 threads of three packed counters; totals through `total`
+  // inclusive scan over the 256 threads of three counters; totals through `total`
   auto block_scan = [&](unsigned (&v)[3], unsigned (&total)[3]) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -157,124 +163,97 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
     }
     __syncthreads();
   };
-  // ---- pass 1: the piece counts of every object (kept for pass 2 in the tile's count words) and of every list
+  // ---- pass 1: the delta counts of every object (kept for pass 2 in the tile's count words) and the total
   int *cw = pl.cw + (size_t)tile * M;
   {
-    int mine[kPieceLists] = {0, 0, 0, 0};
+    int mine = 0;
     for (int mb = 0; mb < M; mb += 256) {
       const int m = mb + tid;
       if (m < M) {
-        int cnt[kPieceLists];
-        // (objects the level probe found far below the call's level — kSegQuiet — take the exact path as well)
         const SegDesc d0 = dtile[m];
-        const bool exact = !walk(m, d0, nullptr, cnt) || (d0.info & kSegQuiet);
-        // plain counts <= 1, ranged ones <= kPieceMaxPerObject + 1
-        cw[m] = exact ? -1 : (cnt[0] | (cnt[2] << 1) | (cnt[1] << 2) | (cnt[3] << 12));
-        if (!exact)
-#pragma unroll
-          for (int l = 0; l < kPieceLists; l++) mine[l] += cnt[l];
+        int nd = walk(m, d0, nullptr);
+        // (objects the level probe found far below the call's level — kSegQuiet — take the exact path as well)
+        if (d0.info & kSegQuiet) nd = -1;
+        cw[m] = nd;
+        if (nd >= 0) mine += 1 + nd;
       }
     }
 #pragma unroll
-    for (int l = 0; l < kPieceLists; l++) {
-      int v = mine[l];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0 && v) atomicAdd(&tot[l], v);
-    }
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0 && mine) atomicAdd(&tot_p, mine);
   }
   __syncthreads();
-  if (tid == 0) {
-    int at = 0;
-    for (int l = 0; l < kPieceLists; l++) {
-      lbase[l] = at;
-      at += (tot[l] + 31) & ~31;
-    }
-    // a tile with more pieces than its lists hold (more than kPieceCapPerObject per object on average):
-    // only the whole-tile pieces are listed, every object with a curve point inside takes the exact path
-    all_exact = at > pl.cap() ? 1 : 0;
-    if (all_exact) {
-      lbase[0] = 0;
-      lbase[1] = lbase[2] = (tot[0] + 31) & ~31;
-      lbase[3] = lbase[2] + ((tot[2] + 31) & ~31);
-      tot[1] = tot[3] = 0;
-    }
-  }
+  // a tile with more pieces than its list holds (more than kPieceCapPerObject per object on average):
+  // every object with a ramp inside takes the exact path, the list holds the base pieces of the others
+  if (tid == 0) all_exact = ((tot_p + 31) & ~31) > pl.cap() ? 1 : 0;
   __syncthreads();
   const bool tile_over = all_exact != 0;
 
-  // ---- pass 2: offsets from ordered scans of the counts, then the segment walk again, writing
+  // ---- pass 2: offsets from an ordered scan of the counts, then the segment walk again, writing
   for (int mb = 0; mb < M; mb += 256) {
     const int m = mb + tid;
-    int cnt[kPieceLists] = {0, 0, 0, 0};
+    int nd = 0;
     bool exact = false;
+    const bool live = m < M;
     SegDesc d;
     d.info = 0;
-    if (m < M) {
-      const int w = cw[m];
+    d.row = 0;
+    if (live) {
+      nd = cw[m];
       d = dtile[m];
-      exact = w < 0;
-      if (!exact) {
-        cnt[0] = w & 1;
-        cnt[2] = (w >> 1) & 1;
-        cnt[1] = (w >> 2) & 1023;
-        cnt[3] = (w >> 12) & 1023;
-        if (tile_over && cnt[1] + cnt[3] > 0) {
-          exact = true;
-          cnt[1] = cnt[3] = 0;
-        }
-      }
+      exact = nd < 0 || (tile_over && nd > 0);
+      if (exact) nd = 0;
     }
-    unsigned v[3] = {(unsigned)cnt[0] | ((unsigned)cnt[2] << 16), (unsigned)cnt[1] | ((unsigned)cnt[3] << 16), exact ? 1u : 0u};
+    unsigned v[3] = {live && !exact ? 1u + (unsigned)nd : 0u, (unsigned)nd, exact ? 1u : 0u};
     const unsigned own[3] = {v[0], v[1], v[2]};
     unsigned last[3];
     block_scan(v, last);
-    if (m < M) {
+    if (live) {
       if (exact) {
         ovf[run_o + (int)(v[2] - own[2])] = m;
       } else {
-        Piece *out[kPieceLists];
-        out[0] = lists + lbase[0] + run[0] + (int)((v[0] - own[0]) & 0xffffu);
-        out[2] = lists + lbase[2] + run[2] + (int)((v[0] - own[0]) >> 16);
-        out[1] = lists + lbase[1] + run[1] + (int)((v[1] - own[1]) & 0xffffu);
-        out[3] = lists + lbase[3] + run[3] + (int)((v[1] - own[1]) >> 16);
-        int c2[kPieceLists];
-        walk(m, d, out, c2);
+        Piece *out = list + run_p + (int)(v[0] - own[0]);
+        Piece b;
+        b.m = (uint32_t)m;
+        b.row = d.row;
+        b.p0 = 1.0f;
+        b.scale = 0.0f;
+        out[0] = b;
+        if (nd > 0) walk(m, d, out + 1);
       }
     }
     __syncthreads();
     if (tid == 0) {
-      run[0] += (int)(last[0] & 0xffffu);
-      run[2] += (int)(last[0] >> 16);
-      run[1] += (int)(last[1] & 0xffffu);
-      run[3] += (int)(last[1] >> 16);
+      run_p += (int)last[0];
+      run_d += (int)last[1];
       run_o += (int)last[2];
     }
     __syncthreads();
   }
-  // pad every list to whole chunks with null pieces; publish the chunk counts
-#pragma unroll
-  for (int l = 0; l < kPieceLists; l++) {
-    const int n = tot[l];
-    const int padded = (n + 31) & ~31;
-    if (n + tid < padded) lists[lbase[l] + n + tid] = null_piece;
-    if (tid == 0) pl.count[tile * 8 + l] = padded >> 5;
+  // pad the list to whole chunks with null pieces; publish the counts
+  {
+    const int np = run_p, pp = (np + 31) & ~31;
+    if (np + tid < pp) list[np + tid] = null_piece;
+    if (tid == 0) {
+      pl.count[tile * 8 + 0] = pp >> 5;
+      pl.count[tile * 8 + 1] = run_d;
+      pl.count[tile * 8 + 4] = run_o;
+    }
   }
-  if (tid == 0) pl.count[tile * 8 + 4] = run_o;
 }
 
 // K1p.  grid = (workgroup tiles, grid-level splits of the chunk schedule, column super-groups),
 // block = 64 NW threads; P.ntiles / P.desc refer to WORKGROUP tiles of 64 NW samples.
-// x_scale, g_scale: exact powers of two (gain_h2.h; g_scale here puts the largest gain at 2^12).
+// x_scale, g_scale: exact powers of two (gain_h2.h).
 template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, const unsigned *level_cur,
               unsigned *level_next) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
-  constexpr int NQ = CH / NW;         // pieces whose gains one wave converts per chunk
-  constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
-  constexpr int RING = 8;             // chunks of piece words (object | range) staged in LDS for the lanes
-  __shared__ u32x4 bfrag[2][NFRAG + 4][64];  // + 4 never-read fragments: the lanes without a column write there
+  constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
+  constexpr int NFRAG = NCT * 2;  // column tiles x {h,l}
+  constexpr int RING = 8;         // chunks of piece words (the object) staged in LDS for the lanes
+  __shared__ u32x4 bfrag[2][NFRAG + 2][64];  // + 2 never-read fragments: the lanes without a column write there
   __shared__ uint32_t ring[RING][CH];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -299,18 +278,18 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   const float *__restrict__ gain = P.ps.gain;
   const unsigned rowlen = (unsigned)P.ps.row;
 
-  // running totals in scaled units: bus = (tot0 + (s - s0) tot1) / (x_scale g_scale)
-  f32x4 tot0[NRT][NCT], tot1[NRT][NCT];
+  // running totals in scaled units: bus = tot / (x_scale g_scale)
+  f32x4 tot[NRT][NCT];
   auto clear_totals = [&]() {
 #pragma unroll
     for (int r = 0; r < NRT; r++)
 #pragma unroll
-      for (int c = 0; c < NCT; c++) tot0[r][c] = tot1[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int c = 0; c < NCT; c++) tot[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   };
   clear_totals();
 
   // ---- exact path: one object, all its pieces inside this wave's 64 samples, f32 MFMA with k = {a, b}
-  // of ONE object (k slots 2, 3 idle), accumulated into tot0 in units of 1 / (sx sg)
+  // of ONE object (k slots 2, 3 idle), accumulated into tot in units of 1 / (sx sg)
   auto single_object = [&](int m, float sx, float sg) {
     if (tile_len <= 0) return;
     const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
@@ -342,7 +321,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         for (int r = 0; r < NRT; r++)
 #pragma unroll
           for (int c = 0; c < NCT; c++)
-            tot0[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot0[r][c], 0, 0, 0);
+            tot[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot[r][c], 0, 0, 0);
         cur = r1;
       }
       if (!(dk.info & kSegMulti)) break;
@@ -351,13 +330,13 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   };
 
   // one piece of a list, exact and unscaled (the wave redoes its share of the schedule this way when an
-  // input left the f16 range): p(s) = p0 + s * scale instead of libear's (float)(d0 + s) * scale — equal
-  // to within an ulp of p, far inside the tolerance of this (non-strict) kernel
+  // input left the f16 range).  Base: x S.  Delta: x clamp(p) (E - S) as the two k slots (-x p) S + (x p) E,
+  // p(s) = p0 + s * scale instead of libear's (float)(d0 + s) * scale — equal to within an ulp of p, far
+  // inside the tolerance of this (non-strict) kernel.
   auto single_piece = [&](const Piece pc) {
     if (tile_len <= 0) return;
-    const int r0 = (int)((pc.mr >> 16) & 0xffu), r1 = (int)(pc.mr >> 24) + 1;
-    const bool ramp = pc.scale != 0.0f;
-    const float *row = P.in + (size_t)(pc.mr & 0xffffu) * P.in_stride + tile_s0;
+    const bool delta = pc.m & kPieceDelta;
+    const float *row = P.in + (size_t)(pc.m & ~kPieceDelta) * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;
     float a[NRT], gv[NCT];
@@ -365,11 +344,11 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
     for (int r = 0; r < NRT; r++) {
       const int s = li * NRT + r, sw = wave_s0 + s;
       const float x = row[min(s, tile_len - 1)];
-      const float p = __builtin_fmaf((float)sw, pc.scale, pc.p0);
-      const float coef = ramp ? (is_b ? p : 1.0f - p) : (is_b ? 0.0f : 1.0f);
-      a[r] = (slot0 && sw >= r0 && sw < r1 && s < tile_len) ? x * coef : 0.0f;
+      const float p = __builtin_amdgcn_fmed3f(__builtin_fmaf((float)sw, pc.scale, pc.p0), 0.0f, 1.0f);
+      const float coef = delta ? (is_b ? p : -p) : (is_b ? 0.0f : 1.0f);
+      a[r] = (slot0 && s < tile_len) ? x * coef : 0.0f;
     }
-    const int grow = pc.row + ((ramp && is_b && slot0) ? 1 : 0);
+    const int grow = pc.row + ((delta && is_b && slot0) ? 1 : 0);
     const float *gp = gain + (size_t)grow * rowlen + col0 + li;
 #pragma unroll
     for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16];
@@ -377,22 +356,21 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
     for (int r = 0; r < NRT; r++)
 #pragma unroll
       for (int c = 0; c < NCT; c++)
-        tot0[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot0[r][c], 0, 0, 0);
+        tot[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot[r][c], 0, 0, 0);
   };
 
   float inv_x = 1.0f / x_scale, inv_g = 1.0f / g_scale;  // exact: powers of two
   const int *cnt = pl.count + wgtile * 8;
 
   if (P.vec_ok) {
-    // ---- the chunk schedule of this workgroup: the four lists back to back, 32 pieces per chunk
+    // ---- the chunk schedule of this workgroup: the tile's list, 32 pieces per chunk
     const Piece *lbase = pl.pieces + (size_t)wgtile * pl.cap();
-    const int n0 = cnt[0], n1 = cnt[1], n2 = cnt[2], n3 = cnt[3];
-    const int total = n0 + n1 + n2 + n3;
+    const int total = cnt[0];
+    const bool has_delta = cnt[1] > 0;  // (else every p is 1: the position factor is skipped)
+    const int zero_row = P.ps.zero_row;
     const int c_lo = (int)(((int64_t)total * part) / nparts), c_hi = (int)(((int64_t)total * (part + 1)) / nparts);
-    const int first_ramp = n0 + n1;
     // first piece of chunk c (clamped: requests past the schedule re-read its last chunk)
     auto chunk_ptr = [&](int c) -> const Piece * { return lbase + 32 * min(c, total - 1); };
-    auto is_ranged = [&](int c) { return (c >= n0 && c < first_ramp) || c >= first_ramp + n2; };
 
     if (c_hi > c_lo) {
       const int nvec = (P.nsamples + 3) & ~3;
@@ -400,75 +378,64 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       // last vector: never stored)
       const unsigned xlane = (unsigned)min(tile_s0 + li * NRT, nvec - 4) * 4u;
       const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
-      // fragment this lane fills: B0 pieces at bfr, bfr+1, B1 pieces NCT*2 further
-      const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;
-      const int bfr1 = lane < 16 * NCT ? NCT * 2 : 2;
+      const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;          // fragment pair (h, l) this lane fills
       const size_t rstride = P.in_stride * sizeof(float);
-      const int lane_s = wave_s0 + li * NRT;  // the lane's first sample inside the workgroup tile
+      const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
 
-      // piece words (object | range) of chunk c for the lanes: wave 0 brings them into the ring,
-      // requested five chunks ahead, stored four ahead (visible after the next barrier), read two
-      // ahead (input addresses) and at the chunk itself (ranges)
-      auto ring_load = [&](int c) -> uint32_t {
-        return chunk_ptr(c)[lane & 31].mr;
-      };
-      // the lane's piece words q0 .. q0 + N - 1 of chunk c (read where they are used: no registers held)
+      // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested
+      // five chunks ahead, stored four ahead (visible after the next barrier), read two ahead (input addresses)
+      auto ring_load = [&](int c) -> uint32_t { return chunk_ptr(c)[lane & 31].m & ~kPieceDelta; };
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
-      // inputs q0 .. q0 + n - 1 (n even) of chunk c.  A piece whose range misses this wave's 64 samples
-      // contributes nothing here (its input scale is 0 for every lane): its request goes to object 0's
-      // row instead — one line the L1 already holds, not another trip to L2 (a quarter of all input
-      // requests on metadata that ignores the block grid).
+      // inputs q0 .. q0 + n - 1 (n even) of chunk c
       auto load_x_part = [&](int c, f32x4 (&x)[8], int q0, int n) {
         const char *bp = reinterpret_cast<const char *>(P.in) + xlane;
-        const bool ranged = is_ranged(c);  // (wave-uniform)
 #pragma unroll
         for (int q = 0; q < 8; q += 2)
           if (q >= q0 && q < q0 + n) {
             const u32x2 mw = lane_word2(c, q);
-            uint32_t o0 = mw[0] & 0xffffu, o1 = mw[1] & 0xffffu;
-            if (ranged) {
-              o0 = (((mw[0] >> 16) & 0xffu) < (unsigned)(wave_s0 + TS) && (mw[0] >> 24) >= (unsigned)wave_s0) ? o0 : 0u;
-              o1 = (((mw[1] >> 16) & 0xffu) < (unsigned)(wave_s0 + TS) && (mw[1] >> 24) >= (unsigned)wave_s0) ? o1 : 0u;
-            }
-            x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)o0 * rstride));
-            x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)o1 * rstride));
+            x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)mw[0] * rstride));
+            x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride));
           }
+      };
+      // (p0, scale) of the lane's 8 pieces of a chunk, requested one chunk ahead (behind that chunk's gain
+      // rows, in front of the inputs of the chunk after it in the in-order queue)
+      f32x2 pcur[8];
+      auto load_ps = [&](int c) {
+        const char *bp = reinterpret_cast<const char *>(chunk_ptr(c) + kg * 8) + 8;
+#pragma unroll
+        for (int q = 0; q < 8; q++) pcur[q] = *reinterpret_cast<const f32x2 *>(bp + q * sizeof(Piece));
       };
       // What this WAVE converts for chunk c: pieces NQ w + q.  Wave-uniform: scalar loads (requested one
       // chunk ahead), scalar row arithmetic; the gain rows come in as (scalar row pointer) + (the lane's column).
       typedef const Piece __attribute__((address_space(4))) *ConstPiece;
-      struct PieceGain {
-        int32_t row;
-        float p0, scale;
-      };
-      struct ChunkDesc {
-        PieceGain d[NQ];
+      // the gain operand of a piece is row X minus row Y: delta (E, S), base (S, the all-zero row)
+      struct ChunkRows {
+        int32_t x[NQ], y[NQ];
       };
       auto load_desc = [&](int c) {
         ConstPiece dp = (ConstPiece)(chunk_ptr(c) + w * NQ);
-        ChunkDesc D;
+        ChunkRows D;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-          D.d[q].row = dp[q].row;
-          D.d[q].p0 = dp[q].p0;
-          D.d[q].scale = dp[q].scale;
+          const uint32_t m = dp[q].m;
+          const int32_t row = dp[q].row;
+          const bool d = m & kPieceDelta;
+          D.x[q] = row + (d ? 1 : 0);
+          D.y[q] = d ? row : zero_row;
         }
         return D;
       };
-      auto load_gains = [&](const ChunkDesc &R, float (&S)[NQ], float (&E)[NQ], auto ramp_tag) {
-        constexpr bool RAMP = decltype(ramp_tag)::value;
+      auto load_gains = [&](const ChunkRows &R, float (&X)[NQ], float (&Y)[NQ]) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-          const float *rps = gain + (size_t)(unsigned)R.d[q].row * rowlen;
-          S[q] = rps[bcol_e];
-          if (RAMP) E[q] = rps[rowlen + bcol_e];
+          X[q] = (gain + (size_t)(unsigned)R.x[q] * rowlen)[bcol_e];
+          Y[q] = (gain + (size_t)(unsigned)R.y[q] * rowlen)[bcol_e];
         }
       };
-      // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's NQ pieces,
-      // scaled and split -> LDS (k = NQ w + q of the fragment entry of lane 16 (k / 8) + column)
-      auto store_b = [&](const ChunkDesc &R, const float (&S)[NQ], const float (&E)[NQ], int buf, int bpart, auto ramp_tag) {
-        constexpr bool RAMP = decltype(ramp_tag)::value;
+      // the B operand of the wave's NQ pieces, scaled and split -> LDS
+      // (k = NQ w + q of the fragment entry of lane 16 (k / 8) + column)
+      auto store_b = [&](const float (&X)[NQ], const float (&Y)[NQ], int buf) {
         uint32_t h[NQ / 2], l[NQ / 2];
 #pragma unroll
         for (int i = 0; i < NQ / 2; i++) {
@@ -476,26 +443,18 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
 #pragma unroll
           for (int j = 0; j < 2; j++) {
             const int q = 2 * i + j;
-            const float p0 = R.d[q].p0;
-            v[j] = (bpart == 0 ? (RAMP ? __builtin_fmaf(1.0f - p0, S[q], p0 * E[q]) : S[q]) : R.d[q].scale * (E[q] - S[q])) *
-                   g_scale;
+            v[j] = (X[q] - Y[q]) * g_scale;
           }
           const uint32_t H = pack_f16(v[0], v[1]);
           h[i] = H;
           l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
         }
-        u32x4 *f = &bfrag[buf][bfr + (bpart ? bfr1 : 0)][0];
+        u32x4 *f = &bfrag[buf][bfr][0];
         const int col = lane & 15;
-        if constexpr (NQ == 16) {  // two whole entries: k groups 2w, 2w + 1
-          f[(2 * w) * 16 + col] = u32x4{h[0], h[1], h[2], h[3]};
-          f[(2 * w + 1) * 16 + col] = u32x4{h[4], h[5], h[6], h[7]};
-          f[64 + (2 * w) * 16 + col] = u32x4{l[0], l[1], l[2], l[3]};
-          f[64 + (2 * w + 1) * 16 + col] = u32x4{l[4], l[5], l[6], l[7]};
-        } else if constexpr (NQ == 8) {
+        if constexpr (NQ == 8) {
           f[w * 16 + col] = u32x4{h[0], h[1], h[2], h[3]};
           f[64 + w * 16 + col] = u32x4{l[0], l[1], l[2], l[3]};
         } else {  // half an entry: words 2 (w & 1), + 1 of k group w / 2
-          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
           u32x2 *g = reinterpret_cast<u32x2 *>(f + (w >> 1) * 16 + col) + (w & 1);
           g[0] = u32x2{h[0], h[1]};
           g[128] = u32x2{l[0], l[1]};
@@ -515,74 +474,52 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       }
       __syncthreads();
       f32x4 X0[8], X1[8];
-      ChunkDesc L;
+      ChunkRows L;
       {
         float S[NQ], E[NQ];
         L = load_desc(c_lo);
-        if (c_lo >= first_ramp) {
-          load_gains(L, S, E, std::true_type{});
-          load_x_part(c_lo, X0, 0, 8);
-          load_x_part(c_lo + 1, X1, 0, 8);
-          store_b(L, S, E, c_lo & 1, 0, std::true_type{});
-          store_b(L, S, E, c_lo & 1, 1, std::true_type{});
-        } else {
-          load_gains(L, S, E, std::false_type{});
-          load_x_part(c_lo, X0, 0, 8);
-          load_x_part(c_lo + 1, X1, 0, 8);
-          store_b(L, S, E, c_lo & 1, 0, std::false_type{});
-        }
+        load_gains(L, S, E);
+        if (has_delta) load_ps(c_lo);
+        load_x_part(c_lo, X0, 0, 8);
+        load_x_part(c_lo + 1, X1, 0, 8);
+        store_b(S, E, c_lo & 1);
         L = load_desc(c_lo + 1);
       }
 
-      // chunk c: inputs in xc, B fragments in bfrag[c & 1].  ONE body for all four lists (the list only
-      // decides, wave-uniformly, whether the B1 half of the products runs and whether the inputs get a
-      // range): six specialised bodies cost more in registers at their joins than they save.
+      // chunk c: inputs in xc, B fragments in bfrag[c & 1]
       auto chunk = [&](int c, f32x4 (&xc)[8]) {
         const int buf = c & 1;
-        const bool ramp = c >= first_ramp;                          // this chunk's pieces are ramps
-        const bool next_ramp = min(c + 1, total - 1) >= first_ramp;  // (past the schedule: its last chunk again)
         __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free; ring slots <= c + 3 are visible
         if (w == 0) {
           if (lane < 32) ring[(c + 4) & (RING - 1)][lane] = ring_next;
           ring_next = ring_load(c + 5);
         }
         float S[NQ], E[NQ];
-        const ChunkDesc Ln = L;  // chunk c + 1 (fetched one chunk ago)
-        if (next_ramp) load_gains(Ln, S, E, std::true_type{});
-        else load_gains(Ln, S, E, std::false_type{});
+        load_gains(L, S, E);  // chunk c + 1 (its rows were fetched one chunk ago)
         L = load_desc(c + 2);
         __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
 
         // A fragments: row tile r = sample 4*li + r of the 8 pieces of this lane.  2 x 2 blocks: an f16
         // pair packs two PIECES (q, q+1) of one row tile, the scaling and the exact residual
-        // subtractions pair two SAMPLES (r, r+1) of one piece.  The range of a piece is part of its
-        // input scale: x_scale inside [r0, r1), 0 outside.
+        // subtractions pair two SAMPLES (r, r+1) of one piece.  A piece's ramp position is part of its
+        // input scale: x_scale clamp(p0 + s scale, 0, 1) (base pieces: p = 1).
         u32x4 ah[NRT], al[NRT];
-        auto split = [&](auto ranged_tag) {
-          constexpr bool RANGED = decltype(ranged_tag)::value;
+        auto split = [&](auto delta_tag) {
+          constexpr bool DELTA = decltype(delta_tag)::value;
 #pragma unroll
           for (int qp = 0; qp < 4; qp++) {
-            f32x2 sc[2][2];  // [piece of the pair][sample pair]
-            u32x2 mwp = {0u, 0u};
-            if (RANGED) mwp = lane_word2(c, 2 * qp);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-              if (RANGED) {
-                const uint32_t m = mwp[j];
-                const int lo = (int)((m >> 16) & 0xffu) - lane_s;          // r0 relative to the lane's first sample
-                const unsigned len = (m >> 24) + 1u - ((m >> 16) & 0xffu);  // r1 - r0
-#pragma unroll
-                for (int rp = 0; rp < 2; rp++)
-                  sc[j][rp] = f32x2{(unsigned)(2 * rp - lo) < len ? x_scale : 0.0f,
-                                    (unsigned)(2 * rp + 1 - lo) < len ? x_scale : 0.0f};
-              } else {
-                sc[j][0] = sc[j][1] = f32x2{x_scale, x_scale};
-              }
-            }
 #pragma unroll
             for (int rp = 0; rp < NRT; rp += 2) {
-              const f32x2 s0 = f32x2{xc[2 * qp][rp], xc[2 * qp][rp + 1]} * sc[0][rp >> 1];          // piece 2qp
-              const f32x2 s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * sc[1][rp >> 1];  // piece 2qp+1
+              f32x2 s0 = f32x2{xc[2 * qp][rp], xc[2 * qp][rp + 1]} * x_scale;          // piece 2qp
+              f32x2 s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;  // piece 2qp+1
+              if (DELTA) {
+                const float f0 = lane_sf + (float)rp, f1 = lane_sf + (float)(rp + 1);
+                const f32x2 a = pcur[2 * qp], b = pcur[2 * qp + 1];
+                s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
+                            __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
+                s1 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, b[1], b[0]), 0.0f, 1.0f),
+                            __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, b[1], b[0]), 0.0f, 1.0f)};
+              }
               const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
               const f32x2 r0 = s0 - f32x2{f16_lo(H0), f16_lo(H1)};  // exact
               const f32x2 r1 = s1 - f32x2{f16_hi(H0), f16_hi(H1)};
@@ -593,12 +530,13 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
             }
           }
         };
-        if (is_ranged(c)) split(std::true_type{});  // (wave-uniform)
+        if (has_delta) split(std::true_type{});  // (uniform over the workgroup)
         else split(std::false_type{});
-        // The B0 half: NCT blocks of 12 MFMAs (three partial products of one column tile, smallest first).
-        // The inputs of chunk c + 2 go into the registers just freed, a few requests per block; the
-        // conversion of the next chunk's B0 is woven between the MFMAs of the last block.
         __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
+        if (has_delta) load_ps(c + 1);      // (pcur is free now)
+        // NCT blocks of 12 MFMAs (three partial products of one column tile, smallest first).  The inputs
+        // of chunk c + 2 go into the registers just freed, a few requests per block; the conversion of the
+        // next chunk's B operand is woven between the MFMAs of the last block.
         constexpr int XB = NCT >= 3 ? 2 : 1;  // blocks that carry input requests (4 or 8 each)
         auto load_b = [&](int fr, u32x4 (&bb)[2]) {
 #pragma unroll
@@ -612,17 +550,14 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
           u32x4(&bc)[2] = b[ct & 1];
           if (ct + 1 < NCT) load_b((ct + 1) * 2, b[(ct + 1) & 1]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(al[r], bc[0], tot0[r][ct]);
+          for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(al[r], bc[0], tot[r][ct]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(ah[r], bc[1], tot0[r][ct]);
+          for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[1], tot[r][ct]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(ah[r], bc[0], tot0[r][ct]);
+          for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
           if (ct < XB) load_x_part(c + 2, xc, ct * (8 / XB), 8 / XB);
           const bool conv = ct == NCT - 1;
-          if (conv) {
-            if (next_ramp) store_b(Ln, S, E, buf ^ 1, 0, std::true_type{});
-            else store_b(Ln, S, E, buf ^ 1, 0, std::false_type{});
-          }
+          if (conv) store_b(S, E, buf ^ 1);
           if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           if (ct < XB && !conv) {
 #pragma unroll
@@ -633,48 +568,29 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
             }
           }
         }
-        // The B1 half (ramp pieces only) with the conversion of the next chunk's B1
-        if (ramp) {
-          load_b(NCT * 2, b[0]);
-#pragma unroll
-          for (int ct = 0; ct < NCT; ct++) {
-            u32x4(&bc)[2] = b[ct & 1];
-            if (ct + 1 < NCT) load_b((NCT + ct + 1) * 2, b[(ct + 1) & 1]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(al[r], bc[0], tot1[r][ct]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[1], tot1[r][ct]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[0], tot1[r][ct]);
-            if (ct == NCT - 1) store_b(Ln, S, E, buf ^ 1, 1, std::true_type{});
-          }
-        } else if (next_ramp) {  // (the one chunk of a tile where the lists change from constant to ramp)
-          store_b(Ln, S, E, buf ^ 1, 1, std::true_type{});
-        }
       };
-      auto run_chunk = [&](int c, f32x4 (&xc)[8]) { chunk(c, xc); };
 #pragma unroll 1
       for (int c = c_lo; c < c_hi; c += 2) {
-        run_chunk(c, X0);
-        if (c + 1 < c_hi) run_chunk(c + 1, X1);
+        chunk(c, X0);
+        if (c + 1 < c_hi) chunk(c + 1, X1);
       }
     }
 
-    // objects that take the exact path (pieces too steep or too many for the lists): part 0 only
+    // objects that take the exact path (too many ramps for the lists, quiet ones): part 0 only
     if (part == 0) {
       const int *ovf = pl.ovf + (size_t)wgtile * P.M;
       const int novf = cnt[4];
       for (int i = 0; i < novf; i++) single_object(ovf[i], x_scale, g_scale);
     }
     // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the wave's tile
-    // exactly, unscaled (every part redoes its share of the objects)
+    // exactly, unscaled (every part redoes its share of the pieces)
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < NRT; r++)
 #pragma unroll
       for (int c = 0; c < NCT; c++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
+        for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot[r][c][e]) < INFINITY);
     if (__ballot(bad)) {
       clear_totals();
       inv_x = inv_g = 1.0f;
@@ -693,8 +609,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
 
   if (tile_len <= 0) return;
   // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
-  // four row tiles are 4 consecutive samples.  (s - s0) of the rows: sample 64w + 16kg + 4e + r.
-  const float wf0 = (float)(wave_s0 + kg * 16);
+  // four row tiles are 4 consecutive samples.
   float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
 #pragma unroll
   for (int c = 0; c < NCT; c++) {
@@ -706,8 +621,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       const int s = kg * 16 + e * 4;
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < NRT; r++)
-        v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_g;
+      for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_g;
       if (P.vec_ok && s + 3 < tile_len) {
         *reinterpret_cast<f32x4 *>(o + s) = v;
       } else {
