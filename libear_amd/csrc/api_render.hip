@@ -520,7 +520,8 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     const bool dbg = getenv("EARHIP_DEBUG_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = dbg ? now() : 0.0;
-    if (in_bytes < ((size_t)16 << 20) || r->M < 16) {
+    const bool short_call = in_bytes < ((size_t)16 << 20) || r->M < 16;
+    if (short_call) {
       // short calls (block mode): one gather, one transfer.  Splitting a 2 MB block into groups whose
       // transfers overlap the gather was measured twice and loses (132 -> 150 us per call at the headline
       // shape: four DMA start-ups cost more than the 30 us of gather they hide).
@@ -548,9 +549,16 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       EARHIP_HIP(err);
     }
     const double t_b = dbg ? now() : 0.0;
-    r->process_device(nblocks, r->d_in.p, n, r->d_out.p, n);
-    EARHIP_HIP(hipMemcpyAsync(r->p_out.p, r->d_out.p, sizeof(float) * n * r->N,
-                              hipMemcpyDeviceToHost, ctx->stream));
+    // Short calls: K2 writes the few output rows straight into the pinned buffer (no D2H copy to start and
+    // wait for: 126 -> 119 us per 512-sample call at the headline shape).  The other direction does not pay —
+    // kernels that read their 2 MB of inputs over PCIe themselves are slower than the copy engine plus
+    // kernels (129 us) — and neither does spinning on a completion word behind one more launch.
+    // (FIRs of several partitions accumulate into the output: that stays in device memory)
+    const bool direct_out = short_call && r->NP <= 1;
+    float *dst = direct_out ? r->p_out.p : r->d_out.p;
+    r->process_device(nblocks, r->d_in.p, n, dst, n);
+    if (!direct_out)
+      EARHIP_HIP(hipMemcpyAsync(r->p_out.p, r->d_out.p, sizeof(float) * n * r->N, hipMemcpyDeviceToHost, ctx->stream));
     const double t_c = dbg ? now() : 0.0;
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     const double t_d = dbg ? now() : 0.0;
