@@ -174,8 +174,14 @@ struct GatherPool {
 
 struct earhip_render {
   earhip_ctx *ctx = nullptr;
-  int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0, L = 0;
-  int NP = 1;  // partitions of the decorrelator FIRs (ceil(n_taps / B))
+  int M = 0, N = 0, B = 0, K = 1, D = 0, T = 0;
+  // The decorrelators' own partition size Bk (and transform size Lk = 2 Bk).  A linear convolution does not
+  // depend on how it is partitioned, so callers' blocks of 1024, 2048 ... samples run through 512-sample
+  // partitions whenever the FIRs fit one of them: the wave kernel (k_decorrelate_wave) exists for that size
+  // and is 2.5 times faster per sample than the workgroup kernel at 2048 points (BASELINE config 5: K2 0.125
+  // -> 0.05 ms).  Otherwise Bk = B, libear's own partitioning (src/dsp/block_convolver_impl.cpp:16-41).
+  int Bk = 0, Lk = 0;
+  int NP = 1;  // partitions of the decorrelator FIRs (ceil(n_taps / Bk))
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
@@ -187,7 +193,7 @@ struct earhip_render {
   DevBuf<float> bus;  // [gsplit][K*N][bus_stride], strides chosen per call
   int max_gsplit = 1;
   DevBuf<cf> H, tw;
-  DevBuf<float> tail[2], dly[2], hist[2];  // tails [NP][N][B]; diffuse-bus history [N][(NP-1) B]
+  DevBuf<float> tail[2], dly[2], hist[2];  // tails [NP][N][Bk]; diffuse-bus history [N][(NP-1) Bk]
   DevBuf<float> ztail, zdly, zhist;  // all-zero state, never written: what the first call after a reset reads
   bool fresh = true;          // no call since create / reset: the state is zero
   int cur = 0;  // which state buffer holds the current state
@@ -288,7 +294,8 @@ struct earhip_render {
       P.bus_stride = bus_stride;
       P.part_stride = part_stride;
       P.nparts = ml.gsplit;
-      const bool wave_k2 = L == 1024 && NP == 1 && !getenv("EARHIP_K2_WG");
+      const bool wave_k2 = Lk == 1024 && NP == 1 && !getenv("EARHIP_K2_WG");
+      const int kblocks = (int)(nblocks * (size_t)(B / Bk));  // the call in decorrelator partitions
       if (wave_k2 && ml.gsplit > 1) {
         // The wave kernel has one wave per run: summing the object splits there is a chain of
         // dependent loads on the call's critical path (block mode).  Sum them into slab 0 with the
@@ -305,29 +312,29 @@ struct earhip_render {
       P.dly_in = fresh ? zdly.p : dly[cur].p;
       P.dly_out = dly[cur ^ 1].p;
       P.N = N;
-      P.T = (int)nblocks;
-      const int R = wave_k2 && !run_len_set ? wave_run_len((int)nblocks, N, ctx->num_cus) : run_len;
+      P.T = kblocks;
+      const int R = wave_k2 && !run_len_set ? wave_run_len(kblocks, N, ctx->num_cus) : run_len;
       P.R = R;
       P.D = D;
-      P.hist_len = (NP - 1) * B;
+      P.hist_len = (NP - 1) * Bk;
       P.hist_in = fresh ? zhist.p : hist[cur].p;
       P.hist_out = hist[cur ^ 1].p;
-      const dim3 grid((unsigned)((nblocks + R - 1) / R), N);
+      const dim3 grid((unsigned)((kblocks + R - 1) / R), N);
       if (evp && P.nparts == ml.gsplit) EARHIP_HIP(hipEventRecord(evp[4], ctx->stream));
       // one launch per partition of the FIRs: partition 0 writes (decorrelated + delayed direct), the
       // others add their share of the decorrelated signal (render_kernels.h)
       for (int part = 0; part < NP; part++) {
-        P.H = H.p + (size_t)part * N * L;
-        P.tail_in = (fresh ? ztail.p : tail[cur].p) + (fresh ? 0 : (size_t)part * N * B);
-        P.tail_out = tail[cur ^ 1].p + (size_t)part * N * B;
-        P.shift = part * B;
+        P.H = H.p + (size_t)part * N * Lk;
+        P.tail_in = (fresh ? ztail.p : tail[cur].p) + (fresh ? 0 : (size_t)part * N * Bk);
+        P.tail_out = tail[cur ^ 1].p + (size_t)part * N * Bk;
+        P.shift = part * Bk;
         P.accumulate = part > 0 ? 1 : 0;
         if (wave_k2) {
           hipLaunchKernelGGL(k_decorrelate_wave, dim3((grid.x + kDecorWaves - 1) / kDecorWaves, grid.y), dim3(64 * kDecorWaves),
                              0, ctx->stream, P);
           EARHIP_HIP(hipGetLastError());
         } else {
-          launch_decor(L, P, grid, ctx->stream, NP > 1);
+          launch_decor(Lk, P, grid, ctx->stream, NP > 1);
         }
       }
       if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
@@ -373,11 +380,13 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->K = cfg->n_buses;
     r->D = cfg->delay;
     r->T = cfg->max_blocks;
-    r->L = 2 * r->B;
+    r->Bk = r->B;
+    if (r->K == 2 && r->B > 512 && r->B % 512 == 0 && cfg->n_taps <= 512 && !getenv("EARHIP_K2_OWN_BLOCK")) r->Bk = 512;
+    r->Lk = 2 * r->Bk;
     // workgroup decorrelator kernel: blocks per run.  Block 1024 (BASELINE config 5, 512 blocks x 24
     // loudspeakers): 7 -> K2 0.113 ms, 5 -> 0.117, 11 -> 0.128, 15 -> 0.140 (two rounds of workgroups that fill
     // the chip evenly beat one ragged round)
-    if (r->L == 2048) r->run_len = 7;
+    if (r->Lk == 2048) r->run_len = 7;
     if (const char *e = getenv("EARHIP_RUN")) {  // tuning knob: blocks per decorrelator run (odd)
       const int v = atoi(e);
       if (v >= 1 && v <= 255) r->run_len = v | 1, r->run_len_set = true;
@@ -399,40 +408,40 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     }
     r->bus.alloc_zero((size_t)r->K * r->N * bus_samples_bound(ctx, max_samples, r->max_gsplit), ctx->stream);
     if (r->K == 2) {
-      const auto tw = make_twiddles(r->L);
-      r->tw.alloc(r->L);
-      EARHIP_HIP(hipMemcpy(r->tw.p, tw.data(), sizeof(cf) * r->L, hipMemcpyHostToDevice));
+      const auto tw = make_twiddles(r->Lk);
+      r->tw.alloc(r->Lk);
+      EARHIP_HIP(hipMemcpy(r->tw.p, tw.data(), sizeof(cf) * r->Lk, hipMemcpyHostToDevice));
       // H[p] = DFT_L(zero-padded partition p of the FIR: taps [p B, (p + 1) B), Filter::Filter,
       // block_convolver_impl.cpp:16-41), computed with the device transform, then made exactly Hermitian so
       // that two real blocks separate cleanly
-      r->NP = (cfg->n_taps + r->B - 1) / r->B;
+      r->NP = (cfg->n_taps + r->Bk - 1) / r->Bk;
       const size_t rows = (size_t)r->NP * r->N;
-      std::vector<float> parts(rows * r->B, 0.0f);  // [NP][N][B]
+      std::vector<float> parts(rows * r->Bk, 0.0f);  // [NP][N][B]
       for (int n = 0; n < r->N; n++)
         for (int t = 0; t < cfg->n_taps; t++)
-          parts[((size_t)(t / r->B) * r->N + n) * r->B + t % r->B] = cfg->decorrelators[(size_t)n * cfg->n_taps + t];
+          parts[((size_t)(t / r->Bk) * r->N + n) * r->Bk + t % r->Bk] = cfg->decorrelators[(size_t)n * cfg->n_taps + t];
       DevBuf<float> taps;
       taps.alloc(parts.size());
       EARHIP_HIP(hipMemcpy(taps.p, parts.data(), sizeof(float) * parts.size(), hipMemcpyHostToDevice));
-      r->H.alloc(rows * r->L);
-      launch_spectrum(r->L, taps.p, r->B, r->B, r->tw.p, r->H.p, (int)rows, ctx->stream);
+      r->H.alloc(rows * r->Lk);
+      launch_spectrum(r->Lk, taps.p, r->Bk, r->Bk, r->tw.p, r->H.p, (int)rows, ctx->stream);
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      std::vector<cf> h(rows * r->L);
+      std::vector<cf> h(rows * r->Lk);
       EARHIP_HIP(hipMemcpy(h.data(), r->H.p, sizeof(cf) * h.size(), hipMemcpyDeviceToHost));
       for (size_t n = 0; n < rows; n++) {
-        cf *hn = h.data() + n * r->L;
+        cf *hn = h.data() + n * r->Lk;
         hn[0].y = 0.0f;
-        hn[r->B].y = 0.0f;
-        for (int k = 1; k < r->B; k++) hn[r->L - k] = cf_conj(hn[k]);
+        hn[r->Bk].y = 0.0f;
+        for (int k = 1; k < r->Bk; k++) hn[r->Lk - k] = cf_conj(hn[k]);
       }
       EARHIP_HIP(hipMemcpy(r->H.p, h.data(), sizeof(cf) * h.size(), hipMemcpyHostToDevice));
-      const size_t hist_n = (size_t)r->N * std::max((r->NP - 1) * r->B, 1);
+      const size_t hist_n = (size_t)r->N * std::max((r->NP - 1) * r->Bk, 1);
       for (int i = 0; i < 2; i++) {
-        r->tail[i].alloc_zero(rows * r->B, ctx->stream);
+        r->tail[i].alloc_zero(rows * r->Bk, ctx->stream);
         r->dly[i].alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
         r->hist[i].alloc_zero(hist_n, ctx->stream);
         if (i == 0) {
-          r->ztail.alloc_zero((size_t)r->N * r->B, ctx->stream);
+          r->ztail.alloc_zero((size_t)r->N * r->Bk, ctx->stream);
           r->zdly.alloc_zero((size_t)r->N * std::max(r->D, 1), ctx->stream);
           r->zhist.alloc_zero(hist_n, ctx->stream);
         }

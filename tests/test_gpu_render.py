@@ -453,6 +453,26 @@ def test_block_sizes_that_are_not_powers_of_two(block, nblocks, calls, m):
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6
 
 
+@pytest.mark.parametrize("block,nblocks,calls", [(1024, 5, [2, 3]), (2048, 3, [1, 2]), (4096, 2, [2])])
+def test_decorrelator_partition_size_is_the_renderers_choice(block, nblocks, calls):
+    """Blocks of 1024, 2048, 4096 samples run their 512-tap decorrelators in 512-sample partitions (the fast
+    wave kernel; a linear convolution does not depend on its partitioning), EARHIP_K2_OWN_BLOCK=1 keeps
+    libear's own partition size = block size (block_convolver_impl.cpp:16-41): both against the oracle, whose
+    BlockConvolver uses the block size, and against each other."""
+    layout, m = "9+10+3", 40
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=900, ramp=200, seed=block)
+    x = scenes.audio(m, total, seed=block + 3)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    fast = run_hip(curves, x, n, block, dec, 255, calls)
+    own = _with_env({"EARHIP_K2_OWN_BLOCK": "1"}, lambda: run_hip(curves, x, n, block, dec, 255, calls))
+    assert scenes.rel_rms_per_channel(fast, want) <= 1e-6
+    assert scenes.rel_rms_per_channel(own, want) <= 1e-6
+    assert scenes.rel_rms(fast, own) <= 5e-7
+
+
 @pytest.mark.parametrize("m,nblocks,calls,run", [(24, 37, [37], None), (24, 37, [1, 20, 3, 13], "3"),
                                                  (200, 9, [9], "5"), (24, 40, [40], "1")])
 def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
