@@ -130,6 +130,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    parity_failed = False
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -553,6 +554,8 @@ def main():
                                 "max_channel_gpu_rel_rms_vs_float64": float(f"{scenes.rel_rms_per_channel(got, truth):.3e}"),
                                 "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
                                 "tolerance": 1e-6}
+            # per channel, against the CPU path: a run whose timed output is off is not a measurement
+            result["parity"]["pass"] = bool(result["parity"]["max_channel_rel_rms_vs_cpu"] <= 1e-6)
 
         # ---- CPU baseline: the scalar restatement on this host, bounded sample -----------------
         if world == 1 and args.cpu_blocks > 0 and not args.stream_only:
@@ -623,6 +626,11 @@ def main():
                 "gain_stage_forms_Msamples_per_s": forms or None,
                 "cpu_model": cpu_model(), "host_cpus": os.cpu_count()}
         print(json.dumps(result), flush=True)
+        if result.get("parity") and not result["parity"]["pass"]:
+            print("bench.py: PARITY FAILED - the timed output differs from the CPU path by "
+                  f"{result['parity']['max_channel_rel_rms_vs_cpu']:.3e} (tolerance 1e-6): the value above is invalid",
+                  file=sys.stderr, flush=True)
+            parity_failed = True
 
     wl.close()
     if native_comm is not None:
@@ -631,6 +639,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -109,8 +109,11 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
       n = ps.off[m + 1] - pbase;
     }
     int k = seg_k(dk.info), cur = 0, nd = 0;
+    const int tile_len = (int)(t_end - t0);
     for (;;) {
-      const int r1 = seg_r1(dk.info);
+      // (the descriptor's 9-bit end field stores 512 as 511: only the end of a piece that ends INSIDE the
+      // tile is exact — a ramp starting at sample 511 of a 512-sample tile must not look empty)
+      const int r1 = (dk.info & kSegMulti) ? seg_r1(dk.info) : tile_len;
       if (dk.info & kSegRamp) {
         Piece a;
         a.m = (uint32_t)m | kPieceDelta;

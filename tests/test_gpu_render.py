@@ -655,7 +655,7 @@ def test_gain_kernel_choice_follows_the_curves():
     assert kernel_for(64, scenes.constant_curves(64, n)) == 3   # static gains: no point inside any tile
 
 
-@pytest.mark.parametrize("tile", ["256", None])
+@pytest.mark.parametrize("tile", ["256", "512", None])
 @pytest.mark.parametrize("kind,m,layout,block,nblocks,calls",
                          [("adm", 64, "9+10+3", 512, 8, [8]), ("adm", 200, "4+5+0", 512, 6, [1, 2, 3]),
                           ("ragged", 100, "9+10+3", 256, 9, [9]), ("dense", 96, "9+10+3", 512, 5, [5]),

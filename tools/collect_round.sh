@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the bench lines of every configuration / scene for profiles/ (on the GPU box):
+#   bash tools/collect_round.sh <tag>     -> gpurun_out/<tag>_bench_<name>.json
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT && mkdir -p gpurun_out
+run() { # name, bench args...
+  local name=$1; shift
+  timeout 400 python bench.py "$@" 2> gpurun_out/${TAG}_bench_${name}.err | tail -1 > gpurun_out/${TAG}_bench_${name}.json
+  python tools/benchline.py < gpurun_out/${TAG}_bench_${name}.json | sed "s/^/$name: /"
+}
+run C4
+run C2 --config C2
+run C3 --config C3
+run C5 --config C5
+run adm --scene adm
+run static --scene static
+run moving --scene moving
+run mixed --scene mixed
+run panned --scene panned
+run panned_adm --scene panned-adm
