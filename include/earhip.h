@@ -60,6 +60,17 @@ int earhip_ctx_synchronize(earhip_ctx *ctx);
  * so M->N results are bit-identical to the CPU path.  Default 0: fused
  * multiply-adds and tree accumulation (faster, within 1e-6 relative RMS). */
 int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
+/* Host memory the device reaches directly (pinned and mapped).  libear's interfaces take `float **` channel
+ * pointers into the caller's own memory (include/ear/dsp/ptr_adapter.hpp:17-24: the columns of a matrix);
+ * when those buffers come from earhip_host_alloc, or were registered once with earhip_host_register
+ * (hipHostRegister: the range must stay allocated until released), AND the channel pointers of a call are
+ * evenly spaced — a column-major matrix — the short-call path of earhip_render_process copies them with
+ * one strided DMA instead of gathering them into a staging buffer first, and writes the outputs in place
+ * (block mode: 0.12 -> 0.09 ms per 512-sample call at the headline shape).  Any other pointers work as
+ * before.  earhip_host_release frees / unregisters a range (by its start); earhip_ctx_destroy the rest. */
+int earhip_host_alloc(earhip_ctx *ctx, size_t bytes, void **out);
+int earhip_host_register(earhip_ctx *ctx, void *ptr, size_t bytes);
+int earhip_host_release(earhip_ctx *ctx, void *ptr);
 /* tuning aid: enqueue a 1-thread kernel that writes {shader-cycle counter,
  * constant-rate counter} (2 x uint64) to device memory */
 int earhip_debug_clock_probe(earhip_ctx *ctx, void *out_dev);

@@ -113,6 +113,27 @@ class Context:
                                                  C.c_size_t(nsamples), int(reps), ms))
         return ms[0], ms[1]
 
+    # --- host memory the device reaches directly (earhip_host_alloc / _register / _release)
+    def pinned_array(self, shape):
+        """float32 array in pinned, device-reachable host memory (C-contiguous: the rows of a [channels][samples]
+        array are evenly spaced channel buffers).  Valid until close() or release(array)."""
+        shape = tuple(int(v) for v in np.atleast_1d(shape))
+        count = int(np.prod(shape))
+        p = C.c_void_p()
+        check(load().earhip_host_alloc(self.h, C.c_size_t(4 * max(count, 1)), C.byref(p)))
+        buf = (C.c_float * max(count, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.float32, count=count).reshape(shape)
+        a[...] = 0.0
+        return a
+
+    def register(self, a):
+        """make the memory of a C-contiguous float32 array reachable by the device (hipHostRegister)"""
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        check(load().earhip_host_register(self.h, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)))
+
+    def release(self, a):
+        check(load().earhip_host_release(self.h, C.c_void_p(a.ctypes.data)))
+
     def close(self):
         if self.h:
             load().earhip_ctx_destroy(self.h)
@@ -457,6 +478,14 @@ class Renderer:
         nblocks = x.shape[1] // self.B
         assert nblocks * self.B == x.shape[1]
         out = np.empty((self.N, x.shape[1]), np.float32)
+        check(load().earhip_render_process(self.h, C.c_size_t(nblocks), _chan_ptrs(x), _chan_ptrs(out)))
+        return out
+
+    def process_into(self, x, out):
+        """the same with the caller's own arrays, used as they are (e.g. Context.pinned_array: no staging copies)"""
+        assert x.dtype == np.float32 and out.dtype == np.float32 and x.flags["C_CONTIGUOUS"] and out.flags["C_CONTIGUOUS"]
+        nblocks = x.shape[1] // self.B
+        assert x.shape == (self.M, nblocks * self.B) and out.shape == (self.N, nblocks * self.B)
         check(load().earhip_render_process(self.h, C.c_size_t(nblocks), _chan_ptrs(x), _chan_ptrs(out)))
         return out
 

@@ -479,8 +479,57 @@ int earhip_ctx_destroy(earhip_ctx *ctx) {
           break;
         }
     }
+    for (const auto &r : ctx->host_ranges) {
+      if (r.owned) (void)hipHostFree(const_cast<char *>(r.base));
+      else (void)hipHostUnregister(const_cast<char *>(r.base));
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+  });
+}
+
+// ---- host memory the device reaches directly (include/earhip.h, group A) ------------------------------
+int earhip_host_alloc(earhip_ctx *ctx, size_t bytes, void **out) {
+  return guarded([&] {
+    require(ctx != nullptr && out != nullptr && bytes > 0, "NULL argument or zero size");
+    ctx->use();
+    void *p = nullptr;
+    EARHIP_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    ctx->host_ranges.push_back({static_cast<const char *>(p), bytes, true});
+    *out = p;
+  });
+}
+
+int earhip_host_register(earhip_ctx *ctx, void *ptr, size_t bytes) {
+  return guarded([&] {
+    require(ctx != nullptr && ptr != nullptr && bytes > 0, "NULL argument or zero size");
+    ctx->use();
+    EARHIP_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    // the kernels use the host address itself: true on this platform (unified addressing), checked once here
+    void *dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, ptr, 0) != hipSuccess || dptr != ptr) {
+      (void)hipHostUnregister(ptr);
+      fail_internal("registered host memory is not mapped at its own address on this platform");
+    }
+    ctx->host_ranges.push_back({static_cast<const char *>(ptr), bytes, false});
+  });
+}
+
+int earhip_host_release(earhip_ctx *ctx, void *ptr) {
+  return guarded([&] {
+    require(ctx != nullptr, "ctx must not be NULL");
+    if (!ptr) return;
+    ctx->use();
+    for (size_t i = 0; i < ctx->host_ranges.size(); i++)
+      if (ctx->host_ranges[i].base == static_cast<const char *>(ptr)) {
+        (void)hipStreamSynchronize(ctx->stream);  // a queued copy or kernel may still use the range
+        const bool owned = ctx->host_ranges[i].owned;
+        ctx->host_ranges.erase(ctx->host_ranges.begin() + i);
+        if (owned) EARHIP_HIP(hipHostFree(ptr));
+        else EARHIP_HIP(hipHostUnregister(ptr));
+        return;
+      }
+    fail_invalid("pointer is not the start of a range of earhip_host_alloc / earhip_host_register");
   });
 }
 

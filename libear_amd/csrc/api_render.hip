@@ -530,7 +530,23 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = dbg ? now() : 0.0;
     const bool short_call = in_bytes < ((size_t)16 << 20) || r->M < 16;
-    if (short_call) {
+    // Channel pointers that are evenly spaced inside memory the device reaches (earhip_host_alloc /
+    // earhip_host_register: the columns of a pinned matrix) need no staging copy: one strided DMA in, and
+    // the output rows written in place.  stride in floats; 0: not that shape.
+    auto direct_stride = [&](const float *const *ch, int count) -> size_t {
+      if (!short_call || ctx->host_ranges.empty() || count < 1) return 0;
+      const ptrdiff_t st = count > 1 ? ch[1] - ch[0] : (ptrdiff_t)n;
+      if (st < (ptrdiff_t)n || st % 4 != 0 || ((uintptr_t)ch[0] & 15) != 0) return 0;
+      for (int c = 1; c < count; c++)
+        if (ch[c] - ch[c - 1] != st) return 0;
+      return ctx->host_reachable(ch[0], sizeof(float) * ((size_t)st * (count - 1) + n)) ? (size_t)st : 0;
+    };
+    const size_t in_st = direct_stride(in, r->M);
+    const size_t out_st = r->NP <= 1 ? direct_stride(out, r->N) : 0;
+    if (in_st) {
+      EARHIP_HIP(hipMemcpy2DAsync(r->d_in.p, sizeof(float) * n, in[0], sizeof(float) * in_st, sizeof(float) * n, r->M,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    } else if (short_call) {
       // short calls (block mode): one gather, one transfer.  Splitting a 2 MB block into groups whose
       // transfers overlap the gather was measured twice and loses (132 -> 150 us per call at the headline
       // shape: four DMA start-ups cost more than the 30 us of gather they hide).
@@ -558,20 +574,22 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       EARHIP_HIP(err);
     }
     const double t_b = dbg ? now() : 0.0;
-    // Short calls: K2 writes the few output rows straight into the pinned buffer (no D2H copy to start and
-    // wait for: 126 -> 119 us per 512-sample call at the headline shape).  The other direction does not pay —
-    // kernels that read their 2 MB of inputs over PCIe themselves are slower than the copy engine plus
-    // kernels (129 us) — and neither does spinning on a completion word behind one more launch.
+    // Short calls: K2 writes the few output rows straight into host memory (the caller's own rows when they
+    // are reachable, else the pinned staging buffer: no D2H copy to start and wait for, 126 -> 119 us per
+    // 512-sample call at the headline shape).  The other direction does not pay — kernels that read their 2 MB
+    // of inputs over PCIe themselves are slower than the copy engine plus kernels (129 us) — and neither does
+    // spinning on a completion word behind one more launch.
     // (FIRs of several partitions accumulate into the output: that stays in device memory)
     const bool direct_out = short_call && r->NP <= 1;
-    float *dst = direct_out ? r->p_out.p : r->d_out.p;
-    r->process_device(nblocks, r->d_in.p, n, dst, n);
+    float *dst = out_st ? out[0] : direct_out ? r->p_out.p : r->d_out.p;
+    r->process_device(nblocks, r->d_in.p, n, dst, out_st ? out_st : n);
     if (!direct_out)
       EARHIP_HIP(hipMemcpyAsync(r->p_out.p, r->d_out.p, sizeof(float) * n * r->N, hipMemcpyDeviceToHost, ctx->stream));
     const double t_c = dbg ? now() : 0.0;
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     const double t_d = dbg ? now() : 0.0;
-    for (int c = 0; c < r->N; c++) std::memcpy(out[c], r->p_out.p + c * n, sizeof(float) * n);
+    if (!out_st)
+      for (int c = 0; c < r->N; c++) std::memcpy(out[c], r->p_out.p + c * n, sizeof(float) * n);
     if (dbg)
       fprintf(stderr, "render_process: gather+H2D enqueue %.1f us, launches %.1f us, wait %.1f us, scatter %.1f us\n", t_b - t_a,
               t_c - t_b, t_d - t_c, now() - t_d);

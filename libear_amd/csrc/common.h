@@ -129,6 +129,20 @@ struct earhip_ctx {
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
   int nrt = 8;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)
   int num_cus = 256;
+  // host memory the device reaches directly: earhip_host_alloc / earhip_host_register ranges (the host-pointer
+  // entry points skip their staging copies for channel pointers that are evenly spaced inside one of them)
+  struct HostRange {
+    const char *base;
+    size_t bytes;
+    bool owned;  // earhip_host_alloc (freed with the context) or registered caller memory
+  };
+  std::vector<HostRange> host_ranges;
+  bool host_reachable(const void *p, size_t bytes) const {
+    const char *c = static_cast<const char *>(p);
+    for (const auto &r : host_ranges)
+      if (c >= r.base && c + bytes <= r.base + r.bytes) return true;
+    return false;
+  }
   // staging for the host-pointer entry points (grown at first use / create)
   earhip::PinBuf<float> pin_in, pin_out;
   earhip::DevBuf<float> dev_in, dev_out, dev_pts;

@@ -31,6 +31,17 @@ namespace ear {
       /// bit-exact libear arithmetic in the gain kernels (slower)
       void set_strict(bool strict) { check(earhip_ctx_set_strict(ctx_, strict ? 1 : 0)); }
       void synchronize() { check(earhip_ctx_synchronize(ctx_)); }
+      /// Host memory the device reaches directly.  Channel buffers taken from here (or registered once with
+      /// register_host: e.g. the storage of an Eigen matrix whose columns PtrAdapter points at,
+      /// include/ear/dsp/ptr_adapter.hpp:17-24) let ObjectsRenderer::process skip its staging copies for
+      /// block-sized calls when the channel pointers are evenly spaced.  Freed with the context or release_host.
+      float *alloc_host(size_t count) {
+        void *p = nullptr;
+        check(earhip_host_alloc(ctx_, count * sizeof(float), &p));
+        return static_cast<float *>(p);
+      }
+      void register_host(void *ptr, size_t bytes) { check(earhip_host_register(ctx_, ptr, bytes)); }
+      void release_host(void *ptr) { check(earhip_host_release(ctx_, ptr)); }
 
      private:
       earhip_ctx *ctx_ = nullptr;

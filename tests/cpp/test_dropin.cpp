@@ -762,9 +762,56 @@ static void test_no_allocation_in_process() {
   CHECK(g_heap_count >= 1);
 }
 
+// ---- channel buffers in device-reachable host memory (ear::hip::Context::alloc_host / register_host) ----
+// the columns of ONE pinned matrix, addressed through PtrAdapter::set_planar-style evenly spaced pointers, take
+// the renderer's short-call path without staging copies: the same bits as ordinary buffers
+static void test_pinned_channel_buffers() {
+  const size_t n_in = 12, n_out = 6, B = 512, T = 4;
+  const auto dec = designDecorrelators("0+5+0");
+  ObjectsRenderer plain(n_in, n_out, B, dec, 255, 1), pinned(n_in, n_out, B, dec, 255, 1);
+  for (size_t m = 0; m < n_in; m++) {
+    const std::vector<std::vector<float>> g = {std::vector<float>(n_out, 0.1f + 0.01f * m), std::vector<float>(n_out, 0.4f)};
+    plain.set_object_points(m, {100, 1700}, g, g);
+    pinned.set_object_points(m, {100, 1700}, g, g);
+  }
+  ear::hip::Context &hc = ear::hip::default_context();
+  float *pin_in = hc.alloc_host(n_in * B), *pin_out = hc.alloc_host(n_out * B);
+  std::vector<float> reg_out(n_out * B);  // ordinary memory, registered
+  hc.register_host(reg_out.data(), reg_out.size() * sizeof(float));
+  std::vector<Vec> in(n_in), out(n_out, Vec(B));
+  for (size_t c = 0; c < n_in; c++) in[c] = random_vec(B * T, 300 + (unsigned)c);
+  std::vector<const float *> ip(n_in), pp(n_in);
+  std::vector<float *> op(n_out), qp(n_out), rp(n_out);
+  for (size_t c = 0; c < n_in; c++) pp[c] = pin_in + c * B;
+  for (size_t c = 0; c < n_out; c++) op[c] = out[c].data(), qp[c] = pin_out + c * B, rp[c] = reg_out.data() + c * B;
+  for (size_t t = 0; t < T; t++) {
+    for (size_t c = 0; c < n_in; c++) {
+      ip[c] = in[c].data() + t * B;
+      std::copy(ip[c], ip[c] + B, pin_in + c * B);
+    }
+    plain.process(ip.data(), op.data());
+    pinned.process(pp.data(), (t & 1) ? rp.data() : qp.data());
+    bool same = true;
+    for (size_t c = 0; c < n_out; c++)
+      for (size_t i = 0; i < B; i++) same = same && out[c][i] == ((t & 1) ? rp[c][i] : qp[c][i]);
+    CHECK(same);
+  }
+  hc.release_host(reg_out.data());
+  hc.release_host(pin_out);
+  hc.release_host(pin_in);
+  bool threw = false;
+  try {
+    hc.release_host(pin_in);
+  } catch (const ear::invalid_argument &) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
 int main() {
   try {
     test_no_allocation_in_process();
+    test_pinned_channel_buffers();
     test_gain_calculator_hoa();
     test_gain_calculator_objects();
     test_ptr_adapter();

@@ -280,6 +280,60 @@ def test_long_stream_properties():
     r.close()
 
 
+@pytest.mark.parametrize("m,layout,two_bus", [(64, "9+10+3", True), (40, "4+5+0", False), (1, "0+5+0", True)])
+def test_pinned_and_registered_channel_matrices_skip_the_staging_copies(m, layout, two_bus):
+    """earhip_host_alloc / earhip_host_register (include/earhip.h): channel pointers evenly spaced inside memory
+    the device reaches take the short-call path without gather, D2H copy or scatter — same bits as the staged
+    path, block by block with state carried across calls; pointers of any other shape keep working."""
+    from libear_amd import capi
+    block, nblocks = 512, 6
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout) if two_bus else None
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, period=600, ramp=150, seed=m)
+    x = scenes.audio(m, total, seed=m + 1)
+    calls = [1, 1, 2, 1, 1]  # (the same partition on both paths: two blocks share one transform in K2)
+    want = run_hip(curves, x, n, block, dec, 255 if two_bus else 0, calls)
+    single = run_hip(curves, x, n, block, dec, 255 if two_bus else 0, [1] * nblocks)
+
+    c = capi.Context(0)
+    try:
+        r = capi.Renderer(c, m, n, block, dec, 255 if two_bus else 0, max_blocks=2)
+        set_renderer_curves(r, curves, two_bus)
+        xin, yout = c.pinned_array((m, block)), c.pinned_array((n, block))  # earhip_host_alloc
+        xreg, yreg = np.zeros((m, 2 * block), np.float32), np.zeros((n, 2 * block), np.float32)
+        c.register(xreg)                                                      # earhip_host_register
+        c.register(yreg)
+        got = np.zeros((n, total), np.float32)
+        b = 0
+        for nb in calls:
+            if nb == 2:  # two blocks through the registered arrays
+                xreg[...] = x[:, b * block:(b + 2) * block]
+                r.process_into(xreg, yreg)
+                got[:, b * block:(b + 2) * block] = yreg
+            else:
+                xin[...] = x[:, b * block:(b + 1) * block]
+                r.process_into(xin, yout)
+                got[:, b * block:(b + 1) * block] = yout
+            b += nb
+        # rows that are NOT evenly spaced inside a reachable range: the staged path, same results
+        r.reset(0)
+        odd = c.pinned_array((m + 1, block + 4))
+        for b in range(nblocks):
+            odd[:m, :block] = x[:, b * block:(b + 1) * block]
+            ptr_rows = np.ascontiguousarray(odd[:m, :block])  # (a copy: ordinary memory)
+            out = r.process(ptr_rows)
+            assert np.array_equal(out, single[:, b * block:(b + 1) * block])
+        c.release(yreg)
+        c.release(xreg)
+        with pytest.raises(capi.InvalidArgument):
+            c.release(xreg)
+        r.close()
+    finally:
+        c.close()
+    assert np.array_equal(got, want)
+
+
 def test_render_errors():
     from libear_amd import capi
     dec = decorrelators("0+5+0")
