@@ -717,8 +717,8 @@ def test_gain_kernel_choice_follows_the_curves():
                           ("adm", 1100, "9+10+3", 512, 12, [5, 7])])
 def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, calls):
     """k_gain_mix_p2 forced for every curve family (EARHIP_MFMA=5): metadata that ignores the tile grid,
-    irregular curves with steps and dense points, block-aligned ramps, static gains, ramps so short that
-    their extension back to the tile start leaves the f16 range (exact path), per channel."""
+    irregular curves with steps and dense points, block-aligned ramps, static gains, ramps of a few samples
+    deep inside a tile (p0 far outside [0, 1] before the clamp), per channel; at both tile sizes."""
     from libear_amd import capi
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
