@@ -192,6 +192,12 @@ typedef int (*earhip_process_func)(const float *const *in, float *const *out,
 int earhip_vbs_create(size_t block_size, size_t num_channels_in,
                       size_t num_channels_out, earhip_process_func process_func,
                       void *user, earhip_vbs **out);
+/* the same with the adapter's two FIFO buffers in device-reachable host memory of `ctx` (earhip_host_alloc): a
+ * renderer called from process_func then takes its no-staging path (the FIFO rows are evenly spaced channel
+ * buffers).  Destroy the adapter before the context. */
+int earhip_vbs_create_pinned(earhip_ctx *ctx, size_t block_size, size_t num_channels_in,
+                             size_t num_channels_out, earhip_process_func process_func, void *user,
+                             earhip_vbs **out);
 int earhip_vbs_destroy(earhip_vbs *v);
 int earhip_vbs_process(earhip_vbs *v, size_t nsamples, const float *const *in,
                        float *const *out);

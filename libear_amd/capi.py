@@ -276,12 +276,17 @@ class DelayBuffer:
 class VariableBlockSizeAdapter:
     """Host-side adapter; fn(in [n_in][B]) -> out [n_out][B]."""
 
-    def __init__(self, block_size, n_in, n_out, fn):
+    def __init__(self, block_size, n_in, n_out, fn, ctx=None, raw=False):
+        """ctx: keep the FIFO buffers in device-reachable host memory of that context (earhip_vbs_create_pinned);
+        raw: fn(in_ptrs, out_ptrs) gets the adapter's own channel pointer arrays (to hand on to a C entry point)"""
         self.B, self.n_in, self.n_out = block_size, n_in, n_out
         self.error = None
 
         def cb(inp, outp, _user):
             try:
+                if raw:
+                    fn(inp, outp)
+                    return OK
                 x = np.stack([np.ctypeslib.as_array(inp[c], (block_size,)) for c in range(n_in)])
                 y = _f32(fn(x))
                 for c in range(n_out):
@@ -293,8 +298,17 @@ class VariableBlockSizeAdapter:
 
         self._cb = PROCESS_FUNC(cb)
         self.h = C.c_void_p()
-        check(load().earhip_vbs_create(C.c_size_t(block_size), C.c_size_t(n_in), C.c_size_t(n_out), self._cb,
-                                       None, C.byref(self.h)))
+        if ctx is not None:
+            check(load().earhip_vbs_create_pinned(ctx.h, C.c_size_t(block_size), C.c_size_t(n_in), C.c_size_t(n_out),
+                                                  self._cb, None, C.byref(self.h)))
+        else:
+            check(load().earhip_vbs_create(C.c_size_t(block_size), C.c_size_t(n_in), C.c_size_t(n_out), self._cb,
+                                           None, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            load().earhip_vbs_destroy(self.h)
+            self.h = C.c_void_p()
 
     def get_delay(self):
         return load().earhip_vbs_get_delay(self.h)

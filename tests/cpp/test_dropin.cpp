@@ -796,6 +796,32 @@ static void test_pinned_channel_buffers() {
       for (size_t i = 0; i < B; i++) same = same && out[c][i] == ((t & 1) ? rp[c][i] : qp[c][i]);
     CHECK(same);
   }
+  // the adapter with its FIFO in pinned memory (5-argument constructor) around the renderer == the plain adapter
+  {
+    ObjectsRenderer ra(n_in, n_out, B, dec, 255, 1), rb(n_in, n_out, B, dec, 255, 1);
+    for (size_t m = 0; m < n_in; m++) {
+      const std::vector<std::vector<float>> g = {std::vector<float>(n_out, 0.2f), std::vector<float>(n_out, 0.3f + 0.01f * m)};
+      ra.set_object_points(m, {0, 900}, g, g);
+      rb.set_object_points(m, {0, 900}, g, g);
+    }
+    VariableBlockSizeAdapter plain_ad(B, n_in, n_out, [&](const float *const *i, float *const *o) { ra.process(i, o); });
+    VariableBlockSizeAdapter pinned_ad(B, n_in, n_out, [&](const float *const *i, float *const *o) { rb.process(i, o); }, hc);
+    std::vector<Vec> oa(n_out, Vec(B * T)), ob(n_out, Vec(B * T));
+    size_t ofs = 0;
+    for (size_t k : {300u, 512u, 700u, 536u}) {
+      std::vector<const float *> i2(n_in);
+      std::vector<float *> a2(n_out), b2(n_out);
+      for (size_t c = 0; c < n_in; c++) i2[c] = in[c].data() + ofs;
+      for (size_t c = 0; c < n_out; c++) a2[c] = oa[c].data() + ofs, b2[c] = ob[c].data() + ofs;
+      plain_ad.process(k, i2.data(), a2.data());
+      pinned_ad.process(k, i2.data(), b2.data());
+      ofs += k;
+    }
+    bool same = true, nonzero = false;
+    for (size_t c = 0; c < n_out; c++)
+      for (size_t i = 0; i < ofs; i++) same = same && oa[c][i] == ob[c][i], nonzero = nonzero || oa[c][i] != 0.0f;
+    CHECK(same && nonzero);
+  }
   hc.release_host(reg_out.data());
   hc.release_host(pin_out);
   hc.release_host(pin_in);

@@ -79,3 +79,43 @@ def test_variable_block_size_adapter_around_device_gain_stage():
         out[:, ofs:ofs + n] = ad.process(x[:, ofs:ofs + n])
         ofs += n
     assert np.array_equal(out, want)
+
+
+def test_adapter_with_pinned_fifo_around_the_renderer():
+    """earhip_vbs_create_pinned: the adapter's FIFO rows are evenly spaced channel buffers in device-reachable host
+    memory, so the renderer called from the callback (docs/dsp.rst:65-71: wrap the whole chain) takes its
+    no-staging path — same bits as the adapter with ordinary buffers, calls of any size."""
+    import ctypes
+    import scenes
+    from layouts import LAYOUTS
+    from libear_amd import capi
+    names = LAYOUTS["0+5+0"]
+    m, n, B = 40, len(names), 512
+    dec = capi.design_decorrelators(names)
+    sizes = [100, 512, 700, 3, 1200, 557]
+    total = sum(sizes)
+    curves = scenes.adm_curves(m, n, total + B, period=500, ramp=120, seed=4)
+    x = scenes.audio(m, total, seed=9)
+    lib = capi.load()
+    outs = []
+    c = capi.Context(0)
+    try:
+        for pinned in (False, True):
+            r = capi.Renderer(c, m, n, B, dec, 255, max_blocks=1)
+            for i, (t, d, f) in enumerate(curves):
+                r.set_object_points(i, t, d, f)
+            ad = capi.VariableBlockSizeAdapter(
+                B, m, n, lambda ip, op: capi.check(lib.earhip_render_process(r.h, ctypes.c_size_t(1), ip, op)),
+                ctx=c if pinned else None, raw=True)
+            out = np.zeros((n, total), np.float32)
+            ofs = 0
+            for k in sizes:
+                out[:, ofs:ofs + k] = ad.process(x[:, ofs:ofs + k])
+                ofs += k
+            outs.append(out)
+            ad.close()
+            r.close()
+    finally:
+        c.close()
+    assert np.all(outs[0][:, :B] == 0.0) and np.abs(outs[0][:, B:]).max() > 0
+    assert np.array_equal(outs[0], outs[1])
