@@ -535,11 +535,13 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     // the output rows written in place.  stride in floats; 0: not that shape.
     auto direct_stride = [&](const float *const *ch, int count) -> size_t {
       if (!short_call || ctx->host_ranges.empty() || count < 1) return 0;
-      const ptrdiff_t st = count > 1 ? ch[1] - ch[0] : (ptrdiff_t)n;
-      if (st < (ptrdiff_t)n || st % 4 != 0 || ((uintptr_t)ch[0] & 15) != 0) return 0;
+      // (addresses as integers: the channel pointers need not belong to one array as far as C++ knows)
+      const uintptr_t a0 = (uintptr_t)ch[0];
+      const uintptr_t step = count > 1 ? (uintptr_t)ch[1] - a0 : sizeof(float) * n;
+      if ((a0 & 15) != 0 || step % 16 != 0 || step < sizeof(float) * n || step > ((uintptr_t)1 << 40)) return 0;
       for (int c = 1; c < count; c++)
-        if (ch[c] - ch[c - 1] != st) return 0;
-      return ctx->host_reachable(ch[0], sizeof(float) * ((size_t)st * (count - 1) + n)) ? (size_t)st : 0;
+        if ((uintptr_t)ch[c] - (uintptr_t)ch[c - 1] != step) return 0;
+      return ctx->host_reachable(ch[0], step * (count - 1) + sizeof(float) * n) ? (size_t)(step / sizeof(float)) : 0;
     };
     const size_t in_st = direct_stride(in, r->M);
     const size_t out_st = r->NP <= 1 ? direct_stride(out, r->N) : 0;
