@@ -26,6 +26,12 @@
 // delta piece per object here, static gains one, ADM-like metadata (interpolate 5 ms, then hold) 1 + the
 // fraction of tiles a ramp touches.
 //
+// Vector-memory instructions are what this kernel is short of (the CU's address unit is busy two thirds of all
+// cycles, profiles/r02_adm_scene_*): per chunk a wave issues its 8 input requests, 2-3 sixteen-byte requests for
+// the gain rows of the pieces it converts (staged through wave-private LDS to the lanes that need them, instead
+// of one 4-byte gather per row) and nothing else — piece words, row indices and ramp positions all come out of
+// an LDS ring that wave 0 fills with one request per chunk.
+//
 // ONE list per tile, written by k_piece_list in object order (deterministic): every object's base piece
 // followed by its delta pieces, padded to whole chunks of 32 with null pieces (object 0, the all-zero gain
 // row).  The pieces of an object are neighbours in k, so its input row is requested from memory once (the
@@ -257,7 +263,10 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   constexpr int NFRAG = NCT * 2;  // column tiles x {h,l}
   constexpr int RING = 8;         // chunks of piece words (the object) staged in LDS for the lanes
   __shared__ u32x4 bfrag[2][NFRAG + 2][64];  // + 2 never-read fragments: the lanes without a column write there
-  __shared__ uint32_t ring[RING][CH];
+  __shared__ uint32_t ring[RING][CH];                                  // ... the objects alone (input addresses)
+  __shared__ __attribute__((aligned(16))) u32x4 ringp[RING][CH];       // ... the whole pieces (rows, p0, scale)
+  constexpr int NGI = (2 * NQ * 4 * NCT + 63) / 64;                    // float4 gain-row requests per wave and chunk
+  __shared__ __attribute__((aligned(16))) f32x4 stage[NW][NGI * 64];   // the wave's gain rows of a chunk: [2 NQ][16 NCT] floats
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
@@ -380,14 +389,20 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       // byte offset of this lane's float4 inside an input row (lanes past the end of the call re-read the
       // last vector: never stored)
       const unsigned xlane = (unsigned)min(tile_s0 + li * NRT, nvec - 4) * 4u;
-      const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
       const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;          // fragment pair (h, l) this lane fills
       const size_t rstride = P.in_stride * sizeof(float);
       const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
 
       // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested
       // five chunks ahead, stored four ahead (visible after the next barrier), read two ahead (input addresses)
-      auto ring_load = [&](int c) -> uint32_t { return chunk_ptr(c)[lane & 31].m & ~kPieceDelta; };
+      // (one 16-byte request per chunk: every other per-piece datum the waves need comes out of this ring)
+      auto ring_load = [&](int c) -> u32x4 { return *reinterpret_cast<const u32x4 *>(chunk_ptr(c) + (lane & 31)); };
+      auto ring_store = [&](int c, u32x4 v) {
+        if (lane < 32) {
+          ring[c & (RING - 1)][lane] = v[0] & ~kPieceDelta;
+          ringp[c & (RING - 1)][lane] = v;
+        }
+      };
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
       // inputs q0 .. q0 + n - 1 (n even) of chunk c
@@ -401,39 +416,38 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
             x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride));
           }
       };
-      // (p0, scale) of the lane's 8 pieces of a chunk, requested one chunk ahead (behind that chunk's gain
-      // rows, in front of the inputs of the chunk after it in the in-order queue)
-      f32x2 pcur[8];
-      auto load_ps = [&](int c) {
-        const char *bp = reinterpret_cast<const char *>(chunk_ptr(c) + kg * 8) + 8;
-#pragma unroll
-        for (int q = 0; q < 8; q++) pcur[q] = *reinterpret_cast<const f32x2 *>(bp + q * sizeof(Piece));
+      // (p0, scale) of the lane's piece q of chunk c, out of the ring (read where it is used)
+      auto piece_ps = [&](int c, int q) {
+        const u32x2 v = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringp[c & (RING - 1)][kg * 8 + q]) + 8);
+        return f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
       };
-      // What this WAVE converts for chunk c: pieces NQ w + q.  Wave-uniform: scalar loads (requested one
-      // chunk ahead), scalar row arithmetic; the gain rows come in as (scalar row pointer) + (the lane's column).
-      typedef const Piece __attribute__((address_space(4))) *ConstPiece;
-      // the gain operand of a piece is row X minus row Y: delta (E, S), base (S, the all-zero row)
-      struct ChunkRows {
-        int32_t x[NQ], y[NQ];
-      };
-      auto load_desc = [&](int c) {
-        ConstPiece dp = (ConstPiece)(chunk_ptr(c) + w * NQ);
-        ChunkRows D;
+      // The gain operand of a piece is row X minus row Y: delta (E, S), base (S, the all-zero row).  What this
+      // WAVE converts for chunk c are pieces NQ w + q: their 2 NQ rows (16 NCT floats each) come in as NGI
+      // requests of 16 bytes per lane — slot s = lane + 64 i covers floats 4 (s mod 4 NCT) .. + 3 of row
+      // s div 4 NCT — instead of one 4-byte gather per row: the vector-memory address unit is the busiest unit
+      // of this kernel (two thirds of all cycles) and pays per instruction, not per byte.  The rows go through a
+      // wave-private piece of LDS to the lanes that convert them (lane = column).
+      constexpr int RS = 4 * NCT;  // 16-byte slots per row
+      auto load_gains = [&](int c, f32x4 (&G)[NGI]) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const uint32_t m = dp[q].m;
-          const int32_t row = dp[q].row;
-          const bool d = m & kPieceDelta;
-          D.x[q] = row + (d ? 1 : 0);
-          D.y[q] = d ? row : zero_row;
+        for (int i = 0; i < NGI; i++) {
+          const int sl = min(lane + 64 * i, 2 * NQ * RS - 1);
+          const int r = sl / RS, cg = sl - r * RS;
+          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringp[c & (RING - 1)][w * NQ + (r >> 1)]);  // (m, row)
+          const bool d = mr[0] & kPieceDelta;
+          const unsigned row = (r & 1) ? (d ? mr[1] : (unsigned)zero_row) : mr[1] + (d ? 1u : 0u);
+          G[i] = *reinterpret_cast<const f32x4 *>(gain + (size_t)row * rowlen + col0 + 4 * cg);
         }
-        return D;
       };
-      auto load_gains = [&](const ChunkRows &R, float (&X)[NQ], float (&Y)[NQ]) {
+      const int col_e = min(lane, 16 * NCT - 1);  // the lane's gain column inside the wave's rows
+      auto stage_gains = [&](const f32x4 (&G)[NGI], float (&X)[NQ], float (&Y)[NQ]) {
+#pragma unroll
+        for (int i = 0; i < NGI; i++) stage[w][lane + 64 * i] = G[i];
+        const float *sf = reinterpret_cast<const float *>(&stage[w][0]);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-          X[q] = (gain + (size_t)(unsigned)R.x[q] * rowlen)[bcol_e];
-          Y[q] = (gain + (size_t)(unsigned)R.y[q] * rowlen)[bcol_e];
+          X[q] = sf[(2 * q) * (16 * NCT) + col_e];
+          Y[q] = sf[(2 * q + 1) * (16 * NCT) + col_e];
         }
       };
       // the B operand of the wave's NQ pieces, scaled and split -> LDS
@@ -466,27 +480,22 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
 
       // ---- prologue: piece words of the first chunks into the ring, gains of the first chunk, inputs of
       // the first two
-      uint32_t ring_next = 0;
+      u32x4 ring_next = {0u, 0u, 0u, 0u};
       if (w == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t v = ring_load(c_lo + j);
-          if (lane < 32) ring[(c_lo + j) & (RING - 1)][lane] = v;
-        }
+        for (int j = 0; j < 4; j++) ring_store(c_lo + j, ring_load(c_lo + j));
         ring_next = ring_load(c_lo + 4);  // (stored by the first chunk)
       }
       __syncthreads();
       f32x4 X0[8], X1[8];
-      ChunkRows L;
       {
+        f32x4 G[NGI];
         float S[NQ], E[NQ];
-        L = load_desc(c_lo);
-        load_gains(L, S, E);
-        if (has_delta) load_ps(c_lo);
+        load_gains(c_lo, G);
         load_x_part(c_lo, X0, 0, 8);
         load_x_part(c_lo + 1, X1, 0, 8);
+        stage_gains(G, S, E);
         store_b(S, E, c_lo & 1);
-        L = load_desc(c_lo + 1);
       }
 
       // chunk c: inputs in xc, B fragments in bfrag[c & 1]
@@ -494,12 +503,11 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         const int buf = c & 1;
         __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free; ring slots <= c + 3 are visible
         if (w == 0) {
-          if (lane < 32) ring[(c + 4) & (RING - 1)][lane] = ring_next;
+          ring_store(c + 4, ring_next);
           ring_next = ring_load(c + 5);
         }
-        float S[NQ], E[NQ];
-        load_gains(L, S, E);  // chunk c + 1 (its rows were fetched one chunk ago)
-        L = load_desc(c + 2);
+        f32x4 G[NGI];
+        load_gains(c + 1, G);  // the rows of chunk c + 1 (its pieces have been in the ring for three chunks)
         __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
 
         // A fragments: row tile r = sample 4*li + r of the 8 pieces of this lane.  2 x 2 blocks: an f16
@@ -517,7 +525,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
               f32x2 s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;  // piece 2qp+1
               if (DELTA) {
                 const float f0 = lane_sf + (float)rp, f1 = lane_sf + (float)(rp + 1);
-                const f32x2 a = pcur[2 * qp], b = pcur[2 * qp + 1];
+                const f32x2 a = piece_ps(c, 2 * qp), b = piece_ps(c, 2 * qp + 1);
                 s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
                             __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
                 s1 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, b[1], b[0]), 0.0f, 1.0f),
@@ -536,7 +544,6 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         if (has_delta) split(std::true_type{});  // (uniform over the workgroup)
         else split(std::false_type{});
         __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
-        if (has_delta) load_ps(c + 1);      // (pcur is free now)
         // NCT blocks of 12 MFMAs (three partial products of one column tile, smallest first).  The inputs
         // of chunk c + 2 go into the registers just freed, a few requests per block; the conversion of the
         // next chunk's B operand is woven between the MFMAs of the last block.
@@ -560,7 +567,11 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
           for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
           if (ct < XB) load_x_part(c + 2, xc, ct * (8 / XB), 8 / XB);
           const bool conv = ct == NCT - 1;
-          if (conv) store_b(S, E, buf ^ 1);
+          if (conv) {
+            float S[NQ], E[NQ];
+            stage_gains(G, S, E);
+            store_b(S, E, buf ^ 1);
+          }
           if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           if (ct < XB && !conv) {
 #pragma unroll
