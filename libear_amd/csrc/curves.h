@@ -340,11 +340,12 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   if (L.pieces) {
     const char *pt = getenv("EARHIP_P2_TILE");
     const int ptile = pt ? atoi(pt) : 0;
-    // 8 waves on 512 samples halve the gain conversions and the list building per sample but keep every ramp's
-    // delta piece alive over twice the samples: right while a tile holds about one curve point per object
-    // (ADM-like metadata, 2 points per 960 samples: whole step 0.74 -> 0.71 ms), wrong for curves that turn
-    // every 240 samples (1.35 -> 1.48 ms).  EARHIP_P2_TILE=256|512 forces.
-    L.pw = ptile == 512 ? 8 : ptile == 256 ? 4 : (point_density * 512.0 < 1.5 && nsamples / 512 >= 2 * ctx->num_cus) ? 8 : 4;
+    // 4 waves on 256 samples.  8 waves on 512 halve the gain conversions and the list building per sample but keep
+    // every ramp's delta piece alive over twice the samples: ADM-like metadata (2 points per 960 samples) K1 0.53-0.55
+    // vs 0.59 ms, K0 + K0p 0.096 vs 0.070 ms, whole step 0.67-0.70 vs 0.70-0.71 ms; curves that turn every 240
+    // samples 1.22 vs 1.48 ms.  EARHIP_P2_TILE=512 selects the long tile.
+    L.pw = ptile == 512 ? 8 : 4;
+    (void)point_density;
   }
   L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
