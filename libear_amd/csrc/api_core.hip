@@ -77,14 +77,22 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     }
     probe.obj_level = ctx->obj_level.p;
   }
+  // (piece lists: K0 also counts every object's ramps per tile, into the list builder's count words)
+  PieceLists pl;
+  pl.pieces = reinterpret_cast<Piece *>(desc + (size_t)M * ml.ntiles);
+  pl.M = M;
+  pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
+  pl.ovf = pl.count + (size_t)8 * ml.ntiles;
+  pl.cw = pl.ovf + (size_t)M * ml.ntiles;
+  int *ramp_count = ml.pieces ? pl.cw : nullptr;
   if (!fused_prep) {
     const dim3 ogrid((M + 15) / 16);
     if (ml.ntiles >= 2048)
       hipLaunchKernelGGL(k_seg_prep<4>, dim3((ml.ntiles + 63) / 64, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject);
     else
       hipLaunchKernelGGL(k_seg_prep<2>, dim3((ml.ntiles + 31) / 32, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject);
   }
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
@@ -98,13 +106,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
                        level_cur);
   // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
-  PieceLists pl;
-  pl.pieces = reinterpret_cast<Piece *>(desc + (size_t)M * ml.ntiles);
-  pl.M = M;
-  pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
-  pl.ovf = pl.count + (size_t)8 * ml.ntiles;
-  pl.cw = pl.ovf + (size_t)M * ml.ntiles;
   if (ml.pieces) {
+    if (fused_prep) fail_internal("piece lists need the descriptors of k_seg_prep");
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(), t_call,
                        t_call + nsamples, desc, pl);

@@ -82,9 +82,9 @@ __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
   return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 8 * M * ntiles + 15) / 16 + 1;
 }
 
-// K0p: one workgroup per tile, behind k_seg_prep: turns the tile's descriptors (coalesced reads, no
-// searching) into its piece list, threads over objects.  A first pass counts the delta pieces of every
-// object; a second pass writes the pieces at offsets from an ordered scan over the objects.
+// K0p: one workgroup per tile, behind k_seg_prep: turns the tile's descriptors and ramp counts (coalesced
+// reads, no searching) into its piece list, threads over objects: the pieces are written at offsets from an
+// ordered scan over the objects' counts.
 static __global__ void __launch_bounds__(256)
 k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end, const SegDesc *desc,
              PieceLists pl) {
@@ -106,8 +106,8 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
   null_piece.scale = 0.0f;
 
   // the delta pieces of object m inside the tile: the segment the tile starts in is described by dk
-  // (k_seg_prep), the others are found by walking on (GainInterpolator::process, gain_interpolator.hpp:58-86).
-  // out == nullptr: count only.  Returns their number, -1 for too many.
+  // (k_seg_prep), the others are found by walking on (GainInterpolator::process, gain_interpolator.hpp:58-86);
+  // k_seg_prep counted them with the same walk.
   auto walk = [&](int m, SegDesc dk, Piece *out) {
     int pbase = 0, n = 0;
     if (dk.info & kSegMulti) {
@@ -172,18 +172,18 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
     }
     __syncthreads();
   };
-  // ---- pass 1: the delta counts of every object (kept for pass 2 in the tile's count words) and the total
+  // ---- the delta counts of every object come from k_seg_prep (which walks the curve points of a tile anyway, with
+  // a thread per object and run of tiles: throughput, where this kernel's walks are a chain of latencies);
+  // here only their sum.  (Objects the level probe found far below the call's level — kSegQuiet, set by
+  // k_mark_quiet after k_seg_prep — take the exact path: -1 like objects with too many ramps.)
   int *cw = pl.cw + (size_t)tile * M;
   {
     int mine = 0;
     for (int mb = 0; mb < M; mb += 256) {
       const int m = mb + tid;
       if (m < M) {
-        const SegDesc d0 = dtile[m];
-        int nd = walk(m, d0, nullptr);
-        // (objects the level probe found far below the call's level — kSegQuiet — take the exact path as well)
-        if (d0.info & kSegQuiet) nd = -1;
-        cw[m] = nd;
+        int nd = cw[m];
+        if (dtile[m].info & kSegQuiet) cw[m] = nd = -1;
         if (nd >= 0) mine += 1 + nd;
       }
     }
