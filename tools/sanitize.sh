@@ -13,6 +13,10 @@ cat > "$OUT/stub.cpp" <<'EOS'
 #include <string>
 namespace earhip { static thread_local std::string g; void set_last_error(const std::string &s) { g = s; } }
 extern "C" const char *earhip_last_error() { return earhip::g.c_str(); }
+// (device-reachable host memory lives in api_core.hip; the FIFO under test here uses ordinary memory)
+struct earhip_ctx;
+extern "C" int earhip_host_alloc(earhip_ctx *, size_t, void **) { return 3; }
+extern "C" int earhip_host_release(earhip_ctx *, void *) { return 3; }
 EOS
 g++ -std=c++17 $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" \
     -o "$OUT/libhost.so" "$ROOT/libear_amd/csrc/api_vbs.cpp" "$ROOT/libear_amd/csrc/api_decorrelate.cpp" "$OUT/stub.cpp"
