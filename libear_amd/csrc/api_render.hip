@@ -396,7 +396,7 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // smallest tile any gain kernel of this context uses (f32 MFMA: 16 * nrt samples)
     const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
     const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
-    r->desc.alloc(std::max(desc_units(r->M, max_tiles), piece_units(r->M, (max_samples + 127) / 128)));
+    r->desc.alloc(std::max(desc_units(r->M, max_tiles), piece_units(r->M, (max_samples + 255) / 256)));  // (the piece-list kernel's tiles: 256 or 512 samples)
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits (gsplit > 1) are only
     // chosen for calls with few tiles: plan_mix doubles gsplit while gsplit * (ntiles / tpw) stays below
     // 2 * num_cus, so gsplit * ntiles < (4 * num_cus + gsplit) * tpw with tiles of at most 256 samples
