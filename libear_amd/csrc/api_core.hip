@@ -85,14 +85,26 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   pl.ovf = pl.count + (size_t)8 * ml.ntiles;
   pl.cw = pl.ovf + (size_t)M * ml.ntiles;
   int *ramp_count = ml.pieces ? pl.cw : nullptr;
+  // f16x2 gain kernel: a word per tile, "some object needs the exact path here" (see gain_h2.h)
+  unsigned *slow_cur = nullptr, *slow_next = nullptr;
+  if (ml.split) {
+    if (ctx->tile_slow_cap < (size_t)ml.ntiles) {
+      EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->tile_slow_cap = std::max<size_t>(2 * (size_t)ml.ntiles, 1024);
+      ctx->tile_slow.alloc_zero(2 * ctx->tile_slow_cap, ctx->stream);
+    }
+    slow_cur = ctx->tile_slow.p + (size_t)ctx->tile_slow_idx * ctx->tile_slow_cap;
+    slow_next = ctx->tile_slow.p + (size_t)(ctx->tile_slow_idx ^ 1) * ctx->tile_slow_cap;
+    ctx->tile_slow_idx ^= 1;
+  }
   if (!fused_prep) {
     const dim3 ogrid((M + 15) / 16);
     if (ml.ntiles >= 2048)
       hipLaunchKernelGGL(k_seg_prep<4>, dim3((ml.ntiles + 63) / 64, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject, slow_cur);
     else
       hipLaunchKernelGGL(k_seg_prep<2>, dim3((ml.ntiles + 31) / 32, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject, slow_cur);
   }
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
@@ -104,7 +116,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
   if (probe.obj_level)
     hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
-                       level_cur);
+                       level_cur, slow_cur);
   // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
   if (ml.pieces) {
     if (fused_prep) fail_internal("piece lists need the descriptors of k_seg_prep");
@@ -177,10 +189,10 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (cp.nct == NCT_) {                                                                                             \
     if (ml.tile() == 512)                                                                                           \
       hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, ps.zero_row, xs, gs,       \
-                         level_cur, level_next);                                                                     \
+                         level_cur, level_next, slow_cur, slow_next);                                                \
     else                                                                                                            \
       hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs,       \
-                         level_cur, level_next);                                                                     \
+                         level_cur, level_next, slow_cur, slow_next);                                                \
   }
     EARHIP_H2_CASE(1) EARHIP_H2_CASE(2) EARHIP_H2_CASE(3)
 #undef EARHIP_H2_CASE

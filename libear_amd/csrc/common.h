@@ -124,6 +124,11 @@ struct earhip_ctx {
   bool x_scale_auto = true;  // ... unless a level estimate of the call's inputs is available (default: K0 probes them)
   earhip::DevBuf<unsigned> level;  // [2] input level words (float bits), used alternately by successive calls
   int level_idx = 0;
+  // [2][tile_slow_cap] words used alternately by successive calls of the f16x2 gain kernel: non-zero = some object
+  // of the tile needs the kernel's exact path (set by K0 / k_mark_quiet, cleared for the call after next by K1)
+  earhip::DevBuf<unsigned> tile_slow;
+  size_t tile_slow_cap = 0;
+  int tile_slow_idx = 0;
   earhip::DevBuf<unsigned> obj_level;  // [objects] per-object input levels of the current call (float bits); all zero between calls
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)

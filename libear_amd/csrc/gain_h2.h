@@ -85,7 +85,7 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const unsigned *level_cur,
-              unsigned *level_next) {
+              unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
   constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
@@ -107,6 +107,10 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *level_next = 0;
   }
+  // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0 and
+  // k_mark_quiet leave a word per tile; this call clears the words of the call after next (they alternate).
+  const bool any_slow = !slow_cur || slow_cur[wgtile] != 0u;
+  if (slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[wgtile] = 0u;
   const int nparts = gridDim.y;
   const int part = blockIdx.y;
   const int m_lo = (int)(((int64_t)P.M * part) / nparts);
@@ -405,7 +409,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
     }
 
     // objects with curve points inside this workgroup tile (zero rows above)
-    for (int b0 = 0; b0 < nobj; b0 += 64) {
+    for (int b0 = 0; any_slow && b0 < nobj; b0 += 64) {
       const SegDesc db = dtile[min(m_lo + b0 + lane, m_hi - 1)];
       unsigned long long multi = __ballot((db.info & (kSegMulti | kSegQuiet)) && b0 + lane < nobj);
       while (multi) {

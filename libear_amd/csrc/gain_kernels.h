@@ -131,7 +131,7 @@ __host__ __device__ __forceinline__ bool level_is_quiet(unsigned obj_level, unsi
 template <int kPrepRun>
 static __global__ void __launch_bounds__(256)
 k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end,
-           SegDesc *desc, LevelProbe probe, int *ramp_count = nullptr, int max_ramps = 0) {
+           SegDesc *desc, LevelProbe probe, int *ramp_count = nullptr, int max_ramps = 0, unsigned *tile_slow = nullptr) {
   // a thread searches the segment of its object at its FIRST tile and walks on from there for the
   // next kPrepRun - 1 (the index only grows): a workgroup covers 16 objects x 16 runs of tiles
   __shared__ SegDesc sh[16 * kPrepRun][17];
@@ -167,6 +167,9 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       }
       const SegDesc d = describe_segment(ps, base, n, k, t0, t_end);
       sh[ti * kPrepRun + j][oi] = d;
+      // (f16x2 gain kernel: a curve point inside the tile sends the object through its exact path there; tiles
+      // without any such object — all of them on block-aligned metadata — skip the scan for them)
+      if (tile_slow && (d.info & kSegMulti)) atomicOr(&tile_slow[tile], 1u);
       if (ramp_count) {
         // piece-list kernel (gain_p2.h): the number of ramps of this object that overlap the tile — one delta
         // piece each; two equal times with different gains (a step inside the tile) count as a ramp of length
@@ -225,13 +228,16 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
 // k_seg_prep's last workgroup instead needs a device-scope fence per workgroup — an L2 write-back on this
 // chip — and made K0 ten times slower.)
 static __global__ void __launch_bounds__(256)
-k_mark_quiet(SegDesc *desc, int M, int ntiles, unsigned *obj_level, const unsigned *level_cur) {
+k_mark_quiet(SegDesc *desc, int M, int ntiles, unsigned *obj_level, const unsigned *level_cur, unsigned *tile_slow) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   const unsigned lv = obj_level[m];
   obj_level[m] = 0u;
   if (!level_is_quiet(lv, *level_cur)) return;
-  for (int t = 0; t < ntiles; t++) desc[(size_t)t * M + m].info |= kSegQuiet;
+  for (int t = 0; t < ntiles; t++) {
+    desc[(size_t)t * M + m].info |= kSegQuiet;
+    if (tile_slow) tile_slow[t] = 1u;  // (every writer writes 1)
+  }
 }
 
 // ---------------------------------------------------------------------------
