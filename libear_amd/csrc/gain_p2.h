@@ -263,6 +263,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   constexpr int NFRAG = NCT * 2;  // column tiles x {h,l}
   constexpr int RING = 8;         // chunks of piece words (the object) staged in LDS for the lanes
   __shared__ u32x4 bfrag[2][NFRAG + 2][64];  // + 2 never-read fragments: the lanes without a column write there
+  // the wave's output tile of one column tile on its way from the D fragments to stores of whole rows (gain_h2.h)
+  constexpr int OP = TS + 4;
+  __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
   __shared__ uint32_t ring[RING][CH];                                  // ... the objects alone (input addresses)
   __shared__ __attribute__((aligned(16))) u32x4 ringp[RING][CH];       // ... the whole pieces (rows, p0, scale)
   constexpr int NGI = (2 * NQ * 4 * NCT + 63) / 64;                    // float4 gain-row requests per wave and chunk
@@ -625,8 +628,26 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
   // four row tiles are 4 consecutive samples.
   float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
+  const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
 #pragma unroll
   for (int c = 0; c < NCT; c++) {
+    if (whole) {  // transposed through wave-private LDS: whole 256-byte rows per store instruction (gain_h2.h)
+      float *ot = otile[w];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_g;
+        *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {  // lane: column 4 j + (lane >> 4), samples 4 (lane & 15) .. + 3
+        const int cl = 4 * j + kg, col = col0 + c * 16 + cl;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + cl * OP + li * 4);
+        if (col < P.ncols) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(op + (size_t)col * P.out_stride + li * 4));
+      }
+      continue;
+    }
     const int col = col0 + c * 16 + li;
     if (col >= P.ncols) continue;
     float *o = op + (size_t)col * P.out_stride;
