@@ -614,11 +614,11 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
   auto bus_at8 = [&](const float *row, int s0, float (&acc)[8]) {
     const float *q = row + s0 + lane;
 #pragma unroll
-    for (int m = 0; m < 8; m++) acc[m] = q[64 * m];
+    for (int m = 0; m < 8; m++) acc[m] = __builtin_nontemporal_load(q + 64 * m);  // (read once)
     for (int p = 1; p < P.nparts; p++) {
       q += P.part_stride;
 #pragma unroll
-      for (int m = 0; m < 8; m++) acc[m] += q[64 * m];
+      for (int m = 0; m < 8; m++) acc[m] += __builtin_nontemporal_load(q + 64 * m);
     }
   };
   auto delayed = [&](int s) {  // direct bus delayed by D
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
     if (have_re) {  // :223-226
       if (tb >= first) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) out[tb * B + lane + 64 * m] = (v[m].x + tl[m]) * norm + dre[m];
+        for (int m = 0; m < 8; m++) __builtin_nontemporal_store((v[m].x + tl[m]) * norm + dre[m], out + tb * B + lane + 64 * m);
       }
 #pragma unroll
       for (int m = 0; m < 8; m++) tl[m] = v[m + 8].x;  // :224
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
     if (have_im) {
 #pragma unroll
       for (int m = 0; m < 8; m++) {
-        out[(tb + 1) * B + lane + 64 * m] = (v[m].y + tl[m]) * norm + dim[m];
+        __builtin_nontemporal_store((v[m].y + tl[m]) * norm + dim[m], out + (tb + 1) * B + lane + 64 * m);
         tl[m] = v[m + 8].y;
       }
     }
