@@ -447,6 +447,10 @@ def main():
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
             "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
+                           "note": "SURVEY 8(d)'s algorithmic bytes of the whole chain (gain + decorrelator + delay/mix) over the step "
+                                   "time: they count both gain rows of every block (the fused path fetches the shared one once) and the "
+                                   "BlockConvolver's spectra and queues (which the fused K2 keeps in registers and LDS), so this figure "
+                                   "can exceed what HBM moves - the roofline object above is the one against the kernel's own bytes",
                            "gain_fp32_equivalent_tflops": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2)},
         }
 
