@@ -241,9 +241,15 @@ int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, 
  * stereo downmix), zero gains on the LFE channels, gain, and the sqrt(1 - diffuse) /
  * sqrt(diffuse) split into the direct and diffuse vectors that feed (F).  A BATCH of
  * positions per call (one device thread each, double precision): what a renderer needs
- * per (object, metadata block).  Not implemented, as in libear's own calculate() or beyond
- * it: Cartesian positions, divergence, channel lock, zone exclusion, screen scaling,
- * extent (width / height / depth != 0).
+ * per (object, metadata block).  Not implemented, as in libear's own calculate(): Cartesian
+ * positions, divergence, channel lock, zone exclusion, screen scaling.
+ * The _extent forms add libear's polar extent panner (src/object_based/polar_extent.cpp:
+ * 12-302 with its core, polar_extent_scalar.cpp:25-108): width and height in degrees, depth in
+ * distance units, each may be NULL (0); one wave per position sums the point source panner's
+ * gains over 1652 points on the sphere weighted by the extent's shape (float, as in libear).
+ * The float sums run in a different order from libear's scalar core: results agree to 1e-5 of
+ * a gain vector's norm, the bound libear's tests put between its own cores
+ * (tests/extent_tests.cpp:140-169).  With all three NULL they are the plain forms.
  * layout: an ITU-R BS.2051 name (group H).  Positions are polar: azimuth, elevation in
  * degrees (ADM convention), distance; distance / gain / diffuse may be NULL (1, 1, 0).
  * direct, diffuse_out: [npos][n_channels] float, LFE columns zero.
@@ -261,6 +267,17 @@ int earhip_panner_calculate_device(earhip_panner *p, size_t npos, const double *
                                    const double *elevation, const double *distance,
                                    const double *gain, const double *diffuse, float *direct,
                                    float *diffuse_out);
+
+int earhip_panner_calculate_extent(earhip_panner *p, size_t npos, const double *azimuth,
+                                   const double *elevation, const double *distance,
+                                   const double *width, const double *height, const double *depth,
+                                   const double *gain, const double *diffuse, float *direct,
+                                   float *diffuse_out);
+int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const double *azimuth,
+                                          const double *elevation, const double *distance,
+                                          const double *width, const double *height,
+                                          const double *depth, const double *gain,
+                                          const double *diffuse, float *direct, float *diffuse_out);
 
 /* (I, HOA) Decode matrix for scene-based (HOA) content — replaces ear::GainCalculatorHOA
  * (include/ear/gain_calculators.hpp:58-70, src/hoa/gain_calculator_hoa.cpp:8-72,

@@ -381,20 +381,29 @@ class Panner:
         check(load().earhip_panner_num_channels(self.h, C.byref(n)))
         self.n_out = n.value
 
-    def calculate(self, az, el, dist=None, gain=None, diffuse=None):
-        """arrays [n] (degrees) -> (direct, diffuse) float32 [n][n_out]"""
+    def calculate(self, az, el, dist=None, gain=None, diffuse=None, width=None, height=None, depth=None):
+        """arrays [n] (degrees) -> (direct, diffuse) float32 [n][n_out]; width / height / depth: the extent
+        panner (all None: point sources)"""
         f64 = C.POINTER(C.c_double)
         az = np.ascontiguousarray(np.atleast_1d(az), np.float64)
         n = az.size
 
         def arr(v):
             return None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (n,)))
+
+        def opt(v):
+            return None if v is None else _ptr(v, f64)
         el, dist, gain, diffuse = arr(el), arr(dist), arr(gain), arr(diffuse)
+        width, height, depth = arr(width), arr(height), arr(depth)
         d = np.empty((n, self.n_out), np.float32)
         f = np.empty((n, self.n_out), np.float32)
-        check(load().earhip_panner_calculate(
-            self.h, C.c_size_t(n), _ptr(az, f64), _ptr(el, f64), None if dist is None else _ptr(dist, f64),
-            None if gain is None else _ptr(gain, f64), None if diffuse is None else _ptr(diffuse, f64), _ptr(d), _ptr(f)))
+        if width is None and height is None and depth is None:
+            check(load().earhip_panner_calculate(self.h, C.c_size_t(n), _ptr(az, f64), _ptr(el, f64), opt(dist), opt(gain),
+                                                 opt(diffuse), _ptr(d), _ptr(f)))
+        else:
+            check(load().earhip_panner_calculate_extent(self.h, C.c_size_t(n), _ptr(az, f64), _ptr(el, f64), opt(dist),
+                                                        opt(width), opt(height), opt(depth), opt(gain), opt(diffuse),
+                                                        _ptr(d), _ptr(f)))
         return d, f
 
     def close(self):

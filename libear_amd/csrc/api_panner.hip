@@ -107,67 +107,74 @@ __device__ inline bool quad_pan(const double *poly, Vec3 p, double &out) {
   return false;
 }
 
-// Gains of the real loudspeakers (without LFE) for one direction: the first region that takes the
-// position (PolarPointSourcePanner::handle, :208-217), the extra loudspeakers mixed down and the result
-// power-normalised (PointSourcePannerDownmix::handle, :239-250).  false: no region took it.
-__device__ inline bool pan_full(const PanTable &T, Vec3 p, double (&real)[kMaxPanOut]) {
-  for (int c = 0; c < T.n_real; c++) real[c] = 0.0;
-  bool found = false;
-  for (int ri = 0; ri < T.n_regions && !found; ri++) {
-    const PanRegion &R = T.regions[ri];
-    if (R.kind == 0) {
-      double pv[3];
-      if (triplet_gains(R.basis[0], p, pv)) {
-        found = true;
-        for (int k = 0; k < 3; k++) real[R.out[k]] += pv[k];
+// One region's answer for a direction: false when the region does not take it, else its gains ADDED into
+// real[] (extra loudspeakers already mixed into the real ones).  Triplet :43-51, VirtualNgon :86-101,
+// QuadRegion :118-136, :157-190.
+__device__ inline bool region_try(const PanRegion &R, Vec3 p, double (&real)[kMaxPanOut]) {
+  if (R.kind == 0) {
+    double pv[3];
+    if (!triplet_gains(R.basis[0], p, pv)) return false;
+    for (int k = 0; k < 3; k++) real[R.out[k]] += pv[k];
+    return true;
+  }
+  if (R.kind == 1) {
+    double x, y;
+    if (!(quad_pan(R.poly_x, p, x) && quad_pan(R.poly_y, p, y))) return false;
+    double pvs[4];
+    pvs[R.order[0]] = (1 - x) * (1 - y);
+    pvs[R.order[1]] = x * (1 - y);
+    pvs[R.order[2]] = x * y;
+    pvs[R.order[3]] = (1 - x) * y;
+    Vec3 vel = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 4; k++) {
+      vel.x += pvs[k] * R.pos[k][0];
+      vel.y += pvs[k] * R.pos[k][1];
+      vel.z += pvs[k] * R.pos[k][2];
+    }
+    if (!(vdot(vel, p) > 0)) return false;
+    const double n = sqrt(pvs[0] * pvs[0] + pvs[1] * pvs[1] + pvs[2] * pvs[2] + pvs[3] * pvs[3]);
+    for (int k = 0; k < 4; k++) real[R.out[k]] += pvs[k] / n;
+    return true;
+  }
+  for (int t = 0; t < R.n; t++) {
+    double pv[3];
+    if (triplet_gains(R.basis[t], p, pv)) {
+      // the virtual centre's gain is distributed to the real loudspeakers, then the n-gon's
+      // gains are normalised (:86-101)
+      double g[kMaxNgon];
+      double n2 = 0.0;
+      for (int k = 0; k < R.n; k++) {
+        double v = 0.0;
+        if (k == R.tri[t][0]) v = pv[0];
+        if (k == R.tri[t][1]) v = pv[1];
+        g[k] = v + R.centre_downmix[k] * pv[2];
+        n2 += g[k] * g[k];
       }
-    } else if (R.kind == 1) {
-      double x, y;
-      if (quad_pan(R.poly_x, p, x) && quad_pan(R.poly_y, p, y)) {
-        double pvs[4];
-        pvs[R.order[0]] = (1 - x) * (1 - y);
-        pvs[R.order[1]] = x * (1 - y);
-        pvs[R.order[2]] = x * y;
-        pvs[R.order[3]] = (1 - x) * y;
-        Vec3 vel = {0.0, 0.0, 0.0};
-        for (int k = 0; k < 4; k++) {
-          vel.x += pvs[k] * R.pos[k][0];
-          vel.y += pvs[k] * R.pos[k][1];
-          vel.z += pvs[k] * R.pos[k][2];
-        }
-        if (vdot(vel, p) > 0) {
-          found = true;
-          const double n = sqrt(pvs[0] * pvs[0] + pvs[1] * pvs[1] + pvs[2] * pvs[2] + pvs[3] * pvs[3]);
-          for (int k = 0; k < 4; k++) real[R.out[k]] += pvs[k] / n;
-        }
-      }
-    } else {
-      for (int t = 0; t < R.n && !found; t++) {
-        double pv[3];
-        if (triplet_gains(R.basis[t], p, pv)) {
-          found = true;
-          // the virtual centre's gain is distributed to the real loudspeakers, then the n-gon's
-          // gains are normalised (:86-101)
-          double g[kMaxNgon];
-          double n2 = 0.0;
-          for (int k = 0; k < R.n; k++) {
-            double v = 0.0;
-            if (k == R.tri[t][0]) v = pv[0];
-            if (k == R.tri[t][1]) v = pv[1];
-            g[k] = v + R.centre_downmix[k] * pv[2];
-            n2 += g[k] * g[k];
-          }
-          const double n = sqrt(n2);
-          for (int k = 0; k < R.n; k++) real[R.out[k]] += g[k] / n;
-        }
-      }
+      const double n = sqrt(n2);
+      for (int k = 0; k < R.n; k++) real[R.out[k]] += g[k] / n;
+      return true;
     }
   }
-  if (!found) return false;
+  return false;
+}
+
+// the mix-down of the extra loudspeakers leaves a vector that is normalised again
+// (PointSourcePannerDownmix::handle, :239-250)
+__device__ inline void pan_normalise(const PanTable &T, double (&real)[kMaxPanOut]) {
   double n2 = 0.0;
   for (int c = 0; c < T.n_real; c++) n2 += real[c] * real[c];
   const double n = sqrt(n2);
   for (int c = 0; c < T.n_real; c++) real[c] /= n;
+}
+
+// Gains of the real loudspeakers (without LFE) for one direction: the first region that takes the
+// position (PolarPointSourcePanner::handle, :208-217).  false: no region took it.
+__device__ inline bool pan_full(const PanTable &T, Vec3 p, double (&real)[kMaxPanOut]) {
+  for (int c = 0; c < T.n_real; c++) real[c] = 0.0;
+  bool found = false;
+  for (int ri = 0; ri < T.n_regions && !found; ri++) found = region_try(T.regions[ri], p, real);
+  if (!found) return false;
+  pan_normalise(T, real);
   return true;
 }
 
@@ -177,18 +184,54 @@ struct PanParams {
   int n_full;          // loudspeakers of the layout incl. LFE
   int full_index[kMaxPanOut];  // real loudspeaker (without LFE) -> index in the full layout
   int stereo_index[2];         // 0+2+0: M+030, M-030
+  int real_of_full[kMaxPanOut]; // channel of the full layout -> the panner output that feeds it, -1: LFE
 };
 
-// one thread per position: direct / diffuse [npos][n_full] float; *missed counts positions no region took
+// real[] -> the panner's output channels: the layout's loudspeakers without LFE, or the two of 0+2+0
+// (StereoPannerDownmix, point_source_panner.cpp:374-398)
+__device__ inline int pan_outputs(const PanParams &P, const double (&real)[kMaxPanOut], double (&pv)[kMaxPanOut]) {
+  if (P.stereo) {
+    const double s3 = sqrt(3.0) / 3.0, s5 = sqrt(0.5);
+    const double l = real[0] + s3 * real[2] + s5 * real[3];
+    const double r = real[1] + s3 * real[2] + s5 * real[4];
+    const double n = sqrt(l * l + r * r);
+    const double front = fmax(real[0], fmax(real[1], real[2])), back = fmax(real[3], real[4]);
+    const double lev = pow(0.5, 0.5 * back / (front + back));  // 0 dB at the front to -3 dB at the back
+    pv[0] = l / n * lev;
+    pv[1] = r / n * lev;
+    return 2;
+  }
+  for (int c = 0; c < P.table.n_real; c++) pv[c] = real[c];
+  return P.table.n_real;
+}
+
+}  // namespace earhip
+#include "extent_kernels.h"
+namespace earhip {
+
+// One thread per position: direct / diffuse [npos][n_full] float; *missed counts positions no region took.
+// Positions that libear spreads over the sphere — an extent, or a distance under 1, which widens even a
+// zero extent (polar_extent.cpp:62-70) — are not computed here: their indices are appended to work_list
+// for k_pan_objects_extent (a wave each).  work_list == NULL: every distance is 1 and there is no extent.
 static __global__ void __launch_bounds__(128)
-k_pan_objects(PanParams P, size_t npos, const double *az, const double *el, const double *dist, const double *gain,
-              const double *diffuse, float *direct, float *diff, unsigned *missed) {
+k_pan_objects(PanParams P, size_t npos, const double *az, const double *el, const double *dist, const double *width,
+              const double *height, const double *depth, const double *gain, const double *diffuse, float *direct,
+              float *diff, unsigned *missed, int *work_list, unsigned *work_count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npos) return;
   const Vec3 p = polar_to_cart(az[i], el[i], dist ? dist[i] : 1.0);
+  ExtentPasses X;
+  X.n_pass = 1;
+  X.spread[0] = X.spread[1] = 0.0;
+  if (work_list) {
+    extent_passes(p, width ? width[i] : 0.0, height ? height[i] : 0.0, depth ? depth[i] : 0.0, X);
+    if (X.spread[0] > 1e-10 || (X.n_pass == 2 && X.spread[1] > 1e-10)) {
+      work_list[atomicAdd(work_count, 1u)] = (int)i;
+      return;
+    }
+  }
   double real[kMaxPanOut];
   double pv[kMaxPanOut];
-  int n_pv;
   const bool ok = pan_full(P.table, p, real);
   float *d = direct + i * P.n_full, *f = diff + i * P.n_full;
   for (int c = 0; c < P.n_full; c++) d[c] = f[c] = 0.0f;
@@ -196,55 +239,40 @@ k_pan_objects(PanParams P, size_t npos, const double *az, const double *el, cons
     atomicAdd(missed, 1u);
     return;
   }
-  if (P.stereo) {
-    const double s3 = sqrt(3.0) / 3.0, s5 = sqrt(0.5);
-    double l = real[0] + s3 * real[2] + s5 * real[3];
-    double r = real[1] + s3 * real[2] + s5 * real[4];
-    const double n = sqrt(l * l + r * r);
-    const double front = fmax(real[0], fmax(real[1], real[2])), back = fmax(real[3], real[4]);
-    const double lev = pow(0.5, 0.5 * back / (front + back));  // 0 dB at the front to -3 dB at the back
-    pv[0] = l / n * lev;
-    pv[1] = r / n * lev;
-    n_pv = 2;
-  } else {
-    n_pv = P.table.n_real;
-    for (int c = 0; c < n_pv; c++) pv[c] = real[c];
-  }
+  const int n_pv = pan_outputs(P, real, pv);
   const double g = gain ? gain[i] : 1.0, df = diffuse ? diffuse[i] : 0.0;
   const double sd = sqrt(1.0 - df), sf = sqrt(df);
   for (int c = 0; c < n_pv; c++) {
-    // PolarExtent at zero extent: sqrt(pv^2) (src/object_based/polar_extent.cpp:247-277); gain; split (:47-56)
-    const double v = sqrt(pv[c] * pv[c]) * g;
+    // PolarExtent without spread: sqrt(amount_point pv^2), with depth the rms of two of them
+    // (src/object_based/polar_extent.cpp:257-302); gain; split (gain_calculator_objects.cpp:47-56)
+    double v = sqrt((1.0 - X.spread[0]) * (pv[c] * pv[c]));
+    if (X.n_pass == 2) {
+      const double v2 = sqrt((1.0 - X.spread[1]) * (pv[c] * pv[c]));
+      v = sqrt((v * v + v2 * v2) / 2.0);
+    }
+    v *= g;
     const int o = P.stereo ? P.stereo_index[c] : P.full_index[c];
     d[o] = (float)(v * sd);
     f[o] = (float)(v * sf);
   }
 }
 
-// HOA decoder design: panning values of unit vectors in double, [npos][n_pv] (2 for 0+2+0)
+// HOA decoder design and the extent panner's point grid: panning values of unit vectors in double,
+// [npos][n_pv] (2 for 0+2+0)
 static __global__ void __launch_bounds__(128)
 k_pan_points(PanParams P, size_t npos, const double *xyz, double *pv_out, unsigned *missed) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npos) return;
   const Vec3 p = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-  double real[kMaxPanOut];
+  double real[kMaxPanOut], pv[kMaxPanOut];
   const int n_pv = P.stereo ? 2 : P.table.n_real;
   if (!pan_full(P.table, p, real)) {
     atomicAdd(missed, 1u);
     for (int c = 0; c < n_pv; c++) pv_out[i * n_pv + c] = 0.0;
     return;
   }
-  if (P.stereo) {
-    const double s3 = sqrt(3.0) / 3.0, s5 = sqrt(0.5);
-    const double l = real[0] + s3 * real[2] + s5 * real[3], r = real[1] + s3 * real[2] + s5 * real[4];
-    const double n = sqrt(l * l + r * r);
-    const double front = fmax(real[0], fmax(real[1], real[2])), back = fmax(real[3], real[4]);
-    const double lev = pow(0.5, 0.5 * back / (front + back));
-    pv_out[2 * i] = l / n * lev;
-    pv_out[2 * i + 1] = r / n * lev;
-  } else {
-    for (int c = 0; c < n_pv; c++) pv_out[i * n_pv + c] = real[c];
-  }
+  pan_outputs(P, real, pv);
+  for (int c = 0; c < n_pv; c++) pv_out[i * n_pv + c] = pv[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,6 +488,12 @@ struct earhip_panner {
   PanParams P;
   DevBuf<PanRegion> regions;
   DevBuf<unsigned> missed;
+  // the extent panner's point grid: positions [3][n_padded], gains [n_pv][n_padded] (float)
+  ExtentTable E;
+  DevBuf<float> ext_pos, ext_gains;
+  // positions the thread-per-position kernel hands to the wave-per-position one (grown at first use)
+  DevBuf<int> work;
+  DevBuf<unsigned> work_count;
   // staging of the host-pointer entry point (grown at first use)
   DevBuf<double> d_in;
   DevBuf<float> d_out;
@@ -467,6 +501,58 @@ struct earhip_panner {
   PinBuf<float> p_out;
   PinBuf<unsigned> p_missed;
 };
+
+// PolarExtent's constructor (src/object_based/polar_extent.cpp:16-50, :96-176): the 37 rows of points and the
+// point source panner's gains at each of them (device, one thread per point, double), kept as float
+static void build_extent_table(earhip_panner &pn) {
+  earhip_ctx *ctx = pn.ctx;
+  const double pi = 3.14159265358979323846264338327950288;
+  std::vector<double> xyz;
+  for (int r = 0; r < kExtentRows; r++) {
+    const double el = -90.0 + r * (180.0 / (kExtentRows - 1));
+    const double radius = std::cos(el * pi / 180.0);
+    int n_points = (int)std::round(((2 * pi * radius) / (2 * pi)) * 2 * (kExtentRows - 1));
+    if (n_points == 0) n_points = 1;
+    for (int i = 0; i < n_points; i++) {
+      const Vec3 q = polar_to_cart(i * (360.0 / n_points), el, 1.0);
+      xyz.push_back(q.x), xyz.push_back(q.y), xyz.push_back(q.z);
+    }
+  }
+  const size_t np = xyz.size() / 3, padded = (np + 63) / 64 * 64;
+  const size_t S = pn.P.stereo ? 2 : (size_t)pn.P.table.n_real;
+  DevBuf<double> d_xyz, d_pv;
+  d_xyz.alloc(3 * np);
+  d_pv.alloc(np * S);
+  EARHIP_HIP(hipMemcpyAsync(d_xyz.p, xyz.data(), sizeof(double) * 3 * np, hipMemcpyHostToDevice, ctx->stream));
+  EARHIP_HIP(hipMemsetAsync(pn.missed.p, 0, sizeof(unsigned), ctx->stream));
+  hipLaunchKernelGGL(k_pan_points, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, ctx->stream, pn.P, np, d_xyz.p, d_pv.p,
+                     pn.missed.p);
+  EARHIP_HIP(hipGetLastError());
+  std::vector<double> G(np * S);
+  unsigned missed = 0;
+  EARHIP_HIP(hipMemcpyAsync(G.data(), d_pv.p, sizeof(double) * np * S, hipMemcpyDeviceToHost, ctx->stream));
+  EARHIP_HIP(hipMemcpyAsync(&missed, pn.missed.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+  if (missed) fail_internal("point source panner: a point of the extent grid was not handled by any region");
+  std::vector<float> pos(3 * padded), gains(S * padded, 0.0f);
+  for (size_t q = 0; q < padded; q++) {
+    const size_t src = std::min(q, np - 1);  // (padding repeats the last point; its gains stay zero)
+    for (int k = 0; k < 3; k++) pos[k * padded + q] = (float)xyz[3 * src + k];
+  }
+  for (size_t q = 0; q < np; q++)
+    for (size_t c = 0; c < S; c++) gains[c * padded + q] = (float)G[q * S + c];
+  pn.ext_pos.alloc(3 * padded);
+  pn.ext_gains.alloc(S * padded);
+  EARHIP_HIP(hipMemcpy(pn.ext_pos.p, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice));
+  EARHIP_HIP(hipMemcpy(pn.ext_gains.p, gains.data(), sizeof(float) * gains.size(), hipMemcpyHostToDevice));
+  pn.E.n_points = (int)np;
+  pn.E.n_padded = (int)padded;
+  pn.E.n_pv = (int)S;
+  pn.E.xs = pn.ext_pos.p;
+  pn.E.ys = pn.ext_pos.p + padded;
+  pn.E.zs = pn.ext_pos.p + 2 * padded;
+  pn.E.gains = pn.ext_gains.p;
+}
 
 extern "C" {
 
@@ -494,6 +580,10 @@ int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **ou
       for (int c = 0; c < L.n; c++)
         if (!L.channels[c].is_lfe) p->P.full_index[k++] = c;
     }
+    require(L.n <= kMaxPanOut, "too many channels");
+    for (int c = 0; c < kMaxPanOut; c++) p->P.real_of_full[c] = -1;
+    const int n_pv = p->P.stereo ? 2 : n_real;
+    for (int k = 0; k < n_pv; k++) p->P.real_of_full[p->P.stereo ? p->P.stereo_index[k] : p->P.full_index[k]] = k;
     p->regions.alloc(regions.size());
     EARHIP_HIP(hipMemcpy(p->regions.p, regions.data(), sizeof(PanRegion) * regions.size(), hipMemcpyHostToDevice));
     p->P.table.n_regions = (int)regions.size();
@@ -502,6 +592,7 @@ int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **ou
     p->missed.alloc_zero(1, ctx->stream);
     p->p_missed.reserve(1);
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    build_extent_table(*p);
     *out = p.release();
   });
 }
@@ -611,23 +702,53 @@ int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, co
   });
 }
 
-int earhip_panner_calculate_device(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
-                                   const double *distance, const double *gain, const double *diffuse, float *direct,
-                                   float *diffuse_out) {
+static void launch_pan(earhip_panner *p, size_t npos, const double *az, const double *el, const double *dist,
+                       const double *width, const double *height, const double *depth, const double *gain,
+                       const double *diffuse, float *direct, float *diffuse_out) {
+  hipStream_t s = p->ctx->stream;
+  // a distance of 1 and no extent: nothing is spread (extentMod(0, 1) = 0)
+  const bool may_spread = dist || width || height || depth;
+  if (may_spread) {
+    p->work.reserve(npos);
+    p->work_count.reserve(1);
+    EARHIP_HIP(hipMemsetAsync(p->work_count.p, 0, sizeof(unsigned), s));
+  }
+  hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, s, p->P, npos, az, el, dist, width,
+                     height, depth, gain, diffuse, direct, diffuse_out, p->missed.p, may_spread ? p->work.p : nullptr,
+                     may_spread ? p->work_count.p : nullptr);
+  EARHIP_HIP(hipGetLastError());
+  if (may_spread) {
+    hipLaunchKernelGGL(k_pan_objects_extent, dim3((unsigned)((npos + kExtentWaves - 1) / kExtentWaves)),
+                       dim3(64 * kExtentWaves), 0, s, p->P, p->E, p->work.p, p->work_count.p, az, el, dist, width, height,
+                       depth, gain, diffuse, direct, diffuse_out, p->missed.p);
+    EARHIP_HIP(hipGetLastError());
+  }
+}
+
+int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
+                                          const double *distance, const double *width, const double *height,
+                                          const double *depth, const double *gain, const double *diffuse, float *direct,
+                                          float *diffuse_out) {
   return guarded([&] {
     require(p != nullptr, "panner must not be NULL");
     require(azimuth && elevation && direct && diffuse_out, "azimuth, elevation and the outputs must not be NULL");
+    require(npos < ((size_t)1 << 28), "too many positions");
     if (npos == 0) return;
     p->ctx->use();
-    hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, p->ctx->stream, p->P, npos,
-                       azimuth, elevation, distance, gain, diffuse, direct, diffuse_out, p->missed.p);
-    EARHIP_HIP(hipGetLastError());
+    launch_pan(p, npos, azimuth, elevation, distance, width, height, depth, gain, diffuse, direct, diffuse_out);
   });
 }
 
-int earhip_panner_calculate(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
-                            const double *distance, const double *gain, const double *diffuse, float *direct,
-                            float *diffuse_out) {
+int earhip_panner_calculate_device(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
+                                   const double *distance, const double *gain, const double *diffuse, float *direct,
+                                   float *diffuse_out) {
+  return earhip_panner_calculate_extent_device(p, npos, azimuth, elevation, distance, nullptr, nullptr, nullptr, gain, diffuse,
+                                               direct, diffuse_out);
+}
+
+int earhip_panner_calculate_extent(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
+                                   const double *distance, const double *width, const double *height, const double *depth,
+                                   const double *gain, const double *diffuse, float *direct, float *diffuse_out) {
   return guarded([&] {
     require(p != nullptr, "panner must not be NULL");
     require(azimuth && elevation && direct && diffuse_out, "azimuth, elevation and the outputs must not be NULL");
@@ -636,19 +757,20 @@ int earhip_panner_calculate(earhip_panner *p, size_t npos, const double *azimuth
     earhip_ctx *ctx = p->ctx;
     ctx->use();
     const size_t N = (size_t)p->P.n_full;
-    p->p_in.reserve(5 * npos);
-    p->d_in.reserve(5 * npos);
+    constexpr int kIn = 8;
+    p->p_in.reserve(kIn * npos);
+    p->d_in.reserve(kIn * npos);
     p->p_out.reserve(2 * npos * N);
     p->d_out.reserve(2 * npos * N);
-    const double *src[5] = {azimuth, elevation, distance, gain, diffuse};
-    for (int k = 0; k < 5; k++)
+    const double *src[kIn] = {azimuth, elevation, distance, width, height, depth, gain, diffuse};
+    const double *dev[kIn];
+    for (int k = 0; k < kIn; k++) {
       if (src[k]) std::memcpy(p->p_in.p + k * npos, src[k], sizeof(double) * npos);
-    EARHIP_HIP(hipMemcpyAsync(p->d_in.p, p->p_in.p, sizeof(double) * 5 * npos, hipMemcpyHostToDevice, ctx->stream));
+      dev[k] = src[k] ? p->d_in.p + k * npos : nullptr;
+    }
+    EARHIP_HIP(hipMemcpyAsync(p->d_in.p, p->p_in.p, sizeof(double) * kIn * npos, hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemsetAsync(p->missed.p, 0, sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, ctx->stream, p->P, npos, p->d_in.p,
-                       p->d_in.p + npos, distance ? p->d_in.p + 2 * npos : nullptr, gain ? p->d_in.p + 3 * npos : nullptr,
-                       diffuse ? p->d_in.p + 4 * npos : nullptr, p->d_out.p, p->d_out.p + npos * N, p->missed.p);
-    EARHIP_HIP(hipGetLastError());
+    launch_pan(p, npos, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], dev[7], p->d_out.p, p->d_out.p + npos * N);
     EARHIP_HIP(hipMemcpyAsync(p->p_out.p, p->d_out.p, sizeof(float) * 2 * npos * N, hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(p->p_missed.p, p->missed.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
@@ -658,6 +780,13 @@ int earhip_panner_calculate(earhip_panner *p, size_t npos, const double *azimuth
     // an error here)
     if (*p->p_missed.p != 0) fail_internal("point source panner: a position was not handled by any region");
   });
+}
+
+int earhip_panner_calculate(earhip_panner *p, size_t npos, const double *azimuth, const double *elevation,
+                            const double *distance, const double *gain, const double *diffuse, float *direct,
+                            float *diffuse_out) {
+  return earhip_panner_calculate_extent(p, npos, azimuth, elevation, distance, nullptr, nullptr, nullptr, gain, diffuse, direct,
+                                        diffuse_out);
 }
 
 }  // extern "C"

@@ -44,7 +44,8 @@ namespace ear {
     void calculate(const std::vector<ObjectsTypeMetadata> &metadata, std::vector<std::vector<T>> &directGains,
                    std::vector<std::vector<T>> &diffuseGains) {
       const size_t n = metadata.size();
-      std::vector<double> az(n), el(n), dist(n), gain(n), diffuse(n);
+      std::vector<double> az(n), el(n), dist(n), gain(n), diffuse(n), width(n), height(n), depth(n);
+      bool extent = false;
       for (size_t i = 0; i < n; i++) {
         const ObjectsTypeMetadata &m = metadata[i];
         // libear's own refusals (src/object_based/gain_calculator_objects.cpp:37-44) ...
@@ -53,8 +54,11 @@ namespace ear {
         if (m.channelLock.flag) throw not_implemented("channelLock");
         if (m.zoneExclusion.zones.size()) throw not_implemented("zoneExclusion");
         if (m.screenRef) throw not_implemented("screenRef");
-        // ... and one more: extent panning is not part of the device path
-        if (m.width != 0.0 || m.height != 0.0 || m.depth != 0.0) throw not_implemented("extent");
+        // width / height / depth: the polar extent panner (src/object_based/polar_extent.cpp:290-302)
+        extent = extent || m.width != 0.0 || m.height != 0.0 || m.depth != 0.0;
+        width[i] = m.width;
+        height[i] = m.height;
+        depth[i] = m.depth;
         az[i] = m.position.polar.azimuth;
         el[i] = m.position.polar.elevation;
         dist[i] = m.position.polar.distance;
@@ -62,8 +66,12 @@ namespace ear {
         diffuse[i] = m.diffuse;
       }
       std::vector<float> d(n * n_full_), f(n * n_full_);
-      hip::check(earhip_panner_calculate(h_, n, az.data(), el.data(), dist.data(), gain.data(), diffuse.data(), d.data(),
-                                         f.data()));
+      if (extent)
+        hip::check(earhip_panner_calculate_extent(h_, n, az.data(), el.data(), dist.data(), width.data(), height.data(),
+                                                  depth.data(), gain.data(), diffuse.data(), d.data(), f.data()));
+      else
+        hip::check(earhip_panner_calculate(h_, n, az.data(), el.data(), dist.data(), gain.data(), diffuse.data(), d.data(),
+                                           f.data()));
       directGains.assign(n, std::vector<T>(keep_.size()));
       diffuseGains.assign(n, std::vector<T>(keep_.size()));
       for (size_t i = 0; i < n; i++)

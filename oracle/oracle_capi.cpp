@@ -262,31 +262,37 @@ int oracle_render_process(ObjectsRenderer *r, size_t n_obj, size_t n_out,
 
 // ---- Objects gain producer (panner_oracle.hpp) -------------------------------------------------
 #include "panner_oracle.hpp"
+#include "extent_oracle.hpp"
+
+namespace {
+typedef extent_oracle::GainCalculatorObjects OracleObjects;  // point source panner + polar extent panner
+const panner_oracle::PannerSetup &setup_of(void *p) { return static_cast<OracleObjects *>(p)->base; }
+}  // namespace
 
 extern "C" {
 
 void *oracle_panner_create(const char *layout) {
   void *out = nullptr;
-  guarded([&] { out = new panner_oracle::GainCalculatorObjects(layout); });
+  guarded([&] { out = new OracleObjects(layout); });
   return out;
 }
-void oracle_panner_destroy(void *p) { delete static_cast<panner_oracle::GainCalculatorObjects *>(p); }
-int oracle_panner_n_out(void *p) { return static_cast<panner_oracle::GainCalculatorObjects *>(p)->n_out(); }
+void oracle_panner_destroy(void *p) { delete static_cast<OracleObjects *>(p); }
+int oracle_panner_n_out(void *p) { return setup_of(p).n_out(); }
 // n positions: az, el, dist, gain, diffuse [n] -> direct, diffuse [n][n_out]; returns the number of
 // positions no region handled (their rows are left untouched)
 int oracle_panner_calculate(void *p, size_t n, const double *az, const double *el, const double *dist,
                             const double *gain, const double *diffuse, float *direct, float *diff) {
-  auto *g = static_cast<panner_oracle::GainCalculatorObjects *>(p);
-  const size_t no = (size_t)g->n_out();
+  auto *g = static_cast<OracleObjects *>(p);
+  const size_t no = (size_t)g->base.n_out();
   int missed = 0;
   for (size_t i = 0; i < n; i++)
-    if (!g->calculate(az[i], el[i], dist[i], gain[i], diffuse[i], direct + i * no, diff + i * no)) missed++;
+    if (!g->calculate(az[i], el[i], dist[i], 0.0, 0.0, 0.0, gain[i], diffuse[i], direct + i * no, diff + i * no)) missed++;
   return missed;
 }
 // the inner point source panner (layout without LFE): pv [n][n_out_without_lfe] in double
-int oracle_psp_n_out(void *p) { return static_cast<panner_oracle::GainCalculatorObjects *>(p)->psp->n_out(); }
+int oracle_psp_n_out(void *p) { return setup_of(p).psp->n_out(); }
 int oracle_psp_handle(void *p, size_t n, const double *xyz, double *pv) {
-  auto *g = static_cast<panner_oracle::GainCalculatorObjects *>(p);
+  const panner_oracle::PannerSetup *g = &setup_of(p);
   const size_t no = (size_t)g->psp->n_out();
   int missed = 0;
   for (size_t i = 0; i < n; i++) {
@@ -380,4 +386,68 @@ void oracle_tdesign_points(double *xyz) {
   const auto p = hoa_oracle::load_points();
   for (size_t i = 0; i < p.size(); i++) xyz[3 * i] = p[i].x, xyz[3 * i + 1] = p[i].y, xyz[3 * i + 2] = p[i].z;
 }
+}  // extern "C"
+
+// ---- polar extent panner (extent_oracle.hpp) ----------------------------------------------------------
+extern "C" {
+
+// (the handles are oracle_panner_create's)
+int oracle_extent_num_points(void *p) { return (int)static_cast<OracleObjects *>(p)->extent.num_points; }
+// the grid: xyz [num_points][3] (double, before the cast to float)
+void oracle_extent_grid(double *xyz) {
+  const auto pos = extent_oracle::panning_positions_even(extent_oracle::kRows);
+  for (size_t i = 0; i < pos.size(); i++) xyz[3 * i] = pos[i].x, xyz[3 * i + 1] = pos[i].y, xyz[3 * i + 2] = pos[i].z;
+}
+// PolarExtent::handle (library form, float core) and the tests' reference form (double): xyz [n][3],
+// width / height / depth [n] -> pv [n][n_out_without_lfe] double; returns the number of unhandled positions
+int oracle_extent_handle(void *p, int which, size_t n, const double *xyz, const double *width, const double *height,
+                         const double *depth, double *pv) {
+  auto *g = static_cast<OracleObjects *>(p);
+  const size_t S = g->extent.num_speakers;
+  int missed = 0;
+  guarded([&] {
+    std::unique_ptr<extent_oracle::test_reference::PolarExtentPanner> ref;
+    if (which == 1) ref.reset(new extent_oracle::test_reference::PolarExtentPanner(g->base.psp));
+    for (size_t i = 0; i < n; i++) {
+      const panner_oracle::V3 pos = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+      panner_oracle::Vec out;
+      if (which == 1) {
+        out = ref->handle(pos, width[i], height[i], depth[i]);
+      } else if (!g->extent.handle(pos, width[i], height[i], depth[i], out)) {
+        missed++;
+        continue;
+      }
+      for (size_t s = 0; s < S; s++) pv[i * S + s] = out[s];
+    }
+  });
+  return missed;
+}
+void oracle_extent_calc_basis(const double *xyz, double *m9) {
+  const extent_oracle::Mat3 b = extent_oracle::calc_basis({xyz[0], xyz[1], xyz[2]});
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) m9[3 * i + j] = b.m[i][j];
+}
+double oracle_extent_mod(double extent, double distance) { return extent_oracle::extent_mod(extent, distance); }
+// weight of `point` for an extent of width x height (degrees) centred on `centre`: which 0 = the library's
+// float core, 1 = the tests' reference weighting function
+double oracle_extent_weight(void *p, int which, const double *centre, double width, double height, const double *point) {
+  const panner_oracle::V3 c = {centre[0], centre[1], centre[2]}, q = {point[0], point[1], point[2]};
+  if (which == 1) return extent_oracle::test_reference::WeightingFunction(c, width, height)(q);
+  auto *g = static_cast<OracleObjects *>(p);
+  g->extent.setup_weighting_function(c, width, height);
+  return (double)g->extent.weight((float)q.x, (float)q.y, (float)q.z);
+}
+// GainCalculatorObjects::calculate with extent: returns the number of unhandled positions
+int oracle_extent_calculate(void *p, size_t n, const double *az, const double *el, const double *dist, const double *width,
+                            const double *height, const double *depth, const double *gain, const double *diffuse,
+                            float *direct, float *diff) {
+  auto *g = static_cast<OracleObjects *>(p);
+  const size_t no = g->base.is_lfe.size();
+  int missed = 0;
+  for (size_t i = 0; i < n; i++)
+    if (!g->calculate(az[i], el[i], dist[i], width[i], height[i], depth[i], gain[i], diffuse[i], direct + i * no, diff + i * no))
+      missed++;
+  return missed;
+}
+
 }  // extern "C"

@@ -1,8 +1,8 @@
 // panner_oracle.hpp — TEST INFRASTRUCTURE (the checker, never the product): a plain C++14 restatement, in
 // double precision and without Eigen/Boost, of libear's gain-vector producer for Objects content:
 //
-//   GainCalculatorObjectsImpl::calculate        src/object_based/gain_calculator_objects.cpp:33-57
-//   PolarExtent::handle at zero extent          src/object_based/polar_extent.cpp:247-302
+//   GainCalculatorObjectsImpl's constructor     src/object_based/gain_calculator_objects.cpp:24-31
+//     (calculate() and PolarExtent: oracle/extent_oracle.hpp)
 //   configurePolarPanner & friends              src/common/point_source_panner.cpp:14-600
 //   cart, ngonVertexOrder                       src/common/geom.cpp:37-92
 //
@@ -445,32 +445,17 @@ inline std::shared_ptr<PointSourcePanner> configure_polar_panner(const std::stri
   return configure_full_polar_panner(name, layout);
 }
 
-// gain_calculator_objects.cpp:24-57 with PolarExtent at width = height = depth = 0
-// (polar_extent.cpp:247-302: amount_point = 1 -> out = sqrt(pv^2))
-struct GainCalculatorObjects {
+// What GainCalculatorObjectsImpl's constructor builds (gain_calculator_objects.cpp:24-31): the polar point
+// source panner of the layout without LFE and the LFE mask.  calculate() itself goes through PolarExtent
+// even for point sources (a distance under 1 widens a zero extent): oracle/extent_oracle.hpp.
+struct PannerSetup {
   std::shared_ptr<PointSourcePanner> psp;
   std::vector<bool> is_lfe;
-  explicit GainCalculatorObjects(const std::string &layout) {
+  explicit PannerSetup(const std::string &layout) {
     layout_without_lfe(layout, &is_lfe);
     psp = configure_polar_panner(layout);
   }
   int n_out() const { return (int)is_lfe.size(); }
-  // returns false when no region handles the position (the reference dereferences an empty optional)
-  bool calculate(double az, double el, double dist, double gain, double diffuse, float *direct, float *diff) const {
-    const Opt pv = psp->handle(cart(az, el, dist));
-    if (!pv.ok) return false;
-    size_t j = 0;
-    for (size_t c = 0; c < is_lfe.size(); c++) {
-      double v = 0.0;
-      if (!is_lfe[c]) {
-        v = std::sqrt(pv.v[j] * pv.v[j]) * gain;
-        j++;
-      }
-      direct[c] = (float)(v * std::sqrt(1.0 - diffuse));
-      diff[c] = (float)(v * std::sqrt(diffuse));
-    }
-    return true;
-  }
 };
 
 }  // namespace panner_oracle

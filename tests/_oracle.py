@@ -26,7 +26,7 @@ def load(native=False):
     path = os.path.join(ODIR, "_build", name)
     src_newer = (not os.path.exists(path)) or any(
         os.path.getmtime(os.path.join(ODIR, f)) > os.path.getmtime(path)
-        for f in ("ear_oracle.hpp", "oracle_capi.cpp", "panner_oracle.hpp", "bs2051_data.h"))
+        for f in ("ear_oracle.hpp", "oracle_capi.cpp", "panner_oracle.hpp", "extent_oracle.hpp", "bs2051_data.h"))
     if src_newer:
         _build()
     lib = C.CDLL(path)
@@ -274,7 +274,8 @@ def cart(az, el, dist=1.0):
 
 
 class GainCalculatorObjects:
-    """Objects gain producer (oracle/panner_oracle.hpp): point-source pan + LFE mask + diffuse split."""
+    """Objects gain producer without extent parameters (oracle/panner_oracle.hpp + extent_oracle.hpp): point-source
+    pan (widened at distances under 1, as libear's PolarExtent does), LFE mask, diffuse split."""
 
     def __init__(self, layout):
         lib().oracle_panner_create.restype = C.c_void_p
@@ -311,6 +312,79 @@ class GainCalculatorObjects:
             lib().oracle_panner_destroy(self.h)
         except Exception:
             pass
+
+
+def _f64(x, n):
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float64), (n,)))
+
+
+class PolarExtent:
+    """libear's polar extent panner behind GainCalculatorObjects (oracle/extent_oracle.hpp): the library's
+    form (float core, `which=0`) and the form libear's tests keep beside it (double, `which=1`)."""
+
+    def __init__(self, layout):
+        L = lib()
+        L.oracle_panner_create.restype = C.c_void_p
+        L.oracle_extent_weight.restype = C.c_double
+        L.oracle_extent_mod.restype = C.c_double
+        self.h = C.c_void_p(L.oracle_panner_create(layout.encode()))
+        if not self.h:
+            raise OracleError(1, L.oracle_last_error().decode())
+        self.n_out = L.oracle_panner_n_out(self.h)
+        self.n_psp = L.oracle_psp_n_out(self.h)
+        self.num_points = L.oracle_extent_num_points(self.h)
+
+    def grid(self):
+        xyz = np.zeros((self.num_points, 3), np.float64)
+        lib().oracle_extent_grid(ptr(xyz, f64p))
+        return xyz
+
+    def handle(self, xyz, width, height, depth=0.0, which=0):
+        """Cartesian positions [n][3], extents in degrees -> pv [n][channels without LFE] float64"""
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        n = xyz.shape[0]
+        w, h, d = _f64(width, n), _f64(height, n), _f64(depth, n)
+        pv = np.zeros((n, self.n_psp), np.float64)
+        missed = lib().oracle_extent_handle(self.h, which, C.c_size_t(n), ptr(xyz, f64p), ptr(w, f64p), ptr(h, f64p),
+                                            ptr(d, f64p), ptr(pv, f64p))
+        assert missed == 0, f"{missed} positions not handled by any region"
+        return pv
+
+    def weight(self, centre, width, height, point, which=0):
+        centre = np.ascontiguousarray(centre, np.float64)
+        point = np.ascontiguousarray(point, np.float64)
+        return lib().oracle_extent_weight(self.h, which, ptr(centre, f64p), C.c_double(width), C.c_double(height),
+                                          ptr(point, f64p))
+
+    def calculate(self, az, el, dist=None, width=0.0, height=0.0, depth=0.0, gain=None, diffuse=None):
+        """GainCalculatorObjects::calculate with extent: arrays [n] -> (direct, diffuse) float32 [n][n_out]"""
+        az = np.ascontiguousarray(np.atleast_1d(az), np.float64)
+        n = az.size
+        a = [_f64(v, n) for v in (el, 1.0 if dist is None else dist, width, height, depth,
+                                  1.0 if gain is None else gain, 0.0 if diffuse is None else diffuse)]
+        d = np.zeros((n, self.n_out), np.float32)
+        f = np.zeros((n, self.n_out), np.float32)
+        missed = lib().oracle_extent_calculate(self.h, C.c_size_t(n), ptr(az, f64p), *[ptr(v, f64p) for v in a], ptr(d), ptr(f))
+        assert missed == 0, f"{missed} positions not handled by any region"
+        return d, f
+
+    def __del__(self):
+        try:
+            lib().oracle_panner_destroy(self.h)
+        except Exception:
+            pass
+
+
+def extent_calc_basis(xyz):
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    m = np.zeros((3, 3), np.float64)
+    lib().oracle_extent_calc_basis(ptr(xyz, f64p), ptr(m, f64p))
+    return m
+
+
+def extent_mod(extent, distance):
+    lib().oracle_extent_mod.restype = C.c_double
+    return lib().oracle_extent_mod(C.c_double(extent), C.c_double(distance))
 
 
 def extra_pos_vertical_nominal(layout):

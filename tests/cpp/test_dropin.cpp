@@ -646,10 +646,38 @@ static void test_gain_calculator_objects() {
   m = base;
   m.screenRef = true;
   CHECK(refuses(m));
-  m = base;
-  m.width = 20.0;
-  CHECK(refuses(m));
   CHECK(!refuses(base));
+  // extent (tests/extent_tests.cpp:116-138): unit power, the velocity vector stays in the median plane and
+  // points forwards (4+7+0 has no layer below, so it tilts up a little), more loudspeakers than a point source
+  m = base;
+  m.position = PolarPosition(0.0, 0.0, 1.0);
+  m.width = 20.0;
+  m.height = 10.0;
+  CHECK(!refuses(m));
+  {
+    double power = 0.0, vx = 0.0, vy = 0.0, vz = 0.0;
+    int nz = 0;
+    for (size_t c = 0; c < direct.size(); c++) {
+      const PolarPosition pp = layout.channels()[c].polarPosition();
+      const double a = -pp.azimuth * M_PI / 180.0, e = pp.elevation * M_PI / 180.0;
+      power += (double)direct[c] * direct[c];
+      vx += direct[c] * std::sin(a) * std::cos(e), vy += direct[c] * std::cos(a) * std::cos(e), vz += direct[c] * std::sin(e);
+      nz += direct[c] > 1e-6f;
+    }
+    const double vn = std::sqrt(vx * vx + vy * vy + vz * vz);
+    CHECK(std::fabs(power - 1.0) < 1e-5);
+    CHECK(std::fabs(vx / vn) < 1e-5 && vy / vn > 0.98 && vz / vn >= 0.0);
+    CHECK(nz >= 3);
+  }
+  m.width = m.height = 360.0;  // everywhere: every loudspeaker carries something
+  calc.calculate(m, direct, diffuse);
+  {
+    bool all = true;
+    for (float g : direct) all = all && g > 0.01f;
+    CHECK(all);
+  }
+  m.width = 30.0, m.height = 0.0, m.depth = 0.5;
+  CHECK(!refuses(m));
   // with the LFE channel kept, its column is zero (gain_calculator_objects.cpp:50-52); a batch in one launch
   GainCalculatorObjects full(getLayout("4+7+0"));
   std::vector<ObjectsTypeMetadata> batch(3);

@@ -39,14 +39,26 @@ def test_batch_panner_equals_oracle(layout):
     p.close()
     o = _oracle.GainCalculatorObjects(layout)
     wd, wf = o.calculate(az, el, dist, gain, diffuse)
-    assert np.max(np.abs(d - wd)) <= 2 * ULP and np.max(np.abs(f - wf)) <= 2 * ULP
-    assert np.mean(d == wd) > 0.999 and np.mean(f == wf) > 0.999  # (identical apart from rounding-boundary cases)
+    # at distances of 1 and more an object without extent is a point source: double on both sides, cast to float
+    far = dist >= 1.0
+    assert np.max(np.abs(d[far] - wd[far])) <= 2 * ULP and np.max(np.abs(f[far] - wf[far])) <= 2 * ULP
+    assert np.mean(d[far] == wd[far]) > 0.999 and np.mean(f[far] == wf[far]) > 0.999  # (apart from rounding boundaries)
+    # closer than 1 libear widens it (polar_extent.cpp:62-70, :290-302): the extent panner's float sums, held to
+    # the 1e-5 of a gain vector's norm that libear's tests put between its own cores (tests/test_gpu_extent.py)
+    near = ~far
+
+    def rel(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        den = np.maximum(np.minimum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)), 1e-30)
+        return np.linalg.norm(a - b, axis=1) / den
+    assert np.max(rel(d[near & (diffuse < 1.0)], wd[near & (diffuse < 1.0)])) <= 1e-5
+    assert np.max(rel(f[near & (diffuse > 0.0)], wf[near & (diffuse > 0.0)])) <= 1e-5
     lfe = [i for i, nm in enumerate(LAYOUTS[layout]) if nm.startswith("LFE")]
     assert not d[:, lfe].any() and not f[:, lfe].any()
     # 3-sparse in practice: at most 4 loudspeakers carry a point source (quads), except under / above the
     # layout where a virtual n-gon spreads it
     nz = (d != 0).sum(axis=1) + 0
-    assert np.median(nz[diffuse < 1.0]) <= 4
+    assert np.median(nz[(diffuse < 1.0) & far]) <= 4
 
 
 def test_reference_known_answers_through_the_c_abi():
