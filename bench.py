@@ -85,6 +85,71 @@ def cpu_model():
     return "unknown"
 
 
+def producer_bench(args):
+    """Secondary measurement: gain vectors per second of the Objects gain producer with extent (one GPU)."""
+    import numpy as np
+    import torch
+    from libear_amd import capi
+    layout = args.layout or PRESETS[args.config]["layout"]
+    n = args.producer
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = capi.Context(0, stream.cuda_stream)
+    pan = capi.Panner(ctx, layout)
+    rng = np.random.default_rng(21)
+    host = {"az": rng.uniform(-180, 180, n), "el": np.degrees(np.arcsin(rng.uniform(-1, 1, n))),
+            "dist": rng.uniform(0.5, 1.5, n), "width": rng.uniform(0, 120, n), "height": rng.uniform(0, 60, n),
+            "depth": np.where(rng.uniform(0, 1, n) < 0.25, rng.uniform(0, 0.5, n), 0.0), "gain": rng.uniform(0.1, 1, n),
+            "diffuse": rng.choice([0.0, 0.3, 1.0], n)}
+    d_in = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
+    direct = torch.empty((n, pan.n_out), dtype=torch.float32, device=dev)
+    diffuse = torch.empty_like(direct)
+
+    def step():
+        pan.calculate_device(n, d_in["az"].data_ptr(), d_in["el"].data_ptr(), d_in["dist"].data_ptr(), d_in["gain"].data_ptr(),
+                             d_in["diffuse"].data_ptr(), direct.data_ptr(), diffuse.data_ptr(), d_in["width"].data_ptr(),
+                             d_in["height"].data_ptr(), d_in["depth"].data_ptr())
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    steps = max(args.steps, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    # parity of what was timed (a sample of it) and the CPU baseline: the oracle's PolarExtent, one thread
+    import _oracle
+    k = min(n, 2000)
+    o = _oracle.PolarExtent(layout)
+    t0 = time.perf_counter()
+    wd, wf = o.calculate(*(host[q][:k] for q in ("az", "el", "dist", "width", "height", "depth", "gain", "diffuse")))
+    cpu_s = time.perf_counter() - t0
+    gd, gf = direct[:k].cpu().numpy().astype(np.float64), diffuse[:k].cpu().numpy().astype(np.float64)
+
+    def rel(a, b):
+        den = np.maximum(np.minimum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)), 1e-30)
+        return float(np.max(np.linalg.norm(a - b, axis=1) / den))
+    md, mf = host["diffuse"][:k] < 1.0, host["diffuse"][:k] > 0.0
+    worst = max(rel(gd[md], wd[md].astype(np.float64)), rel(gf[mf], wf[mf].astype(np.float64)))
+    ok = worst <= 1e-5
+    print(json.dumps({
+        "metric": "gain vectors per second of the Objects gain producer (point source + polar extent panners)",
+        "value": round(n / ms / 1e3, 2), "unit": "Mpositions/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "dtype": "f64 set-up / f32 weights and sums (as libear)", "data": "synthetic",
+        "config": {"workload": f"{n} (object, metadata block) positions, layout {layout}, widths 0-120, heights 0-60 "
+                               "degrees, distances 0.5-1.5, a quarter with depth", "entry": "earhip_panner_calculate_extent_device"},
+        "parity": {"against": "oracle PolarExtent (scalar float core)", "sample": k, "max_rel_norm": worst, "tolerance": 1e-5,
+                   "pass": ok},
+        "cpu_baseline": {"value": round(k / cpu_s / 1e6, 5), "unit": "Mpositions/s", "cores": 1, "kind": "port",
+                         "sample": f"{k} of the same positions", "cpu": cpu_model()}}))
+    pan.close()
+    if not ok:
+        print("producer parity FAILED", file=sys.stderr)
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +184,13 @@ def main():
                     help="floats of padding between the input rows (row stride = samples + pad; multiple of 4)")
     ap.add_argument("--stream-only", action="store_true",
                     help="only the timed stream-mode steps (no block-mode, parity or CPU legs): for PMC profiling passes")
+    ap.add_argument("--producer", type=int, default=0, metavar="POSITIONS",
+                    help="instead of the render path, time the Objects gain producer (libearhip group I: point source "
+                         "+ polar extent panners) on this many (object, metadata block) positions with random extents, "
+                         "device pointers; prints its own JSON line with a CPU baseline (the oracle on a sample)")
     args = ap.parse_args()
+    if args.producer:
+        return producer_bench(args)
     cfg = dict(PRESETS[args.config])
     for key, val in (("objects", args.objects), ("hoa", args.hoa), ("blocks", args.blocks),
                      ("block_size", args.block_size), ("layout", args.layout), ("buses", args.buses)):

@@ -406,6 +406,13 @@ class Panner:
                                                         _ptr(d), _ptr(f)))
         return d, f
 
+    def calculate_device(self, n, az, el, dist, gain, diffuse, direct, diffuse_out, width=None, height=None, depth=None):
+        """device addresses (ints; None = absent): enqueues on the context's stream, does not synchronise"""
+        def vp(a):
+            return None if a is None else C.c_void_p(int(a))
+        check(load().earhip_panner_calculate_extent_device(self.h, C.c_size_t(n), vp(az), vp(el), vp(dist), vp(width), vp(height),
+                                                           vp(depth), vp(gain), vp(diffuse), vp(direct), vp(diffuse_out)))
+
     def close(self):
         if self.h:
             load().earhip_panner_destroy(self.h)

@@ -211,35 +211,55 @@ namespace earhip {
 
 // One thread per position: direct / diffuse [npos][n_full] float; *missed counts positions no region took.
 // Positions that libear spreads over the sphere — an extent, or a distance under 1, which widens even a
-// zero extent (polar_extent.cpp:62-70) — are not computed here: their indices are appended to work_list
-// for k_pan_objects_extent (a wave each).  work_list == NULL: every distance is 1 and there is no extent.
+// zero extent (polar_extent.cpp:62-70) — are prepared here (everything that is scalar double work in libear)
+// and left as a job for k_pan_objects_extent (a wave each).  jobs == NULL: every distance is 1 and there is
+// no extent.
 static __global__ void __launch_bounds__(128)
 k_pan_objects(PanParams P, size_t npos, const double *az, const double *el, const double *dist, const double *width,
               const double *height, const double *depth, const double *gain, const double *diffuse, float *direct,
-              float *diff, unsigned *missed, int *work_list, unsigned *work_count) {
+              float *diff, unsigned *missed, ExtentJob *jobs, unsigned *job_count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npos) return;
   const Vec3 p = polar_to_cart(az[i], el[i], dist ? dist[i] : 1.0);
   ExtentPasses X;
   X.n_pass = 1;
   X.spread[0] = X.spread[1] = 0.0;
-  if (work_list) {
-    extent_passes(p, width ? width[i] : 0.0, height ? height[i] : 0.0, depth ? depth[i] : 0.0, X);
-    if (X.spread[0] > 1e-10 || (X.n_pass == 2 && X.spread[1] > 1e-10)) {
-      work_list[atomicAdd(work_count, 1u)] = (int)i;
-      return;
-    }
+  if (jobs) extent_passes(p, width ? width[i] : 0.0, height ? height[i] : 0.0, depth ? depth[i] : 0.0, X);
+  bool spread_any = false, need_point = false;
+  for (int k = 0; k < X.n_pass; k++) {
+    spread_any = spread_any || X.spread[k] > 1e-10;
+    need_point = need_point || (1.0 - X.spread[k]) > 1e-10;
   }
   double real[kMaxPanOut];
   double pv[kMaxPanOut];
-  const bool ok = pan_full(P.table, p, real);
+  int n_pv = 0;
   float *d = direct + i * P.n_full, *f = diff + i * P.n_full;
-  for (int c = 0; c < P.n_full; c++) d[c] = f[c] = 0.0f;
-  if (!ok) {
-    atomicAdd(missed, 1u);
+  if (need_point) {
+    if (!pan_full(P.table, p, real)) {
+      for (int c = 0; c < P.n_full; c++) d[c] = f[c] = 0.0f;
+      atomicAdd(missed, 1u);
+      return;
+    }
+    n_pv = pan_outputs(P, real, pv);
+  }
+  if (spread_any) {
+    ExtentJob &J = jobs[atomicAdd(job_count, 1u)];
+    J.pos = (int)i;
+    J.n_pass = X.n_pass;
+    for (int k = 0; k < 2; k++) {
+      J.spread[k] = X.spread[k];
+      // (:270-272: at least half the fade width in each dimension)
+      if (k < X.n_pass && X.spread[k] > 1e-10)
+        extent_setup(p, fmax(X.w[k], kExtentFade / 2.0), fmax(X.h[k], kExtentFade / 2.0), J.W[k]);
+    }
+    const double n = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+    J.dir[0] = n < 1e-10 ? 0.0f : (float)(p.x / n);
+    J.dir[1] = n < 1e-10 ? 1.0f : (float)(p.y / n);
+    J.dir[2] = n < 1e-10 ? 0.0f : (float)(p.z / n);
+    for (int c = 0; c < kMaxPanOut; c++) J.psq[c] = c < n_pv ? pv[c] * pv[c] : 0.0;
     return;
   }
-  const int n_pv = pan_outputs(P, real, pv);
+  for (int c = 0; c < P.n_full; c++) d[c] = f[c] = 0.0f;
   const double g = gain ? gain[i] : 1.0, df = diffuse ? diffuse[i] : 0.0;
   const double sd = sqrt(1.0 - df), sf = sqrt(df);
   for (int c = 0; c < n_pv; c++) {
@@ -488,12 +508,14 @@ struct earhip_panner {
   PanParams P;
   DevBuf<PanRegion> regions;
   DevBuf<unsigned> missed;
-  // the extent panner's point grid: positions [3][n_padded], gains [n_pv][n_padded] (float)
+  // the extent panner's point grid: positions [3][n_padded], gains [n_pv][n_padded], per-chunk direction,
+  // radius and gain sum (float)
   ExtentTable E;
-  DevBuf<float> ext_pos, ext_gains;
-  // positions the thread-per-position kernel hands to the wave-per-position one (grown at first use)
-  DevBuf<int> work;
-  DevBuf<unsigned> work_count;
+  DevBuf<float> ext_pos, ext_gains, ext_chunks;
+  // what the thread-per-position kernel leaves for the wave-per-position one (grown at first use; a call is
+  // cut into launches of at most kExtentBatch positions, so at most that many records)
+  DevBuf<ExtentJob> jobs;
+  DevBuf<unsigned> job_count;
   // staging of the host-pointer entry point (grown at first use)
   DevBuf<double> d_in;
   DevBuf<float> d_out;
@@ -507,18 +529,35 @@ struct earhip_panner {
 static void build_extent_table(earhip_panner &pn) {
   earhip_ctx *ctx = pn.ctx;
   const double pi = 3.14159265358979323846264338327950288;
-  std::vector<double> xyz;
+  struct GridPoint {
+    Vec3 v;
+    int band;
+    double az;
+    int row;
+  };
+  std::vector<GridPoint> grid;
   for (int r = 0; r < kExtentRows; r++) {
     const double el = -90.0 + r * (180.0 / (kExtentRows - 1));
     const double radius = std::cos(el * pi / 180.0);
     int n_points = (int)std::round(((2 * pi * radius) / (2 * pi)) * 2 * (kExtentRows - 1));
     if (n_points == 0) n_points = 1;
     for (int i = 0; i < n_points; i++) {
-      const Vec3 q = polar_to_cart(i * (360.0 / n_points), el, 1.0);
-      xyz.push_back(q.x), xyz.push_back(q.y), xyz.push_back(q.z);
+      const double az = i * (360.0 / n_points);
+      grid.push_back({polar_to_cart(az, el, 1.0), r / 8, az, r});
     }
   }
-  const size_t np = xyz.size() / 3, padded = (np + 63) / 64 * 64;
+  // The device kernel classifies CHUNKS of 64 points against an extent, so a chunk should be a compact patch:
+  // bands of 8 rows (40 degrees), each walked along the azimuth.  (The order of the points only changes the
+  // order of the float additions; libear's is row by row.)
+  std::stable_sort(grid.begin(), grid.end(), [](const GridPoint &a, const GridPoint &b) {
+    if (a.band != b.band) return a.band < b.band;
+    if (a.az != b.az) return a.az < b.az;
+    return a.row < b.row;
+  });
+  const size_t np = grid.size(), padded = (np + 63) / 64 * 64, n_chunks = padded / 64;
+  require(n_chunks <= (size_t)kExtentMaxChunks, "extent grid too large");
+  std::vector<double> xyz(3 * np);
+  for (size_t q = 0; q < np; q++) xyz[3 * q] = grid[q].v.x, xyz[3 * q + 1] = grid[q].v.y, xyz[3 * q + 2] = grid[q].v.z;
   const size_t S = pn.P.stereo ? 2 : (size_t)pn.P.table.n_real;
   DevBuf<double> d_xyz, d_pv;
   d_xyz.alloc(3 * np);
@@ -541,17 +580,46 @@ static void build_extent_table(earhip_panner &pn) {
   }
   for (size_t q = 0; q < np; q++)
     for (size_t c = 0; c < S; c++) gains[c * padded + q] = (float)G[q * S + c];
+  // per chunk: mean direction, angular radius around it, float sum of the gain vectors
+  const size_t MC = (size_t)kExtentMaxChunks;
+  std::vector<float> chunks(3 * MC + MC + MC * kMaxPanOut, 0.0f);
+  float *dir = chunks.data(), *rad = dir + 3 * MC, *sum = rad + MC;
+  for (size_t c = 0; c < n_chunks; c++) {
+    const size_t lo = 64 * c, hi = std::min(lo + 64, np);
+    Vec3 m = {0.0, 0.0, 0.0};
+    for (size_t q = lo; q < hi; q++) m = vadd(m, grid[q].v);
+    double n = std::sqrt(vdot(m, m));
+    if (n < 1e-6) m = grid[lo].v, n = 1.0;
+    // (the kernel works with the float direction: measure the radius around that)
+    const float fx = (float)(m.x / n), fy = (float)(m.y / n), fz = (float)(m.z / n);
+    const double fn = std::sqrt((double)fx * fx + (double)fy * fy + (double)fz * fz);
+    double worst = 0.0;
+    for (size_t q = lo; q < hi; q++) {
+      const double cs = (grid[q].v.x * fx + grid[q].v.y * fy + grid[q].v.z * fz) / fn;
+      worst = std::max(worst, std::acos(std::min(1.0, std::max(-1.0, cs))));
+    }
+    dir[c] = fx, dir[MC + c] = fy, dir[2 * MC + c] = fz;
+    rad[c] = (float)(worst + 1e-4);
+    for (size_t q = lo; q < hi; q++)
+      for (size_t k = 0; k < S; k++) sum[c * kMaxPanOut + k] += gains[k * padded + q];
+  }
   pn.ext_pos.alloc(3 * padded);
   pn.ext_gains.alloc(S * padded);
+  pn.ext_chunks.alloc(chunks.size());
   EARHIP_HIP(hipMemcpy(pn.ext_pos.p, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice));
   EARHIP_HIP(hipMemcpy(pn.ext_gains.p, gains.data(), sizeof(float) * gains.size(), hipMemcpyHostToDevice));
+  EARHIP_HIP(hipMemcpy(pn.ext_chunks.p, chunks.data(), sizeof(float) * chunks.size(), hipMemcpyHostToDevice));
   pn.E.n_points = (int)np;
   pn.E.n_padded = (int)padded;
+  pn.E.n_chunks = (int)n_chunks;
   pn.E.n_pv = (int)S;
   pn.E.xs = pn.ext_pos.p;
   pn.E.ys = pn.ext_pos.p + padded;
   pn.E.zs = pn.ext_pos.p + 2 * padded;
   pn.E.gains = pn.ext_gains.p;
+  pn.E.chunk_dir = pn.ext_chunks.p;
+  pn.E.chunk_rad = pn.ext_chunks.p + 3 * MC;
+  pn.E.chunk_sum = pn.ext_chunks.p + 4 * MC;
 }
 
 extern "C" {
@@ -702,25 +770,36 @@ int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, co
   });
 }
 
+constexpr size_t kExtentBatch = (size_t)1 << 18;  // positions per pair of launches (bounds the job buffer: 115 MB)
+
 static void launch_pan(earhip_panner *p, size_t npos, const double *az, const double *el, const double *dist,
                        const double *width, const double *height, const double *depth, const double *gain,
                        const double *diffuse, float *direct, float *diffuse_out) {
   hipStream_t s = p->ctx->stream;
   // a distance of 1 and no extent: nothing is spread (extentMod(0, 1) = 0)
   const bool may_spread = dist || width || height || depth;
-  if (may_spread) {
-    p->work.reserve(npos);
-    p->work_count.reserve(1);
-    EARHIP_HIP(hipMemsetAsync(p->work_count.p, 0, sizeof(unsigned), s));
+  if (!may_spread) {
+    hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, s, p->P, npos, az, el, dist, width,
+                       height, depth, gain, diffuse, direct, diffuse_out, p->missed.p, (ExtentJob *)nullptr,
+                       (unsigned *)nullptr);
+    EARHIP_HIP(hipGetLastError());
+    return;
   }
-  hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((npos + 127) / 128)), dim3(128), 0, s, p->P, npos, az, el, dist, width,
-                     height, depth, gain, diffuse, direct, diffuse_out, p->missed.p, may_spread ? p->work.p : nullptr,
-                     may_spread ? p->work_count.p : nullptr);
-  EARHIP_HIP(hipGetLastError());
-  if (may_spread) {
-    hipLaunchKernelGGL(k_pan_objects_extent, dim3((unsigned)((npos + kExtentWaves - 1) / kExtentWaves)),
-                       dim3(64 * kExtentWaves), 0, s, p->P, p->E, p->work.p, p->work_count.p, az, el, dist, width, height,
-                       depth, gain, diffuse, direct, diffuse_out, p->missed.p);
+  p->jobs.reserve(std::min(npos, kExtentBatch));
+  p->job_count.reserve(1);
+  auto at = [](const double *q, size_t o) { return q ? q + o : q; };
+  for (size_t o = 0; o < npos; o += kExtentBatch) {
+    const size_t n = std::min(kExtentBatch, npos - o);
+    const size_t N = (size_t)p->P.n_full;
+    EARHIP_HIP(hipMemsetAsync(p->job_count.p, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_pan_objects, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, p->P, n, az + o, el + o, at(dist, o),
+                       at(width, o), at(height, o), at(depth, o), at(gain, o), at(diffuse, o), direct + o * N,
+                       diffuse_out + o * N, p->missed.p, p->jobs.p, p->job_count.p);
+    EARHIP_HIP(hipGetLastError());
+    // (launched for the worst case — every position a job; surplus waves leave at once)
+    hipLaunchKernelGGL(k_pan_objects_extent, dim3((unsigned)((n + kExtentWaves - 1) / kExtentWaves)), dim3(64 * kExtentWaves),
+                       0, s, p->P, p->E, p->jobs.p, p->job_count.p, at(gain, o), at(diffuse, o), direct + o * N,
+                       diffuse_out + o * N);
     EARHIP_HIP(hipGetLastError());
   }
 }

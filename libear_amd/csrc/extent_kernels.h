@@ -10,25 +10,39 @@
 // reference's one SIMD kernel (float, xsimd batches of 4-16 points); everything before it is scalar double
 // set-up per call.
 //
-// Here a lane takes every 64th point: the 26 chunks of 64 points are read as whole 256-byte rows (positions
-// and gains stored point-contiguous per loudspeaker), a chunk whose 64 weights are all zero is skipped like
-// the reference's all-zero batches, the per-lane partial sums meet in a butterfly of lane exchanges, and the
-// double-precision set-up (extent_mod, the basis at the object's direction, the stadium's parameters) runs
-// in all lanes at once (uniform, no divergence).  The point-source part, needed for extents under 10 degrees,
-// tests one REGION per lane and takes the lowest lane that accepts the direction (= the first region in the
-// reference's order).  Arithmetic types follow the reference: float weights and sums (extent_float_t), double
-// around them.  The order of the float additions differs from the scalar core's (as it does between the
-// reference's scalar and SIMD cores, which its tests hold to 1e-5: tests/extent_tests.cpp:140-169).
+// Here the work is split between two kernels.  k_pan_objects (a thread per position, api_panner.hip) does what
+// is scalar in libear — extentMod, the share of the spread part, the basis at the object's direction, the
+// stadium's parameters, the point source panner's gains for extents under 10 degrees — and leaves a JOB record
+// per position that needs spreading.  k_pan_objects_extent takes ONE WAVE per job:
+//   * the 1652 points are stored in 26 spatially compact chunks of 64 (bands of 8 rows cut along the azimuth)
+//     with, per chunk, its mean direction, its angular radius and the float sum of its points' gain vectors;
+//   * lane c classifies chunk c against the extent with one dot product: entirely outside (further from the
+//     object than half the larger dimension + fade: every weight is 0), entirely inside (closer than half the
+//     smaller dimension: every weight is 1 — the chunk's precomputed sum is added, like libear's all-ones
+//     batches, polar_extent_simd.hpp:108-121), or on the boundary;
+//   * only boundary chunks are evaluated: a lane per point (positions and gains read as whole 256-byte rows),
+//     the per-lane partial sums meet in a butterfly of lane exchanges;
+//   * from there lane s carries loudspeaker s: normalisation, the blend with the point-source gains, depth's
+//     rms of two renderings, gain, LFE mask, the direct / diffuse split.
+// Arithmetic types follow the reference: float weights and sums (extent_float_t), double around them.  The
+// order of the float additions differs from the scalar core's (as it does between the reference's scalar and
+// SIMD cores, which its tests hold to 1e-5: tests/extent_tests.cpp:140-169).
 #pragma once
 
 namespace earhip {
 
+constexpr int kExtentMaxChunks = 32;
+
 struct ExtentTable {
   int n_points;  // 1652
   int n_padded;  // multiple of 64; padded points carry zero gains
+  int n_chunks;  // n_padded / 64 (26)
   int n_pv;      // panner outputs: loudspeakers without LFE, or 2 for 0+2+0
-  const float *xs, *ys, *zs;  // [n_padded]
+  const float *xs, *ys, *zs;  // [n_padded], chunk after chunk
   const float *gains;         // [n_pv][n_padded]
+  const float *chunk_dir;     // [3][kExtentMaxChunks]: unit mean direction of a chunk's points
+  const float *chunk_rad;     // [kExtentMaxChunks]: largest angle between it and a point of the chunk (radians)
+  const float *chunk_sum;     // [kExtentMaxChunks][kMaxPanOut]: float sum of the chunk's gain vectors
 };
 
 constexpr int kExtentRows = 37;          // polar_extent.cpp:14
@@ -78,6 +92,19 @@ struct ExtentWeighting {
   bool is_circular;
   float basis[9], circle_test[2], right_circle_centre[2];
   float cos_start, cos_end, sin_start, sin_end, m, c;
+  // every point further than r_out from the object's direction weighs 0, every point closer than r_in weighs 1
+  // (radians; r_out = half the larger dimension after its modification + fade, r_in = half the smaller one)
+  float r_in, r_out;
+};
+
+// what k_pan_objects leaves for k_pan_objects_extent
+struct ExtentJob {
+  int pos;                 // index of the position in the call's arrays
+  int n_pass;              // renderings: 1, or 2 with depth
+  double spread[2];        // share of the spread part per rendering (:263-266)
+  ExtentWeighting W[2];
+  float dir[3];            // the object's direction (unit; +y for the origin, :52-60)
+  double psq[kMaxPanOut];  // the point source panner's gains squared (zero when no rendering needs them)
 };
 
 // setup_weighting_function + setup_angle_to_weight (polar_extent.cpp:186-255); calcBasis (:80-91)
@@ -122,6 +149,8 @@ __device__ inline void extent_setup(Vec3 position, double width, double height, 
   W.sin_end = (float)(end_angle < pi / 2 ? sin(end_angle) : 1.0 + 1e-6);
   W.m = (float)(1.0 / (start_angle - end_angle));
   W.c = (float)(-W.m * end_angle);
+  W.r_in = (float)start_angle;
+  W.r_out = (float)(width + ext_radians(kExtentFade));
 }
 
 // polar_extent_scalar.cpp:34-76 (float)
@@ -137,84 +166,78 @@ __device__ inline float extent_weight(const ExtentWeighting &W, float x, float y
   return from_cos(rx * W.right_circle_centre[0] + ty * W.right_circle_centre[1]);
 }
 
-// direct / diffuse [npos][n_full] float for the positions k_pan_objects listed; width / height / depth may
-// be NULL (0).  Wave w of the launch takes work_list[w]; waves past *work_count leave at once.
+// direct / diffuse [npos][n_full] float for the jobs k_pan_objects left.  Wave w of the launch takes jobs[w];
+// waves past *job_count leave at once.
 static __global__ void __launch_bounds__(64 * kExtentWaves)
-k_pan_objects_extent(PanParams P, ExtentTable E, const int *work_list, const unsigned *work_count, const double *az,
-                     const double *el, const double *dist, const double *width, const double *height, const double *depth,
-                     const double *gain, const double *diffuse, float *direct, float *diff, unsigned *missed) {
+k_pan_objects_extent(PanParams P, ExtentTable E, const ExtentJob *jobs, const unsigned *job_count, const double *gain,
+                     const double *diffuse, float *direct, float *diff) {
   const int lane = threadIdx.x & 63;
-  const size_t wi = (size_t)blockIdx.x * kExtentWaves + (threadIdx.x >> 6);
-  if (wi >= *work_count) return;  // (whole waves)
-  const size_t i = (size_t)work_list[wi];
+  const unsigned wi = __builtin_amdgcn_readfirstlane(blockIdx.x * kExtentWaves + (threadIdx.x >> 6));
+  if (wi >= *job_count) return;  // (whole waves)
+  const ExtentJob &J = jobs[wi];
+  const size_t i = (size_t)J.pos;
   const int S = E.n_pv;
-  const Vec3 p = polar_to_cart(az[i], el[i], dist ? dist[i] : 1.0);
-  ExtentPasses X;
-  extent_passes(p, width ? width[i] : 0.0, height ? height[i] : 0.0, depth ? depth[i] : 0.0, X);
-  const int n_pass = X.n_pass;
-  bool need_point = false;
-  for (int k = 0; k < n_pass; k++) need_point = need_point || (1.0 - X.spread[k]) > 1e-10;
-  float *d_row = direct + i * P.n_full, *f_row = diff + i * P.n_full;
-
-  // From here on lane s (< S) carries the panner's output s.
-  // The point source panner's gain squared, when a rendering is narrower than the fade width:
-  double psq = 0.0;
-  if (need_point) {
-    int first = -1;
-    for (int base = 0; base < P.table.n_regions && first < 0; base += 64) {
-      bool hit = false;
-      if (base + lane < P.table.n_regions) {
-        double tmp[kMaxPanOut];
-        for (int c = 0; c < P.table.n_real; c++) tmp[c] = 0.0;
-        hit = region_try(P.table.regions[base + lane], p, tmp);
-      }
-      const unsigned long long m = __ballot(hit);
-      if (m) first = base + __ffsll((long long)m) - 1;
-    }
-    if (first < 0) {
-      if (lane == 0) atomicAdd(missed, 1u);
-      if (lane < P.n_full) d_row[lane] = f_row[lane] = 0.0f;
-      return;
-    }
-    double real[kMaxPanOut], pv[kMaxPanOut];
-    for (int c = 0; c < P.table.n_real; c++) real[c] = 0.0;
-    region_try(P.table.regions[first], p, real);
-    pan_normalise(P.table, real);
-    pan_outputs(P, real, pv);
-    if (lane < S) psq = pv[lane] * pv[lane];
+  const int n_pass = J.n_pass;
+  // lane c looks at chunk c: the angle between its mean direction and the object's
+  float chunk_angle = 0.0f, chunk_rad = 0.0f;
+  if (lane < E.n_chunks) {
+    const float cd = E.chunk_dir[lane] * J.dir[0] + E.chunk_dir[kExtentMaxChunks + lane] * J.dir[1] +
+                     E.chunk_dir[2 * kExtentMaxChunks + lane] * J.dir[2];
+    chunk_angle = acosf(fminf(fmaxf(cd, -1.0f), 1.0f));
+    chunk_rad = E.chunk_rad[lane];
   }
-
+  // From here on lane s (< S) carries the panner's output s.
+  const double psq = lane < S ? J.psq[lane] : 0.0;
   double fin = 0.0;
   for (int k = 0; k < n_pass; k++) {  // calc_pv_spread (:257-288)
-    const double amount_spread = X.spread[k], amount_point = 1.0 - amount_spread;
+    const double amount_spread = J.spread[k], amount_point = 1.0 - amount_spread;
     double out = amount_point > 1e-10 ? amount_point * psq : 0.0;
     if (amount_spread > 1e-10) {
-      ExtentWeighting W;
-      extent_setup(p, fmax(X.w[k], kExtentFade / 2.0), fmax(X.h[k], kExtentFade / 2.0), W);
-      float acc[kMaxPanOut];  // this lane's points, every loudspeaker
+      const ExtentWeighting &W = J.W[k];
+      const float margin = 1e-3f;  // (radians: float rounding of the angles and of the weights' own thresholds)
+      const bool is_chunk = lane < E.n_chunks;
+      const bool outside = is_chunk && chunk_angle - chunk_rad > W.r_out + margin;
+      const bool inside = is_chunk && chunk_angle + chunk_rad + margin < W.r_in;
+      unsigned long long m_inside = __ballot(inside);
+      unsigned long long m_edge = __ballot(is_chunk && !outside && !inside);
+      // chunks entirely inside: their precomputed sums (lane s adds loudspeaker s)
+      float total = 0.0f;
+      while (m_inside) {
+        const int c = __ffsll((long long)m_inside) - 1;
+        m_inside &= m_inside - 1;
+        if (lane < S) total += E.chunk_sum[c * kMaxPanOut + lane];
+      }
+      // chunks on the boundary: a lane per point
+      float acc[kMaxPanOut];
 #pragma unroll
       for (int s = 0; s < kMaxPanOut; s++) acc[s] = 0.0f;
-      for (int base = 0; base < E.n_padded; base += 64) {
-        const int q = base + lane;
+      const bool any_edge = m_edge != 0;
+      while (m_edge) {
+        const int c = __ffsll((long long)m_edge) - 1;
+        m_edge &= m_edge - 1;
+        const int q = c * 64 + lane;
         const float w = extent_weight(W, E.xs[q], E.ys[q], E.zs[q]);
-        if (__ballot(w != 0.0f) == 0) continue;  // (whole chunk outside the extent)
+        if (__ballot(w != 0.0f) == 0) continue;
         const float *g = E.gains + q;
 #pragma unroll
         for (int s = 0; s < kMaxPanOut; s++)
           if (s < S) acc[s] += w * g[(size_t)s * E.n_padded];
       }
-      float n2 = 0.0f, mine = 0.0f;
+      if (any_edge) {
 #pragma unroll
-      for (int s = 0; s < kMaxPanOut; s++)
-        if (s < S) {
-          float v = acc[s];
+        for (int s = 0; s < kMaxPanOut; s++)
+          if (s < S) {
+            float v = acc[s];
 #pragma unroll
-          for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-          n2 += v * v;
-          if (lane == s) mine = v;
-        }
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == s) total += v;
+          }
+      }
+      float n2 = total * total;  // (lanes >= S hold 0)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) n2 += __shfl_xor(n2, off);
       const float scale = (float)(1.0 / (double)sqrtf(n2));  // (:281: float norm, double reciprocal, float scaling)
-      const float r = mine * scale;
+      const float r = total * scale;
       out += amount_spread * (double)(r * r);
     }
     const double v = sqrt(out);
@@ -228,8 +251,8 @@ k_pan_objects_extent(PanParams P, ExtentTable E, const int *work_list, const uns
   if (lane < P.n_full) {
     const double g = gain ? gain[i] : 1.0, df = diffuse ? diffuse[i] : 0.0;
     const double v = src < 0 ? 0.0 : got * g;
-    d_row[lane] = (float)(v * sqrt(1.0 - df));
-    f_row[lane] = (float)(v * sqrt(df));
+    direct[i * P.n_full + lane] = (float)(v * sqrt(1.0 - df));
+    diff[i * P.n_full + lane] = (float)(v * sqrt(df));
   }
 }
 

@@ -81,3 +81,11 @@ def test_multi_rank_control_flow_on_one_gpu_over_gloo(nproc, layout):
     assert line["config"]["objects_total"] == 96 and line["config"]["objects_per_gpu"] == 96 // nproc
     assert line["exchange_check"]["max_rel_err_owned_slice_vs_all_reduce"] <= 1e-6
     assert line["weak_scaling"]["objects_total"] == 96 * nproc and line["weak_scaling"]["value"] > 0
+
+
+def test_producer_line():
+    """bench.py --producer: the Objects gain producer with extent through device pointers, parity-gated"""
+    line = run_bench(["--producer", "20000", "--steps", "3", "--warmup", "1"])
+    assert line["unit"] == "Mpositions/s" and line["value"] > 0
+    assert line["parity"]["pass"] and line["parity"]["max_rel_norm"] <= 1e-5
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
