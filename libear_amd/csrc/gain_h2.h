@@ -83,7 +83,7 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // conversion of a chunk's gains is shared by the whole workgroup, so the 512-sample tile halves that
 // work (and the gain rows' L2 traffic) when no curve point falls inside 512-sample tiles.
 template <int NCT, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
+__global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 4 : (NW == 4 ? 2 : 1))
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const unsigned *level_cur,
               unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
