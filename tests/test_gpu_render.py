@@ -781,3 +781,63 @@ def test_decorrelator_firs_longer_than_a_block(block, n_taps, nblocks, calls):
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6
     whole = run_hip(curves, x, n, block, dec, 255, [nblocks])
     assert scenes.rel_rms(whole, want) <= 1e-6
+
+
+def test_limits_of_the_curve_store():
+    """the most points an object may carry (2^18, one every 3 samples: 1536 blocks in one call) beside an
+    ordinary object, against the oracle; one point more, a ramp of 2^31 samples: invalid_argument"""
+    from libear_amd import capi
+    layout, block = "0+5+0", 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    npts = 1 << 18
+    nblocks = (3 * npts + block - 1) // block
+    total = block * nblocks
+    rng = np.random.default_rng(4)
+    t0 = np.arange(npts, dtype=np.int64) * 3
+    d0 = rng.uniform(0, 1, (npts, n)).astype(np.float32)
+    f0 = rng.uniform(0, 1, (npts, n)).astype(np.float32)
+    d0[1000:1010] = d0[999]  # (a few constant stretches)
+    t1 = np.array([0, 700, 700, total - 5], np.int64)
+    d1 = rng.uniform(0, 1, (4, n)).astype(np.float32)
+    f1 = rng.uniform(0, 1, (4, n)).astype(np.float32)
+    x = scenes.audio(2, total, seed=6)
+    r = capi.Renderer(ctx(), 2, n, block, dec, 255, max_blocks=nblocks)
+    r.set_object_points(0, t0, d0, f0)
+    r.set_object_points(1, t1, d1, f1)
+    got = r.process(x)
+    with pytest.raises(capi.InvalidArgument):
+        r.set_object_points(0, np.arange(npts + 1, dtype=np.int64), np.zeros((npts + 1, n), np.float32),
+                            np.zeros((npts + 1, n), np.float32))
+    with pytest.raises(capi.InvalidArgument):
+        r.set_object_points(0, [0, 1 << 31], np.zeros((2, n)), np.zeros((2, n)))
+    r.close()
+    w = _oracle.ObjectsRenderer(2, n, block, dec, 255)
+    for i, (t, d, f) in enumerate(((t0, d0, f0), (t1, d1, f1))):
+        w.set_points(i, 0, t, d)
+        w.set_points(i, 1, t, f)
+    want = w.process(x)
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
+
+
+@pytest.mark.parametrize("start", [(1 << 40) + 12345, -(1 << 33) - 7])
+@pytest.mark.parametrize("kind", ["dense", "adm"])
+def test_sample_times_far_from_zero(start, kind):
+    """SampleIndex is a long (gain_interpolator.hpp:16): the same scene shifted by 2^40 samples (and to negative
+    times) gives the same bits — only differences of times enter the arithmetic (:225-227)"""
+    from libear_amd import capi
+    m, layout, block, nblocks = 48, "4+5+0", 512, 6
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.dense_curves(m, n, block, nblocks, seed=3) if kind == "dense" else scenes.adm_curves(m, n, total, seed=3)
+    x = scenes.audio(m, total, seed=8)
+    outs = []
+    for shift in (0, start):
+        r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+        for i, (t, d, f) in enumerate(curves):
+            r.set_object_points(i, np.asarray(t, np.int64) + shift, d, f)
+        r.reset(shift)
+        outs.append(r.process(x))
+        r.close()
+    assert np.array_equal(outs[0], outs[1])
