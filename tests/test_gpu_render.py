@@ -841,3 +841,54 @@ def test_sample_times_far_from_zero(start, kind):
         outs.append(r.process(x))
         r.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_contexts_on_concurrent_threads():
+    """libear's objects are single-owner, but different objects may live on different threads: four threads, each
+    with its own context (its own stream), renderer and interpolation-policy calls (a table shared by all
+    contexts sits behind those), working at the same time give the bits a single thread gives"""
+    import threading
+    from libear_amd import capi
+    layout, block, nblocks = "4+5+0", 512, 8
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+
+    def work(seed, context, rounds):
+        m = 24 + 8 * seed
+        curves = scenes.adm_curves(m, n, total, seed=seed) if seed % 2 else scenes.dense_curves(m, n, block, nblocks, seed=seed)
+        x = scenes.audio(m, total, seed=10 + seed)
+        r = capi.Renderer(context, m, n, block, dec, 255, max_blocks=nblocks)
+        set_renderer_curves(r, curves)
+        outs = []
+        rng = np.random.default_rng(seed)
+        sp, ep = rng.uniform(0, 1, (3, n)).astype(np.float32), rng.uniform(0, 1, (3, n)).astype(np.float32)
+        xi = scenes.audio(3, 700, seed=20 + seed)
+        for _ in range(rounds):
+            r.reset(0)
+            outs.append(r.process(x))
+            o = np.zeros((n, 700), np.float32)
+            context.apply_interp(xi, o, 10, 650, 1000, 990, 1800, sp, ep)  # (LinearInterpMatrix policy)
+            outs.append(o)
+        r.close()
+        return outs
+
+    serial = [work(s, ctx(), 1) for s in range(4)]
+    results, errors = [None] * 4, []
+
+    def run(s):
+        try:
+            c = capi.Context(0)
+            results[s] = work(s, c, 6)
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for s in range(4):
+        for k, o in enumerate(results[s]):
+            assert np.array_equal(o, serial[s][k % 2]), (s, k)
