@@ -33,12 +33,13 @@ extern "C" {
 
 #define EARHIP_VERSION 100 /* 0.1.0 */
 
-/* status codes; the C++ shim maps 1 -> ear::invalid_argument and 2,3 ->
- * ear::internal_error (include/ear/exceptions.hpp:8-43) */
+/* status codes; the C++ shim maps 1 -> ear::invalid_argument, 2,3 -> ear::internal_error and
+ * 4 -> ear::not_implemented (include/ear/exceptions.hpp:8-43) */
 #define EARHIP_OK 0
 #define EARHIP_INVALID_ARGUMENT 1
 #define EARHIP_INTERNAL_ERROR 2
 #define EARHIP_DEVICE_ERROR 3
+#define EARHIP_NOT_IMPLEMENTED 4 /* ear::not_implemented: a case libear itself refuses */
 
 int earhip_version(void);
 const char *earhip_last_error(void);
@@ -256,6 +257,15 @@ int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, 
  * ---------------------------------------------------------------------- */
 typedef struct earhip_panner earhip_panner;
 int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **out);
+/* the same for loudspeakers that do not stand at their nominal positions (Channel::polarPosition,
+ * include/ear/layout.hpp:32-40): azimuth / elevation in degrees, one per channel of the full layout
+ * (LFE channels included, ignored); both NULL (n_channels 0): nominal.  As in libear the layer logic
+ * and the triangulation follow the nominal positions and the geometry the real ones
+ * (point_source_panner.cpp:256-349, :431-476); M+SC / M-SC outside 5..25 or 35..60 degrees is
+ * EARHIP_INVALID_ARGUMENT, wider than 25 degrees EARHIP_NOT_IMPLEMENTED (:558-577). */
+int earhip_panner_create_positions(earhip_ctx *ctx, const char *layout, int n_channels,
+                                   const double *azimuth, const double *elevation,
+                                   earhip_panner **out);
 int earhip_panner_destroy(earhip_panner *p);
 int earhip_panner_num_channels(const earhip_panner *p, int *n_channels);
 /* host pointers: H2D, kernel, D2H, synchronise */
@@ -289,6 +299,11 @@ int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const d
  * by libear (with a warning) and are not parameters here. */
 int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, const int *orders,
                              const int *degrees, const char *normalization, float *out);
+/* with the loudspeakers' real positions (see earhip_panner_create_positions) */
+int earhip_hoa_decode_matrix_positions(earhip_ctx *ctx, const char *layout, int n_channels,
+                                       const double *azimuth, const double *elevation, int n_coef,
+                                       const int *orders, const int *degrees,
+                                       const char *normalization, float *out);
 
 /* ------------------------------------------------------------------------
  * (F) Composed Objects render block — the chain libear documents but does not

@@ -15,7 +15,7 @@ f32p = C.POINTER(C.c_float)
 i64p = C.POINTER(C.c_int64)
 pp_f32 = C.POINTER(f32p)
 
-OK, INVALID_ARGUMENT, INTERNAL_ERROR, DEVICE_ERROR = 0, 1, 2, 3
+OK, INVALID_ARGUMENT, INTERNAL_ERROR, DEVICE_ERROR, NOT_IMPLEMENTED = 0, 1, 2, 3, 4
 
 
 class EarHipError(Exception):
@@ -30,6 +30,10 @@ class InvalidArgument(EarHipError, ValueError):
 
 class InternalError(EarHipError, RuntimeError):
     """maps to ear::internal_error"""
+
+
+class NotImplementedInLibear(EarHipError, RuntimeError):
+    """maps to ear::not_implemented: a case libear itself refuses"""
 
 
 class RenderConfig(C.Structure):
@@ -68,6 +72,8 @@ def check(rc):
     msg = load().earhip_last_error().decode()
     if rc == INVALID_ARGUMENT:
         raise InvalidArgument(rc, msg)
+    if rc == NOT_IMPLEMENTED:
+        raise NotImplementedInLibear(rc, msg)
     raise InternalError(rc, msg)
 
 
@@ -374,9 +380,18 @@ def compensation_delay():
 class Panner:
     """(I) gain-vector producer for Objects content (point-source pan, LFE mask, diffuse split), batched."""
 
-    def __init__(self, ctx, layout):
+    def __init__(self, ctx, layout, positions=None):
+        """positions: (azimuths, elevations) in degrees of every channel of the full layout (LFE included): the
+        loudspeakers' real positions; None: nominal"""
         self.h = C.c_void_p()
-        check(load().earhip_panner_create(ctx.h, layout.encode(), C.byref(self.h)))
+        if positions is None:
+            check(load().earhip_panner_create(ctx.h, layout.encode(), C.byref(self.h)))
+        else:
+            f64 = C.POINTER(C.c_double)
+            az, el = (np.ascontiguousarray(v, np.float64) for v in positions)
+            assert az.size == el.size
+            check(load().earhip_panner_create_positions(ctx.h, layout.encode(), int(az.size), _ptr(az, f64), _ptr(el, f64),
+                                                        C.byref(self.h)))
         n = C.c_int(0)
         check(load().earhip_panner_num_channels(self.h, C.byref(n)))
         self.n_out = n.value
@@ -454,8 +469,8 @@ class Comm:
             self.h = C.c_void_p()
 
 
-def hoa_decode_matrix(ctx, layout, orders, degrees, normalization="SN3D"):
-    """(I, HOA) AllRAD decode matrix [n_channels][n_coef] float32"""
+def hoa_decode_matrix(ctx, layout, orders, degrees, normalization="SN3D", positions=None):
+    """(I, HOA) AllRAD decode matrix [n_channels][n_coef] float32; positions: real loudspeaker positions as for Panner"""
     o = np.ascontiguousarray(orders, np.int32)
     d = np.ascontiguousarray(degrees, np.int32)
     if len(o) != len(d):
@@ -463,8 +478,15 @@ def hoa_decode_matrix(ctx, layout, orders, degrees, normalization="SN3D"):
     n = len(layout_channels(layout))
     out = np.zeros((n, max(len(o), 1)), np.float32)
     ip = C.POINTER(C.c_int)
-    check(load().earhip_hoa_decode_matrix(ctx.h, layout.encode(), len(o), o.ctypes.data_as(ip), d.ctypes.data_as(ip),
-                                          normalization.encode(), _ptr(out)))
+    if positions is None:
+        check(load().earhip_hoa_decode_matrix(ctx.h, layout.encode(), len(o), o.ctypes.data_as(ip), d.ctypes.data_as(ip),
+                                              normalization.encode(), _ptr(out)))
+    else:
+        f64 = C.POINTER(C.c_double)
+        az, el = (np.ascontiguousarray(v, np.float64) for v in positions)
+        check(load().earhip_hoa_decode_matrix_positions(ctx.h, layout.encode(), int(az.size), _ptr(az, f64), _ptr(el, f64),
+                                                        len(o), o.ctypes.data_as(ip), d.ctypes.data_as(ip),
+                                                        normalization.encode(), _ptr(out)))
     return out[:, :len(o)]
 
 

@@ -302,7 +302,8 @@ namespace {
 
 struct SetupChannel {
   std::string name;
-  double az, el;
+  double az, el;          // real position (Channel::polarPosition)
+  double az_nom, el_nom;  // nominal position (the BS.2051 table)
 };
 
 void invert3(const Vec3 (&rows)[3], double (&inv)[9]) {
@@ -358,14 +359,28 @@ const LayoutEntry &layout_entry(const char *name) {
   fail_invalid(std::string("unknown layout ") + name);
 }
 
-// the regions of a layout with precomputed hull facets (configureFullPolarPanner, :478-561)
-std::vector<PanRegion> build_regions(const LayoutEntry &L, int &n_real) {
+// the regions of a layout with precomputed hull facets (configureFullPolarPanner, :478-561).
+// real_az / real_el (optional, one per channel of the full layout): the loudspeakers' real positions; the
+// layer logic and the facets follow the nominal ones, the geometry the real ones, as in libear
+std::vector<PanRegion> build_regions(const LayoutEntry &L, int &n_real, const double *real_az = nullptr,
+                                     const double *real_el = nullptr) {
   require(L.facets != nullptr, "layout has no facet table");
   std::vector<SetupChannel> real;
   for (int c = 0; c < L.n; c++)
-    if (!L.channels[c].is_lfe) real.push_back({L.channels[c].name, L.channels[c].azimuth, L.channels[c].elevation});
+    if (!L.channels[c].is_lfe)
+      real.push_back({L.channels[c].name, real_az ? real_az[c] : L.channels[c].azimuth,
+                      real_el ? real_el[c] : L.channels[c].elevation, L.channels[c].azimuth, L.channels[c].elevation});
   n_real = (int)real.size();
   require(n_real <= kMaxPanOut, "too many loudspeakers");
+  // checkScreenSpeakers (:558-577)
+  for (auto &ch : real)
+    if (ch.name == "M+SC" || ch.name == "M-SC") {
+      const double abs_az = std::fabs(ch.az);
+      if (!((5.0 <= abs_az && abs_az < 25.0) || (35.0 <= abs_az && abs_az < 60.0)))
+        fail_invalid("M+SC or M-SC has azimuth not in the allowed ranges of 5 to 25 and 35 to 60 degrees");
+      if (25.0 < abs_az)
+        throw Error{EARHIP_NOT_IMPLEMENTED, "M+SC and M-SC with azimuths wider than 25 degrees are not currently supported"};
+    }
   // extra loudspeakers above / below the mid-layer ones where a layer has none in that direction,
   // each mixed into its mid-layer loudspeaker (extraPosVerticalNominal, :256-349)
   std::vector<Vec3> verts;
@@ -376,11 +391,12 @@ std::vector<PanRegion> build_regions(const LayoutEntry &L, int &n_real) {
     double az_range = -1.0, el_sum = 0.0;
     int in_layer = 0;
     for (auto &ch : real)
-      if (layer[1] <= ch.el && ch.el <= layer[2]) az_range = std::max(az_range, std::fabs(ch.az)), el_sum += ch.el, in_layer++;
+      if (layer[1] <= ch.el_nom && ch.el_nom <= layer[2])
+        az_range = std::max(az_range, std::fabs(ch.az_nom)), el_sum += ch.el, in_layer++;
     const double az_limit = in_layer ? az_range + 40.0 : 0.0;
     const double layer_el = in_layer ? el_sum / in_layer : layer[0];
     for (int c = 0; c < n_real; c++)
-      if (-10 <= real[c].el && real[c].el <= 10 && std::fabs(real[c].az) >= az_limit - 1e-5) {
+      if (-10 <= real[c].el_nom && real[c].el_nom <= 10 && std::fabs(real[c].az) >= az_limit - 1e-5) {
         verts.push_back(polar_to_cart(real[c].az, layer_el, 1.0));
         mix_to.push_back(c);
       }
@@ -625,9 +641,20 @@ static void build_extent_table(earhip_panner &pn) {
 extern "C" {
 
 int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **out) {
+  return earhip_panner_create_positions(ctx, layout, 0, nullptr, nullptr, out);
+}
+
+int earhip_panner_create_positions(earhip_ctx *ctx, const char *layout, int n_channels, const double *azimuth,
+                                   const double *elevation, earhip_panner **out) {
   return guarded([&] {
     require(ctx != nullptr && out != nullptr, "NULL argument");
     const LayoutEntry &L = layout_entry(layout);
+    require((azimuth == nullptr) == (elevation == nullptr), "azimuth and elevation come together");
+    if (azimuth) {
+      require(n_channels == L.n, "one position per channel of the layout (LFE channels included)");
+      for (int c = 0; c < L.n; c++)
+        require(std::isfinite(azimuth[c]) && std::isfinite(elevation[c]), "loudspeaker positions must be finite");
+    }
     ctx->use();
     std::unique_ptr<earhip_panner> p(new earhip_panner);
     p->ctx = ctx;
@@ -635,7 +662,7 @@ int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **ou
     p->P.n_full = L.n;
     int n_real = 0;
     std::vector<PanRegion> regions;
-    if (std::strcmp(L.name, "0+2+0") == 0) {  // configureStereoPolarPanner (:406-429)
+    if (std::strcmp(L.name, "0+2+0") == 0) {  // configureStereoPolarPanner (:406-429): pans on the nominal 0+5+0
       regions = build_regions(layout_entry("0+5+0"), n_real);
       p->P.stereo = 1;
       for (int c = 0; c < L.n; c++) {
@@ -643,7 +670,7 @@ int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **ou
         if (std::strcmp(L.channels[c].name, "M-030") == 0) p->P.stereo_index[1] = c;
       }
     } else {
-      regions = build_regions(L, n_real);
+      regions = build_regions(L, n_real, azimuth, elevation);
       int k = 0;
       for (int c = 0; c < L.n; c++)
         if (!L.channels[c].is_lfe) p->P.full_index[k++] = c;
@@ -687,6 +714,12 @@ int earhip_panner_num_channels(const earhip_panner *p, int *n_channels) {
 // normalised and converted to the requested normalisation.
 int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, const int *orders, const int *degrees,
                              const char *normalization, float *out) {
+  return earhip_hoa_decode_matrix_positions(ctx, layout, 0, nullptr, nullptr, n_coef, orders, degrees, normalization, out);
+}
+
+int earhip_hoa_decode_matrix_positions(earhip_ctx *ctx, const char *layout, int n_channels, const double *azimuth,
+                                       const double *elevation, int n_coef, const int *orders, const int *degrees,
+                                       const char *normalization, float *out) {
   return guarded([&] {
     require(ctx != nullptr && out != nullptr, "NULL argument");
     require(n_coef >= 1 && orders != nullptr && degrees != nullptr, "orders and degrees must be the same size");
@@ -703,7 +736,8 @@ int earhip_hoa_decode_matrix(earhip_ctx *ctx, const char *layout, int n_coef, co
     else if (std::strcmp(normalization, "FuMa") == 0) norm = kFuMa;
     else fail_invalid(std::string("ADM error: unknown normalization type: '") + normalization + "'");
     earhip_panner *pn = nullptr;
-    if (earhip_panner_create(ctx, layout, &pn) != EARHIP_OK) throw Error{EARHIP_INVALID_ARGUMENT, earhip_last_error()};
+    const int st = earhip_panner_create_positions(ctx, layout, n_channels, azimuth, elevation, &pn);
+    if (st != EARHIP_OK) throw Error{st, earhip_last_error()};
     std::unique_ptr<earhip_panner, int (*)(earhip_panner *)> guard(pn, earhip_panner_destroy);
     const size_t P = (size_t)kTDesignPoints, C = (size_t)n_coef;
     const size_t S = pn->P.stereo ? 2 : (size_t)pn->P.table.n_real;

@@ -10,22 +10,36 @@
 #include "metadata.hpp"
 
 namespace ear {
+  namespace detail {
+    /// which channels of the full BS.2051 layout the caller's layout keeps (Layout::withoutLfe drops the LFEs),
+    /// and the real positions of all channels of the full layout (the caller's where it has the channel)
+    inline std::vector<int> match_layout(const Layout &layout, std::vector<double> &az, std::vector<double> &el) {
+      const Layout full = getLayout(layout.name());
+      std::vector<int> keep;
+      for (auto &c : full.channels()) {
+        az.push_back(c.polarPosition().azimuth);
+        el.push_back(c.polarPosition().elevation);
+      }
+      for (auto &c : layout.channels()) {
+        const int i = full.indexForName(c.name());
+        if (i < 0) throw invalid_argument("channel " + c.name() + " is not part of layout " + layout.name());
+        az[i] = c.polarPosition().azimuth;
+        el[i] = c.polarPosition().elevation;
+        keep.push_back(i);
+      }
+      return keep;
+    }
+  }  // namespace detail
+
   class GainCalculatorObjects {
    public:
     /// layout: an ITU-R BS.2051 layout (getLayout), with or without its LFE channels
     explicit GainCalculatorObjects(const Layout &layout, hip::Context &ctx = hip::default_context()) {
-      const Layout full = getLayout(layout.name());
-      // which channels of the full layout the caller's layout keeps (Layout::withoutLfe drops the LFEs)
-      for (auto &c : layout.channels()) {
-        const int i = full.indexForName(c.name());
-        if (i < 0) throw invalid_argument("channel " + c.name() + " is not part of layout " + layout.name());
-        const PolarPosition a = c.polarPosition(), b = full.channels()[i].polarPosition();
-        if (a.azimuth != b.azimuth || a.elevation != b.elevation)
-          throw not_implemented("loudspeaker positions other than the nominal ones");
-        keep_.push_back(i);
-      }
-      n_full_ = full.channels().size();
-      hip::check(earhip_panner_create(ctx.get(), layout.name().c_str(), &h_));
+      std::vector<double> az, el;
+      keep_ = detail::match_layout(layout, az, el);
+      n_full_ = az.size();
+      // the loudspeakers' real positions (Channel::polarPosition) shape the panner, the nominal ones its layers
+      hip::check(earhip_panner_create_positions(ctx.get(), layout.name().c_str(), (int)n_full_, az.data(), el.data(), &h_));
     }
     ~GainCalculatorObjects() { earhip_panner_destroy(h_); }
     GainCalculatorObjects(const GainCalculatorObjects &) = delete;
@@ -101,13 +115,8 @@ namespace ear {
    public:
     explicit GainCalculatorHOA(const Layout &layout, hip::Context &ctx = hip::default_context())
         : name_(layout.name()), ctx_(ctx) {
-      const Layout full = getLayout(layout.name());
-      for (auto &c : layout.channels()) {
-        const int i = full.indexForName(c.name());
-        if (i < 0) throw invalid_argument("channel " + c.name() + " is not part of layout " + layout.name());
-        keep_.push_back(i);
-      }
-      n_full_ = full.channels().size();
+      keep_ = detail::match_layout(layout, az_, el_);
+      n_full_ = az_.size();
     }
     /// gains[coefficient][loudspeaker] (libear's column-major vector of vectors): must have that shape
     template <typename T>
@@ -119,8 +128,9 @@ namespace ear {
       for (auto &col : gains)
         if (col.size() != keep_.size()) throw invalid_argument("incorrect number of rows in output matrix column");
       std::vector<float> D(n_full_ * (C ? C : 1));
-      hip::check(earhip_hoa_decode_matrix(ctx_.get(), name_.c_str(), (int)C, metadata.orders.data(), metadata.degrees.data(),
-                                          metadata.normalization.c_str(), D.data()));
+      hip::check(earhip_hoa_decode_matrix_positions(ctx_.get(), name_.c_str(), (int)n_full_, az_.data(), el_.data(), (int)C,
+                                                    metadata.orders.data(), metadata.degrees.data(),
+                                                    metadata.normalization.c_str(), D.data()));
       for (size_t c = 0; c < C; c++)
         for (size_t r = 0; r < keep_.size(); r++) gains[c][r] = (T)D[(size_t)keep_[r] * C + c];
     }
@@ -129,6 +139,7 @@ namespace ear {
     std::string name_;
     hip::Context &ctx_;
     std::vector<int> keep_;
+    std::vector<double> az_, el_;  // real loudspeaker positions, full layout
     size_t n_full_ = 0;
   };
 }  // namespace ear

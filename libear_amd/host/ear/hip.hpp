@@ -10,11 +10,12 @@
 namespace ear {
   namespace hip {
     /// Translate an earhip status into libear's exception types
-    /// (include/earhip.h: 1 -> ear::invalid_argument, 2/3 -> ear::internal_error).
+    /// (include/earhip.h: 1 -> ear::invalid_argument, 2/3 -> ear::internal_error, 4 -> ear::not_implemented).
     inline void check(int status) {
       if (status == EARHIP_OK) return;
       const std::string msg = earhip_last_error();
       if (status == EARHIP_INVALID_ARGUMENT) throw invalid_argument(msg);
+      if (status == EARHIP_NOT_IMPLEMENTED) throw not_implemented(msg);
       throw internal_error(msg);
     }
 

@@ -1,6 +1,7 @@
 // ear/layout.hpp — what the render path needs of libear's Layout / Channel (include/ear/layout.hpp:12-95)
 // and of ear::loadLayouts / ear::getLayout (include/ear/bs2051.hpp:8-11): the ITU-R BS.2051 layouts from
-// the native table (earhip group H).  Same class and accessor names; positions are the nominal ones.
+// the native table (earhip group H).  Same class and accessor names; getLayout gives the nominal positions, a
+// caller may move the real ones (Channel::polarPosition) as with libear.
 #pragma once
 #include <string>
 #include <vector>
@@ -20,15 +21,21 @@ namespace ear {
   class Channel {
    public:
     Channel() = default;
-    Channel(const std::string &name, PolarPosition pos, bool isLfe = false) : name_(name), pos_(pos), lfe_(isLfe) {}
+    /// real position; the nominal one defaults to it (libear: boost::optional, include/ear/layout.hpp:32-38)
+    Channel(const std::string &name, PolarPosition pos, bool isLfe = false) : name_(name), pos_(pos), nominal_(pos), lfe_(isLfe) {}
+    Channel(const std::string &name, PolarPosition pos, PolarPosition nominal, bool isLfe = false)
+        : name_(name), pos_(pos), nominal_(nominal), lfe_(isLfe) {}
     const std::string &name() const { return name_; }
     PolarPosition polarPosition() const { return pos_; }
-    PolarPosition polarPositionNominal() const { return pos_; }
+    PolarPosition polarPositionNominal() const { return nominal_; }
     bool isLfe() const { return lfe_; }
+    /// where the loudspeaker really stands (the gain calculators pan with it; :47)
+    void polarPosition(PolarPosition p) { pos_ = p; }
+    void polarPositionNominal(PolarPosition p) { nominal_ = p; }
 
    private:
     std::string name_;
-    PolarPosition pos_;
+    PolarPosition pos_, nominal_;
     bool lfe_ = false;
   };
 
@@ -37,6 +44,7 @@ namespace ear {
     Layout(std::string name = "", std::vector<Channel> channels = std::vector<Channel>())
         : name_(std::move(name)), channels_(std::move(channels)) {}
     std::string name() const { return name_; }
+    std::vector<Channel> &channels() { return channels_; }
     const std::vector<Channel> &channels() const { return channels_; }
     Layout withoutLfe() const {
       Layout l(name_);

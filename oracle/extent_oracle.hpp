@@ -350,7 +350,8 @@ struct PolarExtentPanner {
 struct GainCalculatorObjects {
   panner_oracle::PannerSetup base;
   PolarExtent extent;
-  explicit GainCalculatorObjects(const std::string &layout) : base(layout), extent(base.psp) {}
+  explicit GainCalculatorObjects(const std::string &layout, const double *real_az = nullptr, const double *real_el = nullptr)
+      : base(layout, real_az, real_el), extent(base.psp) {}
   bool calculate(double az, double el, double dist, double width, double height, double depth, double gain, double diffuse,
                  float *direct, float *diff) const {
     Vec pv;

@@ -276,6 +276,25 @@ void *oracle_panner_create(const char *layout) {
   guarded([&] { out = new OracleObjects(layout); });
   return out;
 }
+// real loudspeaker positions, one (azimuth, elevation) per channel of the full layout; *status: 0 ok,
+// 1 invalid_argument, 4 not_implemented, 3 other (message: oracle_last_error)
+void *oracle_panner_create_positions(const char *layout, const double *az, const double *el, int *status) {
+  void *out = nullptr;
+  try {
+    out = new OracleObjects(layout, az, el);
+    *status = 0;
+  } catch (const panner_oracle::not_implemented &e) {
+    g_err = e.what();
+    *status = 4;
+  } catch (const std::invalid_argument &e) {
+    g_err = e.what();
+    *status = 1;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    *status = 3;
+  }
+  return out;
+}
 void oracle_panner_destroy(void *p) { delete static_cast<OracleObjects *>(p); }
 int oracle_panner_n_out(void *p) { return setup_of(p).n_out(); }
 // n positions: az, el, dist, gain, diffuse [n] -> direct, diffuse [n][n_out]; returns the number of
@@ -361,13 +380,20 @@ int oracle_stereo_downmix_handle(const double *xyz, double *pv2) {
 // ---- HOA decode matrix (hoa_oracle) -----------------------------------------------------------------
 extern "C" {
 // out [n_channels][n_coef] double; returns 0, or 1 (invalid argument) / 3 (other) with oracle_last_error()
+int oracle_hoa_decode_matrix_positions(const char *layout, const double *az, const double *el, int n_coef, const int *orders,
+                                       const int *degrees, const char *norm, double *out, int *n_channels);
 int oracle_hoa_decode_matrix(const char *layout, int n_coef, const int *orders, const int *degrees, const char *norm,
                              double *out, int *n_channels) {
+  return oracle_hoa_decode_matrix_positions(layout, nullptr, nullptr, n_coef, orders, degrees, norm, out, n_channels);
+}
+// az / el: real loudspeaker positions per channel of the full layout, or NULL (nominal)
+int oracle_hoa_decode_matrix_positions(const char *layout, const double *az, const double *el, int n_coef, const int *orders,
+                                       const int *degrees, const char *norm, double *out, int *n_channels) {
   try {
     std::vector<double> D;
     int nc = 0;
     hoa_oracle::decode_matrix(layout, std::vector<int>(orders, orders + n_coef), std::vector<int>(degrees, degrees + n_coef),
-                              norm, D, nc);
+                              norm, D, nc, az, el);
     std::memcpy(out, D.data(), sizeof(double) * D.size());
     *n_channels = nc;
     return 0;

@@ -60,7 +60,10 @@ struct Chan {
 };
 
 // Layout::withoutLfe of getLayout(name) (src/bs2051.cpp:13-22, include/ear/layout.hpp)
-inline std::vector<Chan> layout_without_lfe(const std::string &name, std::vector<bool> *is_lfe_full = nullptr) {
+// real_az / real_el (optional, one value per channel of the FULL layout): the loudspeakers' real positions
+// (Channel::polarPosition, include/ear/layout.hpp:32-40); without them real = nominal, as getLayout returns
+inline std::vector<Chan> layout_without_lfe(const std::string &name, std::vector<bool> *is_lfe_full = nullptr,
+                                            const double *real_az = nullptr, const double *real_el = nullptr) {
   using namespace ear_oracle_data;
   for (int i = 0; i < kNumLayouts; i++)
     if (name == kLayouts[i].name) {
@@ -68,11 +71,25 @@ inline std::vector<Chan> layout_without_lfe(const std::string &name, std::vector
       for (int c = 0; c < kLayouts[i].n; c++) {
         const LayoutChannel &ch = kLayouts[i].channels[c];
         if (is_lfe_full) is_lfe_full->push_back(ch.is_lfe);
-        if (!ch.is_lfe) out.push_back({ch.name, ch.azimuth, ch.elevation, ch.azimuth, ch.elevation});
+        if (!ch.is_lfe)
+          out.push_back({ch.name, real_az ? real_az[c] : ch.azimuth, real_el ? real_el[c] : ch.elevation, ch.azimuth, ch.elevation});
       }
       return out;
     }
   throw std::invalid_argument("unknown layout " + name);
+}
+struct not_implemented : std::runtime_error {  // ear::not_implemented (include/ear/exceptions.hpp)
+  using std::runtime_error::runtime_error;
+};
+// point_source_panner.cpp:558-577
+inline void check_screen_speakers(const std::vector<Chan> &layout) {
+  for (auto &c : layout)
+    if (c.name == "M+SC" || c.name == "M-SC") {
+      const double abs_az = std::fabs(c.az);
+      if (!((5.0 <= abs_az && abs_az < 25.0) || (35.0 <= abs_az && abs_az < 60.0)))
+        throw std::invalid_argument("M+SC or M-SC has azimuth not in the allowed ranges of 5 to 25 and 35 to 60 degrees");
+      if (25.0 < abs_az) throw not_implemented("M+SC and M-SC with azimuths wider than 25 degrees are not currently supported");
+    }
 }
 inline const int *layout_facets(const std::string &name) {
   using namespace ear_oracle_data;
@@ -428,10 +445,11 @@ struct StereoPannerDownmix : RegionHandler {
   }
 };
 
-// point_source_panner.cpp:406-429, :586-600 (the BS.2051 tables hold no screen loudspeaker outside
-// the supported range: checkScreenSpeakers is a no-op for them)
-inline std::shared_ptr<PointSourcePanner> configure_polar_panner(const std::string &name) {
-  const std::vector<Chan> layout = layout_without_lfe(name);
+// point_source_panner.cpp:406-429, :586-600
+inline std::shared_ptr<PointSourcePanner> configure_polar_panner(const std::string &name, const double *real_az = nullptr,
+                                                                 const double *real_el = nullptr) {
+  const std::vector<Chan> layout = layout_without_lfe(name, nullptr, real_az, real_el);
+  check_screen_speakers(layout);
   if (name == "0+2+0") {
     int li = 0, ri = 0;
     for (size_t i = 0; i < layout.size(); i++) {
@@ -451,9 +469,9 @@ inline std::shared_ptr<PointSourcePanner> configure_polar_panner(const std::stri
 struct PannerSetup {
   std::shared_ptr<PointSourcePanner> psp;
   std::vector<bool> is_lfe;
-  explicit PannerSetup(const std::string &layout) {
+  explicit PannerSetup(const std::string &layout, const double *real_az = nullptr, const double *real_el = nullptr) {
     layout_without_lfe(layout, &is_lfe);
-    psp = configure_polar_panner(layout);
+    psp = configure_polar_panner(layout, real_az, real_el);
   }
   int n_out() const { return (int)is_lfe.size(); }
 };
@@ -530,7 +548,8 @@ inline std::vector<V3> load_points() {
 }
 // gain_calculator_hoa.cpp:25-71; out: D_full [n_channels][n_coef] row-major (LFE rows zero)
 inline void decode_matrix(const std::string &layout, const std::vector<int> &orders, const std::vector<int> &degrees,
-                          const std::string &normalization, std::vector<double> &out, int &n_channels) {
+                          const std::string &normalization, std::vector<double> &out, int &n_channels,
+                          const double *real_az = nullptr, const double *real_el = nullptr) {
   if (orders.size() != degrees.size()) throw std::invalid_argument("orders and degrees must be the same size");
   for (size_t i = 0; i < orders.size(); i++) {
     if (orders[i] < 0) throw std::invalid_argument("orders must not be negative");
@@ -539,7 +558,7 @@ inline void decode_matrix(const std::string &layout, const std::vector<int> &ord
   const norm_f norm = get_norm(normalization);
   std::vector<bool> is_lfe;
   panner_oracle::layout_without_lfe(layout, &is_lfe);
-  const auto psp = panner_oracle::configure_polar_panner(layout);
+  const auto psp = panner_oracle::configure_polar_panner(layout, real_az, real_el);
   const std::vector<V3> points = load_points();
   const size_t P = points.size(), C = orders.size(), S = (size_t)psp->n_out();
   // Y_virt [C][P] (N3D), G_virt [S][P]

@@ -273,15 +273,31 @@ def cart(az, el, dist=1.0):
     return np.stack([np.sin(az) * np.cos(el) * dist, np.cos(az) * np.cos(el) * dist, np.sin(el) * dist + 0 * az], axis=-1)
 
 
+def _panner_handle(layout, positions):
+    """oracle_panner_create[_positions]: positions = (azimuths, elevations) of every channel of the full layout"""
+    L = lib()
+    L.oracle_panner_create.restype = C.c_void_p
+    L.oracle_panner_create_positions.restype = C.c_void_p
+    if positions is None:
+        h = C.c_void_p(L.oracle_panner_create(layout.encode()))
+        if not h:
+            raise OracleError(1, L.oracle_last_error().decode())
+        return h
+    az = np.ascontiguousarray(positions[0], np.float64)
+    el = np.ascontiguousarray(positions[1], np.float64)
+    st = C.c_int(0)
+    h = C.c_void_p(L.oracle_panner_create_positions(layout.encode(), ptr(az, f64p), ptr(el, f64p), C.byref(st)))
+    if st.value:
+        raise OracleError(st.value, L.oracle_last_error().decode())
+    return h
+
+
 class GainCalculatorObjects:
     """Objects gain producer without extent parameters (oracle/panner_oracle.hpp + extent_oracle.hpp): point-source
     pan (widened at distances under 1, as libear's PolarExtent does), LFE mask, diffuse split."""
 
-    def __init__(self, layout):
-        lib().oracle_panner_create.restype = C.c_void_p
-        self.h = C.c_void_p(lib().oracle_panner_create(layout.encode()))
-        if not self.h:
-            raise OracleError(1, lib().oracle_last_error().decode())
+    def __init__(self, layout, positions=None):
+        self.h = _panner_handle(layout, positions)
         self.n_out = lib().oracle_panner_n_out(self.h)
         self.n_psp = lib().oracle_psp_n_out(self.h)
 
@@ -322,14 +338,11 @@ class PolarExtent:
     """libear's polar extent panner behind GainCalculatorObjects (oracle/extent_oracle.hpp): the library's
     form (float core, `which=0`) and the form libear's tests keep beside it (double, `which=1`)."""
 
-    def __init__(self, layout):
+    def __init__(self, layout, positions=None):
         L = lib()
-        L.oracle_panner_create.restype = C.c_void_p
         L.oracle_extent_weight.restype = C.c_double
         L.oracle_extent_mod.restype = C.c_double
-        self.h = C.c_void_p(L.oracle_panner_create(layout.encode()))
-        if not self.h:
-            raise OracleError(1, L.oracle_last_error().decode())
+        self.h = _panner_handle(layout, positions)
         self.n_out = L.oracle_panner_n_out(self.h)
         self.n_psp = L.oracle_psp_n_out(self.h)
         self.num_points = L.oracle_extent_num_points(self.h)
@@ -414,7 +427,7 @@ def stereo_downmix_handle(xyz):
     return pv if lib().oracle_stereo_downmix_handle(ptr(xyz, f64p), ptr(pv, f64p)) else None
 
 
-def hoa_decode_matrix(layout, orders, degrees, normalization="SN3D"):
+def hoa_decode_matrix(layout, orders, degrees, normalization="SN3D", positions=None):
     """AllRAD decode matrix of libear's GainCalculatorHOA (oracle/panner_oracle.hpp, hoa_oracle):
     [n_channels][n_coef] float64, LFE rows zero"""
     o = np.ascontiguousarray(orders, np.int32)
@@ -424,8 +437,12 @@ def hoa_decode_matrix(layout, orders, degrees, normalization="SN3D"):
     out = np.zeros((64, max(len(o), 1)), np.float64)
     nch = C.c_int(0)
     ip = C.POINTER(C.c_int)
-    rc = lib().oracle_hoa_decode_matrix(layout.encode(), len(o), o.ctypes.data_as(ip), d.ctypes.data_as(ip),
-                                        normalization.encode(), ptr(out, f64p), C.byref(nch))
+    az = el = None
+    if positions is not None:
+        az, el = (np.ascontiguousarray(v, np.float64) for v in positions)
+    rc = lib().oracle_hoa_decode_matrix_positions(layout.encode(), None if az is None else ptr(az, f64p),
+                                                  None if el is None else ptr(el, f64p), len(o), o.ctypes.data_as(ip),
+                                                  d.ctypes.data_as(ip), normalization.encode(), ptr(out, f64p), C.byref(nch))
     if rc:
         raise OracleError(rc, lib().oracle_last_error().decode())
     return out.reshape(-1)[:nch.value * len(o)].reshape(nch.value, len(o)).copy()

@@ -678,6 +678,45 @@ static void test_gain_calculator_objects() {
   }
   m.width = 30.0, m.height = 0.0, m.depth = 0.5;
   CHECK(!refuses(m));
+  // loudspeakers off their nominal positions (Channel::polarPosition): a source at a real position plays from
+  // that loudspeaker alone; the screen loudspeakers' ranges (tests/point_source_panner_tests.cpp:522-551)
+  {
+    Layout moved = getLayout("4+7+0").withoutLfe();
+    for (auto &c : moved.channels()) {
+      PolarPosition q = c.polarPosition();
+      if (c.name() == "M+030") q.azimuth = 26.0, q.elevation = 2.0;
+      if (c.name() == "U-045") q.azimuth = -50.0, q.elevation = 33.0;
+      c.polarPosition(q);
+    }
+    GainCalculatorObjects mc(moved);
+    ObjectsTypeMetadata mm;
+    mm.position = PolarPosition(26.0, 2.0, 1.0);
+    mc.calculate(mm, direct, diffuse);
+    CHECK(only(direct, "M+030", 1.0));
+    mm.position = PolarPosition(-50.0, 33.0, 1.0);
+    mc.calculate(mm, direct, diffuse);
+    CHECK(only(direct, "U-045", 1.0));
+    mm.position = PolarPosition(30.0, 0.0, 1.0);  // the nominal place is now between loudspeakers
+    mc.calculate(mm, direct, diffuse);
+    CHECK(!only(direct, "M+030", 1.0));
+    Layout screen = getLayout("4+9+0").withoutLfe();
+    for (auto &c : screen.channels())
+      if (c.name() == "M+SC") c.polarPosition(PolarPosition(40.0, 0.0, 1.0));
+    bool threw_ni = false, threw_ia = false;
+    try {
+      GainCalculatorObjects sc(screen);
+    } catch (const ear::not_implemented &) {
+      threw_ni = true;
+    }
+    for (auto &c : screen.channels())
+      if (c.name() == "M+SC") c.polarPosition(PolarPosition(30.0, 0.0, 1.0));
+    try {
+      GainCalculatorObjects sc(screen);
+    } catch (const ear::invalid_argument &) {
+      threw_ia = true;
+    }
+    CHECK(threw_ni && threw_ia);
+  }
   // with the LFE channel kept, its column is zero (gain_calculator_objects.cpp:50-52); a batch in one launch
   GainCalculatorObjects full(getLayout("4+7+0"));
   std::vector<ObjectsTypeMetadata> batch(3);

@@ -190,3 +190,87 @@ def test_hoa_bed_through_the_renderer_with_the_real_decode_matrix():
         w.set_points(i, 1, t, f)
     want = w.process(x)
     assert scenes.rel_rms(got, want) <= 1e-6 and scenes.rel_rms_per_channel(got, want) <= 1e-6
+
+
+def _moved(layout, seed):
+    """the layout's channels a few degrees off their nominal positions (full layout, LFE included)"""
+    from libear_amd import capi
+    ch = capi.layout_channels(layout)
+    az = np.array([c[1] for c in ch], np.float64)
+    el = np.array([c[2] for c in ch], np.float64)
+    rng = np.random.default_rng(seed)
+    raz = az + rng.uniform(-4, 4, len(az))
+    rel = np.clip(el + rng.uniform(-3, 3, len(el)), -90, 90)
+    raz[np.abs(el) == 90] = az[np.abs(el) == 90]
+    return [c[0] for c in ch], az, el, raz, rel
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+def test_real_loudspeaker_positions_equal_oracle(layout):
+    """earhip_panner_create_positions: loudspeakers off their nominal positions (Channel::polarPosition) — point
+    sources to the last bit of the oracle, objects with extent to 1e-5; the nominal positions given explicitly
+    are the plain constructor"""
+    from libear_amd import capi
+    names, az, el, raz, rel = _moved(layout, sum(map(ord, layout)))
+    rng = np.random.default_rng(5)
+    n = 4000
+    taz = rng.uniform(-180, 180, n)
+    tel = np.degrees(np.arcsin(rng.uniform(-1, 1, n)))
+    k = len(names)
+    taz[:k], tel[:k] = raz, rel  # the real positions themselves
+    p0 = capi.Panner(ctx(), layout)
+    p1 = capi.Panner(ctx(), layout, (az, el))
+    a, b = p0.calculate(taz, tel), p1.calculate(taz, tel)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    p0.close()
+    p1.close()
+    p = capi.Panner(ctx(), layout, (raz, rel))
+    o = _oracle.PolarExtent(layout, (raz, rel))
+    d, f = p.calculate(taz, tel, None, None, 0.25)
+    wd, wf = o.calculate(taz, tel, diffuse=0.25)
+    assert np.max(np.abs(d - wd)) <= 2 * ULP and np.max(np.abs(f - wf)) <= 2 * ULP
+    assert np.mean(d == wd) > 0.999
+    if layout != "0+2+0":  # a source at a real loudspeaker position plays from it alone
+        lfe = np.array([nm.startswith("LFE") for nm in names])
+        got = d[:k][~lfe][:, ~lfe].astype(np.float64) / np.sqrt(0.75)
+        assert np.allclose(got, np.eye(int((~lfe).sum())), atol=1e-6)
+    width, height = rng.uniform(0, 180, 600), rng.uniform(0, 90, 600)
+    d, _ = p.calculate(taz[:600], tel[:600], None, None, None, width, height, None)
+    wd, _ = o.calculate(taz[:600], tel[:600], width=width, height=height)
+    den = np.minimum(np.linalg.norm(d, axis=1), np.linalg.norm(wd, axis=1))
+    assert np.max(np.linalg.norm(d.astype(np.float64) - wd, axis=1) / den) <= 1e-5
+    p.close()
+
+
+def test_screen_loudspeakers_and_position_errors():
+    """tests/point_source_panner_tests.cpp:522-551 through the C ABI; shape errors"""
+    from libear_amd import capi
+    names, az, el, _, _ = _moved("4+9+0", 1)
+    for name, sign in (("M+SC", 1.0), ("M-SC", -1.0)):
+        a = az.copy()
+        a[names.index(name)] = sign * 40.0
+        with pytest.raises(capi.NotImplementedInLibear):
+            capi.Panner(ctx(), "4+9+0", (a, el))
+        a[names.index(name)] = sign * 30.0
+        with pytest.raises(capi.InvalidArgument):
+            capi.Panner(ctx(), "4+9+0", (a, el))
+    with pytest.raises(capi.InvalidArgument):
+        capi.Panner(ctx(), "4+9+0", (az[:-1], el[:-1]))  # one position per channel of the full layout
+    bad = az.copy()
+    bad[0] = np.nan
+    with pytest.raises(capi.InvalidArgument):
+        capi.Panner(ctx(), "4+9+0", (bad, el))
+
+
+def test_hoa_decode_matrix_with_real_positions():
+    from libear_amd import capi
+    layout = "4+5+0"
+    _, az, el, raz, rel = _moved(layout, 9)
+    idx = [(n, m) for n in range(3) for m in range(-n, n + 1)]
+    orders, degrees = [n for n, _ in idx], [m for _, m in idx]
+    got = capi.hoa_decode_matrix(ctx(), layout, orders, degrees, "SN3D", (raz, rel))
+    want = _oracle.hoa_decode_matrix(layout, orders, degrees, "SN3D", (raz, rel))
+    assert np.max(np.abs(got - want)) <= 1e-6 * max(1.0, np.max(np.abs(want)))
+    nominal = capi.hoa_decode_matrix(ctx(), layout, orders, degrees, "SN3D")
+    assert np.array_equal(nominal, capi.hoa_decode_matrix(ctx(), layout, orders, degrees, "SN3D", (az, el)))
+    assert np.max(np.abs(got - nominal)) > 1e-3  # (moving the loudspeakers does change the decoder)

@@ -160,3 +160,50 @@ def test_gain_calculator_objects_reference_cases():
     d, f = g.calculate(rng.uniform(-180, 180, 200), rng.uniform(-90, 90, 200), diffuse=rng.uniform(0, 1, 200))
     assert not d[:, lfe].any() and not f[:, lfe].any()
     assert np.allclose(np.linalg.norm(np.sqrt(d.astype(np.float64) ** 2 + f.astype(np.float64) ** 2), axis=1), 1.0, atol=1e-6)
+
+
+def _full_positions(layout):
+    from libear_amd import capi
+    ch = capi.layout_channels(layout)
+    return [c[0] for c in ch], np.array([c[1] for c in ch], np.float64), np.array([c[2] for c in ch], np.float64)
+
+
+def test_screen_loudspeaker_positions():
+    """tests/point_source_panner_tests.cpp:522-551: M+SC / M-SC wider than 25 degrees is not_implemented, outside
+    5..25 and 35..60 invalid_argument"""
+    names, az, el = _full_positions("4+9+0")
+    for name, sign in (("M+SC", 1.0), ("M-SC", -1.0)):
+        a = az.copy()
+        a[names.index(name)] = sign * 40.0
+        with pytest.raises(_oracle.OracleError) as e:
+            _oracle.GainCalculatorObjects("4+9+0", (a, el))
+        assert e.value.code == 4
+        a[names.index(name)] = sign * 30.0
+        with pytest.raises(_oracle.OracleError) as e:
+            _oracle.GainCalculatorObjects("4+9+0", (a, el))
+        assert e.value.code == 1
+    _oracle.GainCalculatorObjects("4+9+0", (az, el))  # the nominal 15 degrees are fine
+
+
+@pytest.mark.parametrize("layout", ["0+5+0", "4+5+0", "4+9+0", "9+10+3"])
+def test_real_loudspeaker_positions(layout):
+    """loudspeakers a few degrees off their nominal positions (Channel::polarPosition): a source AT a real position
+    plays from that loudspeaker alone, gains stay non-negative and normalised, nominal positions given
+    explicitly change nothing (point_source_panner.cpp:431-476: real positions for the geometry, nominal ones for
+    the triangulation)"""
+    names, az, el = _full_positions(layout)
+    lfe = np.array([n.startswith("LFE") for n in names])
+    g0 = _oracle.GainCalculatorObjects(layout)
+    g1 = _oracle.GainCalculatorObjects(layout, (az, el))
+    rng = np.random.default_rng(len(layout))
+    taz, tel = rng.uniform(-180, 180, 200), rng.uniform(-30, 60, 200)
+    assert np.array_equal(g0.calculate(taz, tel)[0], g1.calculate(taz, tel)[0])
+    raz = az + rng.uniform(-4, 4, len(az))
+    rel_ = np.clip(el + rng.uniform(-3, 3, len(el)), -90, 90)
+    raz[np.abs(el) == 90] = az[np.abs(el) == 90]
+    g = _oracle.GainCalculatorObjects(layout, (raz, rel_))
+    d, _ = g.calculate(raz[~lfe], rel_[~lfe])
+    assert np.allclose(d[:, ~lfe], np.eye(int((~lfe).sum())), atol=1e-6)
+    for a, e in zip(taz[:60], tel[:60]):
+        pv = g.calculate([a], [e])[0][0][~lfe].astype(np.float64)
+        assert abs(np.linalg.norm(pv) - 1.0) < 1e-6 and (pv >= 0).all()
