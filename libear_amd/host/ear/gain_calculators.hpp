@@ -8,6 +8,7 @@
 
 #include "hip.hpp"
 #include "metadata.hpp"
+#include "warnings.hpp"
 
 namespace ear {
   namespace detail {
@@ -47,7 +48,8 @@ namespace ear {
 
     /// one metadata block -> direct and diffuse gain vectors (resized to the layout's channel count)
     template <typename T>
-    void calculate(const ObjectsTypeMetadata &metadata, std::vector<T> &directGains, std::vector<T> &diffuseGains) {
+    void calculate(const ObjectsTypeMetadata &metadata, std::vector<T> &directGains, std::vector<T> &diffuseGains,
+                   const WarningCB & = default_warning_cb) {  // (libear's Objects calculator emits no warnings either)
       std::vector<std::vector<T>> d, f;
       calculate(std::vector<ObjectsTypeMetadata>(1, metadata), d, f);
       directGains = d[0];
@@ -120,7 +122,8 @@ namespace ear {
     }
     /// gains[coefficient][loudspeaker] (libear's column-major vector of vectors): must have that shape
     template <typename T>
-    void calculate(const HOATypeMetadata &metadata, std::vector<std::vector<T>> &gains) {
+    void calculate(const HOATypeMetadata &metadata, std::vector<std::vector<T>> &gains,
+                   const WarningCB &warning_cb = default_warning_cb) {
       if (metadata.orders.size() != metadata.degrees.size())
         throw invalid_argument("orders and degrees must be the same size");
       const size_t C = metadata.orders.size();
@@ -128,6 +131,14 @@ namespace ear {
       for (auto &col : gains)
         if (col.size() != keep_.size()) throw invalid_argument("incorrect number of rows in output matrix column");
       std::vector<float> D(n_full_ * (C ? C : 1));
+      // (an unknown normalization is refused by the C ABI before anything is ignored, as in libear:
+      // src/hoa/gain_calculator_hoa.cpp:36-48)
+      if (metadata.normalization == "N3D" || metadata.normalization == "SN3D" || metadata.normalization == "FuMa") {
+        if (metadata.screenRef)
+          warning_cb({Warning::Code::HOA_SCREENREF_NOT_IMPLEMENTED, "screenRef for HOA is not implemented; ignoring"});
+        if (metadata.nfcRefDist != 0.0)
+          warning_cb({Warning::Code::HOA_NFCREFDIST_NOT_IMPLEMENTED, "nfcRefDist is not implemented; ignoring"});
+      }
       hip::check(earhip_hoa_decode_matrix_positions(ctx_.get(), name_.c_str(), (int)n_full_, az_.data(), el_.data(), (int)C,
                                                     metadata.orders.data(), metadata.degrees.data(),
                                                     metadata.normalization.c_str(), D.data()));

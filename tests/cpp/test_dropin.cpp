@@ -771,6 +771,23 @@ static void test_gain_calculator_hoa() {
   m.normalization = "foo";
   CHECK(throws_invalid(m));
   CHECK(!throws_invalid(tm));
+  // warnings (tests/gain_calculator_hoa_tests.cpp:9-37): what is ignored is reported through the callback
+  {
+    std::vector<ear::Warning> warnings;
+    auto collect = [&](const ear::Warning &w) { warnings.push_back(w); };
+    m = tm;
+    m.screenRef = true;
+    gc.calculate(m, gains, collect);
+    CHECK(warnings.size() == 1 && warnings[0].code == ear::Warning::Code::HOA_SCREENREF_NOT_IMPLEMENTED);
+    warnings.clear();
+    m = tm;
+    m.nfcRefDist = 1.0;
+    gc.calculate(m, gains, collect);
+    CHECK(warnings.size() == 1 && warnings[0].code == ear::Warning::Code::HOA_NFCREFDIST_NOT_IMPLEMENTED);
+    warnings.clear();
+    gc.calculate(tm, gains, collect);
+    CHECK(warnings.empty());
+  }
 }
 
 // ---- no heap allocation in any process() call once warmed up (the reference enforces it for
