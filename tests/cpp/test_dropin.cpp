@@ -18,9 +18,14 @@
 #include <random>
 #include <vector>
 
+// (the include lines of a libear application: the reference's tests use exactly these paths)
+#include "ear/bs2051.hpp"
+#include "ear/common_types.hpp"
 #include "ear/decorrelate.hpp"
 #include "ear/dsp/dsp.hpp"
+#include "ear/ear.hpp"
 #include "ear/gain_calculators.hpp"
+#include "ear/warnings.hpp"
 
 using namespace ear;
 using namespace ear::dsp;
