@@ -230,6 +230,11 @@ int earhip_layout_num_channels(const char *layout, int *n_channels);
 /* any output pointer may be NULL; *name points at static storage */
 int earhip_layout_channel(const char *layout, int index, const char **name, double *azimuth,
                           double *elevation, int *is_lfe);
+/* the ranges BS.2051 allows a real loudspeaker of this channel (Channel::azimuthRange / elevationRange,
+ * include/ear/layout.hpp:41-42, table src/bs2051_layouts.cpp): azimuth from [0] anticlockwise to [1],
+ * elevation from [0] up to [1], degrees; either pointer may be NULL */
+int earhip_layout_channel_ranges(const char *layout, int index, double azimuth_range[2],
+                                 double elevation_range[2]);
 /* designDecorrelators<float>(getLayout(layout)) — or of getLayout(layout).withoutLfe() —
  * out: [channels kept][512] (include/ear/decorrelate.hpp:26-28) */
 int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, float *out);

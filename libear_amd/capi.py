@@ -360,6 +360,18 @@ def layout_channels(layout):
     return out
 
 
+def layout_channel_ranges(layout):
+    """(H) [((az_lo, az_hi), (el_lo, el_hi))] per channel: where BS.2051 allows the real loudspeaker to stand"""
+    n = C.c_int(0)
+    check(load().earhip_layout_num_channels(layout.encode(), C.byref(n)))
+    out = []
+    for i in range(n.value):
+        az, el = (C.c_double * 2)(), (C.c_double * 2)()
+        check(load().earhip_layout_channel_ranges(layout.encode(), i, az, el))
+        out.append(((az[0], az[1]), (el[0], el[1])))
+    return out
+
+
 def design_decorrelators_for_layout(layout, without_lfe=False):
     chans = [c for c in layout_channels(layout) if not (without_lfe and c[3])]
     out = np.empty((len(chans), load().earhip_decorrelator_size()), np.float32)

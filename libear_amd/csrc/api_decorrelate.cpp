@@ -99,6 +99,16 @@ int earhip_layout_channel(const char *layout, int index, const char **name, doub
   });
 }
 
+int earhip_layout_channel_ranges(const char *layout, int index, double azimuth_range[2], double elevation_range[2]) {
+  return guarded([&] {
+    const LayoutEntry &L = find_layout(layout);
+    require(index >= 0 && index < L.n, "channel index out of range");
+    const LayoutChannel &c = L.channels[index];
+    if (azimuth_range) azimuth_range[0] = c.az_lo, azimuth_range[1] = c.az_hi;
+    if (elevation_range) elevation_range[0] = c.el_lo, elevation_range[1] = c.el_hi;
+  });
+}
+
 // designDecorrelators(getLayout(name)) / designDecorrelators(getLayout(name).withoutLfe())
 int earhip_design_decorrelators_for_layout(const char *layout, int without_lfe, float *out) {
   return guarded([&] {

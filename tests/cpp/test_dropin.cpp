@@ -693,6 +693,19 @@ static void test_gain_calculator_objects() {
       if (c.name() == "U-045") q.azimuth = -50.0, q.elevation = 33.0;
       c.polarPosition(q);
     }
+    // (BS.2051 allows M+030 at 30..45 degrees on the horizontal plane and U-045 at -45..-30, 30..55 up: these
+    // positions are outside, which Layout::checkPositions reports and the panner does not mind — src/layout.cpp:54-75,
+    // tests/bs2051_tests.cpp:27-40)
+    std::vector<std::string> complaints;
+    getLayout("4+7+0").checkPositions([&](const std::string &msg) { complaints.push_back(msg); });
+    CHECK(complaints.empty());
+    moved.checkPositions([&](const std::string &msg) { complaints.push_back(msg); });
+    CHECK(complaints.size() == 3 && complaints[0] == "M+030: azimuth 26 out of range [30, 45]" &&
+          complaints[1] == "M+030: elevation 2 out of range [0, 0]" &&
+          complaints[2] == "U-045: azimuth -50 out of range [-45, -30]");
+    CHECK(moved.channelWithName("U-045").azimuthRange() == std::make_pair(-45.0, -30.0));
+    CHECK(moved.channelWithName("U-045").elevationRange() == std::make_pair(30.0, 55.0));
+    CHECK(moved.nominalPositions()[0].azimuth == 30.0 && moved.positions()[0].azimuth == 26.0);
     GainCalculatorObjects mc(moved);
     ObjectsTypeMetadata mm;
     mm.position = PolarPosition(26.0, 2.0, 1.0);

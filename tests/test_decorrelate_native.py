@@ -60,3 +60,39 @@ def test_native_layout_table(where):
     assert f.shape == (len(names), 512)
     assert np.array_equal(f[names.index("M+030")], capi.design_decorrelator_basic(1, 512).astype(np.float32))
     assert np.array_equal(capi.design_decorrelators_for_layout("9+10+3"), capi.design_decorrelators(LAYOUTS["9+10+3"]))
+
+
+@both
+def test_native_layout_ranges(where):
+    """tests/bs2051_tests.cpp:27-56 on the native table: every nominal position lies inside its allowed ranges
+    (all_positions_in_range) and, screen loudspeakers and LFE aside, no azimuth range spans more than 180 degrees
+    (azimuth_ranges: catches inverted ranges); left / right partners mirror each other (test_symmetry)"""
+    from libear_amd import capi
+
+    def inside(x, start, end):  # src/common/geom.cpp:7-28
+        while end - 360.0 > start:
+            end -= 360.0
+        while end < start:
+            end += 360.0
+        while x - 360.0 >= start:
+            x -= 360.0
+        while x < start:
+            x += 360.0
+        return x <= end
+    for layout in capi.layout_names():
+        chans, ranges = capi.layout_channels(layout), capi.layout_channel_ranges(layout)
+        assert len(chans) == len(ranges)
+        by_name = {c[0]: (c, r) for c, r in zip(chans, ranges)}
+        for (name, az, el, lfe), ((a0, a1), (e0, e1)) in zip(chans, ranges):
+            assert inside(az, a0, a1) and e0 <= el <= e1, (layout, name)
+            if not lfe and "SC" not in name:
+                end = a1
+                while end < a0:
+                    end += 360.0
+                assert end - a0 <= 180.0, (layout, name)
+            if "+" in name and name.replace("+", "-") in by_name and not name.endswith(("000", "180")):
+                (_, paz, pel, _), ((p0, p1), pe) = by_name[name.replace("+", "-")]
+                assert (paz, pel) == (-az, el) and (p0, p1) == (-a1, -a0) and pe == (e0, e1), (layout, name)
+    assert capi.layout_channel_ranges("0+5+0")[4] == ((100.0, 120.0), (0.0, 15.0))  # M+110
+    with pytest.raises(capi.InvalidArgument):
+        capi.layout_channel_ranges("1+2+3")
