@@ -64,9 +64,19 @@ namespace ear {
     };
   }  // namespace hip
 
-  /// Device-backed FFT implementation (power-of-two sizes in [64, 8192]).
+  /// Device-backed FFT implementation (even sizes in [4, 8192] whose prime factors are at most 97).
   inline FFTImpl<float> &get_fft_hip() {
     static hip::FFTHip fft;
     return fft;
+  }
+
+  /// libear's accessor of its always-available implementation (include/ear/fft.hpp:64-67), so that application
+  /// code written against libear compiles unchanged: here it IS the device transform (same contract:
+  /// un-normalised r2c / c2r, n/2 + 1 unpacked bins).  float only, like the rest of the DSP path.
+  template <typename Real>
+  FFTImpl<Real> &get_fft_kiss();
+  template <>
+  inline FFTImpl<float> &get_fft_kiss<float>() {
+    return get_fft_hip();
   }
 }  // namespace ear
