@@ -1,11 +1,13 @@
-// ear/decorrelate.hpp — decorrelator design, libear include/ear/decorrelate.hpp:16-34.
-// libear takes a Layout; the hot path needs only the channel names (the filter
-// id of a channel is the rank of its name, src/decorrelate.cpp:55-68).
+// ear/decorrelate.hpp — decorrelator design, libear include/ear/decorrelate.hpp:16-34: designDecorrelator(layout,
+// channelIdx), designDecorrelators(layout), decorrelatorCompensationDelay(), plus forms that take only what the
+// design needs — the channel names (the filter id of a channel is the rank of its name, src/decorrelate.cpp:55-68)
+// or a BS.2051 layout name.
 #pragma once
 #include <string>
 #include <vector>
 
 #include "hip.hpp"
+#include "layout.hpp"
 
 namespace ear {
   inline std::vector<std::vector<float>> designDecorrelators(
@@ -42,4 +44,23 @@ namespace ear {
     return out;
   }
   inline int decorrelatorCompensationDelay() { return earhip_decorrelator_compensation_delay(); }
+
+  /// libear's own signatures (include/ear/decorrelate.hpp:16-27).  T = double gives the design before its cast to
+  /// float (src/decorrelate.cpp:55-80).
+  template <typename T = float>
+  std::vector<T> designDecorrelator(const Layout &layout, size_t channelIdx) {
+    const std::vector<std::string> names = layout.channelNames();
+    if (channelIdx >= names.size()) throw invalid_argument("channel index out of range");
+    int id = 0;  // the number of channel names that sort before this one (:63-65)
+    for (auto &n : names)
+      if (n < names[channelIdx]) id++;
+    const std::vector<double> basic = designDecorrelatorBasic(id, earhip_decorrelator_size());
+    return std::vector<T>(basic.begin(), basic.end());
+  }
+  template <typename T = float>
+  std::vector<std::vector<T>> designDecorrelators(const Layout &layout) {
+    std::vector<std::vector<T>> out;
+    for (size_t i = 0; i < layout.channels().size(); i++) out.push_back(designDecorrelator<T>(layout, i));
+    return out;
+  }
 }  // namespace ear

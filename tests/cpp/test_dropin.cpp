@@ -410,6 +410,19 @@ static void test_objects_renderer() {
   const auto dec = designDecorrelators(names);
   const int delay = decorrelatorCompensationDelay();
   CHECK(delay == 255 && dec.size() == N && dec[0].size() == 512);
+  {  // libear's own signatures (include/ear/decorrelate.hpp:16-27): a Layout in, float by default, double on request
+    const Layout l050 = getLayout("0+5+0");
+    CHECK(designDecorrelators(l050) == dec);
+    CHECK(designDecorrelator(l050, 4) == dec[4]);
+    const std::vector<double> d64 = designDecorrelator<double>(l050, 0);
+    bool same = d64.size() == 512;
+    for (size_t i = 0; same && i < 512; i++) same = (float)d64[i] == dec[0][i];
+    CHECK(same);
+    // M+030 of 4+5+0 without LFE has one name before it (tests/decorrelate_tests.cpp:35-44)
+    const Layout l450 = getLayout("4+5+0").withoutLfe();
+    const std::vector<double> basic1 = designDecorrelatorBasic(1, 512);
+    CHECK(designDecorrelator<double>(l450, (size_t)l450.indexForName("M+030")) == basic1);
+  }
   std::mt19937 g(99);
   auto rnd = [&] { return (float)((double)g() / 4294967296.0); };
   std::vector<Vec> in(M);
