@@ -103,15 +103,6 @@ namespace ear {
     size_t n_full_ = 0;
   };
 
-  /// libear: include/ear/metadata.hpp:162-171
-  struct HOATypeMetadata {
-    std::vector<int> orders;
-    std::vector<int> degrees;
-    std::string normalization = std::string("SN3D");
-    double nfcRefDist = 0.0;  ///< ignored, as in libear (which warns)
-    bool screenRef = false;   ///< ignored, as in libear (which warns)
-  };
-
   /// libear: include/ear/gain_calculators.hpp:58-70
   class GainCalculatorHOA {
    public:

@@ -653,13 +653,16 @@ static void test_gain_calculator_objects() {
   m.position = CartesianPosition(0.0, 1.0, 0.0);
   CHECK(refuses(m));
   m = base;
-  m.objectDivergence = ObjectDivergence(0.5);
+  m.objectDivergence = PolarObjectDivergence(0.5);  // (the reference test's own lines, :142-149)
+  CHECK(refuses(m));
+  m = base;
+  m.objectDivergence = CartesianObjectDivergence(0.5);
   CHECK(refuses(m));
   m = base;
   m.channelLock.flag = true;
   CHECK(refuses(m));
   m = base;
-  m.zoneExclusion.zones.push_back(ExclusionZone());
+  m.zoneExclusion.zones.push_back(PolarExclusionZone{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ""});
   CHECK(refuses(m));
   m = base;
   m.screenRef = true;
