@@ -33,13 +33,16 @@ extern "C" {
 
 #define EARHIP_VERSION 100 /* 0.1.0 */
 
-/* status codes; the C++ shim maps 1 -> ear::invalid_argument, 2,3 -> ear::internal_error and
- * 4 -> ear::not_implemented (include/ear/exceptions.hpp:8-43) */
+/* status codes; the C++ shim maps 1 -> ear::invalid_argument, 2,3 -> ear::internal_error,
+ * 4 -> ear::not_implemented, 5 -> ear::unknown_layout, 6 -> ear::adm_error
+ * (include/ear/exceptions.hpp:8-43) */
 #define EARHIP_OK 0
 #define EARHIP_INVALID_ARGUMENT 1
 #define EARHIP_INTERNAL_ERROR 2
 #define EARHIP_DEVICE_ERROR 3
 #define EARHIP_NOT_IMPLEMENTED 4 /* ear::not_implemented: a case libear itself refuses */
+#define EARHIP_UNKNOWN_LAYOUT 5  /* ear::unknown_layout (an invalid-argument kind: src/bs2051.cpp:19) */
+#define EARHIP_ADM_ERROR 6       /* ear::adm_error: invalid ADM metadata (an invalid-argument kind) */
 
 int earhip_version(void);
 const char *earhip_last_error(void);
@@ -222,7 +225,7 @@ int earhip_design_decorrelators(int n_channels, const char *const *channel_names
  * table src/bs2051_layouts.cpp): what the render path needs of a Layout — channel
  * names in layout order (decorrelator ids), nominal positions (the gain producers) and
  * the LFE flags (zero-gain columns; Layout::withoutLfe, include/ear/layout.hpp).
- * An unknown layout name is EARHIP_INVALID_ARGUMENT (libear throws unknown_layout).
+ * An unknown layout name is EARHIP_UNKNOWN_LAYOUT (libear throws unknown_layout).
  * ---------------------------------------------------------------------- */
 int earhip_layout_count(void);
 const char *earhip_layout_name(int index); /* NULL when out of range */
@@ -298,7 +301,7 @@ int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const d
  * (include/ear/gain_calculators.hpp:58-70, src/hoa/gain_calculator_hoa.cpp:8-72,
  * src/hoa/hoa.hpp:16-182): the AllRAD design over the layout's point source panner.  One
  * (order, degree) pair per input channel; normalization "SN3D", "N3D" or "FuMa" (an unknown
- * one is EARHIP_INVALID_ARGUMENT: libear throws adm_error); out: [n_channels][n_coef],
+ * one is EARHIP_ADM_ERROR: libear throws adm_error); out: [n_channels][n_coef],
  * rows of LFE channels zero.  It is constant over time: feed its COLUMNS to (F) or (A')
  * as single-point gain curves (docs/dsp.rst:73-89).  screenRef and nfcRefDist are ignored
  * by libear (with a warning) and are not parameters here. */

@@ -15,7 +15,7 @@ f32p = C.POINTER(C.c_float)
 i64p = C.POINTER(C.c_int64)
 pp_f32 = C.POINTER(f32p)
 
-OK, INVALID_ARGUMENT, INTERNAL_ERROR, DEVICE_ERROR, NOT_IMPLEMENTED = 0, 1, 2, 3, 4
+OK, INVALID_ARGUMENT, INTERNAL_ERROR, DEVICE_ERROR, NOT_IMPLEMENTED, UNKNOWN_LAYOUT, ADM_ERROR = 0, 1, 2, 3, 4, 5, 6
 
 
 class EarHipError(Exception):
@@ -30,6 +30,14 @@ class InvalidArgument(EarHipError, ValueError):
 
 class InternalError(EarHipError, RuntimeError):
     """maps to ear::internal_error"""
+
+
+class UnknownLayout(InvalidArgument):
+    """maps to ear::unknown_layout"""
+
+
+class AdmError(InvalidArgument):
+    """maps to ear::adm_error"""
 
 
 class NotImplementedInLibear(EarHipError, RuntimeError):
@@ -72,6 +80,10 @@ def check(rc):
     msg = load().earhip_last_error().decode()
     if rc == INVALID_ARGUMENT:
         raise InvalidArgument(rc, msg)
+    if rc == UNKNOWN_LAYOUT:
+        raise UnknownLayout(rc, msg)
+    if rc == ADM_ERROR:
+        raise AdmError(rc, msg)
     if rc == NOT_IMPLEMENTED:
         raise NotImplementedInLibear(rc, msg)
     raise InternalError(rc, msg)

@@ -57,7 +57,7 @@ const LayoutEntry &find_layout(const char *name) {
   require(name != nullptr, "layout name must not be NULL");
   for (int i = 0; i < kNumLayouts; i++)
     if (std::strcmp(kLayouts[i].name, name) == 0) return kLayouts[i];
-  fail_invalid(std::string("unknown layout ") + name);
+  throw Error{EARHIP_UNKNOWN_LAYOUT, std::string("unknown layout: ") + name};
 }
 
 void design_for_names(const std::vector<std::string> &names, float *out) {

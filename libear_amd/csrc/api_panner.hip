@@ -356,7 +356,7 @@ const LayoutEntry &layout_entry(const char *name) {
   require(name != nullptr, "layout name must not be NULL");
   for (int i = 0; i < kNumLayouts; i++)
     if (std::strcmp(kLayouts[i].name, name) == 0) return kLayouts[i];
-  fail_invalid(std::string("unknown layout ") + name);
+  throw Error{EARHIP_UNKNOWN_LAYOUT, std::string("unknown layout: ") + name};
 }
 
 // the regions of a layout with precomputed hull facets (configureFullPolarPanner, :478-561).
@@ -734,7 +734,7 @@ int earhip_hoa_decode_matrix_positions(earhip_ctx *ctx, const char *layout, int 
     if (std::strcmp(normalization, "N3D") == 0) norm = kN3D;
     else if (std::strcmp(normalization, "SN3D") == 0) norm = kSN3D;
     else if (std::strcmp(normalization, "FuMa") == 0) norm = kFuMa;
-    else fail_invalid(std::string("ADM error: unknown normalization type: '") + normalization + "'");
+    else throw Error{EARHIP_ADM_ERROR, std::string("ADM error: unknown normalization type: '") + normalization + "'"};
     earhip_panner *pn = nullptr;
     const int st = earhip_panner_create_positions(ctx, layout, n_channels, azimuth, elevation, &pn);
     if (st != EARHIP_OK) throw Error{st, earhip_last_error()};

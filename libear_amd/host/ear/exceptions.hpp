@@ -21,4 +21,14 @@ namespace ear {
     explicit not_implemented(const std::string &what)
         : std::runtime_error("not implemented: " + what) {}
   };
+  /// invalid ADM metadata
+  class adm_error : public std::invalid_argument {
+   public:
+    explicit adm_error(const std::string &what) : std::invalid_argument("ADM error: " + what) {}
+  };
+  /// an unknown loudspeaker layout is requested
+  class unknown_layout : public std::invalid_argument {
+   public:
+    explicit unknown_layout(const std::string &what) : std::invalid_argument("unknown layout: " + what) {}
+  };
 }  // namespace ear

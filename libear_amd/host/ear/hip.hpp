@@ -10,12 +10,19 @@
 namespace ear {
   namespace hip {
     /// Translate an earhip status into libear's exception types
-    /// (include/earhip.h: 1 -> ear::invalid_argument, 2/3 -> ear::internal_error, 4 -> ear::not_implemented).
+    /// (include/earhip.h: 1 -> ear::invalid_argument, 2/3 -> ear::internal_error, 4 -> ear::not_implemented, 5 -> ear::unknown_layout, 6 -> ear::adm_error).
     inline void check(int status) {
       if (status == EARHIP_OK) return;
       const std::string msg = earhip_last_error();
       if (status == EARHIP_INVALID_ARGUMENT) throw invalid_argument(msg);
       if (status == EARHIP_NOT_IMPLEMENTED) throw not_implemented(msg);
+      // (the C ABI's messages carry the prefix these types add themselves)
+      auto strip = [&](const char *prefix) {
+        const std::string p(prefix);
+        return msg.compare(0, p.size(), p) == 0 ? msg.substr(p.size()) : msg;
+      };
+      if (status == EARHIP_UNKNOWN_LAYOUT) throw unknown_layout(strip("unknown layout: "));
+      if (status == EARHIP_ADM_ERROR) throw adm_error(strip("ADM error: "));
       throw internal_error(msg);
     }
 

@@ -597,7 +597,14 @@ static void test_layout_names() {
   bool threw = false;
   try {
     designDecorrelators("1+2+3");
-  } catch (const ear::invalid_argument &) {
+  } catch (const ear::unknown_layout &e) {  // (tests/bs2051_tests.cpp:25; libear's message)
+    threw = std::string(e.what()) == "unknown layout: 1+2+3";
+  }
+  CHECK(threw);
+  threw = false;
+  try {
+    getLayout("wat");
+  } catch (const std::invalid_argument &) {  // (unknown_layout is a std::invalid_argument, as in libear)
     threw = true;
   }
   CHECK(threw);
@@ -802,8 +809,14 @@ static void test_gain_calculator_hoa() {
   m.degrees[3] = -2;
   CHECK(throws_invalid(m));
   m = tm;
-  m.normalization = "foo";
-  CHECK(throws_invalid(m));
+  m.normalization = "foo";  // invalid ADM metadata: adm_error (src/hoa/gain_calculator_hoa.cpp:36-39)
+  bool adm = false;
+  try {
+    gc.calculate(m, gains);
+  } catch (const ear::adm_error &e) {
+    adm = std::string(e.what()) == "ADM error: unknown normalization type: 'foo'";
+  }
+  CHECK(adm);
   CHECK(!throws_invalid(tm));
   // warnings (tests/gain_calculator_hoa_tests.cpp:9-37): what is ignored is reported through the callback
   {

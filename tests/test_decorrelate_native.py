@@ -53,7 +53,7 @@ def test_native_layout_table(where):
                 assert az == sign * float(name[-3:])
                 assert el == {"M": 0.0, "U": 30.0, "B": -30.0, "T": 90.0}[name[0]] or name.startswith("UH")
     assert capi.layout_channels("9+10+3")[15] == ("T+000", 0.0, 90.0, False)
-    with pytest.raises(capi.InvalidArgument):
+    with pytest.raises(capi.UnknownLayout):
         capi.layout_channels("1+2+3")
     f = capi.design_decorrelators_for_layout("4+5+0", without_lfe=True)
     names = without_lfe(LAYOUTS["4+5+0"])

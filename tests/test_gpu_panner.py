@@ -90,7 +90,7 @@ def test_reference_known_answers_through_the_c_abi():
     d, _ = p.calculate([0.0, -30.0, -110.0, -180.0], [0.0] * 4)
     assert np.allclose(d, [[np.sqrt(0.5)] * 2, [0.0, 1.0], [0.0, np.sqrt(0.5)], [0.5, 0.5]], atol=1e-6)
     p.close()
-    with pytest.raises(capi.InvalidArgument):
+    with pytest.raises(capi.UnknownLayout):  # (an InvalidArgument kind: ear::unknown_layout)
         capi.Panner(ctx(), "7+7+7")
 
 
@@ -151,9 +151,9 @@ def test_hoa_exceptions():
                             ([0, 1, 1, 1], [0, -1, 0, -2])):
         with pytest.raises(capi.InvalidArgument):
             capi.hoa_decode_matrix(ctx(), "0+5+0", orders, degrees)
-    with pytest.raises(capi.InvalidArgument) as e:
+    with pytest.raises(capi.AdmError) as e:  # (an InvalidArgument kind: ear::adm_error)
         capi.hoa_decode_matrix(ctx(), "0+5+0", [0], [0], "foo")
-    assert "unknown normalization" in str(e.value)
+    assert "unknown normalization" in str(e.value) and isinstance(e.value, capi.InvalidArgument)
 
 
 def test_hoa_bed_through_the_renderer_with_the_real_decode_matrix():
