@@ -1,5 +1,6 @@
-// ear/warnings.hpp — libear's warning callback (include/ear/warnings.hpp:6-38, src/warnings.cpp:5-11): the gain
-// calculators report what they ignore through it.  Same type names and codes; header-only.
+// ear/warnings.hpp — the warning callback of libear's gain calculators (interface: include/ear/warnings.hpp:6-38,
+// default printer: src/warnings.cpp:5-11).  Header-only here; the codes keep libear's names and values so that
+// application code that switches on them is unaffected.
 #pragma once
 #include <cstdio>
 #include <functional>
@@ -7,25 +8,19 @@
 
 namespace ear {
   struct Warning {
-    enum class Code {
-      FREQ_SPEAKERLABEL_LFE_MISMATCH = 1,  ///< LFE indication from frequency element does not match speakerLabel
-      FREQ_NOT_LFE,                        ///< frequency indication present but does not indicate an LFE channel
-      FREQ_IGNORED,                        ///< frequency information is not implemented; ignoring
-      HOA_SCREENREF_NOT_IMPLEMENTED,       ///< screenRef for HOA is not implemented; ignoring
-      HOA_NFCREFDIST_NOT_IMPLEMENTED,      ///< nfcRefDist is not implemented; ignoring
+    // 1: LFE indication from the frequency element does not match speakerLabel; 2: frequency indication present
+    // but not that of an LFE channel; 3: frequency information ignored; 4, 5: HOA screenRef / nfcRefDist ignored
+    enum class Code : int {
+      FREQ_SPEAKERLABEL_LFE_MISMATCH = 1, FREQ_NOT_LFE = 2, FREQ_IGNORED = 3,
+      HOA_SCREENREF_NOT_IMPLEMENTED = 4, HOA_NFCREFDIST_NOT_IMPLEMENTED = 5
     };
-    Code code;
-    std::string message;
+    Code code;            // for programs that act on a warning
+    std::string message;  // for people: complete without the code
   };
 
-  /// passed into `calculate` calls, called with any warnings
-  using WarningCB = std::function<void(const Warning &warning)>;
+  // what `calculate` calls take and report through
+  typedef std::function<void(const Warning &)> WarningCB;
 
-  /// prints to stderr with the prefix `libear: warning: `
-  inline void default_warning_cb_fn(const Warning &warning) {
-    std::fputs("libear: warning: ", stderr);
-    std::fputs(warning.message.c_str(), stderr);
-    std::fputc('\n', stderr);
-  }
-  static const WarningCB default_warning_cb = default_warning_cb_fn;
+  // libear's default: one line on stderr, "libear: warning: <message>"
+  static const WarningCB default_warning_cb = [](const Warning &w) { std::fprintf(stderr, "libear: warning: %s\n", w.message.c_str()); };
 }  // namespace ear
