@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "layout.hpp"
+#include "screen.hpp"
 
 namespace ear {
   /// libear: boost::variant<CartesianPosition, PolarPosition> (common_types.hpp:26)
@@ -88,7 +89,8 @@ namespace ear {
     ChannelLock channelLock = {};
     ObjectDivergence objectDivergence = {};
     ZoneExclusion zoneExclusion = {};
-    bool screenRef = false;  ///< (libear also carries a referenceScreen; screen scaling is refused there as here)
+    bool screenRef = false;  ///< refused when set, as in libear
+    Screen referenceScreen = getDefaultScreen();
   };
 
   struct HOATypeMetadata {
@@ -97,5 +99,6 @@ namespace ear {
     std::string normalization = std::string("SN3D");
     double nfcRefDist = 0.0;  ///< ignored, as in libear (which warns)
     bool screenRef = false;   ///< ignored, as in libear (which warns)
+    Screen referenceScreen = getDefaultScreen();
   };
 }  // namespace ear

@@ -25,6 +25,7 @@
 #include "ear/dsp/dsp.hpp"
 #include "ear/ear.hpp"
 #include "ear/gain_calculators.hpp"
+#include "ear/screen.hpp"
 #include "ear/warnings.hpp"
 
 using namespace ear;
@@ -675,6 +676,8 @@ static void test_gain_calculator_objects() {
   m.screenRef = true;
   CHECK(refuses(m));
   CHECK(!refuses(base));
+  CHECK(!base.referenceScreen.isCartesian && base.referenceScreen.polar.widthAzimuth == 58.0 &&
+        getDefaultScreen().polar.aspectRatio == 1.78);  // (include/ear/screen.hpp, src/screen.cpp:4-6)
   // extent (tests/extent_tests.cpp:116-138): unit power, the velocity vector stays in the median plane and
   // points forwards (4+7+0 has no layer below, so it tilts up a little), more loudspeakers than a point source
   m = base;
