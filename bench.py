@@ -150,6 +150,25 @@ def producer_bench(args):
         sys.exit(3)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as a FRESH child
+    (`python -m torch.distributed.run ... bench.py <the same arguments>`), relay its output (rank 0's JSON line)
+    and leave with its exit code.  This process never touches the GPU (no torch import, no HIP call) and does
+    not replace itself: the child is an ordinary subprocess."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only does dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env)
+    sys.exit(res.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +210,8 @@ def main():
     args = ap.parse_args()
     if args.producer:
         return producer_bench(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     cfg = dict(PRESETS[args.config])
     for key, val in (("objects", args.objects), ("hoa", args.hoa), ("blocks", args.blocks),
                      ("block_size", args.block_size), ("layout", args.layout), ("buses", args.buses)):
@@ -209,6 +230,14 @@ def main():
     # one process per GPU; EARHIP_BENCH_BACKEND=gloo lets several ranks share one GPU (a functional
     # check of the multi-rank control flow on a single-GPU box, not a measurement)
     backend = os.environ.get("EARHIP_BENCH_BACKEND", "nccl")
+    shared_gpus = False
+    if world > torch.cuda.device_count() >= 1 and backend == "nccl":
+        # fewer GPUs than ranks (RCCL refuses two ranks on one device): the ranks share the GPUs and the
+        # collective runs over gloo — every rank sees the same count, so they all decide the same
+        backend, shared_gpus = "gloo", True
+        if rank == 0:
+            print(f"bench.py: {world} ranks on {torch.cuda.device_count()} GPU(s): ranks share devices, exchange over gloo "
+                  "(a functional check of the multi-rank path, not a measurement)", file=sys.stderr, flush=True)
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -240,13 +269,28 @@ def main():
     ctx = capi.Context(dev_index, stream.cuda_stream)
     ctx.set_strict(args.strict)
 
-    # the exchange step: torch.distributed's reduce_scatter_tensor (default) or the library's own RCCL
-    # communicator (EARHIP_BENCH_EXCHANGE=native: what a C++ caller of libearhip uses, earhip group J)
-    native_comm = None
-    if world > 1 and backend == "nccl" and os.environ.get("EARHIP_BENCH_EXCHANGE") == "native":
+    # the exchange step: the library's own RCCL communicator (default on the nccl backend: libearhip group J,
+    # what a C++ caller uses — reduce-scatter over the channels + gather of the shared bus on rank 0) or
+    # torch.distributed's reduce_scatter_tensor (EARHIP_BENCH_EXCHANGE=torch; the CPU backends).  Should the
+    # native communicator fail to come up on any rank, ALL ranks fall back to torch and the line says so.
+    native_comm, native_note = None, None
+    want_native = os.environ.get("EARHIP_BENCH_EXCHANGE", "native") != "torch"
+    if world > 1 and backend == "nccl" and want_native:
         box = [capi.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        native_comm = capi.Comm(ctx, rank, world, box[0])
+        err = None
+        try:
+            native_comm = capi.Comm(ctx, rank, world, box[0])
+        except Exception as e:  # noqa: BLE001 - any failure means "not native" for everybody
+            err = str(e)
+        ok = torch.tensor([0 if err else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if native_comm is not None:
+                native_comm.close()
+            native_comm = None
+            native_note = "earhip_comm_create failed on a rank" + (f" ({err})" if err else "") + ": torch.distributed exchange"
+    gather_root = 0  # the rank that ends up with the whole loudspeaker bus (north_star: "the shared loudspeaker bus")
 
     class Workload:
         """this rank's shard of a scene of `objects` objects (+ `hoa` bed channels on rank 0), resident
@@ -304,6 +348,9 @@ def main():
             self.outs = [torch.zeros((n_pad, total), device=dev, dtype=torch.float32) for _ in range(2)]
             self.owned = [torch.zeros((n_pad // world, total), device=dev, dtype=torch.float32) for _ in range(2)] \
                 if world > 1 else None
+            # the gathered bus: [n_pad][total] on the root rank (its first N rows are the loudspeaker feeds)
+            self.full = [torch.zeros((n_pad, total), device=dev, dtype=torch.float32) for _ in range(2)] \
+                if world > 1 and rank == gather_root else None
             self.r = self.renderer(context or ctx)
             self.pending = [None, None]
 
@@ -327,8 +374,15 @@ def main():
             if world > 1 and exchange_outputs:
                 if native_comm is not None:
                     native_comm.exchange_device(buf, self.outs[buf].data_ptr(), self.owned[buf].data_ptr(), n_pad // world, total)
+                    native_comm.gather_device(buf, self.owned[buf].data_ptr(),
+                                              self.full[buf].data_ptr() if self.full is not None else None,
+                                              n_pad // world, total, gather_root)
                 else:
                     _, work = exchange(self.outs[buf], self.owned[buf], async_op=True)
+                    if backend == "nccl":  # (gloo: the all-reduce leaves the whole bus on every rank already)
+                        work.wait()  # stream-orders the gather behind the reduce-scatter; does not block the host
+                        work = dist.gather(self.owned[buf], list(self.full[buf].split(n_pad // world)) if rank == gather_root
+                                           else None, dst=gather_root, async_op=True)
                     self.pending[buf] = work
 
         def drain(self):
@@ -412,9 +466,29 @@ def main():
         ref = part.clone()
         dist.all_reduce(ref, op=dist.ReduceOp.SUM)
         err = ((got - ref[rank * per:(rank + 1) * per]).abs().max() / ref.abs().max().clamp_min(1e-30))
+        if backend == "nccl" and rank == gather_root:  # ... and the bus gathered on the root equals all of it
+            err = torch.maximum(err, (wl.full[last][:, :w] - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
         err = err.to(torch.float64).reshape(1)
         dist.all_reduce(err, op=dist.ReduceOp.MAX)
         exchange_err = float(err.item())
+    # what the exchange moved and how fast (native communicator: HIP events around the collectives of the last
+    # two steps on its own stream — with the renders of the following step running beside them)
+    exchange_info = None
+    if world > 1:
+        per = n_pad // world
+        rs_bytes = (world - 1) * per * total * 4       # reduce-scatter: sent (and received) by every rank
+        ga_bytes = (world - 1) * per * total * 4       # gather: received by the root, one slice from every other rank
+        exchange_info = {"reduce_scatter_bytes_per_rank": rs_bytes, "gather_bytes_into_root": ga_bytes, "root": gather_root,
+                         "rows_per_rank": per, "row_floats": total}
+        if native_comm is not None:
+            ms = max(native_comm.last_exchange_ms(0), native_comm.last_exchange_ms(1))
+            tms = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+            ms = float(tms.item())
+            exchange_info["collectives_ms"] = round(ms, 4)
+            if ms > 0:  # bytes a rank sends in the reduce-scatter + what the root takes in, over the slower of the two
+                exchange_info["xgmi_GBps_per_rank_out"] = round(rs_bytes / ms / 1e6, 1)
+                exchange_info["xgmi_GBps_root_in"] = round((rs_bytes + ga_bytes) / ms / 1e6, 1)
     t_step = dt / args.steps
     value = M_total * total / t_step / 1e6
     rtf = (total / SAMPLE_RATE) / t_step
@@ -497,8 +571,12 @@ def main():
                 "workload": workload, "baseline_config": args.config,
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
                 "blocks_per_step": T, "buses": K, "scene": args.scene, "gains": gains_desc,
-                "parallelism": f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels"
-                               + (" (libearhip's own RCCL communicator)" if native_comm is not None else ""),
+                "parallelism": (f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels"
+                                + (f" + gather of the owned slices on rank {gather_root}" if world > 1 and backend == "nccl" else "")
+                                + (": libearhip's own RCCL communicator (earhip_comm, api_comm.hip)" if native_comm is not None
+                                   else f": torch.distributed ({backend})" if world > 1 else "")
+                                + (f" [{native_note}]" if native_note else "")
+                                + (" [ranks share GPUs: functional check, not a measurement]" if shared_gpus else "")),
                 "strict": bool(args.strict)},
             "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"),
                          "plan": {"tile_samples": plan["tile"], "tiles": plan["ntiles"], "object_splits": plan["gsplit"]},
@@ -513,6 +591,7 @@ def main():
             "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
             "exchange_check": None if exchange_err is None else
                               {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}")},
+            "exchange": exchange_info,
             "weak_scaling": weak,
             "kernel_timing": {"timed_steps": timed_steps, "every": time_every},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),

@@ -130,9 +130,9 @@ int earhip_gain_interp_process_device(earhip_gain_interp *gi, int64_t block_star
  * (B) FFT plugin — an r2c/c2r transform with libear's FFTPlan contract
  * (include/ear/fft.hpp:27-50): forward n_fft reals -> n_fft/2+1 unpacked
  * complex bins; reverse the inverse; both un-normalised.  Like libear's kissfft
- * plan (src/fft_kiss.cpp:104-107) any even n_fft is taken — here up to 8192 with
- * prime factors up to 97 (mixed radix 4/2/3/5 + a generic butterfly; the powers
- * of two from 64 have their own kernels).  Host pointers.
+ * plan (src/fft_kiss.cpp:104-107) any even n_fft is taken — here up to 8192
+ * (mixed radix 4/2/3/5 + kissfft's generic butterfly for every other prime; the
+ * powers of two from 64 have their own kernels).  Host pointers.
  * ---------------------------------------------------------------------- */
 typedef struct earhip_fft_plan earhip_fft_plan;
 int earhip_fft_plan_create(earhip_ctx *ctx, size_t n_fft, earhip_fft_plan **out);
@@ -143,8 +143,8 @@ int earhip_fft_reverse(earhip_fft_plan *plan, const float *in_complex, float *ou
 /* ------------------------------------------------------------------------
  * (C) BlockConvolver — replaces ear::dsp::block_convolver::{Context, Filter,
  * BlockConvolver} (include/ear/dsp/block_convolver.hpp:28-112; behaviour of
- * src/dsp/block_convolver_impl.cpp:10-243).  block_size in [1, 4096] with prime
- * factors up to 97 (480, 960, 1920 ... as well as the powers of two).
+ * src/dsp/block_convolver_impl.cpp:10-243).  block_size in [1, 4096], any
+ * factorisation (480, 960, 1920, 441, primes ... as well as the powers of two).
  * ---------------------------------------------------------------------- */
 typedef struct earhip_conv_ctx earhip_conv_ctx;
 typedef struct earhip_conv_filter earhip_conv_filter;
@@ -296,6 +296,10 @@ int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const d
                                           const double *width, const double *height,
                                           const double *depth, const double *gain,
                                           const double *diffuse, float *direct, float *diffuse_out);
+/* positions of the LAST *_device call that no region of the layout took (libear dereferences an empty
+ * optional there, src/object_based/gain_calculator_objects.cpp:46; the host-pointer forms turn it into
+ * EARHIP_INTERNAL_ERROR themselves): their gain rows are zero.  Synchronises the stream. */
+int earhip_panner_missed(earhip_panner *p, unsigned *count);
 
 /* (I, HOA) Decode matrix for scene-based (HOA) content — replaces ear::GainCalculatorHOA
  * (include/ear/gain_calculators.hpp:58-70, src/hoa/gain_calculator_hoa.cpp:8-72,
@@ -330,8 +334,8 @@ typedef struct earhip_render earhip_render;
 typedef struct earhip_render_config {
   int n_objects;  /* M: input channels handled by this instance (this GPU's shard) */
   int n_out;      /* N: loudspeakers */
-  int block_size; /* B in [16, 4096] with prime factors up to 97; the tuned kernels
-                     are the powers of two from 64 (512 and 1024 above all) */
+  int block_size; /* B in [16, 4096], any factorisation (as libear's kissfft); the tuned
+                     kernels are the powers of two from 64 (512 and 1024 above all) */
   int n_buses;    /* 1: direct bus only, written straight to the output
                      2: direct + diffuse with decorrelation, delay and mix */
   /* n_buses == 2: decorrelator FIRs [n_out][n_taps] (designDecorrelators,
@@ -376,8 +380,10 @@ int earhip_render_enable_timing(earhip_render *r, int enable);
  * launches.  Synchronises the stream. */
 int earhip_render_get_timing(earhip_render *r, double out[6]);
 /* Which gain kernel the last process call used: 0 = VALU with libear's exact
- * arithmetic (strict mode), 1 = f32 MFMA, 2 = bf16x3 MFMA, 3 = f16x2 MFMA (2, 3: all
- * curve points on tile boundaries); -1 before the first call. */
+ * arithmetic (strict mode), 1 = f32 MFMA over slot lists, 3 = f16x2-split MFMA (all
+ * curve points on the kernel's tile boundaries), 4 = f16x2-split MFMA over piece lists
+ * (metadata that ignores the tile grid); -1 before the first call.  (2 was the bf16x3
+ * kernel of the first round: removed.) */
 int earhip_render_gain_kernel(const earhip_render *r, int *kind);
 /* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
@@ -404,9 +410,17 @@ int earhip_render_last_plan(const earhip_render *r, int out[4]);
  *     communicator's own stream, so that it overlaps the next render; does not
  *     synchronise the host.  slot (0 or 1) names one of two exchanges in flight
  *     (double-buffered outputs);
+ *   earhip_comm_gather_device: the shared loudspeaker bus in ONE place — collects the
+ *     owned slices into full_dev [padded_rows][row_stride], on every rank (root < 0: one
+ *     all-gather) or on rank `root` only (the others send their slice straight to it,
+ *     world - 1 transfers over world - 1 different links at once; full_dev may be NULL
+ *     on the ranks that do not receive).  Runs on the communicator's stream behind the
+ *     exchange of the same slot; the first n_out rows of full_dev are the bus;
  *   earhip_comm_wait(slot): work enqueued on the context's stream after this call runs
- *     after the last exchange issued with that slot — call it before rendering into that
- *     slot's partial buffer again and before reading its owned buffer.
+ *     after the last exchange / gather issued with that slot — call it before rendering
+ *     into that slot's partial buffer again and before reading its owned / full buffer;
+ *   earhip_comm_last_exchange_ms: what the collectives of a slot took on the
+ *     communicator's stream (HIP events around them); waits for them.
  * ---------------------------------------------------------------------- */
 typedef struct earhip_comm earhip_comm;
 int earhip_comm_unique_id(void *id128);
@@ -415,7 +429,10 @@ int earhip_comm_destroy(earhip_comm *comm);
 int earhip_comm_channel_range(int n_out, int rank, int world, int *padded_rows, int *lo, int *hi);
 int earhip_render_exchange_device(earhip_comm *comm, int slot, const float *partial_dev,
                                   float *owned_dev, size_t rows_per_rank, size_t row_stride);
+int earhip_comm_gather_device(earhip_comm *comm, int slot, const float *owned_dev, float *full_dev,
+                              size_t rows_per_rank, size_t row_stride, int root);
 int earhip_comm_wait(earhip_comm *comm, int slot);
+int earhip_comm_last_exchange_ms(earhip_comm *comm, int slot, double *ms);
 
 #ifdef __cplusplus
 }

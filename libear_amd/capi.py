@@ -452,6 +452,12 @@ class Panner:
         check(load().earhip_panner_calculate_extent_device(self.h, C.c_size_t(n), vp(az), vp(el), vp(dist), vp(width), vp(height),
                                                            vp(depth), vp(gain), vp(diffuse), vp(direct), vp(diffuse_out)))
 
+    def missed(self):
+        """positions of the last calculate_device call that no region of the layout took (synchronises)"""
+        n = C.c_uint(0)
+        check(load().earhip_panner_missed(self.h, C.byref(n)))
+        return n.value
+
     def close(self):
         if self.h:
             load().earhip_panner_destroy(self.h)
@@ -483,9 +489,21 @@ class Comm:
         check(load().earhip_render_exchange_device(self.h, int(slot), C.c_void_p(partial_ptr), C.c_void_p(owned_ptr),
                                                    C.c_size_t(rows_per_rank), C.c_size_t(row_stride)))
 
+    def gather_device(self, slot, owned_ptr, full_ptr, rows_per_rank, row_stride, root=-1):
+        """the owned slices of all ranks -> full [world * rows_per_rank][row_stride] on every rank (root < 0) or on
+        `root` only (full_ptr may be None elsewhere)"""
+        check(load().earhip_comm_gather_device(self.h, int(slot), C.c_void_p(owned_ptr),
+                                               C.c_void_p(full_ptr) if full_ptr else None, C.c_size_t(rows_per_rank),
+                                               C.c_size_t(row_stride), int(root)))
+
     def wait(self, slot):
-        """orders the context's stream behind the last exchange issued with this slot"""
+        """orders the context's stream behind the last exchange / gather issued with this slot"""
         check(load().earhip_comm_wait(self.h, int(slot)))
+
+    def last_exchange_ms(self, slot):
+        ms = C.c_double(0.0)
+        check(load().earhip_comm_last_exchange_ms(self.h, int(slot), C.byref(ms)))
+        return ms.value
 
     def close(self):
         if self.h:
@@ -581,7 +599,8 @@ class Renderer:
                 "decor_launches": out[3], "prep_ms": out[4], "prep_launches": out[5]}
 
     def gain_kernel(self):
-        """0 strict VALU, 1 f32 MFMA, 2 bf16x3 MFMA, 3 f16x2 MFMA: the gain kernel of the last call"""
+        """0 strict VALU, 1 f32 MFMA (slot lists), 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists: the gain kernel of
+        the last call"""
         kind = C.c_int(-1)
         check(load().earhip_render_gain_kernel(self.h, C.byref(kind)))
         return kind.value

@@ -31,6 +31,10 @@ struct earhip_comm {
   hipStream_t xstream = nullptr;
   hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
   bool issued[2] = {false, false};
+  // timing of the collectives of a slot (events on the communicator's stream): [slot][begin, end]
+  hipEvent_t tev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool timed[2] = {false, false};  // some interval has been recorded
+  bool open_[2] = {false, false};  // an exchange opened the interval and no gather has closed it yet
 };
 
 extern "C" {
@@ -60,6 +64,8 @@ int earhip_comm_create(earhip_ctx *ctx, int rank, int world, const void *id128, 
     EARHIP_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
     EARHIP_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     for (auto &e : c->done) EARHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &s : c->tev)
+      for (auto &e : s) EARHIP_HIP(hipEventCreate(&e));
     *out = c.release();
   });
 }
@@ -74,6 +80,9 @@ int earhip_comm_destroy(earhip_comm *c) {
     if (c->ready) (void)hipEventDestroy(c->ready);
     for (auto e : c->done)
       if (e) (void)hipEventDestroy(e);
+    for (auto &s : c->tev)
+      for (auto e : s)
+        if (e) (void)hipEventDestroy(e);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     delete c;
   });
@@ -101,10 +110,72 @@ int earhip_render_exchange_device(earhip_comm *c, int slot, const float *partial
     // behind everything enqueued on the context's stream so far (the render that wrote partial_dev) ...
     EARHIP_HIP(hipEventRecord(c->ready, c->ctx->stream));
     EARHIP_HIP(hipStreamWaitEvent(c->xstream, c->ready, 0));
+    EARHIP_HIP(hipEventRecord(c->tev[slot][0], c->xstream));
     EARHIP_NCCL(ncclReduceScatter(partial_dev, owned_dev, rows_per_rank * row_stride, ncclFloat, ncclSum, c->comm, c->xstream));
+    EARHIP_HIP(hipEventRecord(c->tev[slot][1], c->xstream));
+    c->timed[slot] = c->open_[slot] = true;
     // ... and ahead of whatever the caller orders behind earhip_comm_wait(slot)
     EARHIP_HIP(hipEventRecord(c->done[slot], c->xstream));
     c->issued[slot] = true;
+  });
+}
+
+// The shared loudspeaker bus in one place: after the reduce-scatter rank r holds rows [r * per, (r + 1) * per);
+// this collects the owned slices into full_dev [world * per][row_stride] — on every rank (root < 0: one
+// ncclAllGather) or on one (root >= 0: the other ranks send their slice straight to it, G - 1 transfers over
+// G - 1 different xGMI links at once; full_dev may be NULL on the ranks that are not the root).  Runs on the
+// communicator's stream behind the exchange of the same slot and behind everything enqueued on the context's
+// stream so far; earhip_comm_wait(slot) orders the context's stream behind it.
+int earhip_comm_gather_device(earhip_comm *c, int slot, const float *owned_dev, float *full_dev,
+                              size_t rows_per_rank, size_t row_stride, int root) {
+  return guarded([&] {
+    require(c != nullptr && owned_dev != nullptr, "NULL argument");
+    require(slot == 0 || slot == 1, "slot must be 0 or 1");
+    require(rows_per_rank >= 1 && row_stride >= 1, "empty gather");
+    require(root < c->world, "root out of range");
+    require(full_dev != nullptr || (root >= 0 && root != c->rank), "full_dev must not be NULL on a rank that receives");
+    c->ctx->use();
+    const size_t count = rows_per_rank * row_stride;
+    EARHIP_HIP(hipEventRecord(c->ready, c->ctx->stream));
+    EARHIP_HIP(hipStreamWaitEvent(c->xstream, c->ready, 0));
+    if (!c->open_[slot]) EARHIP_HIP(hipEventRecord(c->tev[slot][0], c->xstream));
+    if (root < 0) {
+      EARHIP_NCCL(ncclAllGather(owned_dev, full_dev, count, ncclFloat, c->comm, c->xstream));
+    } else if (c->rank == root) {
+      EARHIP_NCCL(ncclGroupStart());
+      ncclResult_t res = ncclSuccess;
+      for (int r = 0; r < c->world && res == ncclSuccess; r++)
+        if (r != root) res = ncclRecv(full_dev + (size_t)r * count, count, ncclFloat, r, c->comm, c->xstream);
+      const ncclResult_t end = ncclGroupEnd();
+      EARHIP_NCCL(res);
+      EARHIP_NCCL(end);
+      if (full_dev + (size_t)root * count != owned_dev)
+        EARHIP_HIP(hipMemcpyAsync(full_dev + (size_t)root * count, owned_dev, sizeof(float) * count, hipMemcpyDeviceToDevice,
+                                  c->xstream));
+    } else {
+      EARHIP_NCCL(ncclSend(owned_dev, count, ncclFloat, root, c->comm, c->xstream));
+    }
+    EARHIP_HIP(hipEventRecord(c->tev[slot][1], c->xstream));
+    c->timed[slot] = true;
+    c->open_[slot] = false;
+    EARHIP_HIP(hipEventRecord(c->done[slot], c->xstream));
+    c->issued[slot] = true;
+  });
+}
+
+// Milliseconds the collectives of `slot` took on the communicator's stream (reduce-scatter, plus the gather
+// when one followed): waits for them.  0 when nothing was issued.
+int earhip_comm_last_exchange_ms(earhip_comm *c, int slot, double *ms) {
+  return guarded([&] {
+    require(c != nullptr && ms != nullptr, "NULL argument");
+    require(slot == 0 || slot == 1, "slot must be 0 or 1");
+    *ms = 0.0;
+    if (!c->timed[slot]) return;
+    c->ctx->use();
+    EARHIP_HIP(hipEventSynchronize(c->tev[slot][1]));
+    float t = 0.0f;
+    EARHIP_HIP(hipEventElapsedTime(&t, c->tev[slot][0], c->tev[slot][1]));
+    *ms = (double)t;
   });
 }
 

@@ -45,7 +45,7 @@ static void conv_ifft_ola_t(const cf *Y, const cf *tw, float *tail, int use_tail
 
 static FftShape shape_of(int L) {
   FftShape S;
-  if (!fft_make_shape(L, &S)) fail_invalid("FFT size must be in [4, 8192] with prime factors up to 97");
+  if (!fft_make_shape(L, &S)) fail_invalid("FFT size must be in [4, 8192]");
   return S;
 }
 static void ifft_real_rt(int L, const cf *in, const cf *tw, float *out, int rows, hipStream_t s) {
@@ -168,7 +168,7 @@ int earhip_fft_plan_create(earhip_ctx *ctx, size_t n_fft, earhip_fft_plan **out)
     // (kissfft's real transform needs an even length, submodules/kissfft/kiss_fftr.c; any factorisation)
     FftShape shape;
     require(n_fft % 2 == 0 && n_fft >= 2 && n_fft <= 8192 && fft_make_shape((int)n_fft, &shape),
-            "n_fft must be even, in [2, 8192], with prime factors up to 97");
+            "n_fft must be even and in [2, 8192]");
     ctx->use();
     std::unique_ptr<earhip_fft_plan> p(new earhip_fft_plan);
     p->ctx = ctx;
@@ -226,7 +226,7 @@ int earhip_conv_ctx_create(earhip_ctx *ctx, size_t block_size, earhip_conv_ctx *
     require(ctx != nullptr && out != nullptr, "NULL argument");
     FftShape shape;
     require(block_size >= 1 && block_size <= 4096 && fft_make_shape(2 * (int)block_size, &shape),
-            "block_size must be in [1, 4096] with prime factors up to 97");
+            "block_size must be in [1, 4096]");
     ctx->use();
     std::unique_ptr<earhip_conv_ctx> c(new earhip_conv_ctx);
     c->ctx = ctx;

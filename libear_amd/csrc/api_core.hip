@@ -494,6 +494,8 @@ int earhip_ctx_destroy(earhip_ctx *ctx) {
           break;
         }
     }
+    for (earhip_vbs *v : ctx->pinned_adapters) vbs_orphan(v);
+    ctx->pinned_adapters.clear();
     for (const auto &r : ctx->host_ranges) {
       if (r.owned) (void)hipHostFree(const_cast<char *>(r.base));
       else (void)hipHostUnregister(const_cast<char *>(r.base));

@@ -638,14 +638,10 @@ static void build_extent_table(earhip_panner &pn) {
   pn.E.chunk_sum = pn.ext_chunks.p + 4 * MC;
 }
 
-extern "C" {
-
-int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **out) {
-  return earhip_panner_create_positions(ctx, layout, 0, nullptr, nullptr, out);
-}
-
-int earhip_panner_create_positions(earhip_ctx *ctx, const char *layout, int n_channels, const double *azimuth,
-                                   const double *elevation, earhip_panner **out) {
+// with_extent = false: the point source panner alone (the HOA design only pans points: no extent grid to pan,
+// upload and wait for on every decode matrix)
+static int panner_create(earhip_ctx *ctx, const char *layout, int n_channels, const double *azimuth,
+                         const double *elevation, earhip_panner **out, bool with_extent) {
   return guarded([&] {
     require(ctx != nullptr && out != nullptr, "NULL argument");
     const LayoutEntry &L = layout_entry(layout);
@@ -687,9 +683,20 @@ int earhip_panner_create_positions(earhip_ctx *ctx, const char *layout, int n_ch
     p->missed.alloc_zero(1, ctx->stream);
     p->p_missed.reserve(1);
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-    build_extent_table(*p);
+    if (with_extent) build_extent_table(*p);
     *out = p.release();
   });
+}
+
+extern "C" {
+
+int earhip_panner_create(earhip_ctx *ctx, const char *layout, earhip_panner **out) {
+  return panner_create(ctx, layout, 0, nullptr, nullptr, out, true);
+}
+
+int earhip_panner_create_positions(earhip_ctx *ctx, const char *layout, int n_channels, const double *azimuth,
+                                   const double *elevation, earhip_panner **out) {
+  return panner_create(ctx, layout, n_channels, azimuth, elevation, out, true);
 }
 
 int earhip_panner_destroy(earhip_panner *p) {
@@ -736,7 +743,7 @@ int earhip_hoa_decode_matrix_positions(earhip_ctx *ctx, const char *layout, int 
     else if (std::strcmp(normalization, "FuMa") == 0) norm = kFuMa;
     else throw Error{EARHIP_ADM_ERROR, std::string("ADM error: unknown normalization type: '") + normalization + "'"};
     earhip_panner *pn = nullptr;
-    const int st = earhip_panner_create_positions(ctx, layout, n_channels, azimuth, elevation, &pn);
+    const int st = panner_create(ctx, layout, n_channels, azimuth, elevation, &pn, false);
     if (st != EARHIP_OK) throw Error{st, earhip_last_error()};
     std::unique_ptr<earhip_panner, int (*)(earhip_panner *)> guard(pn, earhip_panner_destroy);
     const size_t P = (size_t)kTDesignPoints, C = (size_t)n_coef;
@@ -848,7 +855,20 @@ int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const d
     require(npos < ((size_t)1 << 28), "too many positions");
     if (npos == 0) return;
     p->ctx->use();
+    // the counter of positions no region takes means "this call" (earhip_panner_missed reads it)
+    EARHIP_HIP(hipMemsetAsync(p->missed.p, 0, sizeof(unsigned), p->ctx->stream));
     launch_pan(p, npos, azimuth, elevation, distance, width, height, depth, gain, diffuse, direct, diffuse_out);
+  });
+}
+
+int earhip_panner_missed(earhip_panner *p, unsigned *count) {
+  return guarded([&] {
+    require(p != nullptr && count != nullptr, "NULL argument");
+    earhip_ctx *ctx = p->ctx;
+    ctx->use();
+    EARHIP_HIP(hipMemcpyAsync(p->p_missed.p, p->missed.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    *count = *p->p_missed.p;
   });
 }
 

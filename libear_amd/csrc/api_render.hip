@@ -49,7 +49,7 @@ void launch_spectrum(int L, const float *in, size_t stride, int n_valid, const c
     case 8192: launch_spectrum_t<8192>(in, stride, n_valid, tw, out, rows, s); break;
     default: {  // any other size: mixed radix at run time
       FftShape S;
-      if (!fft_make_shape(L, &S)) fail_invalid("FFT size must be in [4, 8192] with prime factors up to 97");
+      if (!fft_make_shape(L, &S)) fail_invalid("FFT size must be in [4, 8192]");
       hipLaunchKernelGGL(k_spectrum_real_rt, dim3(rows), dim3(kFftThreads), fft_rt_lds(k_spectrum_real_rt, L), s, S,
                          in, stride, n_valid, tw, out);
     }
@@ -80,7 +80,7 @@ static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s, 
     case 8192: launch_decor_t<8192>(P, grid, s); break;
     default: {  // any other block size: mixed-radix transforms at run time
       FftShape S;
-      if (!fft_make_shape(L, &S)) fail_invalid("block_size must be in [16, 4096] with prime factors up to 97");
+      if (!fft_make_shape(L, &S)) fail_invalid("block_size must be in [16, 4096]");
       const size_t lds = fft_rt_lds(k_decorrelate_delay_mix_rt, L, sizeof(float) * (L / 2));
       hipLaunchKernelGGL(k_decorrelate_delay_mix_rt, grid, dim3(256), lds, s, P, S);
     }
@@ -353,11 +353,11 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     require(ctx != nullptr && cfg != nullptr && out != nullptr, "NULL argument");
     require(cfg->n_objects >= 1 && cfg->n_out >= 1, "n_objects and n_out must be >= 1");
     require(cfg->n_buses == 1 || cfg->n_buses == 2, "n_buses must be 1 or 2");
-    // (any size libear's kissfft factorises with primes up to 97: 480, 960, 1920 ...; the tuned kernels are the
-    // power-of-two sizes from 64)
+    // (any size, as libear's kissfft: 480, 960, 1920 ... through mixed-radix passes, other primes through the
+    // generic butterfly; the tuned kernels are the power-of-two sizes from 64)
     FftShape shape;
     require(cfg->block_size >= 16 && cfg->block_size <= 4096 && fft_make_shape(2 * cfg->block_size, &shape),
-            "block_size must be in [16, 4096] with prime factors up to 97");
+            "block_size must be in [16, 4096]");
     require(cfg->max_blocks >= 1, "max_blocks must be >= 1");
     require((int64_t)cfg->max_blocks * cfg->block_size < ((int64_t)1 << 30),
             "max_blocks * block_size too large");

@@ -23,7 +23,16 @@ struct earhip_vbs {
   earhip_ctx *ctx = nullptr;
   std::vector<const float *> iptr;
   std::vector<float *> optr;
+  bool orphaned = false;  // the context that owned the pinned buffers was destroyed first
 };
+
+namespace earhip {
+void vbs_orphan(earhip_vbs *v) {
+  v->ctx = nullptr;
+  v->ibuf = v->obuf = nullptr;  // (freed with the context)
+  v->orphaned = true;
+}
+}  // namespace earhip
 
 extern "C" {
 
@@ -48,6 +57,7 @@ static void vbs_create(earhip_ctx *ctx, size_t block_size, size_t num_channels_i
     }
     v->obuf = static_cast<float *>(p);
     v->ctx = ctx;
+    ctx->pinned_adapters.push_back(v.get());
     std::fill(v->ibuf, v->ibuf + ni, 0.0f);
     std::fill(v->obuf, v->obuf + no, 0.0f);
   } else {
@@ -76,9 +86,11 @@ int earhip_vbs_create_pinned(earhip_ctx *ctx, size_t block_size, size_t num_chan
   });
 }
 
-// (an adapter with pinned buffers goes before its context)
+// (either order: a context destroyed first takes the pinned buffers with it and tells its adapters)
 int earhip_vbs_destroy(earhip_vbs *v) {
   if (v && v->ctx) {
+    auto &list = v->ctx->pinned_adapters;
+    list.erase(std::remove(list.begin(), list.end(), v), list.end());
     (void)earhip_host_release(v->ctx, v->ibuf);
     (void)earhip_host_release(v->ctx, v->obuf);
   }
@@ -92,6 +104,7 @@ int earhip_vbs_process(earhip_vbs *v, size_t nsamples, const float *const *in, f
   int cb_status = EARHIP_OK;
   const int rc = guarded([&] {
     require(v != nullptr, "adapter must not be NULL");
+    require(!v->orphaned, "the context that holds this adapter's buffers has been destroyed");
     require(nsamples == 0 || (in != nullptr && out != nullptr), "in and out must not be NULL");
     size_t done = 0;
     while (done < nsamples) {

@@ -112,6 +112,12 @@ struct PinBuf {
 
 }  // namespace earhip
 
+struct earhip_vbs;
+namespace earhip {
+// api_vbs.cpp: the context of an adapter with pinned buffers is going away (its buffers with it)
+void vbs_orphan(earhip_vbs *v);
+}  // namespace earhip
+
 struct earhip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -142,6 +148,9 @@ struct earhip_ctx {
     bool owned;  // earhip_host_alloc (freed with the context) or registered caller memory
   };
   std::vector<HostRange> host_ranges;
+  // adapters whose FIFO lives in this context's pinned memory (earhip_vbs_create_pinned): told when the
+  // context is destroyed first, so that their destroy does not touch a dead context
+  std::vector<earhip_vbs *> pinned_adapters;
   bool host_reachable(const void *p, size_t bytes) const {
     const char *c = static_cast<const char *>(p);
     for (const auto &r : host_ranges)

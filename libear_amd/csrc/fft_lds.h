@@ -1,5 +1,5 @@
 // fft_lds.h — complex FFT passes for data held in LDS: compile-time power-of-two sizes (the hot
-// sizes) and run-time mixed-radix sizes (FftShape, any length whose prime factors are <= 97).
+// sizes) and run-time mixed-radix sizes (FftShape: any length up to 8192, every prime factor).
 //
 // Stockham auto-sort formulation: pass with radix R and Ns = product of the
 // radices of the previous passes maps butterfly j in [0, L/R) as
@@ -108,22 +108,52 @@ struct FftShape {
   int npass;
   int radix[14];  // L <= 8192: at most 13 prime factors
 };
-constexpr int kFftMaxPrime = 97;
+constexpr int kFftMaxLen = 8192;
 
-// false: L has a prime factor above kFftMaxPrime (or is out of range)
+// Any length in [2, 8192], like kissfft (kissfft.hh:36-51: 4s, then 2s, then the odd primes in ascending
+// order, whatever they are — a prime p costs O(p) per output in the generic butterfly, there as here).
+// false: L is out of range.
 inline bool fft_make_shape(int L, FftShape *s) {
   s->L = L;
   s->npass = 0;
-  if (L < 2 || L > 8192) return false;
+  if (L < 2 || L > kFftMaxLen) return false;
   int rest = L;
   while (rest % 4 == 0) s->radix[s->npass++] = 4, rest /= 4;
-  for (int p = 2; p <= kFftMaxPrime && rest > 1; p++)
+  for (int p = 2; p * p <= rest; p++)
     while (rest % p == 0) {
       if (s->npass == 14) return false;
       s->radix[s->npass++] = p;
       rest /= p;
     }
-  return rest == 1;
+  if (rest > 1) {  // what is left is a prime
+    if (s->npass == 14) return false;
+    s->radix[s->npass++] = rest;
+  }
+  return true;
+}
+EARHIP_HD bool fft_radix_is_generic(int R) { return R > 5; }
+
+// output q of the generic radix-R butterfly j (R any prime): X_q = sum_r (in_r W_{Ns R}^{k r}) W_R^{r q},
+// W_R^{r q} = tw[(r q mod R) M] — terms added in the order r = 0, 1, ... (kissfft's kf_bfly_generic,
+// kissfft.hh:300-340).  One (j, q) pair per call so that a pass with few, large butterflies (L = 2 p) still
+// spreads over a whole workgroup.
+template <int DIR>
+EARHIP_HD void stockham_generic_q(const cf *in, cf *out, const cf *tw, int L, int R, int Ns, int j, int q) {
+  const int k = j % Ns;
+  const int M = L / R;
+  const int step = L / (Ns * R);
+  const int base = (j - k) * R + k;
+  cf acc = in[j];
+  int rq = 0, rk = 0;  // r q mod R and r k step (< L)
+  for (int r = 1; r < R; r++) {
+    rq += q;
+    if (rq >= R) rq -= R;
+    rk += k * step;
+    cf v = in[j + r * M];
+    if (Ns > 1) v = cf_mul(v, tw_load<DIR>(tw, rk));
+    acc = cf_add(acc, cf_mul(v, tw_load<DIR>(tw, rq * M)));
+  }
+  out[base + q * Ns] = acc;
 }
 
 // one radix-R butterfly of a pass over L points, j in [0, L / R)
@@ -188,19 +218,8 @@ EARHIP_HD void stockham_any(const cf *in, cf *out, const cf *tw, int L, int R, i
     out[base + 2 * Ns] = cf_add(m2, r2);
     out[base + 3 * Ns] = cf_sub(m2, r2);
     out[base + 4 * Ns] = cf_sub(m1, r1);
-  } else {  // any other prime: X_q = sum_r (in_r W_{Ns R}^{k r}) W_R^{r q},  W_R^{r q} = tw[(r q mod R) M]
-    for (int q = 0; q < R; q++) {
-      cf acc = in[j];
-      int rq = 0;
-      for (int r = 1; r < R; r++) {
-        rq += q;
-        if (rq >= R) rq -= R;
-        cf v = in[j + r * M];
-        if (Ns > 1) v = cf_mul(v, tw_load<DIR>(tw, r * k * step));
-        acc = cf_add(acc, cf_mul(v, tw_load<DIR>(tw, rq * M)));
-      }
-      out[base + q * Ns] = acc;
-    }
+  } else {  // any other prime
+    for (int q = 0; q < R; q++) stockham_generic_q<DIR>(in, out, tw, L, R, Ns, j, q);
   }
 }
 
@@ -246,7 +265,12 @@ __device__ __forceinline__ cf *fft_run_shape(cf *src, cf *dst, const cf *tw, con
   for (int p = 0; p < S.npass; ++p) {
     const int R = S.radix[p];
     __syncthreads();
-    for (int j = tid; j < S.L / R; j += NT) stockham_any<DIR>(src, dst, tw, S.L, R, Ns, j);
+    if (fft_radix_is_generic(R)) {  // one output per thread and step: L outputs of O(R) each
+      const int M = S.L / R;
+      for (int idx = tid; idx < S.L; idx += NT) stockham_generic_q<DIR>(src, dst, tw, S.L, R, Ns, idx % M, idx / M);
+    } else {
+      for (int j = tid; j < S.L / R; j += NT) stockham_any<DIR>(src, dst, tw, S.L, R, Ns, j);
+    }
     cf *t = src;
     src = dst;
     dst = t;

@@ -59,7 +59,8 @@ static_assert(sizeof(SegDesc) == 16, "SegDesc is loaded as one dwordx4");
 constexpr int kSegRamp = 1;
 constexpr int kSegMulti = 2;
 constexpr int kSegQuiet = (int)0x80000000u;  // the object's input level is far below the call's (LevelProbe)
-constexpr int kMaxPointsPerObject = 1 << 18;
+constexpr int kMaxPointsPerObject = (1 << 18) - 1;  // the k field of a descriptor: 18 bits below the quiet flag
+static_assert((((unsigned)kMaxPointsPerObject << 13) & (unsigned)kSegQuiet) == 0u, "the segment index must not reach the quiet flag");
 __host__ __device__ __forceinline__ int seg_r1(int info) { return (info >> 4) & 0x1ff; }
 __host__ __device__ __forceinline__ int seg_k(int info) { return (info >> 13) & 0x3ffff; }
 

@@ -30,9 +30,16 @@ namespace ear {
       /// Static data for one block size; shareable between Filters and BlockConvolvers.
       class Context {
        public:
-        /// The FFT implementation argument is part of libear's signature; the
-        /// device path always uses its own transform, so it is ignored.
-        Context(size_t block_size, FFTImpl<real_t> &) : Context(block_size) {}
+        /// libear's signature (include/ear/dsp/block_convolver.hpp:34).  The device path transforms on the GPU:
+        /// the plugin that IS that transform — get_fft_hip(), which get_fft_kiss<float>() also returns here — is
+        /// accepted; any other FFTImpl would have to run on the host (the CPU fallback this library does not
+        /// have) and is refused with ear::invalid_argument instead of being dropped silently.
+        Context(size_t block_size, FFTImpl<real_t> &fft) : Context(block_size) {
+          if (&fft != &get_fft_hip())
+            throw invalid_argument(
+                "block_convolver::Context: this FFTImpl is not the device transform (pass ear::get_fft_hip() or "
+                "ear::get_fft_kiss<float>(); a host FFT plugin cannot run inside the device BlockConvolver)");
+        }
         explicit Context(size_t block_size) : impl(std::make_shared<detail::CtxHandle>()) {
           hip::check(earhip_conv_ctx_create(hip::default_context().get(), block_size, &impl->h));
         }

@@ -64,7 +64,7 @@ namespace ear {
     };
   }  // namespace hip
 
-  /// Device-backed FFT implementation (even sizes in [4, 8192] whose prime factors are at most 97).
+  /// Device-backed FFT implementation (every even size in [2, 8192], any factorisation, like libear's kissfft).
   inline FFTImpl<float> &get_fft_hip() {
     static hip::FFTHip fft;
     return fft;

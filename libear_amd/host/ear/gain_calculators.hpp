@@ -46,10 +46,13 @@ namespace ear {
     GainCalculatorObjects(const GainCalculatorObjects &) = delete;
     GainCalculatorObjects &operator=(const GainCalculatorObjects &) = delete;
 
-    /// one metadata block -> direct and diffuse gain vectors (resized to the layout's channel count)
+    /// one metadata block -> direct and diffuse gain vectors, which must have the layout's channel count
+    /// (libear: OutputGainsT::check_size, include/ear/helpers/output_gains.hpp:40-43)
     template <typename T>
     void calculate(const ObjectsTypeMetadata &metadata, std::vector<T> &directGains, std::vector<T> &diffuseGains,
                    const WarningCB & = default_warning_cb) {  // (libear's Objects calculator emits no warnings either)
+      if (directGains.size() != keep_.size() || diffuseGains.size() != keep_.size())
+        throw invalid_argument("incorrect size for output vector");
       std::vector<std::vector<T>> d, f;
       calculate(std::vector<ObjectsTypeMetadata>(1, metadata), d, f);
       directGains = d[0];

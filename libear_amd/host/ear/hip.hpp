@@ -87,7 +87,18 @@ namespace ear {
       void exchange(int slot, const float *partial_dev, float *owned_dev, int n_out, size_t row_stride) {
         check(earhip_render_exchange_device(comm_, slot, partial_dev, owned_dev, (size_t)(padded_rows(n_out) / world_), row_stride));
       }
+      /// the shared loudspeaker bus in one place: the owned slices -> full_dev [padded_rows][row_stride] on every
+      /// rank (root < 0) or on rank `root` only (full_dev may be null elsewhere); its first n_out rows are the bus
+      void gather(int slot, const float *owned_dev, float *full_dev, int n_out, size_t row_stride, int root = -1) {
+        check(earhip_comm_gather_device(comm_, slot, owned_dev, full_dev, (size_t)(padded_rows(n_out) / world_), row_stride, root));
+      }
       void wait(int slot) { check(earhip_comm_wait(comm_, slot)); }
+      /// milliseconds the collectives of `slot` took on the communicator's stream (waits for them)
+      double last_exchange_ms(int slot) {
+        double ms = 0.0;
+        check(earhip_comm_last_exchange_ms(comm_, slot, &ms));
+        return ms;
+      }
       int rank() const { return rank_; }
       int world() const { return world_; }
 

@@ -38,10 +38,10 @@ namespace ear {
     /// allowed ranges of the real position: azimuth from .first anticlockwise to .second, elevation from
     /// .first up to .second; default: the nominal position itself (:21-30, src/layout.cpp:26-33)
     std::pair<double, double> azimuthRange() const {
-      return has_az_ ? az_range_ : std::make_pair(nominal_.azimuth, nominal_.azimuth);
+      return has_az_ ? az_range_ : std::make_pair(pos_.azimuth, pos_.azimuth);  // (libear: the REAL position, src/layout.cpp:24-28)
     }
     std::pair<double, double> elevationRange() const {
-      return has_el_ ? el_range_ : std::make_pair(nominal_.elevation, nominal_.elevation);
+      return has_el_ ? el_range_ : std::make_pair(pos_.elevation, pos_.elevation);  // (src/layout.cpp:29-33)
     }
     void azimuthRange(std::pair<double, double> r) { az_range_ = r, has_az_ = true; }
     void elevationRange(std::pair<double, double> r) { el_range_ = r, has_el_ = true; }

@@ -622,9 +622,29 @@ static void test_gain_calculator_objects() {
       ok = std::fabs(g[i] - (layout.channels()[i].name() == name ? value : 0.0)) < 1e-6;
     return ok;
   };
-  std::vector<float> direct, diffuse;
+  std::vector<float> direct(11), diffuse(11);  // (as libear's tests size them, tests/gain_calculator_objects_tests.cpp:80-81)
   ObjectsTypeMetadata otm;
   otm.position = PolarPosition(0.0, 0.0, 1.0);
+  {  // an output vector of the wrong size is refused, not resized (include/ear/helpers/output_gains.hpp:40-43)
+    std::vector<float> small(10), none;
+    bool threw = false;
+    try {
+      calc.calculate(otm, small, diffuse);
+    } catch (const ear::invalid_argument &e) {
+      threw = std::string(e.what()).find("incorrect size for output vector") != std::string::npos;
+    }
+    CHECK(threw);
+    threw = false;
+    try {
+      calc.calculate(otm, direct, none);
+    } catch (const ear::invalid_argument &) {
+      threw = true;
+    }
+    CHECK(threw);
+    // a channel without explicit ranges stands where it really stands (src/layout.cpp:24-33)
+    Channel moved("X", PolarPosition(12.0, 3.0, 1.0), PolarPosition(10.0, 0.0, 1.0));
+    CHECK(moved.azimuthRange() == std::make_pair(12.0, 12.0) && moved.elevationRange() == std::make_pair(3.0, 3.0));
+  }
   calc.calculate(otm, direct, diffuse);
   CHECK(only(direct, "M+000", 1.0) && only(diffuse, "", 0.0));
   otm.position = PolarPosition(30.0, 0.0, 1.0);
@@ -968,9 +988,71 @@ static void test_pinned_channel_buffers() {
   CHECK(threw);
 }
 
+// libear's one run-time plugin point (include/ear/fft.hpp:54-62, include/ear/dsp/block_convolver.hpp:34): the
+// device transform is accepted under both of its names, a foreign FFTImpl is refused — not dropped
+static void test_fft_plugin_point() {
+  struct ForeignFFT : FFTImpl<float> {
+    std::shared_ptr<FFTPlan<float>> plan(size_t) const override { return nullptr; }
+  } foreign;
+  using ear::dsp::block_convolver::Context;
+  bool threw = false;
+  try {
+    Context ctx(512, foreign);
+  } catch (const ear::invalid_argument &) {
+    threw = true;
+  }
+  CHECK(threw);
+  bool ok = true;
+  try {
+    Context a(512, get_fft_hip());
+    Context b(480, get_fft_kiss<float>());
+    Context c(2 * 101, get_fft_hip());  // (a prime above 5: kissfft's generic butterfly, here too)
+  } catch (const std::exception &e) {
+    std::printf("  %s\n", e.what());
+    ok = false;
+  }
+  CHECK(ok);
+  CHECK(&get_fft_kiss<float>() == &get_fft_hip());
+}
+
+// the multi-GPU exchange through the mirror (ear::hip::Communicator), as far as one GPU goes: a one-rank
+// communicator's reduce-scatter and gather are copies; buffers in device-reachable host memory
+static void test_communicator_single_rank() {
+  ear::hip::Context &hc = ear::hip::default_context();
+  const int n_out = 10;
+  const size_t stride = 256;
+  ear::hip::Communicator comm(hc, 0, 1, ear::hip::Communicator::unique_id());
+  CHECK(comm.padded_rows(n_out) == n_out);
+  int lo = -1, hi = -1;
+  comm.channel_range(n_out, lo, hi);
+  CHECK(lo == 0 && hi == n_out);
+  float *partial = hc.alloc_host(n_out * stride), *owned = hc.alloc_host(n_out * stride), *full = hc.alloc_host(n_out * stride);
+  for (size_t i = 0; i < n_out * stride; i++) partial[i] = (float)i * 0.25f, owned[i] = full[i] = -1.0f;
+  comm.exchange(0, partial, owned, n_out, stride);
+  comm.gather(0, owned, full, n_out, stride, 0);
+  comm.wait(0);
+  hc.synchronize();
+  bool same = true;
+  for (size_t i = 0; i < n_out * stride; i++) same = same && owned[i] == partial[i] && full[i] == partial[i];
+  CHECK(same);
+  CHECK(comm.last_exchange_ms(0) >= 0.0);
+  for (size_t i = 0; i < n_out * stride; i++) full[i] = -1.0f;
+  comm.gather(1, owned, full, n_out, stride);  // all-gather form
+  comm.wait(1);
+  hc.synchronize();
+  same = true;
+  for (size_t i = 0; i < n_out * stride; i++) same = same && full[i] == partial[i];
+  CHECK(same);
+  hc.release_host(full);
+  hc.release_host(owned);
+  hc.release_host(partial);
+}
+
 int main() {
   try {
     test_no_allocation_in_process();
+    test_fft_plugin_point();
+    test_communicator_single_rank();
     test_pinned_channel_buffers();
     test_gain_calculator_hoa();
     test_gain_calculator_objects();

@@ -83,6 +83,31 @@ def test_multi_rank_control_flow_on_one_gpu_over_gloo(nproc, layout):
     assert line["weak_scaling"]["objects_total"] == 96 * nproc and line["weak_scaling"]["value"] > 0
 
 
+def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver runs the N = 1 command, no launcher around it: bench.py
+    starts its ranks itself (a fresh torchrun child) and relays rank 0's line.  On a one-GPU box the two ranks share
+    the device and the exchange runs over gloo (said in config.parallelism); on a multi-GPU node the same command
+    runs one rank per GPU on libearhip's own RCCL communicator."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["EARHIP_BENCH_CHECK"] = "force"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--objects", "128", "--blocks", "32", "--steps", "3",
+           "--warmup", "1", "--cpu-blocks", "0"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=e, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["objects_per_gpu"] == 64
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert "ranks share GPUs" in line["config"]["parallelism"]
+    else:
+        assert "earhip_comm" in line["config"]["parallelism"]
+        assert line["exchange"]["collectives_ms"] > 0
+    assert line["exchange"]["reduce_scatter_bytes_per_rank"] == 12 * 32 * 512 * 4
+    assert line["exchange_check"]["max_rel_err_owned_slice_vs_all_reduce"] <= 1e-6
+
+
 def test_producer_line():
     """bench.py --producer: the Objects gain producer with extent through device pointers, parity-gated"""
     line = run_bench(["--producer", "20000", "--steps", "3", "--warmup", "1"])

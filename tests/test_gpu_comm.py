@@ -31,6 +31,7 @@ def test_single_rank_exchange_orders_behind_the_render_and_overlaps():
     x = torch.rand((m, total), device="cuda") * 2 - 1
     part = [torch.zeros((pad, total), device="cuda") for _ in range(2)]
     owned = [torch.full((pad, total), -7.0, device="cuda") for _ in range(2)]
+    full = [torch.full((pad, total), -9.0, device="cuda") for _ in range(2)]
     torch.cuda.synchronize()
     for step in range(6):  # double-buffered: render into slot s, exchange it, meanwhile render the other slot
         s = step % 2
@@ -38,11 +39,19 @@ def test_single_rank_exchange_orders_behind_the_render_and_overlaps():
         r.reset(0)
         r.process_device(nblocks, x.data_ptr(), total, part[s].data_ptr(), total)
         comm.exchange_device(s, part[s].data_ptr(), owned[s].data_ptr(), pad, total)
+        # the shared bus in one place: gather to a root (slot 0) / all-gather (slot 1), behind the exchange
+        comm.gather_device(s, owned[s].data_ptr(), full[s].data_ptr(), pad, total, root=0 if s == 0 else -1)
     comm.wait(0)
     comm.wait(1)
     ctx().synchronize()
     assert torch.equal(owned[0], part[0]) and torch.equal(owned[1], part[1])
     assert torch.equal(owned[0], owned[1]) and float(owned[0].abs().max()) > 0
+    assert torch.equal(full[0], part[0]) and torch.equal(full[1], part[1])
+    assert comm.last_exchange_ms(0) > 0.0 and comm.last_exchange_ms(1) > 0.0
+    with pytest.raises(capi.InvalidArgument):
+        comm.gather_device(0, owned[0].data_ptr(), None, pad, total, root=0)  # the root must have a buffer
+    with pytest.raises(capi.InvalidArgument):
+        comm.gather_device(0, owned[0].data_ptr(), full[0].data_ptr(), pad, total, root=1)  # no such rank
     comm.close()
     r.close()
     for bad in ((10, 4, 4), (0, 0, 1)):

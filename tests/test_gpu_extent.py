@@ -120,6 +120,20 @@ def test_large_batch_and_device_pointers():
     d, f = p.calculate(az, el, dist, gain, diffuse, width, height, depth)
     k = 4096
     d2, f2 = p.calculate(az[:k], el[:k], dist[:k], gain[:k], diffuse[:k], width[:k], height[:k], depth[:k])
+    # the same through device pointers (what a renderer feeds its curves from): same bits, and the counter of
+    # positions no region took — which the host-pointer form turns into an error itself — reads zero for this call
+    import torch
+    dev = {q: torch.from_numpy(np.ascontiguousarray(v[:k], np.float64)).cuda()
+           for q, v in (("az", az), ("el", el), ("dist", dist), ("gain", gain), ("diffuse", diffuse), ("width", width),
+                        ("height", height), ("depth", depth))}
+    dd = torch.empty((k, p.n_out), dtype=torch.float32, device="cuda")
+    df = torch.empty_like(dd)
+    torch.cuda.synchronize()
+    p.calculate_device(k, dev["az"].data_ptr(), dev["el"].data_ptr(), dev["dist"].data_ptr(), dev["gain"].data_ptr(),
+                       dev["diffuse"].data_ptr(), dd.data_ptr(), df.data_ptr(), dev["width"].data_ptr(),
+                       dev["height"].data_ptr(), dev["depth"].data_ptr())
+    assert p.missed() == 0
+    assert np.array_equal(dd.cpu().numpy(), d2) and np.array_equal(df.cpu().numpy(), f2)
     p.close()
     assert np.array_equal(d[:k], d2) and np.array_equal(f[:k], f2)
     o = _oracle.PolarExtent("4+5+0")
