@@ -97,7 +97,35 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     slow_next = ctx->tile_slow.p + (size_t)(ctx->tile_slow_idx ^ 1) * ctx->tile_slow_cap;
     ctx->tile_slow_idx ^= 1;
   }
-  if (!fused_prep) {
+  // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch;
+  // EARHIP_P2_BUILD=0 keeps the three-kernel path of round 2 (k_seg_prep + k_mark_quiet + k_piece_list) for A/B runs
+  static const bool one_pass_env = !(getenv("EARHIP_P2_BUILD") && atoi(getenv("EARHIP_P2_BUILD")) == 0);
+  const bool one_pass = ml.pieces && one_pass_env;
+  if (one_pass) {
+    if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
+    unsigned *obj_lv = nullptr;
+    if (probe.obj_level) {
+      // (its own half of the per-object words: k_seg_prep's form of the probe expects its half zero between calls)
+      obj_lv = ctx->obj_level.p + M + 32;
+      hipLaunchKernelGGL(k_level_probe, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M,
+                         ml.ntiles, ml.tile(), probe.every, level_cur, obj_lv);
+    }
+    // tiles per workgroup: two 1024-thread workgroups fit a CU (52 VGPRs), so up to 2 x CUs workgroups run at once
+    int tpw = 1;
+    while (tpw < 8 && ml.ntiles / (2 * tpw) >= 2 * ctx->num_cus) tpw *= 2;
+    if (const char *e = getenv("EARHIP_BUILD_TPW")) {  // tuning knob
+      const int v = atoi(e);
+      if (v == 1 || v == 2 || v == 4 || v == 8) tpw = v;
+    }
+    const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
+#define EARHIP_BUILD_CASE(T_)                                                                                          \
+  if (tpw == T_)                                                                                                       \
+    hipLaunchKernelGGL(k_piece_build<T_>, bgrid, dim3(kBuildThreads), 0, ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, \
+                       t_call + nsamples, pl, obj_lv, level_cur);
+    EARHIP_BUILD_CASE(1) EARHIP_BUILD_CASE(2) EARHIP_BUILD_CASE(4) EARHIP_BUILD_CASE(8)
+#undef EARHIP_BUILD_CASE
+  }
+  if (!fused_prep && !one_pass) {
     const dim3 ogrid((M + 15) / 16);
     if (ml.ntiles >= 2048)
       hipLaunchKernelGGL(k_seg_prep<4>, dim3((ml.ntiles + 63) / 64, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
@@ -114,11 +142,11 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (slots)
     hipLaunchKernelGGL(k_slot_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
-  if (probe.obj_level)
+  if (probe.obj_level && !one_pass)
     hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
                        level_cur, slow_cur);
   // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
-  if (ml.pieces) {
+  if (ml.pieces && !one_pass) {
     if (fused_prep) fail_internal("piece lists need the descriptors of k_seg_prep");
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(), t_call,

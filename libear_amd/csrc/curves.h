@@ -115,18 +115,20 @@ class CurveSet {
     for (int m = 0; m < M_; m++) P += times_[m].size();
     const size_t row = (size_t)plan_.row;
     if (staged_) EARHIP_HIP(hipEventSynchronize(staged_));  // staging buffers free again
-    if (M_ + 1 > (int)h_off_.n || P > h_time_.n || (P + 2) * row > h_gain_.n) {
+    if (M_ + 1 > (int)h_off_.n || P > h_time_.n || P > h_rec_.n || (P + 2) * row > h_gain_.n) {
       const size_t cap = P + P / 2 + 16;  // grow with headroom: appending points stays cheap
       h_off_.reserve(M_ + 1);
       h_time_.reserve(cap);
       h_flat_.reserve(cap);
+      h_rec_.reserve(cap);
       h_gain_.reserve((cap + 2) * row);
     }
-    if (P > d_time_.n || (P + 2) * row > d_gain_.n || (size_t)M_ + 1 > d_off_.n) {
+    if (P > d_time_.n || P > d_rec_.n || (P + 2) * row > d_gain_.n || (size_t)M_ + 1 > d_off_.n) {
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // the old image may still be in use
       d_off_.reserve(M_ + 1);
       d_time_.reserve(h_time_.n);
       d_flat_.reserve(h_flat_.n);
+      d_rec_.reserve(h_rec_.n);
       d_gain_.reserve(h_gain_.n);
     }
     size_t at = 0;
@@ -136,6 +138,13 @@ class CurveSet {
       std::memcpy(h_time_.p + at, times_[m].data(), n * sizeof(int64_t));
       std::memcpy(h_gain_.p + at * row, gains_[m].data(), n * row * sizeof(float));
       std::memcpy(h_flat_.p + at, flat_[m].data(), n);
+      for (size_t k = 0; k < n; k++) {
+        PointRec &r = h_rec_.p[at + k];
+        r.time = times_[m][k];
+        const int64_t len = k ? times_[m][k] - times_[m][k - 1] : 0;
+        r.scale = len > 0 ? 1.0f / (float)len : 0.0f;  // describe_segment's own expression (gain_kernels.h)
+        r.flat = flat_[m][k];
+      }
       at += n;
     }
     h_off_.p[M_] = (int32_t)at;
@@ -217,6 +226,7 @@ class CurveSet {
     EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, (M_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, P * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, P, hipMemcpyHostToDevice, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(d_rec_.p, h_rec_.p, P * sizeof(PointRec), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, (P + 2) * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (!staged_) EARHIP_HIP(hipEventCreateWithFlags(&staged_, hipEventDisableTiming));
     EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
@@ -264,6 +274,7 @@ class CurveSet {
     ps.off = d_off_.p;
     ps.time = d_time_.p;
     ps.flat = d_flat_.p;
+    ps.rec = d_rec_.p;
     ps.gain = d_gain_.p;
     ps.row = plan_.row;
     ps.bus_cols = ncols_ / nbus_;
@@ -292,10 +303,12 @@ class CurveSet {
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
+  DevBuf<PointRec> d_rec_;
   DevBuf<float> d_gain_;
   PinBuf<int32_t> h_off_;
   PinBuf<int64_t> h_time_;
   PinBuf<uint8_t> h_flat_;
+  PinBuf<PointRec> h_rec_;
   PinBuf<float> h_gain_;
   hipEvent_t staged_ = nullptr;
   std::vector<int64_t> scratch_phase_, scratch_sorted_;

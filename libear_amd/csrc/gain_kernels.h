@@ -30,11 +30,22 @@
 
 namespace earhip {
 
+// One curve point as the list builder of the piece-list kernel reads it (gain_p2.h): everything about the segment
+// that ENDS at this point in one 16-byte load.
+struct PointRec {
+  int64_t time;    // the point's time
+  float scale;     // 1.0f / (float)(time - previous point's time) (gain_interpolator.hpp:191,221,255); 0 for the first
+                   // point of an object and for two equal times
+  uint32_t flat;   // bit b: bus b's gain vector equals the previous point's
+};
+static_assert(sizeof(PointRec) == 16, "PointRec is loaded as one dwordx4");
+
 // Flattened gain curves of all objects (device pointers).
 struct PointStore {
   const int32_t *off;    // [M+1] first point of each object
   const int64_t *time;   // [P]   point times, sorted per object
   const uint8_t *flat;   // [P]   bit b: bus b's gain vector at point k equals point k-1
+  const PointRec *rec;   // [P]   the same three facts per point, packed (time, 1 / segment length, flat bits)
   const float *gain;     // [P][row] gain rows (bus-major columns, zero padded)
   int row;               // floats per row (multiple of 4)
   int bus_cols;          // columns per bus (columns [b*bus_cols, (b+1)*bus_cols) = bus b)

@@ -62,8 +62,10 @@ struct Piece {
 constexpr uint32_t kPieceDelta = 1u << 31;
 static_assert(sizeof(Piece) == 16, "Piece is loaded as one dwordx4");
 
-constexpr int kPieceCapPerObject = 8;     // capacity of a tile's lists: pieces per object on average (+ padding)
-constexpr int kPieceMaxPerObject = 32;    // delta pieces of ONE object in one tile; beyond: exact path
+constexpr int kPieceMaxPerObject = 15;    // delta pieces of ONE object in one tile (a curve point every 17 samples at 256-sample
+                                          // tiles); beyond: the exact path
+constexpr int kPieceCapPerObject = 1 + kPieceMaxPerObject;  // capacity of a tile's list per object: the worst case fits, so a
+                                                            // list cannot overflow (537 MB of lists at 1024 objects x 1024 blocks)
 constexpr int kPieceMaxTile = 512;
 constexpr int kMaxPieceObjects = 1 << 16;
 
@@ -247,6 +249,235 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
       pl.count[tile * 8 + 0] = pp >> 5;
       pl.count[tile * 8 + 1] = run_d;
       pl.count[tile * 8 + 4] = run_o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K0b: the piece lists in ONE pass (round 3; replaces k_seg_prep + k_mark_quiet + k_piece_list for this kernel).
+// k_seg_prep found every (object, tile)'s segment and counted its ramps with a thread per object and run of 2-4
+// tiles, wrote 16-byte descriptors and counts for all of them, and k_piece_list — a 256-thread workgroup per tile —
+// read those back, scanned the counts and walked the curve points of every ramping object a second time, one
+// dependent load after the other: 0.086 ms per call on ADM-like metadata, 0.23 ms when every object ramps all
+// the time (a fifth of the step).  Here a workgroup of 1024 threads owns TPW consecutive tiles and all objects
+// (in batches of 1024): a thread searches its object's segment ONCE (at the first tile), walks on through the
+// TPW tiles counting ramps, the workgroup scans the counts of all TPW tiles together (one pair of barriers), and
+// the thread walks the same points again — cache hits now — writing its pieces at the scanned offsets.  No
+// descriptors, no counts in memory, one launch; the lists are exactly the ones k_piece_list wrote.
+//
+// the ramps of one object inside the tile [t0, t_end) that starts in segment k (k = number of the object's points
+// with time <= t0): returns their number, or -1 beyond kPieceMaxPerObject; out != nullptr: writes the delta
+// pieces.  k is left at the segment that reaches the end of the tile (where the next tile's search starts).
+__device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n, int &k, int64_t t0, int64_t t_end, int m,
+                                          Piece *out) {
+  const int tile_len = (int)(t_end - t0);
+  int cur = 0, nd = 0;
+  if (!ps.force_ramp) {
+    // The same walk over the packed point records: ONE 16-byte load per segment (its end time, 1 / length and flat
+    // bits; its start time is the previous record's) instead of describe_segment's two dependent rounds of loads.
+    const int allflat = (1 << ps.nbus) - 1;
+    const PointRec *rec = ps.rec + base;
+    int64_t prev = k > 0 ? rec[k - 1].time : 0;  // (k == 0: before the first point, never a ramp)
+    for (;;) {
+      PointRec r;
+      r.time = t_end;
+      r.scale = 0.0f;
+      r.flat = (uint32_t)allflat;
+      if (k < n) r = rec[k];
+      const bool ramp = k > 0 && k < n && ((int)r.flat & allflat) != allflat;
+      const bool multi = k < n && r.time < t_end;
+      const int r1 = multi ? (int)(r.time - t0) : tile_len;
+      if (ramp) {
+        Piece a;
+        a.m = (uint32_t)m | kPieceDelta;
+        a.row = base + k - 1;
+        bool emit = true;
+        if (r1 > cur) {
+          a.p0 = (float)(int32_t)(t0 - prev) * r.scale;
+          a.scale = r.scale;
+        } else {
+          a.p0 = (float)(1 - cur);
+          a.scale = 1.0f;
+          emit = cur > 0;
+        }
+        if (emit) {
+          if (out) out[nd] = a;
+          nd++;
+        }
+      }
+      if (r1 > cur) cur = r1;
+      if (!multi) break;
+      if (nd > kPieceMaxPerObject) return -1;
+      prev = r.time;
+      k++;
+    }
+    return nd > kPieceMaxPerObject ? -1 : nd;
+  }
+  for (;;) {
+    const SegDesc dk = describe_segment(ps, base, n, k, t0, t_end);
+    const int r1 = (dk.info & kSegMulti) ? seg_r1(dk.info) : tile_len;
+    if (dk.info & kSegRamp) {
+      Piece a;
+      a.m = (uint32_t)m | kPieceDelta;
+      a.row = dk.row;
+      bool emit = true;
+      if (r1 > cur) {  // a ramp over [cur, r1) of the tile (and beyond): its own line, clamped
+        a.p0 = (float)dk.d0 * dk.scale;  // p(s) = (float)(d0 + s) * scale, gain_interpolator.hpp:272
+        a.scale = dk.scale;
+      } else {  // two equal times with different gains: a step at cur = a ramp from cur - 1 to cur
+        a.p0 = (float)(1 - cur);
+        a.scale = 1.0f;
+        emit = cur > 0;  // (at the tile start the base piece already has the value after the step)
+      }
+      if (emit) {
+        if (out) out[nd] = a;
+        nd++;
+      }
+    }
+    if (r1 > cur) cur = r1;
+    if (!(dk.info & kSegMulti)) break;
+    if (nd > kPieceMaxPerObject) return -1;
+    k++;
+  }
+  return nd > kPieceMaxPerObject ? -1 : nd;
+}
+
+// The level of the call's inputs for the split-operand kernels, as its own small launch ahead of the list builder
+// (which needs the CALL's level to tell which objects are quiet): a thread per object looks at one float4 at the
+// start and one in the middle of the call (every probe is a page walk: two instants), leaves the object's largest
+// magnitude in obj_level[m] (float bits; plain store: every object is written by every call) and raises *level
+// (zero before the launch: the words alternate between calls, gain_h2.h).
+static __global__ void __launch_bounds__(256)
+k_level_probe(const float *in, size_t in_stride, int nsamples, int M, int ntiles, int tile_samples, int every, unsigned *level,
+              unsigned *obj_level) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  unsigned v = 0u;
+  if (m < M) {
+    float4 px[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int tile = i * every;
+      const int s = tile * tile_samples + 4 * ((m + 5 * tile) & 15);
+      px[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if ((i == 0 || every < ntiles) && tile < ntiles && s + 3 < nsamples)
+        px[i] = *reinterpret_cast<const float4 *>(in + (size_t)m * in_stride + s);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      v = max(v, max(max(__float_as_uint(px[i].x) & 0x7fffffffu, __float_as_uint(px[i].y) & 0x7fffffffu),
+                     max(__float_as_uint(px[i].z) & 0x7fffffffu, __float_as_uint(px[i].w) & 0x7fffffffu)));
+    obj_level[m] = v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
+  if ((threadIdx.x & 63) == 0 && v != 0)
+    if (v > __atomic_load_n(level, __ATOMIC_RELAXED)) atomicMax(level, v);
+}
+
+constexpr int kBuildThreads = 1024;
+// grid = ceil(ntiles / TPW) workgroups of 1024 threads; a thread = one (object, tile) pair of a batch of 1024 / TPW
+// objects, the TILE index fastest: the TPW lanes of an object read neighbouring points of its curve (the same
+// cache lines), like k_seg_prep's lanes did — with the object index fastest every load instruction touched 64
+// different lines and the walk was four times slower than the three kernels it replaces.
+template <int TPW>
+__global__ void __launch_bounds__(kBuildThreads)
+k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end, PieceLists pl,
+              const unsigned *obj_level, const unsigned *level_cur) {
+  constexpr int OB = kBuildThreads / TPW;  // objects per batch
+  constexpr int WPT = OB / 64;             // waves that scan one tile's objects
+  static_assert(OB % 64 == 0, "a tile's objects of a batch are whole waves of the scan");
+  __shared__ unsigned lcnt[kBuildThreads];   // [tile][object of the batch]: pieces | exact-path flag << 16; then their scan
+  __shared__ unsigned wtot[kBuildThreads / 64];
+  __shared__ int run[TPW][2];                // pieces and exact-path objects of the batches so far
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = tid % TPW, oi = tid / TPW;   // this thread's tile of the workgroup and object of the batch
+  const int tile = blockIdx.x * TPW + j;
+  const unsigned call_level = level_cur ? *level_cur : 0u;
+  if (tid < TPW) run[tid][0] = run[tid][1] = 0;
+  const int64_t t0 = t_call + (int64_t)tile * tile_samples;
+  const int64_t t1 = t0 + tile_samples > t_call_end ? t_call_end : t0 + tile_samples;
+  __syncthreads();
+  for (int mb = 0; mb < M; mb += OB) {
+    const int m = mb + oi;
+    const bool in = m < M && tile < ntiles;
+    int base = 0, n = 0, kst = 0, cnt = 0;
+    if (in) {
+      base = ps.off[m];
+      n = ps.off[m + 1] - base;
+      kst = upper_bound_time_guess(ps.time + base, n, t0);
+      int k = kst;
+      cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr);
+      if (obj_level && level_is_quiet(obj_level[m], call_level)) cnt = -1;
+    }
+    // ---- ordered scan over the batch's objects, per tile: element e = tile * OB + object, a tile = WPT whole waves
+    lcnt[j * OB + oi] = !in ? 0u : cnt < 0 ? 0x10000u : 1u + (unsigned)cnt;
+    __syncthreads();
+    unsigned v = lcnt[tid];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(v, o, 64);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) wtot[wv] = v;
+    __syncthreads();
+    {
+      unsigned pre = 0;
+      const int w0 = wv - wv % WPT;  // first wave of this tile's segment
+#pragma unroll
+      for (int w = 0; w < WPT; w++) pre += w0 + w < wv ? wtot[w0 + w] : 0u;
+      lcnt[tid] = v + pre;  // inclusive over the tile's objects of the batch
+    }
+    __syncthreads();
+    // ---- the same walk again (its loads hit in the cache), writing at the scanned offsets
+    if (in) {
+      const unsigned incl = lcnt[j * OB + oi];
+      if (cnt < 0) {
+        pl.ovf[(size_t)tile * M + run[j][1] + (int)(incl >> 16) - 1] = m;
+      } else {
+        Piece *out = pl.pieces + (size_t)tile * pl.cap() + run[j][0] + (int)(incl & 0xffffu) - (1 + cnt);
+        int k = kst;
+        // the row of the segment the tile starts in: a ramp's start point, else the point itself (the last one
+        // beyond the end of the curve): describe_segment's rule
+        int row;
+        if (ps.force_ramp) {
+          row = describe_segment(ps, base, n, k, t0, t1).row;
+        } else {
+          const bool ramp = k > 0 && k < n && ((int)ps.rec[base + k].flat & ((1 << ps.nbus) - 1)) != (1 << ps.nbus) - 1;
+          row = base + (ramp ? k - 1 : k == n ? k - 1 : k);
+        }
+        Piece b;
+        b.m = (uint32_t)m;
+        b.row = row;
+        b.p0 = 1.0f;
+        b.scale = 0.0f;
+        out[0] = b;
+        if (cnt > 0) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
+      }
+    }
+    __syncthreads();  // (everybody has read run[] and lcnt[])
+    if (tid < TPW) {
+      const unsigned tot = lcnt[tid * OB + OB - 1];
+      run[tid][0] += (int)(tot & 0xffffu);
+      run[tid][1] += (int)(tot >> 16);
+    }
+    __syncthreads();
+  }
+  // pad the lists to whole chunks with null pieces; publish the counts
+  Piece null_piece;
+  null_piece.m = 0u;
+  null_piece.row = ps.zero_row;
+  null_piece.p0 = 1.0f;
+  null_piece.scale = 0.0f;
+  for (int i = tid; i < TPW * 32; i += kBuildThreads) {
+    const int jj = i >> 5, tl = blockIdx.x * TPW + jj;
+    if (tl >= ntiles) continue;
+    const int np = run[jj][0], pp = (np + 31) & ~31;
+    if (np + (i & 31) < pp) pl.pieces[(size_t)tl * pl.cap() + np + (i & 31)] = null_piece;
+    if ((i & 31) == 0) {
+      const int listed = M - run[jj][1];  // every listed object has one base piece: the rest are deltas
+      pl.count[tl * 8 + 0] = pp >> 5;
+      pl.count[tl * 8 + 1] = np - listed;
+      pl.count[tl * 8 + 4] = run[jj][1];
     }
   }
 }

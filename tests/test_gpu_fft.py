@@ -47,7 +47,7 @@ def test_sizes_that_are_not_powers_of_two(n_fft):
     y = plan.reverse(want)
     want_y = _oracle.irfft_unnorm(want, n_fft)
     assert np.linalg.norm(y - want_y) / np.linalg.norm(want_y) < tol
-    assert np.max(np.abs(y / n_fft - x)) < 3e-6
+    assert np.max(np.abs(y / n_fft - x)) < 3e-6 * tol / 6e-7
     plan.close()
 
 
