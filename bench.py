@@ -190,12 +190,15 @@ def main():
                          "(steps measured right after start-up are ~9 %% slower)")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
-    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed", "panned", "panned-adm"), default="dense",
+    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed", "panned", "panned-adm", "levels", "levels-adm"),
+                    default="dense",
                     help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
                          "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned); "
                          "panned / panned-adm: moving point sources through the device gain producer (libearhip group "
                          "I: real 3-sparse VBAP gains, sqrt(1-d)/sqrt(d) split, zero LFE columns), a new position every "
-                         "block / every 960 samples at a per-object phase")
+                         "block / every 960 samples at a per-object phase; levels / levels-adm: the dense / adm scene with the "
+                         "objects' SIGNAL levels log-uniform over 0 .. -90 dB and 30 %% of the objects digitally silent for the "
+                         "first half of the call (real mixes: pauses, tails, entries)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE config 4): --objects in total, split over the GPUs; "
                          "weak: --objects per GPU")
@@ -305,7 +308,7 @@ def main():
             self.M_hoa = hoa if (rank == 0 or scaling == "weak") else 0  # the bed goes to one rank
             self.M = self.M_obj + self.M_hoa
             m, seed = max(self.M_obj, 1), seed_base + rank
-            if args.scene == "adm":
+            if args.scene in ("adm", "levels-adm"):
                 curves = scenes.adm_curves(m, N, total, seed=11 + seed)
             elif args.scene == "moving":  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
                 curves = scenes.adm_curves(m, N, total, period=240, ramp=240, seed=12 + seed)
@@ -345,6 +348,10 @@ def main():
             rows = max(self.M, 1)
             self.x_full = torch.rand((rows, self.in_stride), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
             self.x = self.x_full[:, :total]  # planar rows, in_stride floats apart
+            if args.scene in ("levels", "levels-adm"):
+                lv, late = scenes.object_levels(rows, seed=77 + seed)
+                self.x_full *= torch.as_tensor(lv, device=dev, dtype=torch.float32)[:, None]
+                self.x_full[torch.as_tensor(late, device=dev), :total // 2] = 0.0
             self.outs = [torch.zeros((n_pad, total), device=dev, dtype=torch.float32) for _ in range(2)]
             self.owned = [torch.zeros((n_pad // world, total), device=dev, dtype=torch.float32) for _ in range(2)] \
                 if world > 1 else None
@@ -557,6 +564,8 @@ def main():
                       "moving": "dense uniform(0,1); a new target every 240 samples at a per-object phase, always ramping",
                       "static": "dense uniform(0,1), one gain vector per object, never changing",
                       "mixed": "the dense scene with 8 of every 1024 objects on ADM-like metadata off the block grid",
+                      "levels": "the dense scene; signal levels log-uniform 0 .. -90 dB, 30 % of the objects silent for the first half",
+                      "levels-adm": "the adm scene; signal levels log-uniform 0 .. -90 dB, 30 % of the objects silent for the first half",
                       "panned": "moving point sources, a new position every block: gains from the device panner "
                                 "(3-sparse VBAP gains, diffuse split, zero LFE columns)",
                       "panned-adm": "moving point sources, a new position every 960 samples at a per-object phase: "

@@ -6,7 +6,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libearhip.so")
+    """the library the package loads; EARHIP_LIB names another build of it (A/B runs of kernel variants)"""
+    return os.environ.get("EARHIP_LIB") or os.path.join(HERE, "lib", "libearhip.so")
 
 
 def build(verbose=False):

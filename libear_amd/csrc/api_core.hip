@@ -58,10 +58,13 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // K0 raises word `li` (zero since the last f16x2 call cleared it), its K1 reads it and clears the other.
   LevelProbe probe;
   unsigned *level_cur = nullptr, *level_next = nullptr;
+  unsigned *wide_cur = nullptr, *wide_next = nullptr;  // f16x2 kernel: "run this call in wide mode" (gain_h2.h)
   if ((ml.split || ml.pieces) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
-    if (!ctx->level.p) ctx->level.alloc_zero(2, ctx->stream);
+    if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);  // [0..1] level words, [2..3] wide-mode words
     level_cur = ctx->level.p + ctx->level_idx;
     level_next = ctx->level.p + (ctx->level_idx ^ 1);
+    wide_cur = ctx->level.p + 2 + ctx->level_idx;
+    wide_next = ctx->level.p + 2 + (ctx->level_idx ^ 1);
     ctx->level_idx ^= 1;
     probe.in = in_dev;
     probe.in_stride = in_stride;
@@ -144,7 +147,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
   if (probe.obj_level && !one_pass)
     hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
-                       level_cur, slow_cur);
+                       level_cur, slow_cur, ml.split ? wide_cur : nullptr);
   // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
   if (ml.pieces && !one_pass) {
     if (fused_prep) fail_internal("piece lists need the descriptors of k_seg_prep");
@@ -197,7 +200,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   bool launched = false;
   if (ml.pieces) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
-    const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale();
+    const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
+    const float *gs = cs.column_scales();
 #define EARHIP_P2_CASE(NCT_)                                                                                        \
   if (cp.nct == NCT_) {                                                                                             \
     if (ml.pw == 4)                                                                                                 \
@@ -212,18 +216,26 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     launched = true;
   } else if (ml.split) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
-    const float xs = std::ldexp(1.0f, ctx->x_scale_log2), gs = cs.gain_scale();
+    const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
+    const float *gs = cs.column_scales();
+    // two forms of the kernel, back to back: the one the device-side mode word names runs, the other returns at once
+    // (gain_h2.h); without a probe only the wide form
+#define EARHIP_H2_LAUNCH(NCT_, NW_, WIDE_)                                                                          \
+  hipLaunchKernelGGL((k_gain_mix_h2<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, ps.zero_row, xs,  \
+                     gs, level_cur, level_next, slow_cur, slow_next, wide_cur, wide_next);
 #define EARHIP_H2_CASE(NCT_)                                                                                        \
   if (cp.nct == NCT_) {                                                                                             \
-    if (ml.tile() == 512)                                                                                           \
-      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, ps.zero_row, xs, gs,       \
-                         level_cur, level_next, slow_cur, slow_next);                                                \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_gain_mix_h2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, ps.zero_row, xs, gs,       \
-                         level_cur, level_next, slow_cur, slow_next);                                                \
+    if (ml.tile() == 512) {                                                                                         \
+      if (wide_cur) EARHIP_H2_LAUNCH(NCT_, 8, false)                                                                \
+      EARHIP_H2_LAUNCH(NCT_, 8, true)                                                                               \
+    } else {                                                                                                        \
+      if (wide_cur) EARHIP_H2_LAUNCH(NCT_, 4, false)                                                                \
+      EARHIP_H2_LAUNCH(NCT_, 4, true)                                                                               \
+    }                                                                                                               \
   }
     EARHIP_H2_CASE(1) EARHIP_H2_CASE(2) EARHIP_H2_CASE(3)
 #undef EARHIP_H2_CASE
+#undef EARHIP_H2_LAUNCH
     launched = true;
   }
 #define EARHIP_MIX_CASE(NOUT_, SPL_, STRICT_)                                   \
@@ -404,7 +416,7 @@ int earhip_debug_read_bandwidth(earhip_ctx *ctx, const float *in_dev, size_t row
                 ((uintptr_t)in_dev & 15) == 0,
             "buffer must be 16-byte aligned with stride and nsamples multiples of 256");
     ctx->use();
-    if (!ctx->level.p) ctx->level.alloc_zero(2, ctx->stream);
+    if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);
     float *sink = reinterpret_cast<float *>(ctx->level.p);  // never written (the kernels' condition is never true)
     hipEvent_t e[4];
     for (auto &x : e) EARHIP_HIP(hipEventCreate(&x));

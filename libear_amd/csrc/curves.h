@@ -223,6 +223,26 @@ class CurveSet {
       gmax = a <= gmax ? gmax : a;  // (a NaN replaces gmax)
     }
     gain_max_ = gmax;
+    // ... and per COLUMN (the split-operand kernels scale every output column's gains by its own power of two:
+    // a loudspeaker that only ever gets small gains — an object 120 dB down alone on it — keeps both f16 pieces of
+    // its gains normal; the inverse is applied to the column's output).  Columns without any gain: the set's scale.
+    h_gcol_.reserve(row);
+    const float set_scale = gain_scale();
+    for (size_t c = 0; c < row; c++) {
+      float cm = 0.0f;
+      for (size_t i = c; i < P * row; i += row) {
+        const float a = std::fabs(h_gain_.p[i]);
+        cm = a <= cm ? cm : a;
+      }
+      int e;
+      std::frexp(cm, &e);
+      h_gcol_.p[c] = (cm >= 1e-30f && cm < 1e30f) ? std::ldexp(1.0f, 14 - e) : (set_scale > 0.0f ? set_scale : 1.0f);
+    }
+    if (d_gcol_.n < row) {
+      EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+      d_gcol_.reserve(row);
+    }
+    EARHIP_HIP(hipMemcpyAsync(d_gcol_.p, h_gcol_.p, row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, (M_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, P * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, P, hipMemcpyHostToDevice, ctx->stream));
@@ -269,6 +289,9 @@ class CurveSet {
     return std::ldexp(1.0f, 14 - e);
   }
 
+  // [row] per-column gain scales of the split-operand kernels (powers of two; device memory)
+  const float *column_scales() const { return d_gcol_.p; }
+
   PointStore device() const {
     PointStore ps;
     ps.off = d_off_.p;
@@ -304,6 +327,8 @@ class CurveSet {
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
   DevBuf<PointRec> d_rec_;
+  DevBuf<float> d_gcol_;
+  PinBuf<float> h_gcol_;
   DevBuf<float> d_gain_;
   PinBuf<int32_t> h_off_;
   PinBuf<int64_t> h_time_;
@@ -360,7 +385,10 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     L.pw = ptile == 512 ? 8 : 4;
     (void)point_density;
   }
-  L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
+  // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
+  // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments
+  // grew a third piece: 0.296 ms against 0.261 for the 4-wave form at three workgroups per CU, same box)
+  L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || (nsamples / 512 >= 2 * ctx->num_cus && cp.nct > 1));
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
   if (L.mfma && !L.split && !L.pieces && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;

@@ -50,6 +50,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gain_kernels.h"
 #include "gain_mfma.h"
 
@@ -72,24 +74,45 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
 __device__ __forceinline__ float f16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
 __device__ __forceinline__ float f16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
 
+// Wide mode: the low piece of an input is kept as (residual x 2^11) and multiplied with (h x 2^-11) of the gain —
+// both exact scalings, the same product — so that it is a normal f16 over 21 binades below the level the prescale
+// aims at instead of 11 (measured relative RMS of the products: 6.5e-8 down to 2^-18, 1.4e-7 at 2^-20, 5e-7 at
+// 2^-22; with the plain residual 2.5e-7 at 2^-10 and 1e-6 at 2^-12).
+constexpr float kLowPieceScale = 2048.0f;
+__device__ __forceinline__ uint32_t scale_f16x2_down(uint32_t h) {  // both halves x 2^-11 (exact unless subnormal)
+  const f16x2_t k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, h) * k);
+}
+
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
                                                 0, 0, 0);
 }
 
-// P.ntiles / P.desc refer to WORKGROUP tiles of kSplitTile samples.  x_scale, g_scale: exact
-// powers of two (see above); zero_row: index of an all-zero gain row.
+// P.ntiles / P.desc refer to WORKGROUP tiles of kSplitTile samples.  x_scale: an exact power of two (see
+// above); gcol: [row] per-COLUMN gain scales, powers of two that put the largest gain a column ever gets at 2^14
+// (CurveSet::commit: a loudspeaker that only gets small gains — an object 120 dB down alone on it — keeps both
+// f16 pieces of its gains normal; the inverse is applied to the column's output); zero_row: index of an all-zero
+// gain row.
+// WIDE: the low pieces of the inputs are kept scaled (kLowPieceScale) — 16 more multiplies and 6 more LDS reads per
+// chunk: 4 % of this kernel on the headline scene (measured by bisection; neither reading the third piece a block
+// ahead, nor making it from h in registers, nor v_fma_mix forms of the split bring that down).  So both forms
+// exist, as two instantiations launched back to back: the level probe decides on the device which one works
+// (k_mark_quiet sets *wide_cur when some object lies more than kPlainBinades below the loudest) and the other
+// returns at once (an empty grid: ~3 us).  Without a probe (wide_cur == NULL) only the wide form is launched.  The
+// mode words alternate between calls like the level words.
 // NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
 // conversion of a chunk's gains is shared by the whole workgroup, so the 512-sample tile halves that
 // work (and the gain rows' L2 traffic) when no curve point falls inside 512-sample tiles.
-template <int NCT, int NW>
+template <int NCT, int NW, bool WIDE>
 __global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 4 : (NW == 4 ? 2 : 1))
-k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const unsigned *level_cur,
-              unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next) {
+k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
+              unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next, const unsigned *wide_cur, unsigned *wide_next) {
+  if (wide_cur && (*wide_cur != 0u) != WIDE) return;  // the other form of this kernel works on this call
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
-  constexpr int NFRAG = 2 * NCT * 2;  // {B0,B1} x column tiles x {h,l}
-  __shared__ u32x4 bfrag[2][NFRAG + 4][64];  // + 4 never-read fragments: the lanes without a column write there
+  constexpr int NFRAG = 2 * NCT * 3;  // {B0,B1} x column tiles x {h, l, h 2^-11 (wide mode)}
+  __shared__ u32x4 bfrag[2][NFRAG + 6][64];  // + 6 never-read fragments: the lanes without a column write there
   // the wave's output tile of one column tile, [16 columns][64 samples (+ 4: bank spread)], on its way from the
   // D fragments (a lane: one column, 16-byte pieces 64 bytes apart) to stores of whole 256-byte rows
   constexpr int OP = TS + 4;
@@ -98,6 +121,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
   const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
+  if (wide_next && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *wide_next = 0u;
   if (level_cur) {
     // input scale of THIS call from the level K0 probed: the largest magnitude seen, in [2^E, 2^(E+1)),
     // goes to [2^7, 2^8) — peaks up to 256x the probed maximum stay inside the f16 range (beyond:
@@ -146,8 +170,12 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
   // (the two scales are applied to the two operands: their product may not be a float)
   // khint >= 0: the segment index K0 found at the start of the WORKGROUP tile (the search then only
   // walks on from there: a few steps instead of log2 n dependent loads per object and wave)
-  auto single_object = [&](int m, float sx, float sg, int khint = -1) {
+  // (sg: the gains are scaled by their column's scale, like the split operands — or not at all)
+  auto single_object = [&](int m, float sx, bool sg, int khint = -1) {
     if (tile_len <= 0) return;
+    float gsc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
     const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
@@ -178,7 +206,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
         const int grow = dk.row + ((ramp && is_b && slot0) ? 1 : 0);
         const float *gp = gain + (size_t)grow * rowlen + col0 + li;
 #pragma unroll
-        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16] * sg;
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16] * gsc[c];
 #pragma unroll
         for (int r = 0; r < NRT; r++)
 #pragma unroll
@@ -193,7 +221,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
 
   const int nobj = m_hi - m_lo;
   const int nch = (P.vec_ok && nobj >= CH) ? (nobj + CH - 1) / CH : 0;
-  float inv_x = 1.0f / x_scale, inv_g = 1.0f / g_scale;  // exact: powers of two
+  float inv_x = 1.0f / x_scale;  // exact: a power of two
+  bool col_scaled = true;        // the totals are in units of 1 / (x_scale x the column's gain scale)
 
   if (nch > 0) {
     // lane-constant part of the input address: byte offset of this lane's float4 (lanes past the
@@ -204,10 +233,11 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
     const unsigned xs = (unsigned)min(tile_s0 + li * NRT, nvec - 4);
     const unsigned xlane = ((unsigned)(kg * 8) * (unsigned)P.in_stride + xs) * 4u;
     const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
+    const float g_scale = gcol[bcol_e];                                   // ... and that column's scale (a power of two)
     // fragment this lane fills: B0 pieces at bfr, bfr+1, B1 pieces NCT*2 further
     const int blane = (w * NQ / 8) * 16 + (lane & 15);
-    const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;
-    const int bfr1 = lane < 16 * NCT ? NCT * 2 : 2;
+    const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;
+    const int bfr1 = lane < 16 * NCT ? NCT * 3 : 3;
     auto chunk_base = [&](int c) { return min(m_lo + c * CH, m_hi - CH); };
 
     // inputs q0 .. q0 + n - 1 of chunk c.  Past the last chunk (the two-chunks-ahead requests of the
@@ -271,7 +301,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
     // B0 (gain at the tile start, part 0) or B1 (slope, part 1) of the wave's NQ objects,
     // scaled and split -> LDS (k = 8 kgw + 2 i + j of the fragment entry of lane 16 kgw + column)
     auto store_b = [&](const ChunkCoef &D, const float (&S)[NQ], const float (&E)[NQ], int buf, int part) {
-      uint32_t h[NQ / 2], l[NQ / 2];
+      uint32_t h[NQ / 2], l[NQ / 2], hs[NQ / 2];
 #pragma unroll
       for (int i = 0; i < NQ / 2; i++) {
         float v[2];
@@ -284,16 +314,19 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
         const uint32_t H = pack_f16(v[0], v[1]);
         h[i] = H;
         l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+        hs[i] = WIDE ? scale_f16x2_down(H) : 0u;                // h 2^-11: the partner of the inputs' scaled low piece
       }
       u32x4 *f = &bfrag[buf][bfr][blane] + (part ? bfr1 * 64 : 0);
       if constexpr (NQ == 8) {
         f[0] = u32x4{h[0], h[1], h[2], h[3]};
         f[64] = u32x4{l[0], l[1], l[2], l[3]};
+        if constexpr (WIDE) f[128] = u32x4{hs[0], hs[1], hs[2], hs[3]};
       } else {  // half an entry: words 2 (w & 1), + 1
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x2 *g = reinterpret_cast<u32x2 *>(f) + (w & 1);
         g[0] = u32x2{h[0], h[1]};
         g[128] = u32x2{l[0], l[1]};
+        if constexpr (WIDE) g[256] = u32x2{hs[0], hs[1]};
       }
     };
 
@@ -337,8 +370,10 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
           const f32x2 s0 = f32x2{xc[2 * qp][rp], xc[2 * qp][rp + 1]} * x_scale;          // object 2qp
           const f32x2 s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;  // object 2qp+1
           const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
-          const f32x2 r0 = s0 - f32x2{f16_lo(H0), f16_lo(H1)};  // exact
-          const f32x2 r1 = s1 - f32x2{f16_hi(H0), f16_hi(H1)};
+          // residuals (exact); wide mode scales them by 2^11 before they are rounded to f16
+          constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
+          const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * LOW;
+          const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * LOW;
           ah[rp][qp] = H0;
           ah[rp + 1][qp] = H1;
           al[rp][qp] = pack_f16(r0[0], r1[0]);
@@ -355,10 +390,13 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
       // woven between the MFMAs of blocks 0 and 1.
       __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
       constexpr int NBLK = 2 * NCT;
-      u32x4 b[2][2];
+      // (h, l) of a block are read one block ahead into alternating registers; wide mode reads the scaled high piece
+      // as its block starts, behind the four MFMAs that do not need it (one register set: the kernel sits at the
+      // register limit)
+      u32x4 b[2][2], b2;
       auto load_b = [&](int blk, u32x4 (&bb)[2]) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][((blk & 1) * NCT + (blk >> 1)) * 2 + q][lane];
+        for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][((blk & 1) * NCT + (blk >> 1)) * 3 + q][lane];
       };
       load_b(0, b[0]);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // (block 0's reads; each block below places the NEXT block's)
@@ -366,28 +404,34 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
       for (int blk = 0; blk < NBLK; blk++) {
         u32x4(&bc)[2] = b[blk & 1];
         const int ct = blk >> 1;
+        if constexpr (WIDE) b2 = bfrag[buf][((blk & 1) * NCT + (blk >> 1)) * 3 + 2][lane];
         if (blk + 1 < NBLK) load_b(blk + 1, b[(blk + 1) & 1]);
-        if ((blk & 1) == 0) {
+        // (the two small products first, the large one last; wide mode: the one whose operand is read last second)
+        f32x4(&tt)[NRT][NCT] = (blk & 1) == 0 ? tot0 : tot1;
+        if constexpr (WIDE) {
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(al[r], bc[0], tot0[r][ct]);
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(ah[r], bc[1], tt[r][ct]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(ah[r], bc[1], tot0[r][ct]);
-#pragma unroll
-          for (int r = 0; r < NRT; r++) tot0[r][ct] = mfma_f16(ah[r], bc[0], tot0[r][ct]);
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(al[r], b2, tt[r][ct]);
         } else {
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(al[r], bc[0], tot1[r][ct]);
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(al[r], bc[0], tt[r][ct]);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[1], tot1[r][ct]);
-#pragma unroll
-          for (int r = 0; r < NRT; r++) tot1[r][ct] = mfma_f16(ah[r], bc[0], tot1[r][ct]);
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(ah[r], bc[1], tt[r][ct]);
         }
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(ah[r], bc[0], tt[r][ct]);
         if (blk < XB) load_x_part(c + 2, xc, blk * (8 / XB), 8 / XB);
         const bool conv0 = blk == NBLK - 2, conv1 = blk == NBLK - 1;
         if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
         if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
         // issue order: the LDS reads first, then every MFMA followed by VALU instructions
-        if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if constexpr (WIDE) {
+          if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        } else {
+          if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
         if (conv0 || conv1) {
 #pragma unroll
           for (int k = 0; k < 12; k++) {
@@ -420,7 +464,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
         const int j = __builtin_ctzll(multi);
         multi &= multi - 1;
         // (the k field of a descriptor is exact for these objects: the piece ends inside the tile)
-        single_object(m_lo + b0 + j, x_scale, g_scale, seg_k(__shfl(db.info, j)));
+        single_object(m_lo + b0 + j, x_scale, true, seg_k(__shfl(db.info, j)));
       }
     }
     // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the
@@ -434,18 +478,23 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
         for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
     if (__ballot(bad)) {
       clear_totals();
-      inv_x = inv_g = 1.0f;
-      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, 1.0f);
+      inv_x = 1.0f;
+      col_scaled = false;
+      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);
     }
   } else {
-    inv_x = inv_g = 1.0f;
-    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, 1.0f);  // unaligned rows
+    inv_x = 1.0f;
+    col_scaled = false;
+    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);  // unaligned rows
   }
 
   if (tile_len <= 0) return;
   // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
   // four row tiles are 4 consecutive samples.  (s - s0) of the rows: sample 64w + 16kg + 4e + r.
   const float wf0 = (float)(w * TS + kg * 16);
+  float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
+#pragma unroll
+  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? 1.0f / gcol[col0 + c * 16 + li] : 1.0f;
   float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
   const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
 #pragma unroll
@@ -461,7 +510,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < NRT; r++)
-          v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_g;
+          v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
         *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
       }
 #pragma unroll
@@ -481,7 +530,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, float g_scale, const
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < NRT; r++)
-        v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_g;
+        v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
       if (P.vec_ok && s + 3 < tile_len) {
         *reinterpret_cast<f32x4 *>(o + s) = v;
       } else {

@@ -131,10 +131,17 @@ struct LevelProbe {
   unsigned *obj_level = nullptr;  // [M], zero before the launch: the same per object (largest magnitude probed)
 };
 // An object whose probed level lies this many binades below the call's is "quiet": the split-operand
-// kernels scale every input of a call by ONE power of two, which keeps 2^-22 relative precision over 11
-// binades (gain_h2.h); a quieter object, alone on a loudspeaker, would be off by more than 1e-6 there, so
-// it takes the exact f32 path of the kernel instead.  (Levels are float bits: biased exponents compare.)
-constexpr int kQuietBinades = 11;
+// kernels scale every input of a call by ONE power of two; with the low piece of an input kept as
+// (residual x 2^11) (gain_h2.h) both pieces are normal f16 numbers — 2^-22 relative precision — over 21
+// binades below the level the prescale aims at (measured: 6.5e-8 relative RMS of the products down to 2^-18,
+// 1.4e-7 at 2^-20, 5e-7 at 2^-22; round 2, with the plain residual: 2.5e-7 at 2^-10, 1e-6 at 2^-12).  An
+// object quieter than that — more than 120 dB below the loudest — alone on a loudspeaker would be off by
+// more than 1e-6 there, so it takes the exact f32 path of the kernel instead.  (Levels are float bits: biased
+// exponents compare.)
+constexpr int kQuietBinades = 20;
+// ... and one more than this many binades below it makes the f16x2 kernel (gain_h2.h) run the call in its wide mode
+// (scaled low pieces); up to here the plain residual is as good (2.5e-7 at 2^-10) and 4 % faster
+constexpr int kPlainBinades = 8;
 __host__ __device__ __forceinline__ bool level_is_quiet(unsigned obj_level, unsigned call_level) {
   return obj_level != 0u && call_level != 0u && (int)(obj_level >> 23) < (int)(call_level >> 23) - kQuietBinades;
 }
@@ -240,11 +247,14 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
 // k_seg_prep's last workgroup instead needs a device-scope fence per workgroup — an L2 write-back on this
 // chip — and made K0 ten times slower.)
 static __global__ void __launch_bounds__(256)
-k_mark_quiet(SegDesc *desc, int M, int ntiles, unsigned *obj_level, const unsigned *level_cur, unsigned *tile_slow) {
+k_mark_quiet(SegDesc *desc, int M, int ntiles, unsigned *obj_level, const unsigned *level_cur, unsigned *tile_slow,
+             unsigned *wide) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   const unsigned lv = obj_level[m];
   obj_level[m] = 0u;
+  // (wide: zero before the launch; every writer writes 1)
+  if (wide && lv != 0u && *level_cur != 0u && (int)(lv >> 23) < (int)(*level_cur >> 23) - kPlainBinades) *wide = 1u;
   if (!level_is_quiet(lv, *level_cur)) return;
   for (int t = 0; t < ntiles; t++) {
     desc[(size_t)t * M + m].info |= kSegQuiet;

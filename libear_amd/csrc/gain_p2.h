@@ -487,13 +487,13 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 // x_scale, g_scale: exact powers of two (gain_h2.h).
 template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
-k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, const unsigned *level_cur,
+k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
-  constexpr int NFRAG = NCT * 2;  // column tiles x {h,l}
+  constexpr int NFRAG = NCT * 3;  // column tiles x {h, l, h 2^-11}
   constexpr int RING = 8;         // chunks of piece words (the object) staged in LDS for the lanes
-  __shared__ u32x4 bfrag[2][NFRAG + 2][64];  // + 2 never-read fragments: the lanes without a column write there
+  __shared__ u32x4 bfrag[2][NFRAG + 3][64];  // + 3 never-read fragments: the lanes without a column write there
   // the wave's output tile of one column tile on its way from the D fragments to stores of whole rows (gain_h2.h)
   constexpr int OP = TS + 4;
   __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
@@ -536,8 +536,12 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
 
   // ---- exact path: one object, all its pieces inside this wave's 64 samples, f32 MFMA with k = {a, b}
   // of ONE object (k slots 2, 3 idle), accumulated into tot in units of 1 / (sx sg)
-  auto single_object = [&](int m, float sx, float sg) {
+  // (sg: the gains are scaled by their column's scale, like the split operands — or not at all)
+  auto single_object = [&](int m, float sx, bool sg) {
     if (tile_len <= 0) return;
+    float gsc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
     const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
@@ -562,7 +566,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         const int grow = dk.row + ((ramp && is_b && slot0) ? 1 : 0);
         const float *gp = gain + (size_t)grow * rowlen + col0 + li;
 #pragma unroll
-        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16] * sg;
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16] * gsc[c];
 #pragma unroll
         for (int r = 0; r < NRT; r++)
 #pragma unroll
@@ -605,7 +609,8 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         tot[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot[r][c], 0, 0, 0);
   };
 
-  float inv_x = 1.0f / x_scale, inv_g = 1.0f / g_scale;  // exact: powers of two
+  float inv_x = 1.0f / x_scale;  // exact: a power of two
+  bool col_scaled = true;        // the totals are in units of 1 / (x_scale x the column's gain scale)
   const int *cnt = pl.count + wgtile * 8;
 
   if (P.vec_ok) {
@@ -623,7 +628,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       // byte offset of this lane's float4 inside an input row (lanes past the end of the call re-read the
       // last vector: never stored)
       const unsigned xlane = (unsigned)min(tile_s0 + li * NRT, nvec - 4) * 4u;
-      const int bfr = lane < 16 * NCT ? (lane >> 4) * 2 : NFRAG;          // fragment pair (h, l) this lane fills
+      const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;          // fragment triple (h, l, h 2^-11) this lane fills
       const size_t rstride = P.in_stride * sizeof(float);
       const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
 
@@ -674,6 +679,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         }
       };
       const int col_e = min(lane, 16 * NCT - 1);  // the lane's gain column inside the wave's rows
+      const float g_scale = gcol[col0 + col_e];   // ... and that column's scale (a power of two)
       auto stage_gains = [&](const f32x4 (&G)[NGI], float (&X)[NQ], float (&Y)[NQ]) {
 #pragma unroll
         for (int i = 0; i < NGI; i++) stage[w][lane + 64 * i] = G[i];
@@ -687,7 +693,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       // the B operand of the wave's NQ pieces, scaled and split -> LDS
       // (k = NQ w + q of the fragment entry of lane 16 (k / 8) + column)
       auto store_b = [&](const float (&X)[NQ], const float (&Y)[NQ], int buf) {
-        uint32_t h[NQ / 2], l[NQ / 2];
+        uint32_t h[NQ / 2], l[NQ / 2], hs[NQ / 2];
 #pragma unroll
         for (int i = 0; i < NQ / 2; i++) {
           float v[2];
@@ -699,16 +705,19 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
           const uint32_t H = pack_f16(v[0], v[1]);
           h[i] = H;
           l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+          hs[i] = scale_f16x2_down(H);                            // h 2^-11: partner of the inputs' scaled low piece (gain_h2.h)
         }
         u32x4 *f = &bfrag[buf][bfr][0];
         const int col = lane & 15;
         if constexpr (NQ == 8) {
           f[w * 16 + col] = u32x4{h[0], h[1], h[2], h[3]};
           f[64 + w * 16 + col] = u32x4{l[0], l[1], l[2], l[3]};
+          f[128 + w * 16 + col] = u32x4{hs[0], hs[1], hs[2], hs[3]};
         } else {  // half an entry: words 2 (w & 1), + 1 of k group w / 2
           u32x2 *g = reinterpret_cast<u32x2 *>(f + (w >> 1) * 16 + col) + (w & 1);
           g[0] = u32x2{h[0], h[1]};
           g[128] = u32x2{l[0], l[1]};
+          g[256] = u32x2{hs[0], hs[1]};
         }
       };
 
@@ -766,10 +775,10 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
                             __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, b[1], b[0]), 0.0f, 1.0f)};
               }
               const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
-              const f32x2 r0 = s0 - f32x2{f16_lo(H0), f16_lo(H1)};  // exact
-              const f32x2 r1 = s1 - f32x2{f16_hi(H0), f16_hi(H1)};
               ah[rp][qp] = H0;
               ah[rp + 1][qp] = H1;
+              const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * kLowPieceScale;  // exact residuals, scaled (gain_h2.h)
+              const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * kLowPieceScale;
               al[rp][qp] = pack_f16(r0[0], r1[0]);
               al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
             }
@@ -786,17 +795,18 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
 #pragma unroll
           for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][fr + q][lane];
         };
-        u32x4 b[2][2];
+        u32x4 b[2][2], b2;  // (the scaled high piece is read as its block starts: gain_h2.h)
         load_b(0, b[0]);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
           u32x4(&bc)[2] = b[ct & 1];
-          if (ct + 1 < NCT) load_b((ct + 1) * 2, b[(ct + 1) & 1]);
-#pragma unroll
-          for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(al[r], bc[0], tot[r][ct]);
+          b2 = bfrag[buf][ct * 3 + 2][lane];
+          if (ct + 1 < NCT) load_b((ct + 1) * 3, b[(ct + 1) & 1]);
 #pragma unroll
           for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[1], tot[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(al[r], b2, tot[r][ct]);
 #pragma unroll
           for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
           if (ct < XB) load_x_part(c + 2, xc, ct * (8 / XB), 8 / XB);
@@ -806,7 +816,8 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
             stage_gains(G, S, E);
             store_b(S, E, buf ^ 1);
           }
-          if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           if (ct < XB && !conv) {
 #pragma unroll
             for (int k = 0; k < 8 / XB; k++) {  // MFMAs, then one request (address arithmetic + load)
@@ -828,7 +839,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
     if (part == 0) {
       const int *ovf = pl.ovf + (size_t)wgtile * P.M;
       const int novf = cnt[4];
-      for (int i = 0; i < novf; i++) single_object(ovf[i], x_scale, g_scale);
+      for (int i = 0; i < novf; i++) single_object(ovf[i], x_scale, true);
     }
     // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the wave's tile
     // exactly, unscaled (every part redoes its share of the pieces)
@@ -841,18 +852,20 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
         for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot[r][c][e]) < INFINITY);
     if (__ballot(bad)) {
       clear_totals();
-      inv_x = inv_g = 1.0f;
+      inv_x = 1.0f;
+      col_scaled = false;
       for (int c = c_lo; c < c_hi; c++)
         for (int j = 0; j < CH; j++) single_piece(chunk_ptr(c)[j]);
       if (part == 0) {
         const int *ovf = pl.ovf + (size_t)wgtile * P.M;
-        for (int i = 0; i < cnt[4]; i++) single_object(ovf[i], 1.0f, 1.0f);
+        for (int i = 0; i < cnt[4]; i++) single_object(ovf[i], 1.0f, false);
       }
     }
   } else {
-    inv_x = inv_g = 1.0f;
+    inv_x = 1.0f;
+    col_scaled = false;
     const int m_lo = (int)(((int64_t)P.M * part) / nparts), m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
-    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, 1.0f);  // unaligned rows
+    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);  // unaligned rows
   }
 
   if (tile_len <= 0) return;
@@ -860,6 +873,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
   // four row tiles are 4 consecutive samples.
   float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
   const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
+  float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
+#pragma unroll
+  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? 1.0f / gcol[col0 + c * 16 + li] : 1.0f;
 #pragma unroll
   for (int c = 0; c < NCT; c++) {
     if (whole) {  // transposed through wave-private LDS: whole 256-byte rows per store instruction (gain_h2.h)
@@ -868,7 +884,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       for (int e = 0; e < 4; e++) {
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_g;
+        for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_gc[c];
         *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
       }
 #pragma unroll
@@ -887,7 +903,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, float g_scale, cons
       const int s = kg * 16 + e * 4;
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_g;
+      for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_gc[c];
       if (P.vec_ok && s + 3 < tile_len) {
         *reinterpret_cast<f32x4 *>(o + s) = v;
       } else {

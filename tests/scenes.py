@@ -206,6 +206,17 @@ def mixed_level_sparse(n_obj, n_out, block, n_blocks, lfe=(), span_db=100.0, see
     return curves, levels
 
 
+def object_levels(n_obj, span_db=90.0, late_share=0.3, seed=77):
+    """per-object signal levels, log-uniform over 0 .. -span_db (object 0 at full scale), and the mask of the objects
+    that are digitally silent for the first half of a call (entries): what a real mix looks like at any instant"""
+    rng = np.random.default_rng(seed)
+    levels = (10.0 ** (-rng.uniform(0.0, span_db, n_obj) / 20.0)).astype(np.float32)
+    levels[0] = 1.0
+    late = rng.uniform(0.0, 1.0, n_obj) < late_share
+    late[0] = False
+    return levels, late
+
+
 def moving_sources(n_obj, total, period=960, seed=31, phase=None, ramp=None):
     """ADM-like trajectories: every `period` samples, at a per-object phase, an object gets a new position
     (a random walk in azimuth / elevation) and diffuseness, reached over a quarter of the period and then

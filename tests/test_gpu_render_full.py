@@ -167,6 +167,53 @@ def test_levels_spread_over_100_db_every_channel_within_tolerance(what, m, nbloc
     print(f"levels over 100 dB ({what}, {m} objects): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
 
+@pytest.mark.parametrize("kind", ["dense", "adm"])
+def test_levels_scene_at_the_headline_size(kind):
+    """bench.py --scene levels / levels-adm at 1024 objects: signal levels log-uniform over 0 .. -90 dB and 30 % of
+    the objects silent for the first half of the call, on dense gains (every loudspeaker carries every object) —
+    block-aligned ramps (k_gain_mix_h2) and ADM-like metadata (k_gain_mix_p2).  No object takes the exact path
+    (the low pieces of the inputs stay normal f16 numbers 21 binades below the call's level): per channel <= 1e-6."""
+    layout, m, block, nblocks = "9+10+3", 1024, 512, 256
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.dense_curves(m, n, block, nblocks) if kind == "dense" else scenes.adm_curves(m, n, total)
+    lv, late = scenes.object_levels(m)
+    x = device_audio(m, total, 99, scale=lv)
+    import torch
+    x[torch.as_tensor(late, device="cuda"), :total // 2] = 0.0
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    if os.environ.get("EARHIP_MFMA") in (None, "3"):
+        assert plan["kernel"] == (3 if kind == "dense" else 4), plan
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks // 2 - 1, 3), (nblocks - 2, 2)])
+    print(f"levels scene ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
+
+
+@pytest.mark.parametrize("scene", ["dense", "adm", "moving"])
+def test_seed_sweep_at_1024_objects(scene):
+    """Eight seeds (curves and audio) x {block-aligned ramps, ADM-like metadata, always-ramping metadata} at 1024
+    objects: the worst channel of every run against the CPU path.  The CPU path's own sequential float32 sum sits
+    6e-7 from a float64 render at this size, so the margin to 1e-6 is thin by nature; the
+    distribution is printed."""
+    layout, m, block, nblocks = "9+10+3", 1024, 512, 16
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    worst = []
+    for seed in range(8):
+        if scene == "dense":
+            curves = scenes.dense_curves(m, n, block, nblocks, seed=100 + seed)
+        elif scene == "adm":
+            curves = scenes.adm_curves(m, n, total, seed=200 + seed)
+        else:
+            curves = scenes.adm_curves(m, n, total, period=240, ramp=240, seed=300 + seed)
+        x = device_audio(m, total, 400 + seed)
+        out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+        worst.append(check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks - 3, 3)]))
+    print(f"seed sweep ({scene}, plan {plan}): worst channel per seed " + " ".join(f"{w:.2e}" for w in worst)
+          + f"; max {max(worst):.3e}")
+
+
 @pytest.mark.parametrize("nblocks", [1, 2, 7, 33, 40, 63, 64])
 def test_call_lengths_between_block_and_stream_mode_off_grid_metadata(nblocks):
     """ADM-like metadata (f32 slot kernel) at 256 objects with max_blocks = 64: calls of 33..63 blocks
@@ -199,6 +246,51 @@ def test_native_decorrelators_equal_the_oracles():
     for layout in ("0+5+0", "4+5+0", "9+10+3"):
         got, want = decorrelators(layout), _oracle.design_decorrelators(LAYOUTS[layout])
         assert np.max(np.abs(got - want)) <= 2e-9
+
+
+@pytest.mark.parametrize("kind", ["aligned", "adm"])
+@pytest.mark.parametrize("gain_db", [-100.0, -120.0, -160.0])
+def test_objects_with_small_gains_alone_on_their_loudspeakers(kind, gain_db):
+    """The same with the level difference in the GAINS: full-scale signals, but the objects on the second half of
+    the loudspeakers carry gains `gain_db` below the others'.  The split-operand kernels scale every output
+    COLUMN's gains by its own power of two (the largest gain that column ever gets), so a loudspeaker that only
+    gets small gains keeps both f16 pieces of them normal; with one scale per curve set (round 2) -120 dB lost
+    3 bits there."""
+    layout, m, block, nblocks = "9+10+3", 128, 512, 16
+    names = LAYOUTS[layout]
+    n = len(names)
+    dec = decorrelators(layout)
+    total = block * nblocks
+    lfe = [i for i, nm in enumerate(names) if nm.startswith("LFE")]
+    spk = [c for c in range(n) if c not in lfe]
+    half = len(spk) // 2
+    rng = np.random.default_rng(int(-gain_db))
+    if kind == "aligned":
+        times = [block * np.arange(nblocks + 1, dtype=np.int64)] * m
+    else:
+        times = [c[0] for c in scenes.adm_curves(m, n, total, seed=3)]
+    small = np.arange(m) % 4 == 1
+    curves = []
+    for i in range(m):
+        k = len(times[i])
+        pool = spk[half:] if small[i] else spk[:half]
+        scale = 10.0 ** (gain_db / 20.0) if small[i] else 1.0
+        d = np.zeros((k, n), np.float32)
+        f = np.zeros((k, n), np.float32)
+        for j in range(k):
+            idx = rng.choice(pool, 3, replace=False)
+            g = rng.uniform(0.1, 1.0, 3)
+            g /= np.sqrt(np.sum(g * g))
+            diff = rng.choice([0.0, 0.5, 1.0])
+            d[j, idx] = g * np.sqrt(1.0 - diff) * scale
+            f[j, idx] = g * np.sqrt(diff) * scale
+        curves.append((times[i], d, f))
+    x = device_audio(m, total, 12)
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    if os.environ.get("EARHIP_MFMA") in (None, "3"):
+        assert plan["kernel"] == (3 if kind == "aligned" else 4), plan
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (7, 2), (nblocks - 2, 2)])
+    print(f"small gains at {gain_db} dB ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
 
 @pytest.mark.parametrize("kind", ["aligned", "adm"])
