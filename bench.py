@@ -150,6 +150,113 @@ def producer_bench(args):
         sys.exit(3)
 
 
+def refbench(args):
+    """The reference's only hot-path benchmark DEFINITION (it records no result), timed here on both sides:
+    GainInterpolator<LinearInterpMatrix>::process, 32 inputs -> 24 outputs, 1024 samples, a random matrix point every
+    100 samples (tests/gain_interpolator_tests.cpp:259-296) — the latency-bound end of the path.  Block mode = that
+    very call through the drop-in entry point (host channel pointers: H2D, kernels, D2H, sync); stream mode = the same
+    curve density over 2^20 samples per call, device resident; the CPU path (the oracle's restatement, -O3 -DNDEBUG,
+    one thread) beside both; and where one host core and the GPU cross over as the call shrinks."""
+    import numpy as np
+    import torch
+    import _oracle
+    import scenes
+    from libear_amd import capi
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = capi.Context(0, stream.cuda_stream)
+    n_out, n = 24, 1024
+    rng = np.random.default_rng(5)
+
+    def points(m, total):
+        t = np.arange(100, total, 100, dtype=np.int64)
+        return t, rng.uniform(0.0, 1.0, (len(t), m, n_out)).astype(np.float32)
+
+    def block_mode(m, calls=200):
+        t, v = points(m, n)
+        x = rng.uniform(-1.0, 1.0, (m, n)).astype(np.float32)
+        g = capi.GainInterp(ctx, m, n_out)
+        g.set_points(t, v)
+        for _ in range(20):
+            got = g.process(0, x)
+        lat = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            g.process(0, x)
+            lat.append(time.perf_counter() - t0)
+        g.close()
+        lat.sort()
+        want = _oracle.gain_interp("matrix", t, v, x, [n])
+        reps, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < 0.25 or reps < 3:
+            _oracle.gain_interp("matrix", t, v, x, [n])
+            reps += 1
+        cpu = (time.perf_counter() - c0) / reps
+        return lat[len(lat) // 2], lat[int(0.95 * len(lat))], cpu, scenes.rel_rms(got, want)
+
+    gpu_ms, gpu_p95, cpu_s, err = block_mode(32)
+    sweep = []
+    for m in (1, 2, 4, 8, 16, 32, 64, 128):
+        g_, _, c_, e_ = block_mode(m, calls=100)
+        sweep.append({"inputs": m, "gpu_block_ms": round(g_ * 1e3, 4), "cpu_ms": round(c_ * 1e3, 4), "rel_rms": float(f"{e_:.2e}")})
+    cross = next((s["inputs"] for s in sweep if s["gpu_block_ms"] < s["cpu_ms"]), None)
+    # stream mode: the same point density over a long device-resident call
+    m, total = 32, n * 1024
+    t, v = points(m, total)
+    g = capi.GainInterp(ctx, m, n_out)
+    g.set_points(t, v)
+    x = torch.rand((m, total), device=dev, dtype=torch.float32) * 2.0 - 1.0
+    out = torch.zeros((n_out, total), device=dev, dtype=torch.float32)
+    steps, warm = max(args.steps, 1), max(args.warmup, 2)
+    for _ in range(warm):
+        g.process_device(0, total, x.data_ptr(), total, out.data_ptr(), total)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.process_device(0, total, x.data_ptr(), total, out.data_ptr(), total)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # parity of the stream call on a window, and the CPU path's rate on the same window
+    w = 8 * n
+    xs = x[:, :w].cpu().numpy()
+    tw = t[t <= w + 100]
+    c0 = time.perf_counter()
+    want = _oracle.gain_interp("matrix", tw, v[:len(tw)], xs, [n] * 8)
+    cpu_stream_s = time.perf_counter() - c0
+    serr = scenes.rel_rms(out[:, :w].cpu().numpy(), want)
+    g.close()
+    bytes_alg = 4 * (m * total + n_out * total) + v.nbytes
+    ok = err <= 1e-6 and serr <= 1e-6
+    print(json.dumps({
+        "metric": "Msamples/s", "value": round(m * total / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1, "steps": steps,
+        "warmup": warm, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 io / f16x2-split MFMA, f32 accumulate", "data": "synthetic",
+        "config": {"workload": "refbench: GainInterpolator<LinearInterpMatrix>::process, 32 -> 24 channels, a random matrix "
+                               "point every 100 samples (the reference's matrix_benchmark, tests/gain_interpolator_tests.cpp:"
+                               "259-296); stream mode: 1024 x 1024 samples per call, device resident", "baseline_config": "refbench"},
+        "roofline": {"bound": "hbm", "achieved": round(bytes_alg / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(bytes_alg / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "note": "algorithmic bytes: inputs + outputs + the matrix points, per call"},
+        "block_mode": {"what": "the reference benchmark's own call (1024 samples) through earhip_gain_interp_process: host "
+                               "channel pointers, H2D, kernels, D2H, sync", "ms_per_call": round(gpu_ms * 1e3, 4),
+                       "p95_ms": round(gpu_p95 * 1e3, 4), "Msamples_per_s": round(32 * n / gpu_ms / 1e6, 1),
+                       "rtf": round((n / SAMPLE_RATE) / gpu_ms, 1)},
+        "cpu_baseline": {"value": round(32 * n / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                         "sample": "the same 1024-sample call, oracle restatement of LinearInterpMatrix, -O3 -DNDEBUG, "
+                                   "mean over >= 0.25 s", "ms_per_call": round(cpu_s * 1e3, 4),
+                         "stream_window_Msamples_per_s": round(32 * w / cpu_stream_s / 1e6, 2), "cpu_model": cpu_model()},
+        "crossover": {"sweep_24_outputs_1024_samples": sweep, "gpu_block_mode_faster_from_inputs": cross,
+                      "note": "one call of 1024 samples from host pointers against one host core; below the crossover the "
+                              "call is launch + PCIe latency on the GPU side"},
+        "parity": {"block_rel_rms_vs_cpu": float(f"{err:.3e}"), "stream_window_rel_rms_vs_cpu": float(f"{serr:.3e}"),
+                   "tolerance": 1e-6, "pass": bool(ok)}}))
+    ctx.close()
+    if not ok:
+        print("refbench parity FAILED", file=sys.stderr)
+        sys.exit(3)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as a FRESH child
     (`python -m torch.distributed.run ... bench.py <the same arguments>`), relay its output (rank 0's JSON line)
@@ -174,7 +281,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=sorted(PRESETS), default="C4", help="BASELINE.json configuration")
+    ap.add_argument("--config", choices=sorted(PRESETS) + ["refbench"], default="C4",
+                    help="BASELINE.json configuration; refbench: the reference's own matrix_benchmark shape (32 -> 24 channels, "
+                         "1024 samples, a point every 100 samples), block and stream mode, CPU path beside it")
     ap.add_argument("--objects", type=int, default=None, help="objects of the scene (in total; --scaling weak: per GPU)")
     ap.add_argument("--hoa", type=int, default=None, help="extra input channels through a constant decode matrix (config 5)")
     ap.add_argument("--blocks", type=int, default=None, help="blocks per step (stream length T)")
@@ -213,6 +322,8 @@ def main():
     args = ap.parse_args()
     if args.producer:
         return producer_bench(args)
+    if args.config == "refbench":
+        return refbench(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)
     cfg = dict(PRESETS[args.config])
@@ -523,6 +634,9 @@ def main():
         k0_ms = timing["prep_ms"] / timed_steps
         achieved = gain_b * T / (k1_ms * 1e-3) / 1e9
         whole = (gain_b + dec_b + dm_b) * T / t_step / 1e9
+        # what the fused chain itself moves: K1's bytes, plus (two buses) K2 reading the buses back and writing the outputs
+        fused_b = gain_b + (4 * (K * N * B) + 4 * N * B + 2 * 4 * N * 255 / max(T, 1) if K == 2 else 0)
+        whole_fused = fused_b * T / t_step / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the
         # figure is attached only when profiles/traffic.json was measured (rocprofv3 --pmc passes,
         # tools/profile_passes.sh) for exactly this kernel instantiation, shape and scene
@@ -605,11 +719,13 @@ def main():
             "kernel_timing": {"timed_steps": timed_steps, "every": time_every},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},
-            "whole_path": {"algorithmic_GBps": round(whole, 1), "frac_of_hbm_peak": round(whole / HBM_PEAK_GBS, 4),
-                           "note": "SURVEY 8(d)'s algorithmic bytes of the whole chain (gain + decorrelator + delay/mix) over the step "
-                                   "time: they count both gain rows of every block (the fused path fetches the shared one once) and the "
-                                   "BlockConvolver's spectra and queues (which the fused K2 keeps in registers and LDS), so this figure "
-                                   "can exceed what HBM moves - the roofline object above is the one against the kernel's own bytes",
+            "whole_path": {"fused_path_GBps": round(whole_fused, 1), "frac_of_hbm_peak": round(whole_fused / HBM_PEAK_GBS, 4),
+                           "survey_8d_algorithmic_GBps": round(whole, 1),
+                           "note": "fused_path: the bytes this implementation's chain has to move per step (inputs, both gain rows of "
+                                   "every block, the buses written by K1 and read once by K2, the delay state, the outputs) over the "
+                                   "step time - the fraction is of THOSE bytes.  survey_8d_algorithmic: SURVEY 8(d)'s per-block bytes, "
+                                   "which also count the BlockConvolver's spectra, filter and queue traffic that the fused K2 keeps in "
+                                   "registers and LDS: a rate, not a fraction of anything HBM does",
                            "gain_fp32_equivalent_tflops": round(4.0 * K * M * N * B * T / (k1_ms * 1e-3) / 1e12, 2)},
         }
 

@@ -196,6 +196,12 @@ class GainInterp:
                                                 _chan_ptrs(x), _chan_ptrs(out)))
         return out
 
+    def process_device(self, block_start, nsamples, in_ptr, in_stride, out_ptr, out_stride):
+        """device-resident planar buffers (16-byte aligned, strides multiples of 4); enqueues, does not synchronise"""
+        check(load().earhip_gain_interp_process_device(self.h, C.c_int64(block_start), C.c_size_t(nsamples),
+                                                       C.c_void_p(in_ptr), C.c_size_t(in_stride), C.c_void_p(out_ptr),
+                                                       C.c_size_t(out_stride)))
+
     def close(self):
         if self.h:
             load().earhip_gain_interp_destroy(self.h)

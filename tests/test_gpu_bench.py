@@ -108,6 +108,16 @@ def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
     assert line["exchange_check"]["max_rel_err_owned_slice_vs_all_reduce"] <= 1e-6
 
 
+def test_refbench_line():
+    """bench.py --config refbench: the reference's own benchmark shape (32 -> 24 channels, 1024 samples, a matrix point
+    every 100 samples) in block and stream mode with the CPU path beside it, parity-gated"""
+    line = run_bench(["--config", "refbench", "--steps", "5", "--warmup", "2"])
+    assert line["config"]["baseline_config"] == "refbench" and line["value"] > 0
+    assert line["block_mode"]["ms_per_call"] > 0 and line["cpu_baseline"]["ms_per_call"] > 0
+    assert line["parity"]["pass"] and line["parity"]["block_rel_rms_vs_cpu"] <= 1e-6
+    assert len(line["crossover"]["sweep_24_outputs_1024_samples"]) == 8
+
+
 def test_producer_line():
     """bench.py --producer: the Objects gain producer with extent through device pointers, parity-gated"""
     line = run_bench(["--producer", "20000", "--steps", "3", "--warmup", "1"])
