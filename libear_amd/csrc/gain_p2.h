@@ -268,8 +268,10 @@ k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_c
 // the ramps of one object inside the tile [t0, t_end) that starts in segment k (k = number of the object's points
 // with time <= t0): returns their number, or -1 beyond kPieceMaxPerObject; out != nullptr: writes the delta
 // pieces.  k is left at the segment that reaches the end of the tile (where the next tile's search starts).
+constexpr int kKeepPieces = 3;
+// keep != nullptr: the first kKeepPieces delta pieces are also left there (registers: indexed by constants only)
 __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n, int &k, int64_t t0, int64_t t_end, int m,
-                                          Piece *out) {
+                                          Piece *out, Piece *keep = nullptr) {
   const int tile_len = (int)(t_end - t0);
   int cur = 0, nd = 0;
   if (!ps.force_ramp) {
@@ -302,6 +304,11 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
         }
         if (emit) {
           if (out) out[nd] = a;
+          if (keep) {
+            if (nd == 0) keep[0] = a;
+            if (nd == 1) keep[1] = a;
+            if (nd == 2) keep[2] = a;
+          }
           nd++;
         }
       }
@@ -331,6 +338,11 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
       }
       if (emit) {
         if (out) out[nd] = a;
+        if (keep) {
+          if (nd == 0) keep[0] = a;
+          if (nd == 1) keep[1] = a;
+          if (nd == 2) keep[2] = a;
+        }
         nd++;
       }
     }
@@ -401,12 +413,13 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
     const int m = mb + oi;
     const bool in = m < M && tile < ntiles;
     int base = 0, n = 0, kst = 0, cnt = 0;
+    Piece keep[kKeepPieces];
     if (in) {
       base = ps.off[m];
       n = ps.off[m + 1] - base;
       kst = upper_bound_time_guess(ps.time + base, n, t0);
       int k = kst;
-      cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr);
+      cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr, keep);
       if (obj_level && level_is_quiet(obj_level[m], call_level)) cnt = -1;
     }
     // ---- ordered scan over the batch's objects, per tile: element e = tile * OB + object, a tile = WPT whole waves
@@ -451,7 +464,12 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
         b.p0 = 1.0f;
         b.scale = 0.0f;
         out[0] = b;
-        if (cnt > 0) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
+        // the first kKeepPieces delta pieces are still in registers from the counting walk; only an object with more
+        // walks its curve points a second time
+        if (cnt >= 1) out[1] = keep[0];
+        if (cnt >= 2) out[2] = keep[1];
+        if (cnt >= 3) out[3] = keep[2];
+        if (cnt > kKeepPieces) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
       }
     }
     __syncthreads();  // (everybody has read run[] and lcnt[])
@@ -769,6 +787,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
               if (DELTA) {
                 const float f0 = lane_sf + (float)rp, f1 = lane_sf + (float)(rp + 1);
                 const f32x2 a = piece_ps(c, 2 * qp), b = piece_ps(c, 2 * qp + 1);
+                // (the compiler folds the median-of-three into the FMA's output clamp: one instruction per value)
                 s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
                             __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
                 s1 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, b[1], b[0]), 0.0f, 1.0f),
