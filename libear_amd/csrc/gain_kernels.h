@@ -180,7 +180,7 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       int64_t t_end = t0 + tile_samples;
       if (t_end > t_call_end) t_end = t_call_end;
       if (j == 0) {
-        k = upper_bound_time_guess(ps.time + base, n, t0);
+        k = upper_bound_time_window(ps.time + base, n, t0);
       } else {
         while (k < n && ps.time[base + k] <= t0) k++;  // = upper_bound_time(.., t0), from the previous tile's
       }
@@ -396,7 +396,7 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
         d = desc[(size_t)tile * M + m];
       } else {  // no descriptor pass: find the segment here
         const int base = ps.off[m], n = ps.off[m + 1] - base;
-        d = describe_segment(ps, base, n, upper_bound_time_guess(ps.time + base, n, t0), t0, t_end);
+        d = describe_segment(ps, base, n, upper_bound_time_window(ps.time + base, n, t0), t0, t_end);
       }
       walk(m, d, nullptr, nullptr, cp, cm, nx, true);
     }

@@ -417,7 +417,7 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
     if (in) {
       base = ps.off[m];
       n = ps.off[m + 1] - base;
-      kst = upper_bound_time_guess(ps.time + base, n, t0);
+      kst = upper_bound_time_window(ps.time + base, n, t0);
       int k = kst;
       cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr, keep);
       if (obj_level && level_is_quiet(obj_level[m], call_level)) cnt = -1;

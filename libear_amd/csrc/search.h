@@ -62,4 +62,27 @@ EARHIP_SEARCH_HD int upper_bound_time_guess(const int64_t *t, int n, int64_t v) 
   return hi;
 }
 
+// The same result with ONE round of loads behind the end points when the points are evenly spaced, as metadata
+// mostly is: eight neighbouring times around the guess are requested together (the loads do not depend on each
+// other) and the answer is read off them; only when it lies outside the window does the bracketing search run.
+// The list builder of the piece-list kernel does one such search per (object, tile): its dependent rounds of loads
+// are what that kernel's time is made of.
+EARHIP_SEARCH_HD int upper_bound_time_window(const int64_t *t, int n, int64_t v) {
+  if (n < 16) return upper_bound_time(t, n, v);
+  const int64_t first = t[0], last = t[n - 1];
+  if (v < first) return 0;
+  if (v >= last) return n;
+  int g = (int)((double)(v - first) / (double)(last - first) * (double)(n - 1));
+  int lo = g - 3;
+  lo = lo < 0 ? 0 : (lo > n - 8 ? n - 8 : lo);
+  int64_t w[8];
+  for (int i = 0; i < 8; i++) w[i] = t[lo + i];
+  if (w[0] <= v && v < w[7]) {
+    int k = lo;
+    for (int i = 0; i < 8; i++) k += w[i] <= v ? 1 : 0;
+    return k;
+  }
+  return upper_bound_time_guess(t, n, v);
+}
+
 }  // namespace earhip

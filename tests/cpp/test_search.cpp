@@ -1,4 +1,4 @@
-// CPU unit test of libear_amd/csrc/search.h: the guess-started search returns exactly what the
+// CPU unit test of libear_amd/csrc/search.h: the guess-started and the windowed search return exactly what the
 // plain upper bound returns (= libear's find_block, gain_interpolator.hpp:110-129) for sorted
 // times with duplicates, clusters, evenly spaced grids and queries before / inside / past them.
 #include <cstdint>
@@ -28,8 +28,9 @@ int main() {
       if (q % 7 == 0) v = t[rand() % n];
       const int a = earhip::upper_bound_time(t.data(), n, v);
       const int b = earhip::upper_bound_time_guess(t.data(), n, v);
+      const int c = earhip::upper_bound_time_window(t.data(), n, v);
       tests++;
-      if (a != b) {
+      if (a != b || a != c) {
         if (bad < 5) printf("mismatch n=%d v=%lld a=%d b=%d\n", n, (long long)v, a, b);
         bad++;
       }
