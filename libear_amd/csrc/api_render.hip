@@ -92,7 +92,7 @@ static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s, 
 // call of T blocks on N loudspeakers.  A run of R blocks costs (R+1)/2 pair transforms, each
 // workgroup puts one wave on every SIMD, and a CU holds three workgroups (LDS): the cost of a
 // round of k = 1..3 resident workgroups per CU is pairs x c[k] with the measured pair times
-// c = 6.9, 9.3, 12.2 us (latency-bound at this occupancy).  DESIGN.md section 4, K2.
+// c = 6.9, 9.3, 12.2 us (latency-bound at this occupancy).  NOTES.md (round 2, section 4, K2).
 static int wave_run_len(int T, int N, int num_cus) {
   const double c[4] = {0.0, 6.9, 9.3, 12.2};
   int best = 1;

@@ -25,7 +25,7 @@
 //     scale);
 //   * of the four partial products the three of order >= 2^-11 are kept: xl*bh, xh*bl,
 //     xh*bh (relative error of the contraction on the headline scene: 7e-8, see
-//     tests/test_gpu_render.py and DESIGN.md section 4);
+//     tests/test_gpu_render.py and DESIGN.md section 4 / NOTES.md);
 //   * products of f16 pairs are exact in the fp32 accumulate of
 //     v_mfma_f32_16x16x32_f16, so the chunks accumulate straight into two running sets of
 //     accumulators (B0 terms and B1 terms: no per-chunk fold), in scaled units; the ramp

@@ -106,8 +106,10 @@ def test_headline_call_at_its_own_size_vs_oracle_windows():
     out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
     if os.environ.get("EARHIP_MFMA") in (None, "3") and os.environ.get("EARHIP_H2_TILE") is None:
         assert plan["kernel"] == 3 and plan["tile"] == 512 and plan["gsplit"] == 1, plan
-    # (forced onto the f32 slot kernel, 1024 objects summed in another order than the CPU's sit 1.03e-6 from the
-    # CPU path, whose own distance from a float64 render is 6e-7: the default kernels are held to 1e-6)
+    # (forced onto the exact-f32 slot kernel the scene is 1.03e-6 from the CPU path: that kernel adds TWO terms per
+    # ramping object — 2048 in one float32 chain where the CPU adds 1024 — so its own distance from a float64 render
+    # is sqrt 2 times the CPU's 6.2e-7; the two roundings are independent and add in quadrature.  The kernels that
+    # run by default are held to 1e-6; this forced configuration to 1.5e-6)
     tol = 1.5e-6 if os.environ.get("EARHIP_MFMA") == "1" else TOL
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (511, 2), (1021, 3)], tol=tol)
     print(f"headline call: worst per-channel rel RMS vs oracle {worst:.3e}, plan {plan}")
@@ -195,7 +197,7 @@ def test_seed_sweep_at_1024_objects(scene):
     objects: the worst channel of every run against the CPU path.  The CPU path's own sequential float32 sum sits
     6e-7 from a float64 render at this size, so the margin to 1e-6 is thin by nature; the
     distribution is printed."""
-    layout, m, block, nblocks = "9+10+3", 1024, 512, 16
+    layout, m, block, nblocks = "9+10+3", 1024, 512, 256  # (long enough for the launch plan of a stream: no object splits)
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
     total = block * nblocks

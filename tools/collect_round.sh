@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the bench lines of every configuration / scene for profiles/ (on the GPU box):
 #   bash tools/collect_round.sh <tag>     -> gpurun_out/<tag>_bench_<name>.json
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT && mkdir -p gpurun_out
 run() { # name, bench args...
@@ -19,3 +19,6 @@ run moving --scene moving
 run mixed --scene mixed
 run panned --scene panned
 run panned_adm --scene panned-adm
+run levels --scene levels
+run levels_adm --scene levels-adm
+run refbench --config refbench --steps 50 --warmup 5
