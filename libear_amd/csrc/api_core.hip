@@ -63,7 +63,10 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);  // [0..1] level words, [2..3] wide-mode words
     level_cur = ctx->level.p + ctx->level_idx;
     level_next = ctx->level.p + (ctx->level_idx ^ 1);
-    wide_cur = ctx->level.p + 2 + ctx->level_idx;
+    // a short call (less than two rounds of workgroups: block mode) runs the wide form only: its latency does not
+    // depend on the form, and the second launch — the form that returns at once — is 4-5 us of it
+    // (every call clears the word the NEXT call decides with, whether it decides itself or not)
+    if ((size_t)ml.ntiles * ml.gsplit >= 2 * (size_t)ctx->num_cus) wide_cur = ctx->level.p + 2 + ctx->level_idx;
     wide_next = ctx->level.p + 2 + (ctx->level_idx ^ 1);
     ctx->level_idx ^= 1;
     probe.in = in_dev;

@@ -248,19 +248,28 @@ struct earhip_render {
     pending.clear();
   }
 
+  // the launch plan of a call of nblocks blocks at the current sample clock
+  MixLaunch plan_call(size_t nblocks) {
+    const int nsamples = (int)(nblocks * (size_t)B);
+    MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, ctx->strict, max_gsplit, curves->aligned_tile(t),
+                            curves->ramp_share(), curves->gain_scale(), curves->point_density());
+    const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
+    while (ml.gsplit > 1 && bus_stride * K * N * ml.gsplit > bus.n) ml.gsplit /= 2;
+    return ml;
+  }
+
   void process_device(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev,
                       size_t out_stride) {
     const int nsamples = (int)(nblocks * (size_t)B);
     curves->commit(ctx);
     const bool strict = ctx->strict;
-    MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, strict, max_gsplit,
-                            curves->aligned_tile(t), curves->ramp_share(), curves->gain_scale(), curves->point_density());
+    MixLaunch ml = plan_call(nblocks);
+
     last_kind = ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
-    // the bus is sized for every plan plan_mix can make (earhip_render_create); should a tuning knob
-    // push a plan beyond it, fewer object splits are always a valid plan
-    while (ml.gsplit > 1 && part_stride * ml.gsplit > bus.n) ml.gsplit /= 2;
+    // (the bus is sized for every plan plan_mix can make, earhip_render_create; should a tuning knob push a plan
+    // beyond it, plan_call has taken fewer object splits, always a valid plan)
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");
     last_plan[0] = ml.tile();
     last_plan[1] = ml.ntiles;
@@ -552,8 +561,21 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       // short calls (block mode): one gather, one transfer.  Splitting a 2 MB block into groups whose
       // transfers overlap the gather was measured twice and loses (132 -> 150 us per call at the headline
       // shape: four DMA start-ups cost more than the 30 us of gather they hide).
-      for (int m = 0; m < r->M; m++) std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
-      EARHIP_HIP(hipMemcpyAsync(r->d_in.p, r->p_in.p, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+      // ... in `groups` parts, the transfer of a part starting while the next is gathered (EARHIP_BLOCK_GROUPS;
+      // default 2 above 1 MB: a second DMA start-up costs less than the half gather it hides, four cost more:
+      // 0.134 / 0.126 / 0.138 ms per 512-sample call of 1024 objects with 1 / 2 / 4 groups, same box.  Enqueueing the
+      // segment descriptors — the part of K0 that does not look at the inputs — ahead of the gather was measured
+      // too and loses: 0.146 / 0.125 / 0.138: the launch is host time in front of the gather, and the probe it
+      // leaves behind the transfer is one more kernel in the chain)
+      static const int groups_env = getenv("EARHIP_BLOCK_GROUPS") ? atoi(getenv("EARHIP_BLOCK_GROUPS")) : 0;
+      const int groups = groups_env >= 1 && groups_env <= 8 ? groups_env : (in_bytes >= ((size_t)1 << 20) ? 2 : 1);
+      for (int g = 0; g < groups; g++) {
+        const int m0 = (int)((int64_t)r->M * g / groups), m1 = (int)((int64_t)r->M * (g + 1) / groups);
+        for (int m = m0; m < m1; m++) std::memcpy(r->p_in.p + (size_t)m * n, in[m], sizeof(float) * n);
+        if (m1 > m0)
+          EARHIP_HIP(hipMemcpyAsync(r->d_in.p + (size_t)m0 * n, r->p_in.p + (size_t)m0 * n, sizeof(float) * n * (m1 - m0),
+                                    hipMemcpyHostToDevice, ctx->stream));
+      }
     } else {
       // Long calls: the staging copy is what bounds the host-pointer path, so several (persistent)
       // threads gather the channels into the pinned buffer, group of channels by group, and each
