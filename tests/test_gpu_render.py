@@ -712,7 +712,7 @@ def test_gain_kernel_choice_follows_the_curves():
                          [("adm", 64, "9+10+3", 512, 8, [8]), ("adm", 200, "4+5+0", 512, 6, [1, 2, 3]),
                           ("ragged", 100, "9+10+3", 256, 9, [9]), ("dense", 96, "9+10+3", 512, 5, [5]),
                           ("constant", 130, "0+5+0", 1024, 3, [3]), ("short", 64, "9+10+3", 512, 4, [4]),
-                          ("adm", 1100, "9+10+3", 512, 12, [5, 7])])
+                          ("adm", 1100, "9+10+3", 512, 12, [5, 7]), ("busy", 70, "4+5+0", 512, 4, [1, 3])])
 def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, calls):
     """k_gain_mix_p2 forced for every curve family (EARHIP_MFMA=5): metadata that ignores the tile grid,
     irregular curves with steps and dense points, block-aligned ramps, static gains, ramps of a few samples
@@ -729,6 +729,12 @@ def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, call
         curves = scenes.dense_curves(m, n, block, nblocks, seed=m)
     elif kind == "constant":
         curves = scenes.constant_curves(m, n, seed=m)
+    elif kind == "busy":  # a few objects with more ramps in one tile than a list takes per object (15): the exact path
+        curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
+        rng = np.random.default_rng(m)
+        for i, step in ((3, 5), (40, 11), (69, 16)):
+            t = np.arange(-40, total + 40, step, dtype=np.int64)
+            curves[i] = (t, rng.uniform(0, 1, (len(t), n)).astype(np.float32), rng.uniform(0, 1, (len(t), n)).astype(np.float32))
     else:  # 9-sample ramps at arbitrary times
         curves = scenes.adm_curves(m, n, total, period=333, ramp=9, seed=m)
     x = scenes.audio(m, total, seed=m)
