@@ -89,8 +89,6 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   pl.M = M;
   pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
   pl.ovf = pl.count + (size_t)8 * ml.ntiles;
-  pl.cw = pl.ovf + (size_t)M * ml.ntiles;
-  int *ramp_count = ml.pieces ? pl.cw : nullptr;
   // f16x2 gain kernel: a word per tile, "some object needs the exact path here" (see gain_h2.h)
   unsigned *slow_cur = nullptr, *slow_next = nullptr;
   if (ml.split) {
@@ -103,10 +101,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     slow_next = ctx->tile_slow.p + (size_t)(ctx->tile_slow_idx ^ 1) * ctx->tile_slow_cap;
     ctx->tile_slow_idx ^= 1;
   }
-  // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch;
-  // EARHIP_P2_BUILD=0 keeps the three-kernel path of round 2 (k_seg_prep + k_mark_quiet + k_piece_list) for A/B runs
-  static const bool one_pass_env = !(getenv("EARHIP_P2_BUILD") && atoi(getenv("EARHIP_P2_BUILD")) == 0);
-  const bool one_pass = ml.pieces && one_pass_env;
+  // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch
+  const bool one_pass = ml.pieces;
   if (one_pass) {
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     unsigned *obj_lv = nullptr;
@@ -136,10 +132,10 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 ogrid((M + 15) / 16);
     if (ml.ntiles >= 2048)
       hipLaunchKernelGGL(k_seg_prep<4>, dim3((ml.ntiles + 63) / 64, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject, slow_cur);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, slow_cur);
     else
       hipLaunchKernelGGL(k_seg_prep<2>, dim3((ml.ntiles + 31) / 32, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, ramp_count, kPieceMaxPerObject, slow_cur);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, slow_cur);
   }
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
@@ -152,28 +148,6 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (probe.obj_level && !one_pass)
     hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
                        level_cur, slow_cur, ml.split ? wide_cur : nullptr);
-  // piece-list kernel: K0p turns the descriptors into the tiles' piece lists (behind the descriptors)
-  if (ml.pieces && !one_pass) {
-    if (fused_prep) fail_internal("piece lists need the descriptors of k_seg_prep");
-    if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
-    hipLaunchKernelGGL(k_piece_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(), t_call,
-                       t_call + nsamples, desc, pl);
-    if (getenv("EARHIP_DEBUG_P2")) {  // debug aid: the lists as K0p wrote them
-      EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      std::vector<int> cnt((size_t)8 * ml.ntiles);
-      EARHIP_HIP(hipMemcpy(cnt.data(), pl.count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-      std::vector<Piece> pc((size_t)pl.cap());
-      for (int t = 0; t < ml.ntiles; t++) {
-        fprintf(stderr, "tile %d: base chunks %d delta chunks %d exact objects %d\n", t, cnt[t * 8], cnt[t * 8 + 1], cnt[t * 8 + 4]);
-        EARHIP_HIP(hipMemcpy(pc.data(), pl.pieces + (size_t)t * pl.cap(), pc.size() * sizeof(Piece), hipMemcpyDeviceToHost));
-        for (int l = 0, at = 0; l < 2; at += 32 * cnt[t * 8 + l], l++)
-          for (int i = 0; i < std::min(32 * cnt[t * 8 + l], 3); i++) {
-            const Piece &q = pc[at + i];
-            fprintf(stderr, "   list %d [%d]: m %u row %d p0 %g scale %g\n", l, i, q.m, q.row, q.p0, q.scale);
-          }
-      }
-    }
-  }
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
   P.sl = sl;

@@ -150,11 +150,10 @@ __host__ __device__ __forceinline__ bool level_is_quiet(unsigned obj_level, unsi
 template <int kPrepRun>
 static __global__ void __launch_bounds__(256)
 k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end,
-           SegDesc *desc, LevelProbe probe, int *ramp_count = nullptr, int max_ramps = 0, unsigned *tile_slow = nullptr) {
+           SegDesc *desc, LevelProbe probe, unsigned *tile_slow = nullptr) {
   // a thread searches the segment of its object at its FIRST tile and walks on from there for the
   // next kPrepRun - 1 (the index only grows): a workgroup covers 16 objects x 16 runs of tiles
   __shared__ SegDesc sh[16 * kPrepRun][17];
-  __shared__ int shc[16 * kPrepRun][17];
   const int ti = threadIdx.x & 15, oi = threadIdx.x >> 4;
   const int tile0 = (blockIdx.x * 16 + ti) * kPrepRun, m = blockIdx.y * 16 + oi;
   // the probe is requested first and looked at last: its latency (a TLB miss, typically) hides behind
@@ -189,28 +188,6 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       // (f16x2 gain kernel: a curve point inside the tile sends the object through its exact path there; tiles
       // without any such object — all of them on block-aligned metadata — skip the scan for them)
       if (tile_slow && (d.info & kSegMulti)) atomicOr(&tile_slow[tile], 1u);
-      if (ramp_count) {
-        // piece-list kernel (gain_p2.h): the number of ramps of this object that overlap the tile — one delta
-        // piece each; two equal times with different gains (a step inside the tile) count as a ramp of length
-        // one — found by walking on through the tile's curve points (the index the next tile starts from).
-        // More than max_ramps: -1 (the object takes the exact path in this tile).
-        SegDesc dk = d;
-        const int tile_len = (int)(t_end - t0);
-        int nd = 0, cur = 0;
-        for (;;) {
-          const int r1 = (dk.info & kSegMulti) ? seg_r1(dk.info) : tile_len;
-          if (dk.info & kSegRamp) nd += (r1 > cur || cur > 0) ? 1 : 0;
-          if (r1 > cur) cur = r1;
-          if (!(dk.info & kSegMulti)) break;
-          if (nd > max_ramps) {
-            nd = -1;
-            break;
-          }
-          k++;
-          dk = describe_segment(ps, base, n, k, t0, t_end);
-        }
-        shc[ti * kPrepRun + j][oi] = nd;
-      }
     }
   }
   __syncthreads();
@@ -219,10 +196,7 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
   for (int j = 0; j < kPrepRun; j++) {
     const int to = (threadIdx.x >> 4) + 16 * j, oo = threadIdx.x & 15;
     const int tile_o = blockIdx.x * 16 * kPrepRun + to, m_o = blockIdx.y * 16 + oo;
-    if (tile_o < ntiles && m_o < M) {
-      desc[(size_t)tile_o * M + m_o] = sh[to][oo];
-      if (ramp_count) ramp_count[(size_t)tile_o * M + m_o] = shc[to][oo];
-    }
+    if (tile_o < ntiles && m_o < M) desc[(size_t)tile_o * M + m_o] = sh[to][oo];
   }
   if (probe.in) {
     unsigned v = max(max(__float_as_uint(px.x) & 0x7fffffffu, __float_as_uint(px.y) & 0x7fffffffu),

@@ -32,7 +32,7 @@
 // of one 4-byte gather per row) and nothing else — piece words, row indices and ramp positions all come out of
 // an LDS ring that wave 0 fills with one request per chunk.
 //
-// ONE list per tile, written by k_piece_list in object order (deterministic): every object's base piece
+// ONE list per tile, written by k_piece_build in object order (deterministic): every object's base piece
 // followed by its delta pieces, padded to whole chunks of 32 with null pieces (object 0, the all-zero gain
 // row).  The pieces of an object are neighbours in k, so its input row is requested from memory once (the
 // repeats hit in the cache): a call reads its inputs once however many curve points it has.  All pieces
@@ -73,7 +73,6 @@ struct PieceLists {
   Piece *pieces;  // [ntiles][cap()]: the tile's pieces in object order, padded to a multiple of 32 with null pieces
   int *count;     // [ntiles][8]: [0] CHUNKS (32 pieces) of the list, [1] delta pieces in it, [4] exact-path objects
   int *ovf;       // [ntiles][M]: objects that take the exact per-object path
-  int *cw;        // [ntiles][M]: scratch of k_piece_list (delta pieces per object)
   int M;
   __host__ __device__ int cap() const { return kPieceCapPerObject * M + 4 * 32; }
 };
@@ -81,180 +80,11 @@ struct PieceLists {
 __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
   PieceLists pl;
   pl.M = (int)M;
-  return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 8 * M * ntiles + 15) / 16 + 1;
-}
-
-// K0p: one workgroup per tile, behind k_seg_prep: turns the tile's descriptors and ramp counts (coalesced
-// reads, no searching) into its piece list, threads over objects: the pieces are written at offsets from an
-// ordered scan over the objects' counts.
-static __global__ void __launch_bounds__(256)
-k_piece_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_call_end, const SegDesc *desc,
-             PieceLists pl) {
-  __shared__ unsigned wsum[3][4];
-  __shared__ int tot_p, run_p, run_d, run_o, all_exact;
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t t0 = t_call + (int64_t)tile * tile_samples;
-  int64_t t_end = t0 + tile_samples;
-  if (t_end > t_call_end) t_end = t_call_end;
-  Piece *list = pl.pieces + (size_t)tile * pl.cap();
-  int *ovf = pl.ovf + (size_t)tile * M;
-  const SegDesc *dtile = desc + (size_t)tile * M;
-  if (tid == 0) tot_p = run_p = run_d = run_o = 0;
-  __syncthreads();
-  Piece null_piece;
-  null_piece.m = 0u;
-  null_piece.row = ps.zero_row;
-  null_piece.p0 = 1.0f;
-  null_piece.scale = 0.0f;
-
-  // the delta pieces of object m inside the tile: the segment the tile starts in is described by dk
-  // (k_seg_prep), the others are found by walking on (GainInterpolator::process, gain_interpolator.hpp:58-86);
-  // k_seg_prep counted them with the same walk.
-  auto walk = [&](int m, SegDesc dk, Piece *out) {
-    int pbase = 0, n = 0;
-    if (dk.info & kSegMulti) {
-      pbase = ps.off[m];
-      n = ps.off[m + 1] - pbase;
-    }
-    int k = seg_k(dk.info), cur = 0, nd = 0;
-    const int tile_len = (int)(t_end - t0);
-    for (;;) {
-      // (the descriptor's 9-bit end field stores 512 as 511: only the end of a piece that ends INSIDE the
-      // tile is exact — a ramp starting at sample 511 of a 512-sample tile must not look empty)
-      const int r1 = (dk.info & kSegMulti) ? seg_r1(dk.info) : tile_len;
-      if (dk.info & kSegRamp) {
-        Piece a;
-        a.m = (uint32_t)m | kPieceDelta;
-        a.row = dk.row;
-        bool emit = true;
-        if (r1 > cur) {  // a ramp over [cur, r1) of the tile (and beyond): its own line, clamped
-          a.p0 = (float)dk.d0 * dk.scale;  // p(s) = (float)(d0 + s) * scale, :272
-          a.scale = dk.scale;
-        } else {  // two equal times with different gains: a step at cur = a ramp from cur - 1 to cur
-          a.p0 = (float)(1 - cur);
-          a.scale = 1.0f;
-          emit = cur > 0;  // (at the tile start the base piece already has the value after the step)
-        }
-        if (emit) {
-          if (out) out[nd] = a;
-          nd++;
-        }
-      }
-      if (r1 > cur) cur = r1;
-      if (!(dk.info & kSegMulti)) break;
-      if (nd > kPieceMaxPerObject) return -1;
-      k++;
-      dk = describe_segment(ps, pbase, n, k, t0, t_end);
-    }
-    return nd;
-  };
-  // inclusive scan over the 256 threads of three counters; totals through `total`
-  auto block_scan = [&](unsigned (&v)[3], unsigned (&total)[3]) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned u = __shfl_up(v[j], o, 64);
-        if (lane >= o) v[j] += u;
-      }
-      if (lane == 63) wsum[j][wv] = v[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      unsigned pre = 0, t = 0;
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const unsigned x = wsum[j][w];
-        if (w < wv) pre += x;
-        t += x;
-      }
-      total[j] = t;
-      v[j] += pre;
-    }
-    __syncthreads();
-  };
-  // ---- the delta counts of every object come from k_seg_prep (which walks the curve points of a tile anyway, with
-  // a thread per object and run of tiles: throughput, where this kernel's walks are a chain of latencies);
-  // here only their sum.  (Objects the level probe found far below the call's level — kSegQuiet, set by
-  // k_mark_quiet after k_seg_prep — take the exact path: -1 like objects with too many ramps.)
-  int *cw = pl.cw + (size_t)tile * M;
-  {
-    int mine = 0;
-    for (int mb = 0; mb < M; mb += 256) {
-      const int m = mb + tid;
-      if (m < M) {
-        int nd = cw[m];
-        if (dtile[m].info & kSegQuiet) cw[m] = nd = -1;
-        if (nd >= 0) mine += 1 + nd;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
-    if (lane == 0 && mine) atomicAdd(&tot_p, mine);
-  }
-  __syncthreads();
-  // a tile with more pieces than its list holds (more than kPieceCapPerObject per object on average):
-  // every object with a ramp inside takes the exact path, the list holds the base pieces of the others
-  if (tid == 0) all_exact = ((tot_p + 31) & ~31) > pl.cap() ? 1 : 0;
-  __syncthreads();
-  const bool tile_over = all_exact != 0;
-
-  // ---- pass 2: offsets from an ordered scan of the counts, then the segment walk again, writing
-  for (int mb = 0; mb < M; mb += 256) {
-    const int m = mb + tid;
-    int nd = 0;
-    bool exact = false;
-    const bool live = m < M;
-    SegDesc d;
-    d.info = 0;
-    d.row = 0;
-    if (live) {
-      nd = cw[m];
-      d = dtile[m];
-      exact = nd < 0 || (tile_over && nd > 0);
-      if (exact) nd = 0;
-    }
-    unsigned v[3] = {live && !exact ? 1u + (unsigned)nd : 0u, (unsigned)nd, exact ? 1u : 0u};
-    const unsigned own[3] = {v[0], v[1], v[2]};
-    unsigned last[3];
-    block_scan(v, last);
-    if (live) {
-      if (exact) {
-        ovf[run_o + (int)(v[2] - own[2])] = m;
-      } else {
-        Piece *out = list + run_p + (int)(v[0] - own[0]);
-        Piece b;
-        b.m = (uint32_t)m;
-        b.row = d.row;
-        b.p0 = 1.0f;
-        b.scale = 0.0f;
-        out[0] = b;
-        if (nd > 0) walk(m, d, out + 1);
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      run_p += (int)last[0];
-      run_d += (int)last[1];
-      run_o += (int)last[2];
-    }
-    __syncthreads();
-  }
-  // pad the list to whole chunks with null pieces; publish the counts
-  {
-    const int np = run_p, pp = (np + 31) & ~31;
-    if (np + tid < pp) list[np + tid] = null_piece;
-    if (tid == 0) {
-      pl.count[tile * 8 + 0] = pp >> 5;
-      pl.count[tile * 8 + 1] = run_d;
-      pl.count[tile * 8 + 4] = run_o;
-    }
-  }
+  return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
 }
 
 // ---------------------------------------------------------------------------
-// K0b: the piece lists in ONE pass (round 3; replaces k_seg_prep + k_mark_quiet + k_piece_list for this kernel).
+// K0: the piece lists in ONE pass (round 3; replaces k_seg_prep + k_mark_quiet + k_piece_list of round 2).
 // k_seg_prep found every (object, tile)'s segment and counted its ramps with a thread per object and run of 2-4
 // tiles, wrote 16-byte descriptors and counts for all of them, and k_piece_list — a 256-thread workgroup per tile —
 // read those back, scanned the counts and walked the curve points of every ramping object a second time, one
