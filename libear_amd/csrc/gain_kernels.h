@@ -114,6 +114,39 @@ __device__ __forceinline__ SegDesc describe_segment(const PointStore &ps, int ba
   return d;
 }
 
+// The same from the packed point records: ONE 16-byte load for the point the segment ends at (time, 1 / length,
+// flat bits) beside one for the point it starts at, instead of two dependent rounds of loads over three arrays.
+__device__ __forceinline__ SegDesc describe_segment_rec(const PointStore &ps, int base, int n, int k, int64_t t0,
+                                                        int64_t t_end) {
+  if (ps.force_ramp) return describe_segment(ps, base, n, k, t0, t_end);
+  const int allflat = (1 << ps.nbus) - 1;
+  PointRec r, q;
+  r.time = t_end;
+  r.scale = 0.0f;
+  r.flat = (uint32_t)allflat;
+  q = r;
+  if (k < n) r = ps.rec[base + k];
+  if (k > 0) q = ps.rec[base + k - 1];
+  const int fb = (k > 0 && k < n) ? ((int)r.flat & allflat) : allflat;
+  const bool ramp = fb != allflat;
+  const bool multi = k < n && r.time < t_end;
+  const int r1 = min((int)((multi ? r.time : t_end) - t0), 511);
+  SegDesc d;
+  d.info = (k << 13) | (r1 << 4) | (fb << 2) | (multi ? kSegMulti : 0) | (ramp ? kSegRamp : 0);
+  if (ramp) {
+    d.row = base + k - 1;
+    d.d0 = (int32_t)(t0 - q.time);
+    // (the record holds 1.0f / (float)(end - start); two equal times with different gains: 0 there, inf in
+    // describe_segment — such a segment is empty, its scale is never used)
+    d.scale = r.scale;
+  } else {
+    d.row = base + (k == n ? k - 1 : k);
+    d.d0 = 0;
+    d.scale = 0.0f;
+  }
+  return d;
+}
+
 // K0: one thread per (object, tile); a 256-thread block covers 16 objects x 16
 // tiles.  Lanes that are neighbours in `tile` share their object's time array
 // (the searches hit the same lines); the block transposes through LDS so that
@@ -183,7 +216,7 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       } else {
         while (k < n && ps.time[base + k] <= t0) k++;  // = upper_bound_time(.., t0), from the previous tile's
       }
-      const SegDesc d = describe_segment(ps, base, n, k, t0, t_end);
+      const SegDesc d = describe_segment_rec(ps, base, n, k, t0, t_end);
       sh[ti * kPrepRun + j][oi] = d;
       // (f16x2 gain kernel: a curve point inside the tile sends the object through its exact path there; tiles
       // without any such object — all of them on block-aligned metadata — skip the scan for them)
