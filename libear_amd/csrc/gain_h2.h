@@ -117,6 +117,10 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   // D fragments (a lane: one column, 16-byte pieces 64 bytes apart) to stores of whole 256-byte rows
   constexpr int OP = TS + 4;
   __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
+  __shared__ float inv_gcol[16 * NCT];  // 1 / the gain scale of the workgroup's columns: read at the END of a tile, where a
+                                        // round trip to memory would stand in the open
+  if (threadIdx.x < 16 * NCT) inv_gcol[threadIdx.x] = 1.0f / gcol[blockIdx.z * 16 * NCT + threadIdx.x];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
@@ -494,7 +498,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   const float wf0 = (float)(w * TS + kg * 16);
   float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
 #pragma unroll
-  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? 1.0f / gcol[col0 + c * 16 + li] : 1.0f;
+  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
   float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
   const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
 #pragma unroll

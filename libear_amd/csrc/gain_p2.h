@@ -345,6 +345,8 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   // the wave's output tile of one column tile on its way from the D fragments to stores of whole rows (gain_h2.h)
   constexpr int OP = TS + 4;
   __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
+  __shared__ float inv_gcol[16 * NCT];  // 1 / the gain scale of the workgroup's columns: read at the END of a tile, where a
+                                        // round trip to memory would stand in the open (3 us of a 130-us tile)
   __shared__ uint32_t ring[RING][CH];                                  // ... the objects alone (input addresses)
   __shared__ __attribute__((aligned(16))) u32x4 ringp[RING][CH];       // ... the whole pieces (rows, p0, scale)
   constexpr int NGI = (2 * NQ * 4 * NCT + 63) / 64;                    // float4 gain-row requests per wave and chunk
@@ -353,6 +355,8 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
   const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
+  if (threadIdx.x < 16 * NCT) inv_gcol[threadIdx.x] = 1.0f / gcol[blockIdx.z * 16 * NCT + threadIdx.x];
+  __syncthreads();
   if (level_cur) {  // input scale of THIS call from the level K0 probed (gain_h2.h)
     const unsigned lv = *level_cur;
     if (lv) {
@@ -724,7 +728,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
   float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
 #pragma unroll
-  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? 1.0f / gcol[col0 + c * 16 + li] : 1.0f;
+  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
 #pragma unroll
   for (int c = 0; c < NCT; c++) {
     if (whole) {  // transposed through wave-private LDS: whole 256-byte rows per store instruction (gain_h2.h)
