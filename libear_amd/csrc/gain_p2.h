@@ -503,8 +503,11 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
         for (int q = 0; q < 8; q += 2)
           if (q >= q0 && q < q0 + n) {
             const u32x2 mw = lane_word2(c, q);
-            x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)mw[0] * rstride));
-            x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride));
+            // (ordinary loads, not streaming ones: the pieces of one object are neighbours in the list, so a lane asks
+            // for the same 16 bytes again in its next request — found in the first-level cache, the repeat costs no
+            // second trip to L2: ADM scene K1 0.545 -> 0.503 ms, always-ramping 0.91 -> 0.84)
+            x[q] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[0] * rstride);
+            x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride);
           }
       };
       // (p0, scale) of the lane's piece q of chunk c, out of the ring (read where it is used)
