@@ -87,6 +87,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   PieceLists pl;
   pl.pieces = reinterpret_cast<Piece *>(desc + (size_t)M * ml.ntiles);
   pl.M = M;
+  pl.paired = ml.paired ? 1 : 0;
   pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
   pl.ovf = pl.count + (size_t)8 * ml.ntiles;
   // f16x2 gain kernel: a word per tile, "some object needs the exact path here" (see gain_h2.h)
@@ -180,16 +181,17 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
-#define EARHIP_P2_CASE(NCT_)                                                                                        \
-  if (cp.nct == NCT_) {                                                                                             \
+#define EARHIP_P2_CASE(NCT_, PR_)                                                                                   \
+  if (cp.nct == NCT_ && ml.paired == PR_) {                                                                         \
     if (ml.pw == 4)                                                                                                 \
-      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
+      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4, PR_>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur, \
                          level_next);                                                                                \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur,     \
+      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8, PR_>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur, \
                          level_next);                                                                                \
   }
-    EARHIP_P2_CASE(1) EARHIP_P2_CASE(2) EARHIP_P2_CASE(3)
+    EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
+    EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)
 #undef EARHIP_P2_CASE
     launched = true;
   } else if (ml.split) {
@@ -263,7 +265,8 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
-                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density());
+                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
+                            curves.pair_waste());
     desc.reserve(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

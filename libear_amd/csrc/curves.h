@@ -240,6 +240,28 @@ class CurveSet {
     for (int m = 0; m < M_; m++)
       if (times_[m].size() > 1) npts += (double)(times_[m].size() - 1);
     point_density_ = span > 0 ? npts / span : 0.0;
+    // The piece-list kernel's paired layout spends two slots on every delta piece (gain_p2.h): an object with k > 1
+    // ramps in one tile costs k - 1 slots more than in the packed layout.  Share of such extra slots among the slots
+    // of the packed layout, over the curves' whole span, on a grid of 256-sample tiles from time 0 (a call's grid
+    // starts at its own first sample: same statistics).
+    {
+      double incid = 0, touched = 0, tiles = 0;
+      for (int m = 0; m < M_; m++) {
+        const auto &t = times_[m];
+        if (t.size() > 1) tiles += (double)(t.back() - t.front()) / 256.0;
+        int64_t last_tile = INT64_MIN;
+        for (size_t k = 1; k < t.size(); k++) {
+          if ((flat_[m][k] & allflat) == allflat) continue;
+          // a step (two equal times) is a ramp of length one ending at the time
+          const int64_t a = t[k] > t[k - 1] ? t[k - 1] : t[k] - 1, b = t[k];  // the ramp covers samples [a, b)
+          const int64_t ta = a >= 0 ? a / 256 : -((-a + 255) / 256), tb = (b - 1) >= 0 ? (b - 1) / 256 : -((-(b - 1) + 255) / 256);
+          incid += (double)(tb - ta + 1);
+          touched += (double)(tb - ta + 1) - (ta == last_tile ? 1.0 : 0.0);
+          last_tile = tb;
+        }
+      }
+      pair_waste_ = (incid - touched) / std::max(1.0, tiles + incid);
+    }
     // largest |gain| (k_gain_mix_h2 scales the gains to the top of the f16 range); NaN / inf count as huge
     float gmax = 0.0f;
     for (size_t i = 0; i < P * row; i++) {
@@ -302,6 +324,7 @@ class CurveSet {
   double ramp_share() const { return ramp_share_; }
   // curve points per sample and object (0 for static gains)
   double point_density() const { return point_density_; }
+  double pair_waste() const { return pair_waste_; }
 
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
@@ -346,6 +369,7 @@ class CurveSet {
   int grid_off_[2] = {0, 0};        // objects whose points are not all on that phase
   double ramp_share_ = 0;
   double point_density_ = 0;
+  double pair_waste_ = 0;
   float gain_max_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
@@ -370,6 +394,7 @@ struct MixLaunch {
   bool wide = false;           // with split: 8 waves on 512-sample tiles
   bool pieces = false;         // matrix-core kernel on f16x2 split operands over per-tile piece lists (gain_p2.h)
   int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
+  bool paired = false;         // with pieces: the lists' paired layout (gain_p2.h)
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
@@ -379,7 +404,7 @@ struct MixLaunch {
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
-                          float gain_scale = 0.0f, double point_density = 0.0) {
+                          float gain_scale = 0.0f, double point_density = 0.0, double pair_waste = 1.0) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
@@ -408,6 +433,12 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // samples 1.22 vs 1.48 ms.  EARHIP_P2_TILE=512 selects the long tile.
     L.pw = ptile == 512 ? 8 : 4;
     (void)point_density;
+    // Layout of the lists: paired (an object's base and delta piece share one input request, and the objects without a
+    // ramp in a tile skip the position factors) unless objects often have several ramps inside one tile — every ramp
+    // beyond the first costs a slot more than in the packed layout (always-ramping curves: a third more chunks).
+    // EARHIP_P2_PAIRS=0|1 forces one of them (tests, tuning).
+    L.paired = pair_waste < 0.06;
+    if (const char *e = getenv("EARHIP_P2_PAIRS")) L.paired = atoi(e) != 0;
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
   // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments

@@ -27,21 +27,27 @@
 // fraction of tiles a ramp touches.
 //
 // Vector-memory instructions are what this kernel is short of (the CU's address unit is busy two thirds of all
-// cycles, profiles/r02_adm_scene_*): per chunk a wave issues its 8 input requests, 2-3 sixteen-byte requests for
+// cycles, profiles/r02_adm_scene_*): per chunk a wave issues its 4-8 input requests, 2-3 sixteen-byte requests for
 // the gain rows of the pieces it converts (staged through wave-private LDS to the lanes that need them, instead
 // of one 4-byte gather per row) and nothing else — piece words, row indices and ramp positions all come out of
-// an LDS ring that wave 0 fills with one request per chunk.
+// an LDS ring that wave 0 fills with one request per chunk.  And latency: a chunk of 36 MFMAs is shorter than a
+// loaded trip to L2 or to memory, so gain rows are requested two chunks ahead of their conversion (three of their
+// use) and inputs two chunks (pair chunks, which carry half the bytes: four chunks) ahead.
 //
-// ONE list per tile, written by k_piece_build in object order (deterministic): every object's base piece
-// followed by its delta pieces, padded to whole chunks of 32 with null pieces (object 0, the all-zero gain
-// row).  The pieces of an object are neighbours in k, so its input row is requested from memory once (the
-// repeats hit in the cache): a call reads its inputs once however many curve points it has.  All pieces
-// go through the same arithmetic — a base piece is a delta piece with p = 1 (p0 = 1, scale = 0) whose gain
-// operand is S - 0 instead of E - S — so there are no chunk kinds and no branches in the loop; a tile
-// without any delta piece (static gains) skips the position factor altogether.  Objects with more than
-// kPieceMaxPerObject ramps in one tile, objects the level probe found far below the call's level
-// (kSegQuiet) and, in a tile whose list would overflow, every object with a delta piece take the exact
-// per-object path.
+// ONE list per tile, written by k_piece_build in object order (deterministic), padded to whole chunks of 32 with
+// null pieces (object 0, the all-zero gain row), in one of two layouts (k_piece_build; CurveSet::pair_waste picks):
+//   packed  every object's base piece followed by its delta pieces.  The pieces of an object are neighbours in k:
+//           the repeats of its input request hit in the first-level cache.  All pieces go through the same
+//           arithmetic — a base piece is a delta piece with p = 1 (p0 = 1, scale = 0) whose gain operand is S - 0
+//           instead of E - S; a tile without any delta piece (static gains) skips the position factors.  For curves
+//           that have several ramps of one object inside a tile (always-ramping metadata).
+//   paired  the objects without a ramp in the tile in front (SINGLE chunks: 32 base pieces, no position factors),
+//           the others behind them as pairs of slots (base piece, delta piece) on ONE input request (PAIR chunks: 16
+//           objects, 4 requests per lane, position factors for the odd slots only).  For ADM-like metadata
+//           (interpolate for a while, then hold): K1 0.50 -> 0.45-0.46 ms on the ADM scene.
+// Either way a call reads its inputs from memory once however many curve points it has.  Objects with more than
+// kPieceMaxPerObject ramps in one tile (paired: kPairMaxPerObject) and objects the level probe found far below the
+// call's level (kSegQuiet) take the exact per-object path.
 //
 // Operand scaling and splitting as in gain_h2.h (x by the probed power of two, gains by 2^14 / the curve
 // set's largest gain: |E - S| <= 2^15 stays inside the f16 range).
@@ -71,15 +77,24 @@ constexpr int kMaxPieceObjects = 1 << 16;
 
 struct PieceLists {
   Piece *pieces;  // [ntiles][cap()]: the tile's pieces in object order, padded to a multiple of 32 with null pieces
-  int *count;     // [ntiles][8]: [0] CHUNKS (32 pieces) of the list, [1] delta pieces in it, [4] exact-path objects
+  int *count;     // [ntiles][8]: [0] CHUNKS (32 pieces) of the list, [1] delta pieces in it, [2] the SINGLE chunks among
+                  // them (the first ones), [4] exact-path objects
   int *ovf;       // [ntiles][M]: objects that take the exact per-object path
   int M;
+  int paired;     // layout of a tile's list (see k_gain_mix_p2): 0 packed, 1 singles + pairs
   __host__ __device__ int cap() const { return kPieceCapPerObject * M + 4 * 32; }
+  // paired layout: the pairs start here (the singles — at most one per object, padded to a chunk — lie in front)
+  __host__ __device__ int pair_off() const { return (M + 63) & ~63; }
 };
+// paired layout: pairs of ONE object in one tile (2 slots each: with the singles' region they fit cap()); beyond: the
+// exact path
+constexpr int kPairMaxPerObject = 7;
+static_assert(2 * kPairMaxPerObject + 1 <= kPieceCapPerObject, "singles + pairs fit the tile's list");
 // 16-byte units of a buffer holding the descriptors (SegDesc[ntiles][M]) and, behind them, the piece lists
 __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
   PieceLists pl;
   pl.M = (int)M;
+  pl.paired = 0;
   return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
 }
 
@@ -100,8 +115,9 @@ __host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
 // pieces.  k is left at the segment that reaches the end of the tile (where the next tile's search starts).
 constexpr int kKeepPieces = 3;
 // keep != nullptr: the first kKeepPieces delta pieces are also left there (registers: indexed by constants only)
+// (ostride: distance of the pieces written to out — 2 fills the odd slots of a run of pairs)
 __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n, int &k, int64_t t0, int64_t t_end, int m,
-                                          Piece *out, Piece *keep = nullptr) {
+                                          Piece *out, Piece *keep = nullptr, int ostride = 1) {
   const int tile_len = (int)(t_end - t0);
   int cur = 0, nd = 0;
   if (!ps.force_ramp) {
@@ -133,7 +149,7 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
           emit = cur > 0;
         }
         if (emit) {
-          if (out) out[nd] = a;
+          if (out) out[nd * ostride] = a;
           if (keep) {
             if (nd == 0) keep[0] = a;
             if (nd == 1) keep[1] = a;
@@ -167,7 +183,7 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
         emit = cur > 0;  // (at the tile start the base piece already has the value after the step)
       }
       if (emit) {
-        if (out) out[nd] = a;
+        if (out) out[nd * ostride] = a;
         if (keep) {
           if (nd == 0) keep[0] = a;
           if (nd == 1) keep[1] = a;
@@ -221,6 +237,14 @@ constexpr int kBuildThreads = 1024;
 // objects, the TILE index fastest: the TPW lanes of an object read neighbouring points of its curve (the same
 // cache lines), like k_seg_prep's lanes did — with the object index fastest every load instruction touched 64
 // different lines and the walk was four times slower than the three kernels it replaces.
+//
+// Two layouts of a tile's list (pl.paired, chosen per call from the curves: CurveSet::pair_waste):
+//   packed  every object's base piece followed by its delta pieces, all in one run;
+//   paired  the objects WITHOUT a delta piece in this tile in front ("singles": one base piece each, padded to whole
+//           chunks), behind them (from pl.pair_off()) the others as PAIRS of slots (even slot: the base piece — or,
+//           from the object's second pair on, a piece with the all-zero gain row —, odd slot: a delta piece), padded to
+//           whole chunks: the two slots of a pair take the same input, which the kernel then requests ONCE.
+// The scan carries three counters in one word: pieces (packed) or singles (paired), pairs, exact-path objects.
 template <int TPW>
 __global__ void __launch_bounds__(kBuildThreads)
 k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end, PieceLists pl,
@@ -228,14 +252,23 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
   constexpr int OB = kBuildThreads / TPW;  // objects per batch
   constexpr int WPT = OB / 64;             // waves that scan one tile's objects
   static_assert(OB % 64 == 0, "a tile's objects of a batch are whole waves of the scan");
-  __shared__ unsigned lcnt[kBuildThreads];   // [tile][object of the batch]: pieces | exact-path flag << 16; then their scan
-  __shared__ unsigned wtot[kBuildThreads / 64];
-  __shared__ int run[TPW][2];                // pieces and exact-path objects of the batches so far
+  // (a batch of 128 objects — eight tiles per workgroup, the long calls — has at most 2048 pieces, 896 pairs and 128
+  // exact-path objects: the counters fit 32 bits, and the scan's shuffles move half the words)
+  constexpr bool kNarrow = OB <= 128;
+  typedef typename std::conditional<kNarrow, unsigned, unsigned long long>::type u64;
+  constexpr int kShB = kNarrow ? 12 : 20, kShC = kNarrow ? 23 : 44;
+  constexpr u64 kOne = 1, kPairUnit = (u64)1 << kShB, kExactUnit = (u64)1 << kShC;
+  constexpr u64 kMaskA = ((u64)1 << kShB) - 1, kMaskB = ((u64)1 << (kShC - kShB)) - 1;
+  static_assert(kPieceCapPerObject * OB <= (int)kMaskA && kPairMaxPerObject * OB <= (int)kMaskB, "the scan's counters hold a batch");
+  __shared__ u64 lcnt[kBuildThreads];   // [tile][object of the batch]: the three counters; then their scan
+  __shared__ u64 wtot[kBuildThreads / 64];
+  __shared__ int run[TPW][3];           // pieces / singles, pairs and exact-path objects of the batches so far
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = tid % TPW, oi = tid / TPW;   // this thread's tile of the workgroup and object of the batch
   const int tile = blockIdx.x * TPW + j;
+  const bool paired = pl.paired != 0;
   const unsigned call_level = level_cur ? *level_cur : 0u;
-  if (tid < TPW) run[tid][0] = run[tid][1] = 0;
+  if (tid < TPW) run[tid][0] = run[tid][1] = run[tid][2] = 0;
   const int64_t t0 = t_call + (int64_t)tile * tile_samples;
   const int64_t t1 = t0 + tile_samples > t_call_end ? t_call_end : t0 + tile_samples;
   __syncthreads();
@@ -250,34 +283,36 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
       kst = upper_bound_time_window(ps.time + base, n, t0);
       int k = kst;
       cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr, keep);
+      if (paired && cnt > kPairMaxPerObject) cnt = -1;
       if (obj_level && level_is_quiet(obj_level[m], call_level)) cnt = -1;
     }
     // ---- ordered scan over the batch's objects, per tile: element e = tile * OB + object, a tile = WPT whole waves
-    lcnt[j * OB + oi] = !in ? 0u : cnt < 0 ? 0x10000u : 1u + (unsigned)cnt;
+    lcnt[j * OB + oi] = !in ? (u64)0 : cnt < 0 ? kExactUnit : !paired ? kOne * (u64)(1 + cnt) : cnt == 0 ? kOne : kPairUnit * (u64)cnt;
     __syncthreads();
-    unsigned v = lcnt[tid];
+    u64 v = lcnt[tid];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const unsigned u = __shfl_up(v, o, 64);
+      const u64 u = __shfl_up(v, o, 64);
       if (lane >= o) v += u;
     }
     if (lane == 63) wtot[wv] = v;
     __syncthreads();
     {
-      unsigned pre = 0;
+      u64 pre = 0;
       const int w0 = wv - wv % WPT;  // first wave of this tile's segment
 #pragma unroll
-      for (int w = 0; w < WPT; w++) pre += w0 + w < wv ? wtot[w0 + w] : 0u;
+      for (int w = 0; w < WPT; w++) pre += w0 + w < wv ? wtot[w0 + w] : (u64)0;
       lcnt[tid] = v + pre;  // inclusive over the tile's objects of the batch
     }
     __syncthreads();
-    // ---- the same walk again (its loads hit in the cache), writing at the scanned offsets
+    // ---- the pieces, at the scanned offsets
     if (in) {
-      const unsigned incl = lcnt[j * OB + oi];
+      const u64 incl = lcnt[j * OB + oi];
+      const int iA = (int)(incl & kMaskA), iB = (int)((incl >> kShB) & kMaskB), iC = (int)(incl >> kShC);
       if (cnt < 0) {
-        pl.ovf[(size_t)tile * M + run[j][1] + (int)(incl >> 16) - 1] = m;
+        pl.ovf[(size_t)tile * M + run[j][2] + iC - 1] = m;
       } else {
-        Piece *out = pl.pieces + (size_t)tile * pl.cap() + run[j][0] + (int)(incl & 0xffffu) - (1 + cnt);
+        Piece *tl = pl.pieces + (size_t)tile * pl.cap();
         int k = kst;
         // the row of the segment the tile starts in: a ramp's start point, else the point itself (the last one
         // beyond the end of the curve): describe_segment's rule
@@ -293,20 +328,37 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
         b.row = row;
         b.p0 = 1.0f;
         b.scale = 0.0f;
-        out[0] = b;
         // the first kKeepPieces delta pieces are still in registers from the counting walk; only an object with more
-        // walks its curve points a second time
-        if (cnt >= 1) out[1] = keep[0];
-        if (cnt >= 2) out[2] = keep[1];
-        if (cnt >= 3) out[3] = keep[2];
-        if (cnt > kKeepPieces) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
+        // walks its curve points a second time (cache hits now)
+        if (!paired) {
+          Piece *out = tl + run[j][0] + iA - (1 + cnt);
+          out[0] = b;
+          if (cnt >= 1) out[1] = keep[0];
+          if (cnt >= 2) out[2] = keep[1];
+          if (cnt >= 3) out[3] = keep[2];
+          if (cnt > kKeepPieces) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
+        } else if (cnt == 0) {
+          tl[run[j][0] + iA - 1] = b;
+        } else {
+          Piece *out = tl + pl.pair_off() + 2 * (run[j][1] + iB - cnt);
+          out[0] = b;
+          out[1] = keep[0];
+          b.row = ps.zero_row;  // the even slots of the object's further pairs: its input, no gain
+          if (cnt >= 2) out[2] = b, out[3] = keep[1];
+          if (cnt >= 3) out[4] = b, out[5] = keep[2];
+          if (cnt > kKeepPieces) {
+            (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1, nullptr, 2);
+            for (int i = kKeepPieces; i < cnt; i++) out[2 * i] = b;
+          }
+        }
       }
     }
     __syncthreads();  // (everybody has read run[] and lcnt[])
     if (tid < TPW) {
-      const unsigned tot = lcnt[tid * OB + OB - 1];
-      run[tid][0] += (int)(tot & 0xffffu);
-      run[tid][1] += (int)(tot >> 16);
+      const u64 tot = lcnt[tid * OB + OB - 1];
+      run[tid][0] += (int)(tot & kMaskA);
+      run[tid][1] += (int)((tot >> kShB) & kMaskB);
+      run[tid][2] += (int)(tot >> kShC);
     }
     __syncthreads();
   }
@@ -316,16 +368,22 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
   null_piece.row = ps.zero_row;
   null_piece.p0 = 1.0f;
   null_piece.scale = 0.0f;
-  for (int i = tid; i < TPW * 32; i += kBuildThreads) {
-    const int jj = i >> 5, tl = blockIdx.x * TPW + jj;
+  // (paired: the singles fill an EVEN number of chunks — the kernel takes them in twos)
+  for (int i = tid; i < TPW * 64; i += kBuildThreads) {
+    const int jj = i >> 6, tl = blockIdx.x * TPW + jj;
     if (tl >= ntiles) continue;
-    const int np = run[jj][0], pp = (np + 31) & ~31;
-    if (np + (i & 31) < pp) pl.pieces[(size_t)tl * pl.cap() + np + (i & 31)] = null_piece;
-    if ((i & 31) == 0) {
-      const int listed = M - run[jj][1];  // every listed object has one base piece: the rest are deltas
-      pl.count[tl * 8 + 0] = pp >> 5;
-      pl.count[tl * 8 + 1] = np - listed;
-      pl.count[tl * 8 + 4] = run[jj][1];
+    Piece *lst = pl.pieces + (size_t)tl * pl.cap();
+    const int np = run[jj][0], pp = paired ? (np + 63) & ~63 : (np + 31) & ~31;
+    if (np + (i & 63) < pp) lst[np + (i & 63)] = null_piece;
+    const int np2 = 2 * run[jj][1], pp2 = (np2 + 31) & ~31;  // (packed: no pairs)
+    if (np2 + (i & 63) < pp2) lst[pl.pair_off() + np2 + (i & 63)] = null_piece;
+    if ((i & 63) == 0) {
+      const int listed = M - run[jj][2];  // (packed) every listed object has one base piece: the rest are deltas
+      const int deltas = paired ? run[jj][1] : np - listed;
+      pl.count[tl * 8 + 0] = (pp + pp2) >> 5;
+      pl.count[tl * 8 + 1] = deltas;
+      pl.count[tl * 8 + 2] = paired || deltas == 0 ? pp >> 5 : 0;
+      pl.count[tl * 8 + 4] = run[jj][2];
     }
   }
 }
@@ -333,7 +391,7 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 // K1p.  grid = (workgroup tiles, grid-level splits of the chunk schedule, column super-groups),
 // block = 64 NW threads; P.ntiles / P.desc refer to WORKGROUP tiles of 64 NW samples.
 // x_scale, g_scale: exact powers of two (gain_h2.h).
-template <int NCT, int NW>
+template <int NCT, int NW, bool PAIRED>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next) {
@@ -467,13 +525,28 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
 
   if (P.vec_ok) {
     // ---- the chunk schedule of this workgroup: the tile's list, 32 pieces per chunk
+    // Three KINDS of chunk (k_piece_build's two layouts):
+    //   single  32 base pieces of 32 objects: every p is 1, the position factor is skipped (the first cnt[2] chunks of
+    //           a list: all of them when the tile has no delta piece at all, the singles of the paired layout);
+    //   pair    16 pairs (base or null-gain piece, delta piece) of 16 objects: 4 input requests per lane instead of 8,
+    //           position factors for the odd slots only;
+    //   packed  any 32 pieces in a row: a position factor for all of them, 8 requests of which the repeats hit in the
+    //           first-level cache.
     const Piece *lbase = pl.pieces + (size_t)wgtile * pl.cap();
     const int total = cnt[0];
-    const bool has_delta = cnt[1] > 0;  // (else every p is 1: the position factor is skipped)
+    const int n_single = cnt[2];
+    const bool has_delta = cnt[1] > 0;
+    const int pair_adj = PAIRED ? pl.pair_off() - 32 * n_single : 0;  // the pairs' region starts at pl.pair_off()
     const int zero_row = P.ps.zero_row;
-    const int c_lo = (int)(((int64_t)total * part) / nparts), c_hi = (int)(((int64_t)total * (part + 1)) / nparts);
+    // (paired layout: parts start at even chunks — the single chunks come in twos, k_piece_build pads them so)
+    const int tunits = PAIRED ? (total + 1) / 2 : total, tu = PAIRED ? 2 : 1;
+    const int c_lo = tu * (int)(((int64_t)tunits * part) / nparts), c_hi = min(total, tu * (int)(((int64_t)tunits * (part + 1)) / nparts));
     // first piece of chunk c (clamped: requests past the schedule re-read its last chunk)
-    auto chunk_ptr = [&](int c) -> const Piece * { return lbase + 32 * min(c, total - 1); };
+    auto chunk_ptr = [&](int c) -> const Piece * {
+      c = min(c, total - 1);
+      return lbase + 32 * c + (c >= n_single ? pair_adj : 0);
+    };
+    constexpr int KS = 0, KP = 1, KK = 2;
 
     if (c_hi > c_lo) {
       const int nvec = (P.nsamples + 3) & ~3;
@@ -496,19 +569,40 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       };
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
-      // inputs q0 .. q0 + n - 1 (n even) of chunk c
-      auto load_x_part = [&](int c, f32x4 (&x)[8], int q0, int n) {
+      // inputs q0 .. q0 + n - 1 (n even) of chunk c, requested as a chunk of kind K.  Single and pair chunks ask for
+      // every input once: streaming requests.  Packed chunks: ordinary ones — the pieces of one object are neighbours
+      // in the list, so a lane asks for the same 16 bytes again in its next request; found in the first-level cache,
+      // the repeat costs no second trip to L2 (ADM scene K1 0.545 -> 0.503 ms, always-ramping 0.91 -> 0.84).
+      // Pair chunks need the even slots' inputs only — four registers: a chunk's go to the even (PAR = 0) or the odd
+      // (PAR = 1) half of x, so that FOUR pair chunks are in flight in the registers that hold two others (half the
+      // bytes per chunk: with two in flight the requests outstanding no longer cover the memory latency).
+      // tr ("transition", single kind): the odd half takes the even slots of chunk c + 2 instead of the odd slots of
+      // chunk c — what the last two single chunks request for the first four pair chunks behind them.
+      auto lane_word = [&](int c, int slot) { return ring[c & (RING - 1)][kg * 8 + slot]; };
+      auto load_x_part = [&](auto kind_tag, auto par_tag, int c, f32x4 (&x)[8], int q0, int n, bool tr) __attribute__((always_inline)) {
+        constexpr int K = decltype(kind_tag)::value, PAR = decltype(par_tag)::value;
         const char *bp = reinterpret_cast<const char *>(P.in) + xlane;
 #pragma unroll
         for (int q = 0; q < 8; q += 2)
           if (q >= q0 && q < q0 + n) {
-            const u32x2 mw = lane_word2(c, q);
-            // (ordinary loads, not streaming ones: the pieces of one object are neighbours in the list, so a lane asks
-            // for the same 16 bytes again in its next request — found in the first-level cache, the repeat costs no
-            // second trip to L2: ADM scene K1 0.545 -> 0.503 ms, always-ramping 0.91 -> 0.84)
-            x[q] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[0] * rstride);
-            x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride);
+            if constexpr (K == KK) {
+              const u32x2 mw = lane_word2(c, q);
+              x[q] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[0] * rstride);
+              x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride);
+            } else if constexpr (K == KS) {
+              const uint32_t m0 = lane_word(c, q), m1 = lane_word(tr ? c + 2 : c, tr ? q : q + 1);
+              x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)m0 * rstride));
+              x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)m1 * rstride));
+            } else {
+              const uint32_t m0 = lane_word(c, q);
+              x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)m0 * rstride));
+            }
           }
+      };
+      // (prologue.  Paired kernel: as single chunks do — a part without single chunks starts in the transition form)
+      auto load_x_all = [&](int c, f32x4 (&x)[8]) __attribute__((always_inline)) {
+        load_x_part(std::integral_constant<int, PAIRED ? KS : KK>{}, std::integral_constant<int, 0>{}, c, x, 0, 8,
+                    PAIRED && c_lo >= n_single);
       };
       // (p0, scale) of the lane's piece q of chunk c, out of the ring (read where it is used)
       auto piece_ps = [&](int c, int q) {
@@ -578,34 +672,42 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
 
       // ---- prologue: piece words of the first chunks into the ring, gains of the first chunk, inputs of
       // the first two
+      constexpr int RD = PAIRED ? 5 : 4;  // ring slots up to chunk c + RD - 1 are visible during chunk c
       u32x4 ring_next = {0u, 0u, 0u, 0u};
       if (w == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) ring_store(c_lo + j, ring_load(c_lo + j));
-        ring_next = ring_load(c_lo + 4);  // (stored by the first chunk)
+        for (int j = 0; j < RD; j++) ring_store(c_lo + j, ring_load(c_lo + j));
+        ring_next = ring_load(c_lo + RD);  // (stored by the first chunk)
       }
       __syncthreads();
       f32x4 X0[8], X1[8];
+      // gain rows on their way: requested TWO chunks ahead of their use, converted one chunk ahead (a chunk of 36 MFMAs
+      // is shorter than a loaded trip to L2): the chunks that use X0 request into GA and convert GB, the others the
+      // other way round
+      f32x4 GA[NGI], GB[NGI];
       {
         f32x4 G[NGI];
         float S[NQ], E[NQ];
         load_gains(c_lo, G);
-        load_x_part(c_lo, X0, 0, 8);
-        load_x_part(c_lo + 1, X1, 0, 8);
+        load_gains(c_lo + 1, GB);  // (converted by the first chunk)
+        load_x_all(c_lo, X0);
+        load_x_all(c_lo + 1, X1);
         stage_gains(G, S, E);
         store_b(S, E, c_lo & 1);
       }
 
-      // chunk c: inputs in xc, B fragments in bfrag[c & 1]
-      auto chunk = [&](int c, f32x4 (&xc)[8]) {
+      // chunk c: inputs in xc, B fragments in bfrag[c & 1].  KC: its kind — the inputs it requests (chunk c + 2; a pair
+      // chunk: c + 4) are requested as that kind's; PAR: the half of xc a pair chunk's inputs are in; tr: see
+      // load_x_part; Gld / Gcv: the gain rows it requests (chunk c + 2) and converts (chunk c + 1)
+      auto chunk = [&](auto kc_tag, auto par_tag, int c, f32x4 (&xc)[8], f32x4 (&Gld)[NGI], f32x4 (&Gcv)[NGI], bool tr) __attribute__((always_inline)) {
+        constexpr int KC = decltype(kc_tag)::value, K2 = KC, PAR = decltype(par_tag)::value;
         const int buf = c & 1;
         __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free; ring slots <= c + 3 are visible
         if (w == 0) {
-          ring_store(c + 4, ring_next);
-          ring_next = ring_load(c + 5);
+          ring_store(c + RD, ring_next);
+          ring_next = ring_load(c + RD + 1);
         }
-        f32x4 G[NGI];
-        load_gains(c + 1, G);  // the rows of chunk c + 1 (its pieces have been in the ring for three chunks)
+        load_gains(c + 2, Gld);  // the rows of chunk c + 2 (its pieces have been in the ring for two chunks or more)
         __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
 
         // A fragments: row tile r = sample 4*li + r of the 8 pieces of this lane.  2 x 2 blocks: an f16
@@ -613,20 +715,26 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
         // subtractions pair two SAMPLES (r, r+1) of one piece.  A piece's ramp position is part of its
         // input scale: x_scale clamp(p0 + s scale, 0, 1) (base pieces: p = 1).
         u32x4 ah[NRT], al[NRT];
-        auto split = [&](auto delta_tag) {
-          constexpr bool DELTA = decltype(delta_tag)::value;
+        auto split = [&](auto ks_tag) __attribute__((always_inline)) {
+          constexpr int KSP = decltype(ks_tag)::value;  // how the pieces' inputs become operands: as a single, pair or packed chunk's
 #pragma unroll
           for (int qp = 0; qp < 4; qp++) {
 #pragma unroll
             for (int rp = 0; rp < NRT; rp += 2) {
-              f32x2 s0 = f32x2{xc[2 * qp][rp], xc[2 * qp][rp + 1]} * x_scale;          // piece 2qp
-              f32x2 s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;  // piece 2qp+1
-              if (DELTA) {
+              const int XE = KSP == KP ? 2 * qp + PAR : 2 * qp;  // (a pair chunk's inputs: one half of xc)
+              f32x2 s0 = f32x2{xc[XE][rp], xc[XE][rp + 1]} * x_scale;  // piece 2qp
+              f32x2 s1;                                                        // piece 2qp+1
+              if constexpr (KSP == KP) s1 = s0;  // (the same input)
+              else s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;
+              if constexpr (KSP != KS) {
                 const float f0 = lane_sf + (float)rp, f1 = lane_sf + (float)(rp + 1);
-                const f32x2 a = piece_ps(c, 2 * qp), b = piece_ps(c, 2 * qp + 1);
                 // (the compiler folds the median-of-three into the FMA's output clamp: one instruction per value)
-                s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
-                            __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
+                if constexpr (KSP == KK) {
+                  const f32x2 a = piece_ps(c, 2 * qp);
+                  s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
+                              __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
+                }
+                const f32x2 b = piece_ps(c, 2 * qp + 1);
                 s1 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, b[1], b[0]), 0.0f, 1.0f),
                             __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, b[1], b[0]), 0.0f, 1.0f)};
               }
@@ -640,8 +748,12 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
             }
           }
         };
-        if (has_delta) split(std::true_type{});  // (uniform over the workgroup)
-        else split(std::false_type{});
+        if constexpr (KC == KK) {  // (a packed list without any delta piece: every p is 1 — uniform over the workgroup)
+          if (has_delta) split(std::integral_constant<int, KK>{});
+          else split(std::integral_constant<int, KS>{});
+        } else {
+          split(kc_tag);
+        }
         __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
         // NCT blocks of 12 MFMAs (three partial products of one column tile, smallest first).  The inputs
         // of chunk c + 2 go into the registers just freed, a few requests per block; the conversion of the
@@ -665,29 +777,59 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
           for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(al[r], b2, tot[r][ct]);
 #pragma unroll
           for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
-          if (ct < XB) load_x_part(c + 2, xc, ct * (8 / XB), 8 / XB);
+          if (ct < XB) load_x_part(kc_tag, par_tag, KC == KP ? c + 4 : c + 2, xc, ct * (8 / XB), 8 / XB, tr);
           const bool conv = ct == NCT - 1;
           if (conv) {
             float S[NQ], E[NQ];
-            stage_gains(G, S, E);
+            stage_gains(Gcv, S, E);  // (the rows of chunk c + 1)
             store_b(S, E, buf ^ 1);
           }
           if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
           else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           if (ct < XB && !conv) {
+            constexpr int NL = (K2 == KP ? 4 : 8) / XB;  // requests of this block
 #pragma unroll
-            for (int k = 0; k < 8 / XB; k++) {  // MFMAs, then one request (address arithmetic + load)
-              __builtin_amdgcn_sched_group_barrier(0x008, 12 / (8 / XB), 0);
+            for (int k = 0; k < NL; k++) {  // MFMAs, then one request (address arithmetic + load)
+              __builtin_amdgcn_sched_group_barrier(0x008, 12 / NL, 0);
               __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
           }
         }
       };
+      constexpr std::integral_constant<int, 0> p0{};
+      constexpr std::integral_constant<int, 1> p1{};
+      if constexpr (PAIRED) {
+        // the single chunks of this part (an even number), the last two of them in the transition form, then its
+        // pair chunks, four in flight
+        const int c_mid = min(max(n_single, c_lo), c_hi);
+        constexpr std::integral_constant<int, KS> ks{};
+        constexpr std::integral_constant<int, KP> kp{};
+        int c = c_lo;
 #pragma unroll 1
-      for (int c = c_lo; c < c_hi; c += 2) {
-        chunk(c, X0);
-        if (c + 1 < c_hi) chunk(c + 1, X1);
+        for (; c + 3 < c_mid; c += 2) {
+          chunk(ks, p0, c, X0, GA, GB, false);
+          chunk(ks, p0, c + 1, X1, GB, GA, false);
+        }
+        if (c < c_mid) {
+          chunk(ks, p0, c, X0, GA, GB, true);
+          chunk(ks, p0, c + 1, X1, GB, GA, true);
+          c += 2;
+        }
+#pragma unroll 1
+        for (; c < c_hi; c += 4) {
+          chunk(kp, p0, c, X0, GA, GB, false);
+          if (c + 1 < c_hi) chunk(kp, p0, c + 1, X1, GB, GA, false);
+          if (c + 2 < c_hi) chunk(kp, p1, c + 2, X0, GA, GB, false);
+          if (c + 3 < c_hi) chunk(kp, p1, c + 3, X1, GB, GA, false);
+        }
+      } else {
+        constexpr std::integral_constant<int, KK> kk{};
+#pragma unroll 1
+        for (int c = c_lo; c < c_hi; c += 2) {
+          chunk(kk, p0, c, X0, GA, GB, false);
+          if (c + 1 < c_hi) chunk(kk, p0, c + 1, X1, GB, GA, false);
+        }
       }
     }
 

@@ -707,16 +707,18 @@ def test_gain_kernel_choice_follows_the_curves():
     assert kernel_for(64, scenes.constant_curves(64, n)) == 3   # static gains: no point inside any tile
 
 
+@pytest.mark.parametrize("pairs", ["0", "1", None])
 @pytest.mark.parametrize("tile", ["256", "512", None])
 @pytest.mark.parametrize("kind,m,layout,block,nblocks,calls",
                          [("adm", 64, "9+10+3", 512, 8, [8]), ("adm", 200, "4+5+0", 512, 6, [1, 2, 3]),
                           ("ragged", 100, "9+10+3", 256, 9, [9]), ("dense", 96, "9+10+3", 512, 5, [5]),
                           ("constant", 130, "0+5+0", 1024, 3, [3]), ("short", 64, "9+10+3", 512, 4, [4]),
                           ("adm", 1100, "9+10+3", 512, 12, [5, 7]), ("busy", 70, "4+5+0", 512, 4, [1, 3])])
-def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, calls):
+def test_piece_list_kernel_vs_oracle(pairs, tile, kind, m, layout, block, nblocks, calls):
     """k_gain_mix_p2 forced for every curve family (EARHIP_MFMA=5): metadata that ignores the tile grid,
     irregular curves with steps and dense points, block-aligned ramps, static gains, ramps of a few samples
-    deep inside a tile (p0 far outside [0, 1] before the clamp), per channel; at both tile sizes."""
+    deep inside a tile (p0 far outside [0, 1] before the clamp), per channel; at both tile sizes and in both
+    layouts of the piece lists (EARHIP_P2_PAIRS: packed, singles + pairs; None: the library's own choice)."""
     from libear_amd import capi
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
@@ -756,7 +758,7 @@ def test_piece_list_kernel_vs_oracle(tile, kind, m, layout, block, nblocks, call
             c.close()
         return out, plan
 
-    got, plan = _with_env({"EARHIP_MFMA": "5", "EARHIP_P2_TILE": tile}, render)
+    got, plan = _with_env({"EARHIP_MFMA": "5", "EARHIP_P2_TILE": tile, "EARHIP_P2_PAIRS": pairs}, render)
     assert plan["kernel"] == 4, plan
     assert np.isfinite(got).all()
     assert scenes.rel_rms(got, want) <= 1e-6, (scenes.rel_rms(got, want), plan)
