@@ -266,7 +266,7 @@ struct GainStage {
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
                             curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
-                            curves.pair_waste());
+                            curves.pair_waste(256), curves.pair_waste(512));
     desc.reserve(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

@@ -252,7 +252,7 @@ struct earhip_render {
   MixLaunch plan_call(size_t nblocks) {
     const int nsamples = (int)(nblocks * (size_t)B);
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, ctx->strict, max_gsplit, curves->aligned_tile(t),
-                            curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste());
+                            curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste(256), curves->pair_waste(512));
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     while (ml.gsplit > 1 && bus_stride * K * N * ml.gsplit > bus.n) ml.gsplit /= 2;
     return ml;

@@ -242,25 +242,27 @@ class CurveSet {
     point_density_ = span > 0 ? npts / span : 0.0;
     // The piece-list kernel's paired layout spends two slots on every delta piece (gain_p2.h): an object with k > 1
     // ramps in one tile costs k - 1 slots more than in the packed layout.  Share of such extra slots among the slots
-    // of the packed layout, over the curves' whole span, on a grid of 256-sample tiles from time 0 (a call's grid
-    // starts at its own first sample: same statistics).
-    {
+    // of the packed layout, over the curves' whole span, on grids of 256- and of 512-sample tiles from time 0 (a
+    // call's grid starts at its own first sample: same statistics).
+    for (int gi = 0; gi < 2; gi++) {
+      const int64_t T = gi ? 512 : 256;
+      auto tile_of = [T](int64_t a) { return a >= 0 ? a / T : -((-a + T - 1) / T); };
       double incid = 0, touched = 0, tiles = 0;
       for (int m = 0; m < M_; m++) {
         const auto &t = times_[m];
-        if (t.size() > 1) tiles += (double)(t.back() - t.front()) / 256.0;
+        if (t.size() > 1) tiles += (double)(t.back() - t.front()) / (double)T;
         int64_t last_tile = INT64_MIN;
         for (size_t k = 1; k < t.size(); k++) {
           if ((flat_[m][k] & allflat) == allflat) continue;
           // a step (two equal times) is a ramp of length one ending at the time
           const int64_t a = t[k] > t[k - 1] ? t[k - 1] : t[k] - 1, b = t[k];  // the ramp covers samples [a, b)
-          const int64_t ta = a >= 0 ? a / 256 : -((-a + 255) / 256), tb = (b - 1) >= 0 ? (b - 1) / 256 : -((-(b - 1) + 255) / 256);
+          const int64_t ta = tile_of(a), tb = tile_of(b - 1);
           incid += (double)(tb - ta + 1);
           touched += (double)(tb - ta + 1) - (ta == last_tile ? 1.0 : 0.0);
           last_tile = tb;
         }
       }
-      pair_waste_ = (incid - touched) / std::max(1.0, tiles + incid);
+      pair_waste_[gi] = (incid - touched) / std::max(1.0, tiles + incid);
     }
     // largest |gain| (k_gain_mix_h2 scales the gains to the top of the f16 range); NaN / inf count as huge
     float gmax = 0.0f;
@@ -324,7 +326,7 @@ class CurveSet {
   double ramp_share() const { return ramp_share_; }
   // curve points per sample and object (0 for static gains)
   double point_density() const { return point_density_; }
-  double pair_waste() const { return pair_waste_; }
+  double pair_waste(int tile) const { return pair_waste_[tile >= 512 ? 1 : 0]; }
 
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
@@ -369,7 +371,7 @@ class CurveSet {
   int grid_off_[2] = {0, 0};        // objects whose points are not all on that phase
   double ramp_share_ = 0;
   double point_density_ = 0;
-  double pair_waste_ = 0;
+  double pair_waste_[2] = {0, 0};  // on 256- and 512-sample tiles
   float gain_max_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
@@ -404,7 +406,8 @@ struct MixLaunch {
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
-                          float gain_scale = 0.0f, double point_density = 0.0, double pair_waste = 1.0) {
+                          float gain_scale = 0.0f, double point_density = 0.0, double pair_waste256 = 1.0,
+                          double pair_waste512 = 1.0) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
@@ -427,18 +430,21 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   if (L.pieces) {
     const char *pt = getenv("EARHIP_P2_TILE");
     const int ptile = pt ? atoi(pt) : 0;
-    // 4 waves on 256 samples.  8 waves on 512 halve the gain conversions and the list building per sample but keep
-    // every ramp's delta piece alive over twice the samples: ADM-like metadata (2 points per 960 samples) K1 0.53-0.55
-    // vs 0.59 ms, K0 + K0p 0.096 vs 0.070 ms, whole step 0.67-0.70 vs 0.70-0.71 ms; curves that turn every 240
-    // samples 1.22 vs 1.48 ms.  EARHIP_P2_TILE=512 selects the long tile.
-    L.pw = ptile == 512 ? 8 : 4;
-    (void)point_density;
     // Layout of the lists: paired (an object's base and delta piece share one input request, and the objects without a
     // ramp in a tile skip the position factors) unless objects often have several ramps inside one tile — every ramp
     // beyond the first costs a slot more than in the packed layout (always-ramping curves: a third more chunks).
-    // EARHIP_P2_PAIRS=0|1 forces one of them (tests, tuning).
-    L.paired = pair_waste < 0.06;
+    // Tile: the paired layout on 512 samples (8 waves) where the curves allow it — as many chunks per sample as on
+    // 256, but half the lists to build and half the gain rows to fetch (ADM scene: K0 0.072 -> 0.050 ms, moving point
+    // sources on ADM metadata K1 0.463 -> 0.440 as well); the packed layout on 256 (a ramp's delta piece lives on
+    // over the whole tile: always-ramping curves K1 0.82 vs 0.97 ms on 512).
+    // EARHIP_P2_PAIRS=0|1 and EARHIP_P2_TILE=256|512 force one of them (tests, tuning).
+    const double kPairWaste = 0.06;
+    L.paired = pair_waste256 < kPairWaste;
     if (const char *e = getenv("EARHIP_P2_PAIRS")) L.paired = atoi(e) != 0;
+    // (short calls — block mode — keep the 256-sample tiles: twice the workgroups)
+    const bool long_call = nsamples / 512 >= 2 * ctx->num_cus;
+    L.pw = ptile == 512 ? 8 : ptile == 256 ? 4 : (L.paired && long_call && pair_waste512 < kPairWaste) ? 8 : 4;
+    (void)point_density;
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
   // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments
