@@ -640,7 +640,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read inside this process; the
         # figure is attached only when profiles/traffic.json was measured (rocprofv3 --pmc passes,
         # tools/profile_passes.sh) for exactly this kernel instantiation, shape and scene
-        traffic, traffic_source = None, None
+        traffic, traffic_source, l2_requests = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -651,6 +651,9 @@ def main():
                     if same:
                         traffic = int(tj.get("gain_mix_hbm_bytes_per_step") / k1_launches)
                         traffic_source = "profiles/traffic.json: " + tj.get("kernel", "") + ", " + tj.get("source", "")
+                        nreq = tj.get("raw_per_launch", {}).get("TCP_TCC_READ_REQ_sum")
+                        if nreq:  # what the CUs ask L2 for (128 B a request): the inputs AND the gain rows, which hit in L2
+                            l2_requests = int(128 * nreq / k1_launches)
             except Exception:
                 traffic = None
         # what a kernel that only reads gets out of this box, measured in this run: the 100 % mark
@@ -706,6 +709,12 @@ def main():
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
+                         "l1_to_l2_read_requests": None if not l2_requests else {
+                             "bytes_per_launch": l2_requests,
+                             "GBps": round(l2_requests / (k1_ms / k1_launches) / 1e6, 1),
+                             "note": "TCP_TCC_READ_REQ x 128 B of the same PMC passes over this run's launch time: every read the "
+                                     "CUs send to L2 (inputs from HBM + gain rows that hit in L2); compare with peak_measured — a "
+                                     "read-only kernel's rate through the same path"},
                          "peak_measured": peak_measured,
                          "frac_of_measured_read": round(achieved / best_read, 4) if best_read else None,
                          "launches_per_step": round(k1_launches, 2),

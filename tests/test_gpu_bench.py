@@ -57,14 +57,16 @@ def test_every_baseline_config_gives_a_complete_parity_checked_line(config):
     assert line["step_ms"]["median"] > 0 and line["block_mode"]["ms_per_block"] > 0
 
 
-@pytest.mark.parametrize("scene,kernel", [("adm", "k_gain_mix_p2"), ("moving", "k_gain_mix_p2"), ("mixed", "k_gain_mix_h2"),
-                                          ("panned-adm", "k_gain_mix_p2")])
-def test_scenes_at_the_headline_size_pass_the_parity_gate_of_their_own_launch_plan(scene, kernel):
+@pytest.mark.parametrize("scene,kernel,tile", [("adm", "k_gain_mix_p2", 512), ("moving", "k_gain_mix_p2", 256),
+                                               ("mixed", "k_gain_mix_h2", 512), ("panned-adm", "k_gain_mix_p2", 512)])
+def test_scenes_at_the_headline_size_pass_the_parity_gate_of_their_own_launch_plan(scene, kernel, tile):
     """1024 objects x 512 blocks: the calls long enough for the launch plans only long calls get (the piece-list
-    kernel's 8-wave, 512-sample tiles; a ramp that starts on a tile's last sample was lost there once) — the
-    parity gate compares the timed call's own output with the CPU path, per channel"""
+    kernel's paired lists on 8-wave, 512-sample tiles for ADM-like metadata, its packed lists on 256 for curves that
+    ramp all the time; a ramp that starts on a tile's last sample was lost there once) — the parity gate compares the
+    timed call's own output with the CPU path, per channel"""
     line = run_bench(["--scene", scene, "--blocks", "512", "--steps", "2", "--warmup", "1", "--cpu-blocks", "0"])
     assert kernel in line["roofline"]["kernel"], line["roofline"]["kernel"]
+    assert line["roofline"]["plan"]["tile_samples"] == tile, line["roofline"]["plan"]
     p = line["parity"]
     assert p["same_plan_as_timed"] and p["pass"], p
     assert p["max_channel_rel_rms_vs_cpu"] <= 1e-6
