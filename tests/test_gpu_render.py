@@ -731,10 +731,11 @@ def test_piece_list_kernel_vs_oracle(pairs, tile, kind, m, layout, block, nblock
         curves = scenes.dense_curves(m, n, block, nblocks, seed=m)
     elif kind == "constant":
         curves = scenes.constant_curves(m, n, seed=m)
-    elif kind == "busy":  # a few objects with more ramps in one tile than a list takes per object (15): the exact path
+    elif kind == "busy":  # a few objects with more ramps in one tile than a list takes per object (15; paired lists 7):
+        # the exact path; and some with 4-7 (more than the list builder keeps in registers: its second walk)
         curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
         rng = np.random.default_rng(m)
-        for i, step in ((3, 5), (40, 11), (69, 16)):
+        for i, step in ((3, 5), (40, 11), (69, 16), (10, 45), (20, 70), (21, 37)):
             t = np.arange(-40, total + 40, step, dtype=np.int64)
             curves[i] = (t, rng.uniform(0, 1, (len(t), n)).astype(np.float32), rng.uniform(0, 1, (len(t), n)).astype(np.float32))
     else:  # 9-sample ramps at arbitrary times
