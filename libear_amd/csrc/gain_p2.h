@@ -557,8 +557,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       const size_t rstride = P.in_stride * sizeof(float);
       const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
 
-      // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested
-      // five chunks ahead, stored four ahead (visible after the next barrier), read two ahead (input addresses)
+      // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested RD + 1
+      // chunks ahead, stored RD ahead (visible after the next barrier), read two — pair chunks four — ahead (input
+      // addresses, gain rows)
       // (one 16-byte request per chunk: every other per-piece datum the waves need comes out of this ring)
       auto ring_load = [&](int c) -> u32x4 { return *reinterpret_cast<const u32x4 *>(chunk_ptr(c) + (lane & 31)); };
       auto ring_store = [&](int c, u32x4 v) {
