@@ -191,12 +191,13 @@ def test_levels_scene_at_the_headline_size(kind):
     print(f"levels scene ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
 
-@pytest.mark.parametrize("scene", ["dense", "adm", "moving"])
+@pytest.mark.parametrize("scene", ["dense", "adm", "adm-512", "moving"])
 def test_seed_sweep_at_1024_objects(scene):
     """Eight seeds (curves and audio) x {block-aligned ramps, ADM-like metadata, always-ramping metadata} at 1024
     objects: the worst channel of every run against the CPU path.  The CPU path's own sequential float32 sum sits
     6e-7 from a float64 render at this size, so the margin to 1e-6 is thin by nature; the
-    distribution is printed."""
+    distribution is printed.  (adm-512: the 8-wave, 512-sample tiles the piece-list kernel's paired lists get in
+    calls of 512 blocks and more, forced here — read per call.)"""
     layout, m, block, nblocks = "9+10+3", 1024, 512, 256  # (long enough for the launch plan of a stream: no object splits)
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
@@ -205,12 +206,23 @@ def test_seed_sweep_at_1024_objects(scene):
     for seed in range(8):
         if scene == "dense":
             curves = scenes.dense_curves(m, n, block, nblocks, seed=100 + seed)
-        elif scene == "adm":
+        elif scene in ("adm", "adm-512"):
             curves = scenes.adm_curves(m, n, total, seed=200 + seed)
         else:
             curves = scenes.adm_curves(m, n, total, period=240, ramp=240, seed=300 + seed)
         x = device_audio(m, total, 400 + seed)
-        out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+        keep = os.environ.get("EARHIP_P2_TILE")
+        if scene == "adm-512":
+            os.environ["EARHIP_P2_TILE"] = "512"
+        try:
+            out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+        finally:
+            if scene == "adm-512":
+                os.environ.pop("EARHIP_P2_TILE", None)
+                if keep is not None:
+                    os.environ["EARHIP_P2_TILE"] = keep
+        if scene == "adm-512":
+            assert plan["kernel"] == 4 and plan["tile"] == 512, plan
         worst.append(check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks - 3, 3)]))
     print(f"seed sweep ({scene}, plan {plan}): worst channel per seed " + " ".join(f"{w:.2e}" for w in worst)
           + f"; max {max(worst):.3e}")
