@@ -558,7 +558,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       // last vector: never stored)
       const unsigned xlane = (unsigned)min(tile_s0 + li * NRT, nvec - 4) * 4u;
       const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;          // fragment triple (h, l, h 2^-11) this lane fills
-      const size_t rstride = P.in_stride * sizeof(float);
+      // (32 bits: object x row stride is then ONE 32 x 32 -> 64-bit multiply-add per address instead of four
+      // instructions; launch_gain_mix sends calls whose rows are 4 GB apart or more down the unaligned path)
+      const uint32_t rstride = (uint32_t)(P.in_stride * sizeof(float));
       const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
 
       // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested RD + 1
@@ -592,15 +594,15 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
           if (q >= q0 && q < q0 + n) {
             if constexpr (K == KK) {
               const u32x2 mw = lane_word2(c, q);
-              x[q] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[0] * rstride);
-              x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + (size_t)mw[1] * rstride);
+              x[q] = *reinterpret_cast<const f32x4 *>(bp + (uint64_t)mw[0] * rstride);
+              x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + (uint64_t)mw[1] * rstride);
             } else if constexpr (K == KS) {
               const uint32_t m0 = lane_word(c, q), m1 = lane_word(tr ? c + 2 : c, tr ? q : q + 1);
-              x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)m0 * rstride));
-              x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)m1 * rstride));
+              x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (uint64_t)m0 * rstride));
+              x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (uint64_t)m1 * rstride));
             } else {
               const uint32_t m0 = lane_word(c, q);
-              x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)m0 * rstride));
+              x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (uint64_t)m0 * rstride));
             }
           }
       };
@@ -769,6 +771,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
           for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][fr + q][lane];
         };
         u32x4 b[2][2], b2;  // (the scaled high piece is read as its block starts: gain_h2.h)
+        f32x4 tsum[2][NRT];  // (packed chunks: the sums of a block's products, see below)
         load_b(0, b[0]);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
@@ -780,15 +783,19 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
             // Packed lists have the longest chains (three pieces per object when every object ramps all the time: ~300
             // MFMAs on one accumulator, each of which rounds the running total): the chunk's three products are summed
             // among themselves first, the total takes ONE addition per chunk (rounding error of the total ~ 1 / sqrt 3)
-            f32x4 t[NRT];
+            // (a block's sums are added behind the first MFMAs of the NEXT block — the last block's behind the conversion
+            // of the next chunk's gains —, where they do not wait for the chain they close)
+            f32x4(&t)[NRT] = tsum[ct & 1];
 #pragma unroll
             for (int r = 0; r < NRT; r++) t[r] = mfma_f16(ah[r], bc[1], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            if (ct > 0) {
+#pragma unroll
+              for (int r = 0; r < NRT; r++) tot[r][ct - 1] += tsum[(ct - 1) & 1][r];
+            }
 #pragma unroll
             for (int r = 0; r < NRT; r++) t[r] = mfma_f16(al[r], b2, t[r]);
 #pragma unroll
             for (int r = 0; r < NRT; r++) t[r] = mfma_f16(ah[r], bc[0], t[r]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot[r][ct] += t[r];
           } else {
 #pragma unroll
             for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[1], tot[r][ct]);
@@ -815,6 +822,10 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
               __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
           }
+        }
+        if constexpr (KC == KK && kChunkSums) {
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot[r][NCT - 1] += tsum[(NCT - 1) & 1][r];
         }
       };
       constexpr std::integral_constant<int, 0> p0{};
