@@ -167,7 +167,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   P.ngroups = ml.mfma ? cp.mgroups : cp.ngroups;
   P.wsplit = ml.wsplit;
   P.tiles_per_wg = ml.mfma ? ml.tpw : 1;
-  P.vec_ok = (in_stride % 4 == 0 && out_stride % 4 == 0 && part_stride % 4 == 0 && in_stride < ((size_t)1 << 30) &&
+  P.vec_ok = (in_stride % 4 == 0 && out_stride % 4 == 0 && part_stride % 4 == 0 &&
               ((uintptr_t)in_dev & 15) == 0 && ((uintptr_t)out_dev & 15) == 0)
                  ? 1
                  : 0;

@@ -409,7 +409,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
   __shared__ float inv_gcol[16 * NCT];  // 1 / the gain scale of the workgroup's columns: read at the END of a tile, where a
                                         // round trip to memory would stand in the open (3 us of a 130-us tile)
-  __shared__ uint32_t ring[RING][CH];                                  // ... the objects alone (input addresses)
+  __shared__ __attribute__((aligned(16))) uint64_t ring[RING][CH];     // ... byte offsets of the objects' input rows (object x row
+                                                                       // stride: one 64-bit multiply per piece by wave 0 instead
+                                                                       // of one per request by every wave — quarter-rate each)
   __shared__ __attribute__((aligned(16))) u32x4 ringp[RING][CH];       // ... the whole pieces (rows, p0, scale)
   constexpr int NGI = (2 * NQ * 4 * NCT + 63) / 64;                    // float4 gain-row requests per wave and chunk
   __shared__ __attribute__((aligned(16))) f32x4 stage[NW][NGI * 64];   // the wave's gain rows of a chunk: [2 NQ][16 NCT] floats
@@ -558,9 +560,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       // last vector: never stored)
       const unsigned xlane = (unsigned)min(tile_s0 + li * NRT, nvec - 4) * 4u;
       const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;          // fragment triple (h, l, h 2^-11) this lane fills
-      // (32 bits: object x row stride is then ONE 32 x 32 -> 64-bit multiply-add per address instead of four
-      // instructions; launch_gain_mix sends calls whose rows are 4 GB apart or more down the unaligned path)
-      const uint32_t rstride = (uint32_t)(P.in_stride * sizeof(float));
+      const uint64_t rstride = P.in_stride * sizeof(float);
       const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
 
       // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested RD + 1
@@ -570,12 +570,13 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       auto ring_load = [&](int c) -> u32x4 { return *reinterpret_cast<const u32x4 *>(chunk_ptr(c) + (lane & 31)); };
       auto ring_store = [&](int c, u32x4 v) {
         if (lane < 32) {
-          ring[c & (RING - 1)][lane] = v[0] & ~kPieceDelta;
+          ring[c & (RING - 1)][lane] = (uint64_t)(v[0] & ~kPieceDelta) * rstride;
           ringp[c & (RING - 1)][lane] = v;
         }
       };
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
+      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+      auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u64x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
       // inputs q0 .. q0 + n - 1 (n even) of chunk c, requested as a chunk of kind K.  Single and pair chunks ask for
       // every input once: streaming requests.  Packed chunks: ordinary ones — the pieces of one object are neighbours
       // in the list, so a lane asks for the same 16 bytes again in its next request; found in the first-level cache,
@@ -593,16 +594,16 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
         for (int q = 0; q < 8; q += 2)
           if (q >= q0 && q < q0 + n) {
             if constexpr (K == KK) {
-              const u32x2 mw = lane_word2(c, q);
-              x[q] = *reinterpret_cast<const f32x4 *>(bp + (uint64_t)mw[0] * rstride);
-              x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + (uint64_t)mw[1] * rstride);
+              const u64x2 mw = lane_word2(c, q);
+              x[q] = *reinterpret_cast<const f32x4 *>(bp + mw[0]);
+              x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + mw[1]);
             } else if constexpr (K == KS) {
-              const uint32_t m0 = lane_word(c, q), m1 = lane_word(tr ? c + 2 : c, tr ? q : q + 1);
-              x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (uint64_t)m0 * rstride));
-              x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (uint64_t)m1 * rstride));
+              const uint64_t m0 = lane_word(c, q), m1 = lane_word(tr ? c + 2 : c, tr ? q : q + 1);
+              x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m0));
+              x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m1));
             } else {
-              const uint32_t m0 = lane_word(c, q);
-              x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (uint64_t)m0 * rstride));
+              const uint64_t m0 = lane_word(c, q);
+              x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m0));
             }
           }
       };
