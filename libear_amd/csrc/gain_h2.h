@@ -294,7 +294,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
         // curve points inside the tile (slow path) get the all-zero row
         const bool valid = m0 + q >= m_lo + cc * CH && !(d.info & (kSegMulti | kSegQuiet));
         const unsigned rs = (unsigned)(valid ? d.row : zero_row);
-        const unsigned re = rs + ((valid && (d.info & kSegRamp)) ? 1u : 0u);
+        // (a select between two uniform values: "rs + (ramp ? 1 : 0)" turns the uniform condition into a lane value and
+        // the row products into eight quarter-rate vector multiplies per chunk)
+        const unsigned re = (valid && (d.info & kSegRamp)) ? (unsigned)d.row + 1u : rs;
         D.p0[q] = (float)d.d0 * d.scale;  // gain_interpolator.hpp:272 at the tile start
         D.scale[q] = d.scale;             // constant segments: scale = 0, d0 = 0
         const float *rps = gain + (size_t)rs * rowlen, *rpe = gain + (size_t)re * rowlen;
