@@ -492,7 +492,7 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
     }
     if (const char *e = getenv("EARHIP_TPW")) {
       const int v = atoi(e);
-      if (v >= 1 && v <= 8) c->tiles_per_wg = v;
+      if (v >= 1 && v <= 8) c->tiles_per_wg = v, c->tiles_per_wg_forced = true;
     }
     if (const char *e = getenv("EARHIP_NRT")) {
       const int v = atoi(e);

@@ -138,6 +138,7 @@ struct earhip_ctx {
   earhip::DevBuf<unsigned> obj_level;  // [objects] per-object input levels of the current call (float bits); all zero between calls
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
+  bool tiles_per_wg_forced = false;  // (EARHIP_TPW: taken as given)
   int nrt = 8;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)
   int num_cus = 256;
   // host memory the device reaches directly: earhip_host_alloc / earhip_host_register ranges (the host-pointer

@@ -474,6 +474,11 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // 8 waves per workgroup: what the column groups leave goes to object splits
   const int groups = L.mfma ? cp.mgroups : cp.ngroups;
   if (L.mfma) L.tpw = std::max(1, std::min(std::min(ctx->tiles_per_wg, L.ntiles), ctx->max_waves / groups));
+  // The exact f32 kernel adds every term to its running total in its own rounding step (an MFMA of k = 4 is four fused
+  // multiply-adds in a row): with many objects the waves of a workgroup split the slot list rather than taking adjacent
+  // tiles, so that no wave's chain is longer than ~256 terms (1024 ramping objects, one wave: 8.5e-7 from a float64 render
+  // and 1.06e-6 from the CPU path; eight waves: 4.6e-7 and 7.9e-7, for 3 % of that kernel's time)
+  if (L.mfma && !ctx->tiles_per_wg_forced) L.tpw = std::max(1, std::min(L.tpw, (ctx->max_waves / groups) / std::max(1, (M + 127) / 128)));
   L.wsplit = std::max(1, std::min(std::max(1, ctx->max_waves / (groups * L.tpw)), std::max(1, M / 8)));
   // few tiles (block mode): split the objects across workgroups as well until
   // the grid covers the chip about twice over

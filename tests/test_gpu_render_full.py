@@ -106,12 +106,9 @@ def test_headline_call_at_its_own_size_vs_oracle_windows():
     out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
     if os.environ.get("EARHIP_MFMA") in (None, "3") and os.environ.get("EARHIP_H2_TILE") is None:
         assert plan["kernel"] == 3 and plan["tile"] == 512 and plan["gsplit"] == 1, plan
-    # (forced onto the exact-f32 slot kernel the scene is 1.03e-6 from the CPU path: that kernel adds TWO terms per
-    # ramping object — 2048 in one float32 chain where the CPU adds 1024 — so its own distance from a float64 render
-    # is sqrt 2 times the CPU's 6.2e-7; the two roundings are independent and add in quadrature.  The kernels that
-    # run by default are held to 1e-6; this forced configuration to 1.5e-6)
-    tol = 1.5e-6 if os.environ.get("EARHIP_MFMA") == "1" else TOL
-    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (511, 2), (1021, 3)], tol=tol)
+    # (forced onto the exact-f32 slot kernel — EARHIP_MFMA=1 — the same bar holds: its waves split the slot list so that
+    # no float32 chain is longer than ~256 terms)
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (511, 2), (1021, 3)])
     print(f"headline call: worst per-channel rel RMS vs oracle {worst:.3e}, plan {plan}")
 
 
@@ -221,7 +218,7 @@ def test_seed_sweep_at_1024_objects(scene):
                 os.environ.pop("EARHIP_P2_TILE", None)
                 if keep is not None:
                     os.environ["EARHIP_P2_TILE"] = keep
-        if scene == "adm-512":
+        if scene == "adm-512" and os.environ.get("EARHIP_MFMA") in (None, "3", "5"):
             assert plan["kernel"] == 4 and plan["tile"] == 512, plan
         worst.append(check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks - 3, 3)]))
     print(f"seed sweep ({scene}, plan {plan}): worst channel per seed " + " ".join(f"{w:.2e}" for w in worst)
