@@ -132,7 +132,10 @@ int earhip_gain_interp_process_device(earhip_gain_interp *gi, int64_t block_star
  * complex bins; reverse the inverse; both un-normalised.  Like libear's kissfft
  * plan (src/fft_kiss.cpp:104-107) any even n_fft is taken — here up to 8192
  * (mixed radix 4/2/3/5 + kissfft's generic butterfly for every other prime; the
- * powers of two from 64 have their own kernels).  Host pointers.
+ * powers of two from 64 have their own kernels).  Cost: a prime factor p > 5 costs
+ * n_fft * p complex multiply-adds per transform, as in kissfft — n_fft = 2 * 4093
+ * is ~33 M of them, thousands of times a neighbouring size: correct, not fast.
+ * Host pointers.
  * ---------------------------------------------------------------------- */
 typedef struct earhip_fft_plan earhip_fft_plan;
 int earhip_fft_plan_create(earhip_ctx *ctx, size_t n_fft, earhip_fft_plan **out);
@@ -144,7 +147,8 @@ int earhip_fft_reverse(earhip_fft_plan *plan, const float *in_complex, float *ou
  * (C) BlockConvolver — replaces ear::dsp::block_convolver::{Context, Filter,
  * BlockConvolver} (include/ear/dsp/block_convolver.hpp:28-112; behaviour of
  * src/dsp/block_convolver_impl.cpp:10-243).  block_size in [1, 4096], any
- * factorisation (480, 960, 1920, 441, primes ... as well as the powers of two).
+ * factorisation (480, 960, 1920, 441, primes ... as well as the powers of two;
+ * large prime factors at the cost stated under (B)).
  * ---------------------------------------------------------------------- */
 typedef struct earhip_conv_ctx earhip_conv_ctx;
 typedef struct earhip_conv_filter earhip_conv_filter;

@@ -77,11 +77,15 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     probe.level = level_cur;
     // per-object levels: raised by K0; k_mark_quiet flags the quiet objects' descriptors and clears them
     // again (all zero between calls)
-    if (ctx->obj_level.n < (size_t)M) {
+    // (two buffers: k_seg_prep's form of the probe raises its words with atomicMax and k_mark_quiet clears them again —
+    // all zero between calls —, the list builders' probe stores every object's word plainly.  Both grow with the
+    // largest M this context has seen: contexts are shared by gain stages of different sizes.)
+    DevBuf<unsigned> &lv = (ml.pieces ? ctx->obj_level_lists : ctx->obj_level);
+    if (lv.n < (size_t)M) {
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      ctx->obj_level.alloc_zero(2 * (size_t)M + 64, ctx->stream);
+      lv.alloc_zero((size_t)M + M / 2 + 64, ctx->stream);
     }
-    probe.obj_level = ctx->obj_level.p;
+    probe.obj_level = lv.p;
   }
   // (piece lists: K0 also counts every object's ramps per tile, into the list builder's count words)
   PieceLists pl;
@@ -108,8 +112,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     unsigned *obj_lv = nullptr;
     if (probe.obj_level) {
-      // (its own half of the per-object words: k_seg_prep's form of the probe expects its half zero between calls)
-      obj_lv = ctx->obj_level.p + M + 32;
+      obj_lv = probe.obj_level;  // (ctx->obj_level_lists: its own buffer, see above)
       hipLaunchKernelGGL(k_level_probe, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M,
                          ml.ntiles, ml.tile(), probe.every, level_cur, obj_lv);
     }
@@ -185,10 +188,10 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (cp.nct == NCT_ && ml.paired == PR_) {                                                                         \
     if (ml.pw == 4)                                                                                                 \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4, PR_>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next);                                                                                \
+                         level_next, wide_next);                                                                     \
     else                                                                                                            \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8, PR_>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next);                                                                                \
+                         level_next, wide_next);                                                                     \
   }
     EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
     EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)

@@ -853,10 +853,10 @@ int earhip_panner_calculate_extent_device(earhip_panner *p, size_t npos, const d
     require(p != nullptr, "panner must not be NULL");
     require(azimuth && elevation && direct && diffuse_out, "azimuth, elevation and the outputs must not be NULL");
     require(npos < ((size_t)1 << 28), "too many positions");
-    if (npos == 0) return;
     p->ctx->use();
-    // the counter of positions no region takes means "this call" (earhip_panner_missed reads it)
+    // the counter of positions no region takes means "this call" (earhip_panner_missed reads it) — an empty call too
     EARHIP_HIP(hipMemsetAsync(p->missed.p, 0, sizeof(unsigned), p->ctx->stream));
+    if (npos == 0) return;
     launch_pan(p, npos, azimuth, elevation, distance, width, height, depth, gain, diffuse, direct, diffuse_out);
   });
 }

@@ -136,6 +136,7 @@ struct earhip_ctx {
   size_t tile_slow_cap = 0;
   int tile_slow_idx = 0;
   earhip::DevBuf<unsigned> obj_level;  // [objects] per-object input levels of the current call (float bits); all zero between calls
+  earhip::DevBuf<unsigned> obj_level_lists;  // [objects] the same for the list-building kernels (plain stores: no state between calls)
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
   bool tiles_per_wg_forced = false;  // (EARHIP_TPW: taken as given)

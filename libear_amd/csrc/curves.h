@@ -265,23 +265,26 @@ class CurveSet {
       pair_waste_[gi] = (incid - touched) / std::max(1.0, tiles + incid);
     }
     // largest |gain| (k_gain_mix_h2 scales the gains to the top of the f16 range); NaN / inf count as huge
-    float gmax = 0.0f;
-    for (size_t i = 0; i < P * row; i++) {
-      const float a = std::fabs(h_gain_.p[i]);
-      gmax = a <= gmax ? gmax : a;  // (a NaN replaces gmax)
-    }
-    gain_max_ = gmax;
     // ... and per COLUMN (the split-operand kernels scale every output column's gains by its own power of two:
     // a loudspeaker that only ever gets small gains — an object 120 dB down alone on it — keeps both f16 pieces of
     // its gains normal; the inverse is applied to the column's output).  Columns without any gain: the set's scale.
+    // One row-major sweep for both (commit runs inside process calls: no strided passes over the image).
+    scratch_cmax_.assign(row, 0.0f);
+    float gmax = 0.0f;
+    for (size_t k = 0; k < P; k++) {
+      const float *g = h_gain_.p + k * row;
+      for (size_t c = 0; c < row; c++) {
+        const float a = std::fabs(g[c]);
+        float &cm = scratch_cmax_[c];
+        cm = a <= cm ? cm : a;  // (a NaN replaces the maximum)
+      }
+    }
+    for (size_t c = 0; c < row; c++) gmax = scratch_cmax_[c] <= gmax ? gmax : scratch_cmax_[c];
+    gain_max_ = gmax;
     h_gcol_.reserve(row);
     const float set_scale = gain_scale();
     for (size_t c = 0; c < row; c++) {
-      float cm = 0.0f;
-      for (size_t i = c; i < P * row; i += row) {
-        const float a = std::fabs(h_gain_.p[i]);
-        cm = a <= cm ? cm : a;
-      }
+      const float cm = scratch_cmax_[c];
       int e;
       std::frexp(cm, &e);
       h_gcol_.p[c] = (cm >= 1e-30f && cm < 1e30f) ? std::ldexp(1.0f, 14 - e) : (set_scale > 0.0f ? set_scale : 1.0f);
@@ -387,6 +390,7 @@ class CurveSet {
   PinBuf<float> h_gain_;
   hipEvent_t staged_ = nullptr;
   std::vector<int64_t> scratch_phase_, scratch_sorted_;
+  std::vector<float> scratch_cmax_;
 };
 
 // How K1 is spread over the chip for one call.

@@ -398,7 +398,7 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 template <int NCT, int NW, bool PAIRED>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next) {
+              unsigned *level_next, unsigned *wide_next) {
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
   constexpr int NFRAG = NCT * 3;  // column tiles x {h, l, h 2^-11}
@@ -427,7 +427,12 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       const int E = max(-60, min(20, (int)(lv >> 23) - 127));
       x_scale = __uint_as_float((unsigned)(127 + 7 - E) << 23);
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *level_next = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+      *level_next = 0;
+      // (the grid kernel's mode word of the NEXT call: whichever kernel runs a call clears it, or a "wide" left by an
+      // earlier call would keep the grid kernel in its slower form two calls later)
+      if (wide_next) *wide_next = 0u;
+    }
   }
   const int nparts = gridDim.y;
   const int part = blockIdx.y;

@@ -35,7 +35,8 @@ def test_scenario(sc):
     assert np.max(np.abs(got - ref)) < 1e-6
 
 
-@pytest.mark.parametrize("block", [32, 64, 256, 1024, 2048, 1, 2, 3, 16, 45, 100, 441, 480, 960, 1920, 3000, 4096])
+@pytest.mark.parametrize("block", [32, 64, 256, 1024, 2048, 1, 2, 3, 16, 45, 100, 441, 480, 960, 1920, 3000, 4096,
+                                   2039, 4093])  # large primes: the generic butterfly does all the work (L = 2 p)
 def test_other_block_sizes_dense_input(block):
     """full-scale dense input (not sparse impulses), 3 partitions, one crossfade; block sizes that are not
     powers of two take the mixed-radix transforms (kissfft factorises any length, kissfft.hh:34-51)"""

@@ -99,7 +99,8 @@ def test_gain_stage_ragged_curves_strict_bit_exact():
 
 
 @pytest.mark.parametrize("m,layout,block,nblocks,kind",
-                         [(64, "4+5+0", 512, 4, "dense"), (256, "9+10+3", 512, 3, "dense"),
+                         [(1, "0+5+0", 512, 4, "dense"),  # BASELINE config 1 on the HIP path (1 -> N: exact arithmetic)
+                          (64, "4+5+0", 512, 4, "dense"), (256, "9+10+3", 512, 3, "dense"),
                           (16, "0+5+0", 1024, 3, "dense"), (48, "9+10+3", 512, 4, "sparse"),
                           (20, "4+5+0", 128, 9, "ragged"), (12, "0+5+0", 2048, 2, "constant")])
 def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
@@ -119,6 +120,9 @@ def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
     want = run_oracle(curves, x, n, block, dec, 255)
     got = run_hip(curves, x, n, block, dec, 255, [nblocks])
     assert scenes.rel_rms(got, want) <= 1e-6
+    if m == 1:  # config 1: the gain stage alone is libear's LinearInterpVector, bit for bit
+        direct = run_hip(curves, x, n, block, None, 0, [nblocks])
+        assert np.array_equal(direct, run_oracle(curves, x, n, block, None, 0))
     step = run_hip(curves, x, n, block, dec, 255, [1] * nblocks)
     assert scenes.rel_rms(step, want) <= 1e-6
     assert scenes.rel_rms(step, got) <= 1e-6
@@ -899,3 +903,41 @@ def test_contexts_on_concurrent_threads():
     for s in range(4):
         for k, o in enumerate(results[s]):
             assert np.array_equal(o, serial[s][k % 2]), (s, k)
+
+
+def test_one_context_shared_by_renderers_of_growing_size():
+    """One context, gain stages of different object counts, both list-building and grid kernels: the per-object
+    level words the probes leave behind must fit the largest stage and must not leak between the kernels' forms
+    (round-3 review: a stage of M objects sized them, a later stage of up to 2 M + 64 wrote past the end)."""
+    layout, block, nblocks = "4+5+0", 512, 4
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+
+    def check(m, shift):
+        curves = [(t + shift, d, f) for t, d, f in scenes.dense_curves(m, n, block, nblocks, seed=m)]
+        x = scenes.audio(m, total, seed=m)
+        got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+        assert scenes.rel_rms_per_channel(got, run_oracle(curves, x, n, block, dec, 255)) <= 1e-6, (m, shift)
+
+    check(96, 37)    # piece lists, small
+    check(96, 0)     # grid kernel right after them, same size
+    check(200, 37)   # piece lists: > M + 16 of the first stage, <= 2 M + 64
+    check(520, 37)   # piece lists, far beyond
+    check(520, 0)
+    check(64, 0)     # and smaller again
+    check(64, 37)
+
+
+def test_render_block_size_with_a_large_prime_factor():
+    """block 1019 (prime): the transform of 2038 points is one radix-2 pass and kissfft's generic butterfly of
+    radix 1019 (kissfft.hh:321-352) — every output a sum of 1019 products, thousands of times the work of a
+    neighbouring size, and the only path such sizes have: checked through the fused render against the oracle"""
+    layout, block, nblocks, m = "0+5+0", 1019, 3, 5
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    x = scenes.audio(m, block * nblocks)
+    want = run_oracle(curves, x, n, block, dec, 255)
+    got = run_hip(curves, x, n, block, dec, 255, [nblocks])
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6

@@ -85,3 +85,29 @@ def test_empty_points_are_an_error():
     x = np.zeros(10, np.float32)
     with pytest.raises(_oracle.OracleError):
         _oracle.gain_interp("single", [], np.zeros((0, 1, 1), np.float32), x, [10])
+
+
+def test_config1_one_object_to_0_5_0_vector_closed_form():
+    """BASELINE config 1 as written: 1 object -> 0+5+0 (6 channels incl. LFE1), block 512, a full-length ramp per
+    block through GainInterpolator<LinearInterpVector> (gain_interpolator.hpp:53-87,214-241), against the closed
+    form of the reference's own test (tests/gain_interpolator_tests.cpp:58-70: p = (float)(t - start) * (1.0f /
+    (float)(end - start)), g = (1 - p) s + p e, out = in * g), bit for bit, for several chunkings of the stream."""
+    from layouts import LAYOUTS
+    n, block, nblocks = len(LAYOUTS["0+5+0"]), 512, 4
+    assert n == 6
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, block * nblocks).astype(np.float32)
+    times = [block * k for k in range(nblocks + 1)]
+    vals = rng.uniform(0, 1, (nblocks + 1, 1, n)).astype(np.float32)
+    vals[:, 0, 3] = 0.0  # LFE1: the gain calculators leave it at exactly zero (gain_calculator_objects.cpp:51-52)
+    want = np.zeros((n, block * nblocks), np.float32)
+    for k in range(nblocks):
+        t = np.arange(block * k, block * (k + 1))
+        p = ((t - block * k).astype(np.float32) * (np.float32(1.0) / np.float32(block))).astype(np.float32)
+        for c in range(n):
+            g = ((np.float32(1) - p) * vals[k, 0, c] + p * vals[k + 1, 0, c]).astype(np.float32)
+            want[c, t] = x[t] * g
+    for sizes in ([block] * nblocks, [block * nblocks], chunks(block * nblocks, 100)):
+        got = _oracle.gain_interp("vector", times, vals, x, sizes)
+        assert np.array_equal(got, want)
+    assert not want[3].any()
