@@ -59,7 +59,7 @@ def algorithmic_bytes(m, n, b, k, m_static=0):
 
 
 GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 3: "k_gain_mix_h2 (f16x2 MFMA)",
-                4: "k_gain_mix_p2 (f16x2 MFMA over piece lists)"}
+                4: "k_gain_mix_p2 (f16x2 MFMA over piece lists)", 5: "k_gain_mix_hg (f16x2 MFMA, hinges)"}
 GAIN_DTYPES = {0: "f32 (VALU, libear's exact arithmetic)", 1: "f32 (f32 MFMA, f32 accumulate)",
                3: "f32 io / f16x2-split MFMA, f32 accumulate", 4: "f32 io / f16x2-split MFMA, f32 accumulate"}
 

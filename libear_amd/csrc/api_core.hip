@@ -11,6 +11,7 @@
 #include "gain_mfma.h"
 #include "gain_h2.h"
 #include "gain_p2.h"
+#include "gain_hg.h"
 
 namespace earhip {
 
@@ -20,7 +21,7 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml) {
-  if (ml.wsplit <= 1 || ml.split || ml.pieces) return 0;
+  if (ml.wsplit <= 1 || ml.split || ml.pieces || ml.hinge) return 0;
   if (ml.mfma) return (size_t)cp.mgroups * ml.tpw * cp.nct * 16 * ml.tile() * sizeof(float);
   return (size_t)cp.ngroups * cp.nout * ml.tile() * sizeof(float);
 }
@@ -44,7 +45,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const ColumnPlan &cp = cs.plan();
   const PointStore ps = cs.device();
   const int M = cs.M();
-  const bool slots = ml.mfma && !ml.split && !ml.pieces;
+  const bool slots = ml.mfma && !ml.split && !ml.pieces && !ml.hinge;
   if (slots && M > kMaxSlotObjects) fail_internal("slot lists address objects with 16 bits");
   if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
   // K0: segment descriptors; for the f32 MFMA kernel K0s then turns them into the
@@ -59,7 +60,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   LevelProbe probe;
   unsigned *level_cur = nullptr, *level_next = nullptr;
   unsigned *wide_cur = nullptr, *wide_next = nullptr;  // f16x2 kernel: "run this call in wide mode" (gain_h2.h)
-  if ((ml.split || ml.pieces) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
+  if ((ml.split || ml.pieces || ml.hinge) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
     if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);  // [0..1] level words, [2..3] wide-mode words
     level_cur = ctx->level.p + ctx->level_idx;
     level_next = ctx->level.p + (ctx->level_idx ^ 1);
@@ -80,7 +81,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // (two buffers: k_seg_prep's form of the probe raises its words with atomicMax and k_mark_quiet clears them again —
     // all zero between calls —, the list builders' probe stores every object's word plainly.  Both grow with the
     // largest M this context has seen: contexts are shared by gain stages of different sizes.)
-    DevBuf<unsigned> &lv = (ml.pieces ? ctx->obj_level_lists : ctx->obj_level);
+    DevBuf<unsigned> &lv = (ml.pieces || ml.hinge ? ctx->obj_level_lists : ctx->obj_level);
     if (lv.n < (size_t)M) {
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
       lv.alloc_zero((size_t)M + M / 2 + 64, ctx->stream);
@@ -106,9 +107,30 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     slow_next = ctx->tile_slow.p + (size_t)(ctx->tile_slow_idx ^ 1) * ctx->tile_slow_cap;
     ctx->tile_slow_idx ^= 1;
   }
+  // hinge kernel: its own list builder (k_hinge_build, gain_hg.h) behind the same probe launch
+  HingeLists hl = hinge_lists(desc, M, ml.ntiles);
+  if (ml.hinge) {
+    if (M > kMaxHingeCached || ml.tile() != kHingeTile) fail_internal("hinge lists: object count or tile out of range");
+    unsigned *obj_lv = nullptr;
+    if (probe.obj_level) {
+      obj_lv = probe.obj_level;
+      hipLaunchKernelGGL(k_level_probe, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M,
+                         ml.ntiles, ml.tile(), probe.every, level_cur, obj_lv);
+    }
+    int tpw = 1;
+    while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
+    const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
+    const size_t lds = sizeof(int) * (size_t)M * tpw;
+#define EARHIP_HBUILD_CASE(T_)                                                                                        \
+  if (tpw == T_)                                                                                                      \
+    hipLaunchKernelGGL(k_hinge_build<T_>, bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
+                       t_call + nsamples, hl, obj_lv, level_cur);
+    EARHIP_HBUILD_CASE(1) EARHIP_HBUILD_CASE(2) EARHIP_HBUILD_CASE(4) EARHIP_HBUILD_CASE(8)
+#undef EARHIP_HBUILD_CASE
+  }
   // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch
-  const bool one_pass = ml.pieces;
-  if (one_pass) {
+  const bool one_pass = ml.pieces || ml.hinge;
+  if (ml.pieces) {
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     unsigned *obj_lv = nullptr;
     if (probe.obj_level) {
@@ -180,7 +202,17 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const size_t lds = mix_lds_bytes(cp, ml);
   if (ev) EARHIP_HIP(hipEventRecord(ev[2], ctx->stream));
   bool launched = false;
-  if (ml.pieces) {
+  if (ml.hinge) {
+    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+    const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
+    const float *gs = cs.column_scales();
+#define EARHIP_HG_CASE(NCT_)                                                                                          \
+  if (cp.nct == NCT_)                                                                                                 \
+    hipLaunchKernelGGL((k_gain_mix_hg<NCT_>), bgrid, dim3(256), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next);
+    EARHIP_HG_CASE(1) EARHIP_HG_CASE(2) EARHIP_HG_CASE(3)
+#undef EARHIP_HG_CASE
+    launched = true;
+  } else if (ml.pieces) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
@@ -234,7 +266,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   EARHIP_MFMA_CASE(1, 8) EARHIP_MFMA_CASE(2, 8) EARHIP_MFMA_CASE(3, 8)
   EARHIP_MFMA_CASE(1, 4) EARHIP_MFMA_CASE(2, 4) EARHIP_MFMA_CASE(3, 4)
 #undef EARHIP_MFMA_CASE
-  if (!ml.mfma) {
+  if (!ml.mfma && !launched) {
   EARHIP_MIX_CASE(8, 4, false) EARHIP_MIX_CASE(8, 4, true)
   EARHIP_MIX_CASE(16, 4, false) EARHIP_MIX_CASE(16, 4, true)
   EARHIP_MIX_CASE(24, 4, false) EARHIP_MIX_CASE(24, 4, true)
@@ -269,8 +301,8 @@ struct GainStage {
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
                             curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
-                            curves.pair_waste(256), curves.pair_waste(512));
-    desc.reserve(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)));
+                            curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share());
+    desc.reserve(std::max(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)), hinge_units(n_in, ml.ntiles)));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,
                       out_stride, 0, desc.p, nullptr);

@@ -185,7 +185,8 @@ struct earhip_render {
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
-  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists
+  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
+                       // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
   bool run_len_set = false;  // EARHIP_RUN given: also fixes the run length of the wave kernel
 
@@ -252,7 +253,8 @@ struct earhip_render {
   MixLaunch plan_call(size_t nblocks) {
     const int nsamples = (int)(nblocks * (size_t)B);
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, ctx->strict, max_gsplit, curves->aligned_tile(t),
-                            curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste(256), curves->pair_waste(512));
+                            curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste(256), curves->pair_waste(512),
+                            curves->hinge_exact_share());
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     while (ml.gsplit > 1 && bus_stride * K * N * ml.gsplit > bus.n) ml.gsplit /= 2;
     return ml;
@@ -265,7 +267,7 @@ struct earhip_render {
     const bool strict = ctx->strict;
     MixLaunch ml = plan_call(nblocks);
 
-    last_kind = ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
+    last_kind = ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
     // (the bus is sized for every plan plan_mix can make, earhip_render_create; should a tuning knob push a plan
@@ -405,7 +407,8 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // smallest tile any gain kernel of this context uses (f32 MFMA: 16 * nrt samples)
     const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
     const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
-    r->desc.alloc(std::max(desc_units(r->M, max_tiles), piece_units(r->M, (max_samples + 255) / 256)));  // (the piece-list kernel's tiles: 256 or 512 samples)
+    r->desc.alloc(std::max(std::max(desc_units(r->M, max_tiles), piece_units(r->M, (max_samples + 255) / 256)),
+                           hinge_units(r->M, (max_samples + 255) / 256)));  // (the piece-list kernel's tiles: 256 or 512 samples)
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits (gsplit > 1) are only
     // chosen for calls with few tiles: plan_mix doubles gsplit while gsplit * (ntiles / tpw) stays below
     // 2 * num_cus, so gsplit * ntiles < (4 * num_cus + gsplit) * tpw with tiles of at most 256 samples

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "gain_kernels.h"
 #include "gain_p2.h"
+#include "gain_hg.h"
 
 namespace earhip {
 
@@ -235,6 +236,22 @@ class CurveSet {
       }
     }
     ramp_share_ = span > 0 ? ramp / span : 0.0;
+    // What the hinge kernel (gain_hg.h) would have to send through its exact path: (object, tile) pairs with a ramp
+    // shorter than kHingeMinLen (a step: a ramp of no length) or with curve points closer together than that — as a share
+    // of all pairs on 256-sample tiles.  A short ramp spoils the tiles it touches, two close points on a constant stretch
+    // the tile they share about every other time.
+    {
+      double bad = 0;
+      for (int m = 0; m < M_; m++) {
+        const auto &t = times_[m];
+        for (size_t k = 1; k < t.size(); k++) {
+          const int64_t len = t[k] - t[k - 1];
+          if (len >= kHingeMinLen) continue;
+          bad += (flat_[m][k] & allflat) != allflat ? 1.0 + (double)len / kHingeTile : 0.5;
+        }
+      }
+      hinge_exact_share_ = span > 0 ? std::min(1.0, bad / std::max(1.0, span / kHingeTile)) : 0.0;
+    }
     // curve points per sample and object over the time the curves span (the piece kernel picks its tile from it)
     double npts = 0;
     for (int m = 0; m < M_; m++)
@@ -330,6 +347,8 @@ class CurveSet {
   // curve points per sample and object (0 for static gains)
   double point_density() const { return point_density_; }
   double pair_waste(int tile) const { return pair_waste_[tile >= 512 ? 1 : 0]; }
+  // share of the (object, tile) pairs the hinge kernel would send through its exact path; > 1: not a curve set for it
+  double hinge_exact_share() const { return force_ramp_ ? 2.0 : hinge_exact_share_; }
 
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
@@ -375,6 +394,7 @@ class CurveSet {
   double ramp_share_ = 0;
   double point_density_ = 0;
   double pair_waste_[2] = {0, 0};  // on 256- and 512-sample tiles
+  double hinge_exact_share_ = 1.0;
   float gain_max_ = 0;
   DevBuf<int32_t> d_off_;
   DevBuf<int64_t> d_time_;
@@ -401,17 +421,18 @@ struct MixLaunch {
   bool pieces = false;         // matrix-core kernel on f16x2 split operands over per-tile piece lists (gain_p2.h)
   int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
   bool paired = false;         // with pieces: the lists' paired layout (gain_p2.h)
+  bool hinge = false;          // matrix-core kernel on f16x2 split operands with the curve points inside a tile as hinges (gain_hg.h)
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
   int tpw = 1;                 // MFMA: adjacent tiles per workgroup
-  int tile() const { return pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
+  int tile() const { return hinge ? kHingeTile : pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
                           float gain_scale = 0.0f, double point_density = 0.0, double pair_waste256 = 1.0,
-                          double pair_waste512 = 1.0) {
+                          double pair_waste512 = 1.0, double hinge_exact_share = 1.0) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
@@ -419,7 +440,7 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // gains allow): f16x2 when the gains can be scaled into f16 range — its cost does not depend on the
   // curves and is below the f32 slot kernel's even for static gains.  Curve sets with non-finite gains
   // stay on the f32 slot kernel.
-  L.split = L.mfma && M >= 32 && gain_scale > 0.0f && ctx->use_mfma != 5 &&
+  L.split = L.mfma && M >= 32 && gain_scale > 0.0f && ctx->use_mfma != 5 && ctx->use_mfma != 6 &&
             (ctx->use_mfma == 4 || (ctx->use_mfma == 3 && aligned));
   // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (two rounds of workgroups or more:
   // 512 blocks of 512: K1 0.215 vs 0.236 ms; one round, 256 blocks: 0.127 vs 0.120)
@@ -429,8 +450,8 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // Piece-list kernel: everything else the f16x2 operands can represent — metadata that ignores the tile
   // grid costs its curve points, not a different kernel (5 forces it for aligned curves as well).
   L.pieces = L.mfma && !L.split && M >= 32 && M <= kMaxPieceObjects && gain_scale > 0.0f &&
-             (ctx->use_mfma == 3 || ctx->use_mfma == 5);
-  if (ctx->use_mfma == 5 && L.pieces) L.split = false;
+             (ctx->use_mfma == 3 || ctx->use_mfma == 5 || ctx->use_mfma == 6);
+  if ((ctx->use_mfma == 5 || ctx->use_mfma == 6) && L.pieces) L.split = false;
   if (L.pieces) {
     const char *pt = getenv("EARHIP_P2_TILE");
     const int ptile = pt ? atoi(pt) : 0;
@@ -449,17 +470,28 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     const bool long_call = nsamples / 512 >= 2 * ctx->num_cus;
     L.pw = ptile == 512 ? 8 : ptile == 256 ? 4 : (L.paired && long_call && pair_waste512 < kPairWaste) ? 8 : 4;
     (void)point_density;
+    // Hinge kernel (gain_hg.h): curves that ramp most of the time in ramps of half a tile or more — every object always on
+    // its way to its next target, the points at arbitrary times.  There the piece lists cost an operand split per ramp
+    // and tile; the hinge kernel one per object and tile.  Every (object, tile) pair it cannot take (short ramps, steps,
+    // points close together) goes through its exact path at ~12 times the cost: such pairs have to be rare.  Curves that
+    // hold most of the time (ramp for a while, then constant) stay on the paired piece lists, which skip the position
+    // factors of the objects at rest.  6 forces it, EARHIP_HINGE=0 / 1 overrides the choice.
+    const double kHingeExact = 0.005, kHingeRamps = 0.5;
+    L.hinge = M <= kMaxHingeCached && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps;
+    if (const char *e = getenv("EARHIP_HINGE")) L.hinge = atoi(e) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
+    if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
+    if (L.hinge) L.pieces = false;
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
   // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments
   // grew a third piece: 0.296 ms against 0.261 for the 4-wave form at three workgroups per CU, same box)
   L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || (nsamples / 512 >= 2 * ctx->num_cus && cp.nct > 1));
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
-  if (L.mfma && !L.split && !L.pieces && M > kMaxSlotObjects) L.mfma = false;
+  if (L.mfma && !L.split && !L.pieces && !L.hinge && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
-  if (L.split || L.pieces) {
+  if (L.split || L.pieces || L.hinge) {
     // one workgroup = 4 adjacent 64-sample tiles x all objects of its grid-level
     // split; few tiles (block mode): split the objects across workgroups
     L.wsplit = 1;

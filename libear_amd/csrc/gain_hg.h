@@ -1,0 +1,813 @@
+// gain_hg.h — K1 on the f16 matrix cores for gain curves that RAMP ALL THE TIME with points that ignore the tile grid
+// (ADM blocks whose interpolationLength is the block duration: every object is always on its way to its next
+// target), the "hinge kernel".
+//
+// libear evaluates a curve segment by segment (GainInterpolator::process, include/ear/dsp/gain_interpolator.hpp:
+// 53-87; a ramp is g(s) = (1 - p) S + p E with p = (float)(s - start) * (1.0f / (float)(end - start)), :264-277).
+// A curve through its points is continuous and piecewise linear, so inside a tile of T samples that starts at s0
+//
+//     g(s) = L(s) + sum_k relu(+-(s - r_k)) * D_k ,      D_k = (slope after r_k) - (slope before r_k),
+//
+// where L is the LINE of the segment that holds the tile's centre, extended over the whole tile, and the sum runs
+// over the curve points r_k inside the tile ("kinks"): a point behind the centre opens FORWARD (relu(s - r)), a point
+// in front of it BACKWARD (relu(r - s)) — both with the same D.  The piece-list kernel (gain_p2.h) spends one operand
+// split of the inputs per ramp and tile (3.07 per object and tile when a new target arrives every 240 samples on
+// 256-sample tiles), which makes it issue-bound (profiles/r03_moving_scene_*: 271 M VALU against 29 M MFMA
+// instructions, 0.38 of the HBM roofline).  Here
+//
+//   * L costs what it costs the grid kernel (gain_h2.h): ONE split of the inputs, two gain operands B0 = L(s0) and
+//     B1 = the slope, and (s - s0) applied to the accumulators of the B1 products at the end of the tile;
+//   * a kink costs no split at all: its factor F(s) = clamp(+-(s - r) / T, 0, 1) is exact in f16 (8 bits), so the
+//     operand pieces of x F come out of the pieces (xh, xl) the line's split left in registers by PACKED f16
+//     arithmetic: Ah = rn(F xh), the exact residual fma(F, xh, -Ah), plus F xl — five v_pk instructions per
+//     register of two operands instead of the ~20 of a position factor and a split from f32;  the gain operand of
+//     the kink is T D, one MFMA set (the line has two);
+//   * the objects of a tile are ordered by where their kinks lie, so that whole chunks of 32 have their kinks in the
+//     same quarter of the tile, and a wave (= a quarter: 64 samples) skips the kink sets that cannot reach its
+//     samples: a forward kink in the last quarter only costs the wave of that quarter.
+//
+// What qualifies: an (object, tile) pair whose curve points inside the tile are at most the two ends of the centre
+// segment, with every ramp that meets such a point at least T / 2 long (so that T x slope stays within twice the
+// gains' range: the operands are scaled to half the f16 range the other split kernels use).  Everything else —
+// several points in one half of a tile, short ramps, steps, quiet objects — takes the exact per-object path; curve
+// sets made of such things are the piece-list kernel's (plan_mix decides from the curves).
+//
+// Lists (k_hinge_build): per tile the objects in the order  no kink | forward kink in quarter 3 | forward in 2 | both |
+// backward in 1 | backward in 0,  padded to a multiple of 32 at the end only; per slot a LinEntry and, in chunks that
+// have any, a forward and a backward HingeEntry; per chunk a flag word (has forward / backward kinks, and which waves
+// they can reach).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gain_p2.h"
+
+namespace earhip {
+
+constexpr int kHingeTile = 256;     // samples per workgroup tile (4 waves)
+constexpr int kHingeMinLen = 128;   // ramps that meet a kink are at least this long (T / 2)
+constexpr int kMaxHingeCached = 12288;  // (object, tile) pairs a list-building workgroup keeps between its two passes
+
+struct LinEntry {
+  uint32_t m;   // object | the rows' places (kLinRowShift) | kLinNull
+  int32_t row;  // gain row R1 of the point the centre segment starts at (kc - 1, clipped into the object's points); the rows
+                // around it: R0 = R1 - d0 (point kc - 2), R2 = R1 + d2 (point kc: the segment's end), R3 = R2 + d3 (point kc + 1),
+                // d = 0 where the object has no such point (the clipped row repeats: differences of rows vanish there)
+  float p0;     // libear's p at the tile start, (float)(s0 - start) * scale (gain_interpolator.hpp:272); negative when the
+                // segment starts inside the tile; 0: constant
+  float scale;  // 1.0f / (float)(end - start) of the centre segment; 0: constant
+};
+struct HingeEntry {
+  uint32_t fac_f, fac_b;  // forward / backward kink: f16 pair (slope of F: +-1/T, offset of F: -+(r - s0)/T), F(s) = clamp(s * slope +
+                          // offset, 0, 1), s counted from the tile start; 0: no such kink (F = 0)
+  float s_before, s_after;  // 1 / length of the ramp before the centre segment (points kc - 2, kc - 1) and behind it (kc, kc + 1); 0: constant
+};
+static_assert(sizeof(LinEntry) == 16 && sizeof(HingeEntry) == 16, "list entries are loaded as one dwordx4");
+constexpr uint32_t kLinNull = 1u << 31, kLinObjMask = 0xffffu;
+constexpr int kLinRowShift = 16;  // bits 16 + 2 i, 17 + 2 i of m: (row R_i) - (row R1) + 1, i = 0..3
+
+struct HingeLists {
+  LinEntry *lin;     // [ntiles][cap]
+  HingeEntry *hinge; // [ntiles][cap]
+  uint32_t *cflags;  // [ntiles][cap / 32]: bit 0 / 1: the chunk has forward / backward kinks; bits 8-11 / 12-15: the waves they reach
+  int *count;        // [ntiles][4]: chunks, exact-path objects
+  int *ovf;          // [ntiles][M]: objects that take the exact per-object path
+  int M, cap;
+};
+__host__ __device__ inline int hinge_cap(int M) { return (M + 31) & ~31; }
+// 16-byte units of the scratch buffer of a call of `ntiles` tiles
+__host__ __device__ inline size_t hinge_units(size_t M, size_t ntiles) {
+  const size_t cap = (size_t)hinge_cap((int)M);
+  return 2 * cap * ntiles + (4 * (cap / 32) * ntiles + 16 * ntiles + 4 * M * ntiles + 15) / 16 + 4;
+}
+inline HingeLists hinge_lists(void *scratch, int M, int ntiles) {
+  HingeLists hl;
+  hl.M = M;
+  hl.cap = hinge_cap(M);
+  hl.lin = reinterpret_cast<LinEntry *>(scratch);
+  hl.hinge = reinterpret_cast<HingeEntry *>(hl.lin + (size_t)hl.cap * ntiles);
+  hl.cflags = reinterpret_cast<uint32_t *>(hl.hinge + (size_t)hl.cap * ntiles);
+  hl.count = reinterpret_cast<int *>(hl.cflags + (size_t)(hl.cap / 32) * ntiles);
+  hl.ovf = hl.count + (size_t)4 * ntiles;
+  return hl;
+}
+
+__device__ __forceinline__ uint32_t f16_bits(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); }
+
+// ---------------------------------------------------------------------------
+// K0.  What one (object, tile) pair is for the hinge kernel.
+constexpr int kHgNone = 0, kHgF3 = 1, kHgF2 = 2, kHgBoth = 3, kHgB1 = 4, kHgB0 = 5, kHgExact = 6;
+// the four records around the centre: points kc - 2 .. kc + 1 (missing ones: never looked at)
+struct HingeRecs {
+  PointRec r[4];
+  bool has[4];
+};
+__device__ __forceinline__ HingeRecs hinge_load(const PointStore &ps, int base, int n, int kc) {
+  HingeRecs R;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int k = kc - 2 + i;
+    R.has[i] = k >= 0 && k < n;
+    R.r[i] = ps.rec[base + min(max(k, 0), n - 1)];
+  }
+  return R;
+}
+// t0, t1: the tile [t0, t1) (t1 clipped to the end of the call); fwd / bwd: is there a kink behind / in front of the centre
+__device__ __forceinline__ int hinge_classify(const PointStore &ps, const HingeRecs &R, int64_t t0, int64_t t1, bool &fwd, bool &bwd) {
+  const uint32_t allflat = (1u << ps.nbus) - 1;
+  // the segment ending at point kc - 2 + i (i = 1..3) is flat when the point repeats its predecessor on every bus; the
+  // stretches before the first and behind the last point are constant (gain_interpolator.hpp:68-75)
+  auto seg_flat = [&](int i) { return !R.has[i] || !R.has[i - 1] || (R.r[i].flat & allflat) == allflat; };
+  auto seg_len = [&](int i) { return R.r[i].time - R.r[i - 1].time; };
+  bool simple = true;
+  // a point in (t0, centre]: the start of the centre segment
+  bwd = R.has[1] && R.r[1].time > t0;
+  if (bwd) {
+    if (R.has[0] && R.r[0].time > t0) simple = false;  // a second point in this half (a step: two equal times)
+    const bool bf = seg_flat(1), af = seg_flat(2);
+    if (bf && af) bwd = false;  // constant on both sides: no kink
+    if (!bf && seg_len(1) < kHingeMinLen) simple = false;
+    if (!af && seg_len(2) < kHingeMinLen) simple = false;
+  }
+  // a point in (centre, t1): the end of the centre segment
+  fwd = R.has[2] && R.r[2].time < t1;
+  if (fwd) {
+    if (R.has[3] && R.r[3].time < t1) simple = false;
+    const bool bf = seg_flat(2), af = seg_flat(3);
+    if (bf && af) fwd = false;
+    if (!bf && seg_len(2) < kHingeMinLen) simple = false;
+    if (!af && seg_len(3) < kHingeMinLen) simple = false;
+  }
+  if (!simple) return kHgExact;
+  if (fwd && bwd) return kHgBoth;
+  if (fwd) return (int)(R.r[2].time - t0) >= 191 ? kHgF3 : kHgF2;  // relu(s - r) > 0 from s = r + 1 on: quarter 3 alone from r = 191
+  if (bwd) return (int)(R.r[1].time - t0) <= 64 ? kHgB0 : kHgB1;   // relu(r - s) > 0 up to s = r - 1: quarter 0 alone up to r = 64
+  return kHgNone;
+}
+// the two list entries of a pair (fwd, bwd: hinge_classify's)
+__device__ __forceinline__ void hinge_entries(const PointStore &ps, const HingeRecs &R, int base, int n, int kc, int m, int64_t t0,
+                                              bool fwd, bool bwd, LinEntry &e, HingeEntry &h) {
+  const uint32_t allflat = (1u << ps.nbus) - 1;
+  auto seg_ramp = [&](int i) { return R.has[i] && R.has[i - 1] && (R.r[i].flat & allflat) != allflat; };
+  const int k1 = min(max(kc - 1, 0), n - 1);  // the point R1 stands for
+  const uint32_t d0 = kc - 2 >= 0 && kc - 2 < k1 ? 1u : 0u, d2 = kc < n && kc > k1 ? 1u : 0u, d3 = kc + 1 < n ? 1u : 0u;
+  e.m = (uint32_t)m | (1u - d0) << 16 | 1u << 18 | (1u + d2) << 20 | (1u + d2 + d3) << 22;
+  e.row = base + k1;
+  e.p0 = 0.0f;
+  e.scale = 0.0f;
+  if (seg_ramp(2)) {  // (constant on every bus: E == S bit for bit, nothing to interpolate)
+    e.scale = R.r[2].scale;
+    e.p0 = (float)(int32_t)(t0 - R.r[1].time) * R.r[2].scale;
+  }
+  const float slope = 1.0f / kHingeTile;
+  h.fac_f = h.fac_b = 0u;
+  if (fwd) h.fac_f = f16_bits(slope) | f16_bits(-(float)(int)(R.r[2].time - t0) * slope) << 16;
+  if (bwd) h.fac_b = f16_bits(-slope) | f16_bits((float)(int)(R.r[1].time - t0) * slope) << 16;
+  h.s_before = seg_ramp(1) ? R.r[1].scale : 0.0f;
+  h.s_after = seg_ramp(3) ? R.r[3].scale : 0.0f;
+}
+
+constexpr int kHingeBuildThreads = 1024;
+// grid = ceil(ntiles / TPW) workgroups of 1024 threads; a thread = one (object, tile) pair of a batch of 1024 / TPW
+// objects, the tile index fastest (the lanes of an object read neighbouring points: gain_p2.h, k_piece_build).  Two
+// passes over the objects: the first finds every pair's centre segment (one search) and class and counts the classes of
+// each tile, the second — the classes' places in the list known — ranks the pairs of a class in object order (ballots:
+// the lists are deterministic) and writes the entries.  What the first pass found is kept in LDS (dynamic: 4 M TPW
+// bytes).
+template <int TPW>
+__global__ void __launch_bounds__(kHingeBuildThreads)
+k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
+              const unsigned *level_cur) {
+  constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
+  constexpr int NWV = kHingeBuildThreads / 64;
+  constexpr int T = kHingeTile;
+  static_assert(7 * TPW <= 64, "one lane per (tile, class) of a wave's counts");
+  extern __shared__ int hg_cache[];         // [M][TPW]: kc << 3 | class
+  __shared__ int cnt[TPW][8];               // objects per class
+  __shared__ int start[TPW][8];             // first slot of a class (classes 0..5), [6]: listed objects, [7]: chunks
+  __shared__ int run[TPW][8];               // objects of a class placed by the batches so far
+  __shared__ int wcnt[NWV][TPW][8];         // ... by the waves of this batch
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = tid % TPW, oi = tid / TPW;
+  const int tile = blockIdx.x * TPW + j;
+  const unsigned call_level = level_cur ? *level_cur : 0u;
+  if (tid < TPW * 8) (&cnt[0][0])[tid] = 0, (&run[0][0])[tid] = 0;
+  const int64_t t0 = t_call + (int64_t)tile * T;
+  const int64_t t1 = t0 + T > t_call_end ? t_call_end : t0 + T;
+  __syncthreads();
+  // ---- pass 1
+  for (int mb = 0; mb < M; mb += OB) {
+    const int m = mb + oi;
+    if (m < M && tile < ntiles) {
+      const int base = ps.off[m], n = ps.off[m + 1] - base;
+      const int kc = upper_bound_time_window(ps.time + base, n, t0 + T / 2);
+      const HingeRecs R = hinge_load(ps, base, n, kc);
+      bool fwd, bwd;
+      int cls = hinge_classify(ps, R, t0, t1, fwd, bwd);
+      if (obj_level && level_is_quiet(obj_level[m], call_level)) cls = kHgExact;
+      hg_cache[(size_t)m * TPW + j] = kc << 3 | cls;
+      atomicAdd(&cnt[j][cls], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < TPW) {
+    int at = 0;
+    for (int b = 0; b < 6; b++) start[tid][b] = at, at += cnt[tid][b];
+    start[tid][6] = at;
+    start[tid][7] = (at + 31) >> 5;
+  }
+  __syncthreads();
+  // flags of the chunk a slot lies in: which classes share the chunk
+  auto chunk_flags = [&](int jj, int c) -> uint32_t {
+    auto hits = [&](int b) { return cnt[jj][b] > 0 && start[jj][b] < 32 * c + 32 && start[jj][b] + cnt[jj][b] > 32 * c; };
+    uint32_t f = 0;
+    if (hits(kHgF3)) f |= 1u | 0x8u << 8;
+    if (hits(kHgF2)) f |= 1u | 0xcu << 8;
+    if (hits(kHgBoth)) f |= 3u | 0xcu << 8 | 0x3u << 12;
+    if (hits(kHgB1)) f |= 2u | 0x3u << 12;
+    if (hits(kHgB0)) f |= 2u | 0x1u << 12;
+    return f;
+  };
+  // ---- pass 2
+  const unsigned long long samej = [&] {  // the lanes of this wave with the same tile
+    unsigned long long v = 0;
+    for (int l = j; l < 64; l += TPW) v |= 1ull << l;
+    return v;
+  }();
+  for (int mb = 0; mb < M; mb += OB) {
+    const int m = mb + oi;
+    const bool in = m < M && tile < ntiles;
+    const int code = in ? hg_cache[(size_t)m * TPW + j] : 7;
+    const int cls = code & 7, kc = code >> 3;
+    unsigned long long bal[7];
+#pragma unroll
+    for (int b = 0; b < 7; b++) bal[b] = __ballot(cls == b);
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int b = 0; b < 7; b++) mine = cls == b ? bal[b] : mine;
+    const int rank = __popcll(mine & samej & ((1ull << lane) - 1));
+    if (lane < 7 * TPW) {  // lane = class * TPW + tile
+      const int b = lane / TPW, jj = lane % TPW;
+      unsigned long long v = 0;
+#pragma unroll
+      for (int q = 0; q < 7; q++) v = b == q ? bal[q] : v;
+      unsigned long long sj = 0;
+      for (int l = jj; l < 64; l += TPW) sj |= 1ull << l;
+      wcnt[wv][jj][b] = __popcll(v & sj);
+    }
+    __syncthreads();
+    if (in) {
+      int at = run[j][cls] + rank;
+      for (int w2 = 0; w2 < wv; w2++) at += wcnt[w2][j][cls];
+      if (cls == kHgExact) {
+        hl.ovf[(size_t)tile * M + at] = m;
+      } else {
+        const int slot = start[j][cls] + at;
+        const int base = ps.off[m], n = ps.off[m + 1] - base;
+        const HingeRecs R = hinge_load(ps, base, n, kc);
+        const bool fwd = cls == kHgF3 || cls == kHgF2 || cls == kHgBoth, bwd = cls == kHgB1 || cls == kHgB0 || cls == kHgBoth;
+        LinEntry e;
+        HingeEntry h;
+        hinge_entries(ps, R, base, n, kc, m, t0, fwd, bwd, e, h);
+        hl.lin[(size_t)tile * hl.cap + slot] = e;
+        if (chunk_flags(j, slot >> 5) & 3u) hl.hinge[(size_t)tile * hl.cap + slot] = h;
+      }
+    }
+    __syncthreads();
+    if (tid < 7 * TPW) {
+      const int b = tid / TPW, jj = tid % TPW;
+      int s = 0;
+      for (int w2 = 0; w2 < NWV; w2++) s += wcnt[w2][jj][b];
+      run[jj][b] += s;
+    }
+    __syncthreads();
+  }
+  // pad the lists to whole chunks with null entries; publish counts and chunk flags
+  for (int i = tid; i < TPW * 32; i += kHingeBuildThreads) {
+    const int jj = i >> 5, tl = blockIdx.x * TPW + jj;
+    if (tl >= ntiles) continue;
+    const int listed = start[jj][6], nch = start[jj][7], slot = listed + (i & 31);
+    if (slot < 32 * nch) {
+      LinEntry e;
+      e.m = kLinNull | 0x55u << kLinRowShift;  // (object 0's inputs against the all-zero gain row, four times)
+      e.row = ps.zero_row;
+      e.p0 = e.scale = 0.0f;
+      hl.lin[(size_t)tl * hl.cap + slot] = e;
+      HingeEntry h;
+      h.fac_f = h.fac_b = 0u;
+      h.s_before = h.s_after = 0.0f;
+      if (chunk_flags(jj, slot >> 5) & 3u) hl.hinge[(size_t)tl * hl.cap + slot] = h;
+    }
+    if ((i & 31) == 0) {
+      hl.count[tl * 4 + 0] = nch;
+      hl.count[tl * 4 + 1] = cnt[jj][kHgExact];
+    }
+  }
+  for (int i = tid; i < TPW * (hl.cap / 32); i += kHingeBuildThreads) {
+    const int jj = i / (hl.cap / 32), c = i % (hl.cap / 32), tl = blockIdx.x * TPW + jj;
+    if (tl < ntiles && c < start[jj][7]) hl.cflags[(size_t)tl * (hl.cap / 32) + c] = chunk_flags(jj, c);
+  }
+}
+
+typedef _Float16 hg_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hg_h2 as_h2(uint32_t u) { return __builtin_bit_cast(hg_h2, u); }
+__device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast(uint32_t, h); }
+
+// K1.  grid = (tiles, grid-level splits of the chunk schedule, column super-groups), block = 256 threads:
+// wave w = samples [64 w, 64 w + 64) of the workgroup's 256-sample tile.
+//
+// A chunk of 32 list slots is up to three STEPS, each between two workgroup barriers: the line step (inputs split,
+// 72 MFMAs per 48 columns), then — where the chunk has them — the forward and the backward kink step (36 each; a wave
+// skips those that cannot reach its samples).  The vector-memory counter is in order, so everything a chunk needs from
+// memory is requested in ONE place, the line step of the chunk before: first the gain rows of the next chunk (four rows
+// per slot: the points kc - 2 .. kc + 1 cover its line and both its kinks), then the inputs of the next chunk into
+// the registers the split has just freed (one chunk ahead: two sets of inputs do not fit the register file beside
+// the 96 accumulators, the operand pieces the kink steps need, and the rows on their way).  The rows go through a wave-private piece of LDS; the kink steps request
+// nothing.  Operand fragments: the line's alternate between two buffers, the kinks' have their own (written during
+// the line step of their chunk); the scaled high piece (h 2^-11, gain_h2.h) is made from h where it is used.
+template <int NCT>
+__global__ void __launch_bounds__(256, 2)
+k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
+              unsigned *level_next, unsigned *wide_next) {
+  constexpr int NW = 4, NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = kHingeTile;
+  constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
+  constexpr int RING = 8;
+  constexpr int RS = 4 * NCT;        // 16-byte slots per gain row
+  constexpr int NG = (4 * NQ * RS + 63) / 64;  // 1 KB pieces of a wave's staged gain rows
+  constexpr int OP = TS + 4;
+  // fragments (1 KB each: 64 lanes x 8 f16): line of even / odd chunks {B0, B1} x column tiles x {h, l}, forward kinks,
+  // backward kinks (column tiles x {h, l}), and two nobody reads (the lanes without a column write there)
+  constexpr int FL = 4 * NCT, FH0 = 2 * FL, FH = 2 * NCT, FDUMMY = FH0 + 2 * FH, NFRAGS = FDUMMY + 2;
+  constexpr size_t kFragBytes = sizeof(u32x4) * NFRAGS * 64, kTileBytes = sizeof(float) * NW * 16 * OP;
+  __shared__ __attribute__((aligned(16))) unsigned char fmem[kFragBytes > kTileBytes ? kFragBytes : kTileBytes];  // (the waves' output
+                                                                                            // tiles, once the last step is through)
+  auto frag = reinterpret_cast<u32x4(*)[64]>(fmem);
+  __shared__ float inv_gcol[16 * NCT];
+  __shared__ __attribute__((aligned(16))) uint64_t ring[RING][CH];   // byte offsets of the slots' input rows
+  __shared__ __attribute__((aligned(16))) u32x4 ringe[RING][2 * CH];  // the LinEntries [0, 32) and the HingeEntries [32, 64)
+  __shared__ __attribute__((aligned(16))) uint32_t ringf[RING][2][CH];  // ... their factor words, packed for the lanes
+  __shared__ uint32_t ringc[RING];                                    // chunk flags
+  __shared__ __attribute__((aligned(16))) f32x4 stage[NW][NG * 64];  // a wave's gain rows: [slot][4 rows][16 NCT columns]
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
+  // gains are scaled to HALF the range the other split kernels use (T x slope of a ramp of T / 2 samples or more is at
+  // most twice the gains' range; differences of two such slopes stay inside the f16 range for gains of one sign, and
+  // what does not shows as non-finite totals: exact redo below)
+  if (threadIdx.x < 16 * NCT) inv_gcol[threadIdx.x] = 2.0f / gcol[blockIdx.z * 16 * NCT + threadIdx.x];
+  __syncthreads();
+  if (level_cur) {  // input scale of THIS call from the level K0 probed (gain_h2.h)
+    const unsigned lv = *level_cur;
+    if (lv) {
+      const int E = max(-60, min(20, (int)(lv >> 23) - 127));
+      x_scale = __uint_as_float((unsigned)(127 + 7 - E) << 23);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+      *level_next = 0;
+      if (wide_next) *wide_next = 0u;
+    }
+  }
+  const int nparts = gridDim.y, part = blockIdx.y;
+  const int col0 = blockIdx.z * 16 * NCT;
+  const int wave_s0 = w * TS;
+  const int tile_s0 = wgtile * T + wave_s0;
+  const int tile_len = max(0, min(TS, P.nsamples - tile_s0));
+  const int64_t tile_t0 = P.t_call + tile_s0;
+  const int64_t tile_t1 = tile_t0 + tile_len;
+  const float *__restrict__ gain = P.ps.gain;
+  const unsigned rowlen = (unsigned)P.ps.row;
+
+  // running totals in scaled units: bus = (tot0 + (s - s0) tot1) / (x_scale g_scale)
+  f32x4 tot0[NRT][NCT], tot1[NRT][NCT];
+  auto clear_totals = [&]() {
+#pragma unroll
+    for (int r = 0; r < NRT; r++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++) tot0[r][c] = tot1[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  clear_totals();
+
+  // ---- exact path: one object, all its pieces inside this wave's 64 samples, f32 MFMA with k = {a, b} of ONE
+  // object, accumulated into tot0 in units of 1 / (sx sg) (gain_p2.h)
+  auto single_object = [&](int m, float sx, bool sg) {
+    if (tile_len <= 0) return;
+    float gsc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) gsc[c] = sg ? 0.5f * gcol[col0 + c * 16 + li] : 1.0f;
+    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
+    const bool is_b = kg & 1;
+    const bool slot0 = kg < 2;
+    int k = upper_bound_time(P.ps.time + base, n, tile_t0);
+    int cur = 0;
+    while (cur < tile_len) {
+      const SegDesc dk = describe_segment(P.ps, base, n, k, tile_t0, tile_t1);
+      const int r1 = min(seg_r1(dk.info), tile_len);
+      if (r1 > cur) {
+        const bool ramp = dk.info & kSegRamp;
+        float a[NRT], gv[NCT];
+#pragma unroll
+        for (int r = 0; r < NRT; r++) {
+          const int s = li * NRT + r;
+          const float x = row[min(s, tile_len - 1)];
+          const float p = (float)(dk.d0 + s) * dk.scale;  // gain_interpolator.hpp:272
+          float coef = ramp ? (is_b ? p : 1.0f - p) : (is_b ? 0.0f : 1.0f);
+          coef = (slot0 && s >= cur && s < r1) ? coef : 0.0f;
+          a[r] = (x * coef) * sx;
+        }
+        const int grow = dk.row + ((ramp && is_b && slot0) ? 1 : 0);
+        const float *gp = gain + (size_t)grow * rowlen + col0 + li;
+#pragma unroll
+        for (int c = 0; c < NCT; c++) gv[c] = gp[c * 16] * gsc[c];
+#pragma unroll
+        for (int r = 0; r < NRT; r++)
+#pragma unroll
+          for (int c = 0; c < NCT; c++)
+            tot0[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot0[r][c], 0, 0, 0);
+        cur = r1;
+      }
+      if (!(dk.info & kSegMulti)) break;
+      k++;
+    }
+  };
+
+  float inv_x = 1.0f / x_scale;  // exact: a power of two
+  bool col_scaled = true;
+  const int *cnt = hl.count + wgtile * 4;
+  const LinEntry *lbase = hl.lin + (size_t)wgtile * hl.cap;
+  const HingeEntry *hbase = hl.hinge + (size_t)wgtile * hl.cap;
+  const uint32_t *cfbase = hl.cflags + (size_t)wgtile * (hl.cap / 32);
+
+  if (P.vec_ok) {
+    const int total = cnt[0];
+    const int c_lo = (int)(((int64_t)total * part) / nparts), c_hi = (int)(((int64_t)total * (part + 1)) / nparts);
+    if (c_hi > c_lo) {
+      const int nvec = (P.nsamples + 3) & ~3;
+      const uint64_t rstride = P.in_stride * sizeof(float);
+      const float g_scale = 0.5f * gcol[col0 + min(lane, 16 * NCT - 1)];  // the scale of the lane's gain column
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x3 __attribute__((ext_vector_type(3)));
+      typedef const uint32_t __attribute__((address_space(4))) *ConstWords;  // (K0 wrote them, this kernel only reads: scalar loads)
+      // What a step needs to know about its lane.  Made anew from the lane number in every chunk (through an opaque
+      // copy of it): carried through the chunk loop as so many loop invariants these addresses and offsets were what the
+      // register allocator spilled, and a reload behind the input requests waits for the inputs (the vector-memory
+      // counter is in order).
+      struct LaneCtx {
+        int lane, li, kg;
+        unsigned xlane;      // byte offset of the lane's float4 inside an input row
+        const float *glane;  // the lane's 12 bytes of a gain row (less the row)
+        int rsh;             // where the place of the lane's row (R_kg) is in a LinEntry's first word
+        float *sw;           // where the lane's 12 bytes of slot 0 go in the wave's staged rows
+        const float *sf;     // the lane's column in them
+        int fe;              // the lane's entry in a fragment its wave fills
+        int fpair;           // the lane's fragment pair (h, l) inside a set of column tiles, or -1: no column
+      };
+      auto lane_ctx = [&](bool opaque) {
+        unsigned lv = threadIdx.x;
+        if (opaque) asm volatile("" : "+v"(lv));
+        LaneCtx L;
+        L.lane = (int)(lv & 63u);
+        L.li = L.lane & 15;
+        L.kg = L.lane >> 4;
+        L.xlane = (unsigned)min(tile_s0 + L.li * NRT, nvec - 4) * 4u;
+        L.glane = gain + col0 + NCT * L.li;
+        L.rsh = kLinRowShift + 2 * L.kg;
+        L.sw = reinterpret_cast<float *>(&stage[w][0]) + L.kg * (16 * NCT) + NCT * L.li;
+        L.sf = reinterpret_cast<const float *>(&stage[w][0]) + min(L.lane, 16 * NCT - 1);
+        L.fe = w * 16 + L.li;
+        L.fpair = L.lane < 16 * NCT ? 2 * L.kg : -1;
+        return L;
+      };
+
+      // ---- the ring: wave 0 brings the entries of chunk c + RD into LDS during the line step of chunk c (requested ahead of
+      // its MFMAs, stored behind them): lanes 0-31 the LinEntries, 32-63 the HingeEntries
+      constexpr int RD = 3;
+      u32x4 ring_next = {0u, 0u, 0u, 0u};
+      uint32_t ring_next_cf = 0u;
+      auto ring_load = [&](const LaneCtx &L, int c) {
+        const int cc = min(c, total - 1);
+        const int s = 32 * cc + (L.lane & 31);
+        ring_next_cf = c < c_hi ? ((ConstWords)cfbase)[cc] : 0u;
+        const bool want = L.lane < 32 || (ring_next_cf & 3u);
+        const u32x4 *pa = L.lane < 32 ? reinterpret_cast<const u32x4 *>(lbase + s) : reinterpret_cast<const u32x4 *>(hbase + s);
+        ring_next = want ? *pa : u32x4{0u, 0u, 0u, 0u};
+      };
+      auto ring_store = [&](const LaneCtx &L, int c) {
+        const int sl = c & (RING - 1);
+        ringe[sl][L.lane] = ring_next;
+        if (L.lane < 32) {
+          ring[sl][L.lane] = (uint64_t)(ring_next[0] & kLinObjMask) * rstride;
+          if (L.lane == 0) ringc[sl] = ring_next_cf;
+        } else {
+          ringf[sl][0][L.lane - 32] = ring_next[0];
+          ringf[sl][1][L.lane - 32] = ring_next[1];
+        }
+      };
+      // ---- inputs of chunk c: 8 requests of 16 bytes per lane (slots 8 kg .. 8 kg + 7, the lane's 4 samples)
+      auto load_x = [&](const LaneCtx &L, int c, f32x4 (&x)[8]) {
+        const char *bp = reinterpret_cast<const char *>(P.in) + L.xlane;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          const u64x2 mw = *reinterpret_cast<const u64x2 *>(&ring[c & (RING - 1)][L.kg * 8 + q]);
+          x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + mw[0]));
+          x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + mw[1]));
+        }
+      };
+      // ---- gain rows of the slots NQ w .. NQ w + NQ - 1 of chunk c, four rows each (R0 .. R3 of its LinEntry): request q
+      // is slot q's — lane (kg, li) takes 12 bytes (columns 3 li .. 3 li + 2 of the workgroup's 48) of row R_kg — so that
+      // nothing about a request depends on the lane but its row
+      auto load_gains = [&](const LaneCtx &L, int c, f32x3 (&G)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringe[c & (RING - 1)][w * NQ + q]);  // (m | rows' places, row R1)
+          const unsigned row = mr[1] + ((mr[0] >> L.rsh) & 3u) - 1u;
+          const float *gp = L.glane + (size_t)row * rowlen;
+          if constexpr (NCT == 3) G[q] = *reinterpret_cast<const f32x3 *>(gp);
+          else if constexpr (NCT == 2) G[q] = f32x3{gp[0], gp[1], 0.0f};
+          else G[q] = f32x3{gp[0], 0.0f, 0.0f};
+        }
+      };
+      auto stage_gains = [&](const LaneCtx &L, const f32x3 (&G)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          float *d = L.sw + q * (4 * 16 * NCT);
+          if constexpr (NCT == 3) *reinterpret_cast<f32x3 *>(d) = G[q];
+          else if constexpr (NCT == 2) d[0] = G[q][0], d[1] = G[q][1];
+          else d[0] = G[q][0];
+        }
+      };
+      // scaled and split -> LDS: v[q] of the wave's NQ slots into the fragment pair (h, l) at f (k = NQ w + q: entry 16 w + column)
+      auto store_frag = [&](const LaneCtx &L, const float (&v)[NQ], int f) {
+        uint32_t h[NQ / 2], l[NQ / 2];
+#pragma unroll
+        for (int i = 0; i < NQ / 2; i++) {
+          const uint32_t H = pack_f16(v[2 * i], v[2 * i + 1]);
+          h[i] = H;
+          l[i] = pack_f16(v[2 * i] - f16_lo(H), v[2 * i + 1] - f16_hi(H));  // residuals: exact in fp32
+        }
+        f = L.fpair >= 0 ? f + L.fpair : FDUMMY;
+        frag[f][L.fe] = u32x4{h[0], h[1], h[2], h[3]};
+        frag[f + 1][L.fe] = u32x4{l[0], l[1], l[2], l[3]};
+      };
+      // the line of chunk c from the staged rows -> its fragment set
+      auto convert_lin = [&](const LaneCtx &L, int c) {
+        float b0[NQ], b1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const float R1 = L.sf[(4 * q + 1) * (16 * NCT)], dC = L.sf[(4 * q + 2) * (16 * NCT)] - R1;
+          const u32x2 ps2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][w * NQ + q]) + 8);
+          const float p0 = __uint_as_float(ps2[0]), sc = __uint_as_float(ps2[1]);
+          b0[q] = __builtin_fmaf(p0, dC, R1) * g_scale;  // the line at the tile start: S + p (E - S) (gain_interpolator.hpp:272-274)
+          b1[q] = (sc * dC) * g_scale;                   // its slope per sample
+        }
+        const int f0 = (c & 1) * FL;
+        store_frag(L, b0, f0);
+        store_frag(L, b1, f0 + 2 * NCT);
+      };
+      // the kinks of chunk c: T x (slope behind the kink - slope in front of it)
+      auto convert_hinges = [&](const LaneCtx &L, int c, uint32_t cf) {
+        float dF[NQ], dB[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const float R0 = L.sf[(4 * q) * (16 * NCT)], R1 = L.sf[(4 * q + 1) * (16 * NCT)], R2 = L.sf[(4 * q + 2) * (16 * NCT)],
+                      R3 = L.sf[(4 * q + 3) * (16 * NCT)];
+          const float sc = __uint_as_float(ringe[c & (RING - 1)][w * NQ + q][3]);
+          const u32x2 s2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][32 + w * NQ + q]) + 8);
+          const float mc = sc * (R2 - R1), ma = __uint_as_float(s2[0]) * (R1 - R0), mb = __uint_as_float(s2[1]) * (R3 - R2);
+          dF[q] = (mb - mc) * (g_scale * (float)T);
+          dB[q] = (mc - ma) * (g_scale * (float)T);
+        }
+        if (cf & 1u) store_frag(L, dF, FH0);
+        if (cf & 2u) store_frag(L, dB, FH0 + FH);
+      };
+
+      // ---- prologue
+      f32x4 X0[8];
+      u32x4 ah[NRT], al[NRT];
+      {
+        const LaneCtx L = lane_ctx(false);
+        if (w == 0) {
+#pragma unroll
+          for (int jn = 0; jn < RD; jn++) {
+            ring_load(L, c_lo + jn);
+            ring_store(L, c_lo + jn);
+          }
+        }
+        __syncthreads();
+        f32x3 G[NQ];
+        load_gains(L, c_lo, G);
+        load_x(L, c_lo, X0);
+        stage_gains(L, G);
+        convert_lin(L, c_lo);
+      }
+
+      // 12 MFMAs of one operand against the fragment pair at f: the three partial products of split operands, small ones first
+      auto mfma12 = [&](int ln, const u32x4 (&Ah)[NRT], const u32x4 (&Al)[NRT], int f, f32x4 (&tt)[NRT][NCT], int ct) {
+        const u32x4 bh = frag[f][ln];
+        u32x4 bs;
+#pragma unroll
+        for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(bh[i]);  // h 2^-11: partner of the inputs' scaled low piece
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(Al[r], bs, tt[r][ct]);
+        const u32x4 bl = frag[f + 1][ln];
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(Ah[r], bl, tt[r][ct]);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(Ah[r], bh, tt[r][ct]);
+      };
+
+      auto chunk_body = [&](int c, f32x4 (&X)[8]) __attribute__((always_inline)) {
+        // ======== the line step of chunk c
+        __syncthreads();  // its fragments are in place; ring slots up to c + RD - 1 are visible
+        const LaneCtx L = lane_ctx(true);
+        const uint32_t cf = ringc[c & (RING - 1)];
+        f32x3 G[NQ];
+        load_gains(L, c + 1, G);  // (past the schedule: the clamped last chunk's, never used)
+        __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
+        // this chunk's kink operands from the rows staged a chunk ago (before the split: the registers are free now)
+        if (cf & 3u) convert_hinges(L, c, cf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (w == 0) ring_load(L, c + RD);  // (stored at the end of this step)
+        // operand split of the inputs (gain_h2.h, wide form): 2 x 2 blocks, an f16 pair packs two SLOTS of one row tile
+#pragma unroll
+        for (int qp = 0; qp < 4; qp++)
+#pragma unroll
+          for (int rp = 0; rp < NRT; rp += 2) {
+            const f32x2 s0 = f32x2{X[2 * qp][rp], X[2 * qp][rp + 1]} * x_scale;
+            const f32x2 s1 = f32x2{X[2 * qp + 1][rp], X[2 * qp + 1][rp + 1]} * x_scale;
+            const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
+            const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * kLowPieceScale;
+            const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * kLowPieceScale;
+            ah[rp][qp] = H0;
+            ah[rp + 1][qp] = H1;
+            al[rp][qp] = pack_f16(r0[0], r1[0]);
+            al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(L, min(c + 1, c_hi - 1), X);  // the inputs of the next chunk, into the registers just freed
+        const int f0 = (c & 1) * FL;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) {
+          mfma12(L.lane, ah, al, f0 + 2 * ct, tot0, ct);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma12(L.lane, ah, al, f0 + 2 * NCT + 2 * ct, tot1, ct);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ct == (NCT - 1) / 2) {
+            stage_gains(L, G);  // the next chunk's rows replace this chunk's (same wave: in order)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (w == 0) ring_store(L, c + RD);
+        if (!(cf & 3u)) convert_lin(L, c + 1);
+        // ======== its kink steps: forward, then backward
+#pragma unroll 1
+        for (int g = (cf & 1u) ? 0 : 1; g < 2 && ((cf >> g) & 1u); g++) {
+          __syncthreads();
+          const LaneCtx H = lane_ctx(true);
+          if ((cf >> (8 + 4 * g + w)) & 1u) {  // (wave-uniform) can these kinks reach this wave's samples?
+            // the lane's 8 factor words -> (slope, slope) and (offset, offset) pairs of its slot pairs
+            const u32x4 fa = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][H.kg * 8]);
+            const u32x4 fb = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][H.kg * 8 + 4]);
+            uint32_t SC[4], P0[4];
+#pragma unroll
+            for (int qp = 0; qp < 4; qp++) {
+              const uint32_t w0 = qp < 2 ? fa[2 * qp] : fb[2 * qp - 4], w1 = qp < 2 ? fa[2 * qp + 1] : fb[2 * qp - 3];
+              SC[qp] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // (lo16 of w0, lo16 of w1)
+              P0[qp] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // (hi16 of w0, hi16 of w1)
+            }
+            const int fh = FH0 + g * FH;
+            // the lane's samples as f16 pairs (s, s), s counted from the start of the workgroup tile: the factor of a kink
+            // is F = clamp(s * slope + offset) in packed f16 arithmetic (exact: 8 bits)
+            uint32_t SS[NRT];
+#pragma unroll
+            for (int r = 0; r < NRT; r++) SS[r] = f16_bits((float)(wave_s0 + H.li * NRT + r)) * 0x10001u;
+#pragma unroll
+            for (int rh = 0; rh < NRT; rh += 2) {  // two row tiles at a time (registers)
+              u32x4 Fh[2], Fl[2];
+#pragma unroll
+              for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+                for (int qp = 0; qp < 4; qp++) {
+                  const int r = rh + r2;
+                  const hg_h2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+                  const hg_h2 k2048 = {(_Float16)kLowPieceScale, (_Float16)kLowPieceScale};
+                  const hg_h2 F = __builtin_elementwise_min(
+                      __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero), one);
+                  const hg_h2 xh = as_h2(ah[r][qp]), xl = as_h2(al[r][qp]);
+                  const hg_h2 Ah = F * xh;                                         // rn(F xh)
+                  const hg_h2 res = __builtin_elementwise_fma(F, xh, -Ah);         // ... its residual: exact
+                  const hg_h2 Al = __builtin_elementwise_fma(res, k2048, F * xl);  // low piece, in the scaled units of xl
+                  Fh[r2][qp] = h2_bits(Ah);
+                  Fl[r2][qp] = h2_bits(Al);
+                }
+#pragma unroll
+              for (int ct = 0; ct < NCT; ct++) {
+                const u32x4 bh = frag[fh + 2 * ct][H.lane];
+                u32x4 bs;
+#pragma unroll
+                for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(bh[i]);
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fl[r2], bs, tot0[rh + r2][ct]);
+                const u32x4 bl = frag[fh + 2 * ct + 1][H.lane];
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fh[r2], bl, tot0[rh + r2][ct]);
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fh[r2], bh, tot0[rh + r2][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          if (g == 1 || !(cf & 2u)) convert_lin(H, c + 1);  // the chunk's last step: the next line's operands
+        }
+      };
+#pragma unroll 1
+      for (int c = c_lo; c < c_hi; c++) chunk_body(c, X0);
+    }
+    __syncthreads();  // (the fragments' memory becomes the output tiles below)
+
+    // objects that take the exact path: part 0 only
+    if (part == 0) {
+      const int *ovf = hl.ovf + (size_t)wgtile * P.M;
+      for (int i = 0; i < cnt[1]; i++) single_object(ovf[i], x_scale, true);
+    }
+    // an operand beyond the f16 range (or not finite) shows as non-finite totals: redo the wave's tile exactly, unscaled
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < NRT; r++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
+    if (__ballot(bad)) {
+      clear_totals();
+      inv_x = 1.0f;
+      col_scaled = false;
+      for (int s = 32 * c_lo; s < 32 * c_hi; s++) {
+        const uint32_t mw = lbase[s].m;
+        if (!(mw & kLinNull)) single_object((int)(mw & kLinObjMask), 1.0f, false);
+      }
+      if (part == 0) {
+        const int *ovf = hl.ovf + (size_t)wgtile * P.M;
+        for (int i = 0; i < cnt[1]; i++) single_object(ovf[i], 1.0f, false);
+      }
+    }
+  } else {
+    inv_x = 1.0f;
+    col_scaled = false;
+    const int m_lo = (int)(((int64_t)P.M * part) / nparts), m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
+    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);  // unaligned rows
+  }
+
+  if (tile_len <= 0) return;
+  // D fragment of row tile r: rows 4 kg + e = samples 16 kg + 4 e + r; (s - s0) counts from the WORKGROUP tile's start
+  const float wf0 = (float)(wave_s0 + kg * 16);
+  float inv_gc[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
+  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
+  const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
+  float *ot = reinterpret_cast<float *>(fmem) + w * 16 * OP;
+#pragma unroll
+  for (int c = 0; c < NCT; c++) {
+    if (whole) {  // transposed through wave-private LDS: whole 256-byte rows per store instruction (gain_h2.h)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < NRT; r++)
+          v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
+        *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
+      }
+#pragma unroll
+      for (int jn = 0; jn < 4; jn++) {
+        const int cl = 4 * jn + kg, col = col0 + c * 16 + cl;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + cl * OP + li * 4);
+        if (col < P.ncols) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(op + (size_t)col * P.out_stride + li * 4));
+      }
+      continue;
+    }
+    const int col = col0 + c * 16 + li;
+    if (col >= P.ncols) continue;
+    float *o = op + (size_t)col * P.out_stride;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int s = kg * 16 + e * 4;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < NRT; r++)
+        v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
+      if (P.vec_ok && s + 3 < tile_len) {
+        *reinterpret_cast<f32x4 *>(o + s) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (s + i < tile_len) o[s + i] = v[i];
+      }
+    }
+  }
+}
+
+}  // namespace earhip
