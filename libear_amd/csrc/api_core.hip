@@ -111,6 +111,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   HingeLists hl = hinge_lists(desc, M, ml.ntiles);
   if (ml.hinge) {
     if (M > kMaxHingeCached || ml.tile() != kHingeTile) fail_internal("hinge lists: object count or tile out of range");
+    // (the kernel addresses input rows and gain rows with 32-bit byte offsets; plan_mix only picks it within these limits)
+    if (!hinge_addressable(M, in_stride, nsamples, ps.zero_row + 2, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
     unsigned *obj_lv = nullptr;
     if (probe.obj_level) {
       obj_lv = probe.obj_level;
@@ -301,7 +303,7 @@ struct GainStage {
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
                             curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
-                            curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share());
+                            curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share(in_stride, (size_t)nsamples));
     desc.reserve(std::max(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)), hinge_units(n_in, ml.ntiles)));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

@@ -250,11 +250,11 @@ struct earhip_render {
   }
 
   // the launch plan of a call of nblocks blocks at the current sample clock
-  MixLaunch plan_call(size_t nblocks) {
+  MixLaunch plan_call(size_t nblocks, size_t in_stride) {
     const int nsamples = (int)(nblocks * (size_t)B);
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, ctx->strict, max_gsplit, curves->aligned_tile(t),
                             curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste(256), curves->pair_waste(512),
-                            curves->hinge_exact_share());
+                            curves->hinge_exact_share(in_stride, (size_t)nsamples));
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     while (ml.gsplit > 1 && bus_stride * K * N * ml.gsplit > bus.n) ml.gsplit /= 2;
     return ml;
@@ -265,7 +265,7 @@ struct earhip_render {
     const int nsamples = (int)(nblocks * (size_t)B);
     curves->commit(ctx);
     const bool strict = ctx->strict;
-    MixLaunch ml = plan_call(nblocks);
+    MixLaunch ml = plan_call(nblocks, in_stride);
 
     last_kind = ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;

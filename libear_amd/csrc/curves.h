@@ -348,7 +348,10 @@ class CurveSet {
   double point_density() const { return point_density_; }
   double pair_waste(int tile) const { return pair_waste_[tile >= 512 ? 1 : 0]; }
   // share of the (object, tile) pairs the hinge kernel would send through its exact path; > 1: not a curve set for it
-  double hinge_exact_share() const { return force_ramp_ ? 2.0 : hinge_exact_share_; }
+  // (in_stride, nsamples: the input rows of the call — the kernel addresses them, and the gain rows, with 32-bit offsets)
+  double hinge_exact_share(size_t in_stride, size_t nsamples) const {
+    return force_ramp_ || !hinge_addressable((size_t)M_, in_stride, nsamples, (size_t)npoints_ + 2, (size_t)plan_.row) ? 2.0 : hinge_exact_share_;
+  }
 
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
@@ -432,7 +435,7 @@ struct MixLaunch {
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
                           float gain_scale = 0.0f, double point_density = 0.0, double pair_waste256 = 1.0,
-                          double pair_waste512 = 1.0, double hinge_exact_share = 1.0) {
+                          double pair_waste512 = 1.0, double hinge_exact_share = 2.0) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;

@@ -92,6 +92,10 @@ inline HingeLists hinge_lists(void *scratch, int M, int ntiles) {
   return hl;
 }
 
+// input rows and gain rows are addressed with 32-bit byte offsets from their first row
+inline bool hinge_addressable(size_t M, size_t in_stride, size_t nsamples, size_t gain_rows, size_t rowlen) {
+  return ((M - 1) * in_stride + nsamples + 4) * sizeof(float) < ((size_t)1 << 32) && gain_rows * rowlen * sizeof(float) < ((size_t)1 << 32);
+}
 __device__ __forceinline__ uint32_t f16_bits(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); }
 
 // ---------------------------------------------------------------------------
@@ -151,7 +155,9 @@ __device__ __forceinline__ void hinge_entries(const PointStore &ps, const HingeR
   auto seg_ramp = [&](int i) { return R.has[i] && R.has[i - 1] && (R.r[i].flat & allflat) != allflat; };
   const int k1 = min(max(kc - 1, 0), n - 1);  // the point R1 stands for
   const uint32_t d0 = kc - 2 >= 0 && kc - 2 < k1 ? 1u : 0u, d2 = kc < n && kc > k1 ? 1u : 0u, d3 = kc + 1 < n ? 1u : 0u;
-  e.m = (uint32_t)m | (1u - d0) << 16 | 1u << 18 | (1u + d2) << 20 | (1u + d2 + d3) << 22;
+  // (a row no kink needs — R0 without a backward, R3 without a forward kink — is asked for as its neighbour R1 / R2: the same
+  // cache lines again instead of another row's, and a difference of rows that vanishes)
+  e.m = (uint32_t)m | (bwd ? 1u - d0 : 1u) << 16 | 1u << 18 | (1u + d2) << 20 | (1u + d2 + (fwd ? d3 : 0u)) << 22;
   e.row = base + k1;
   e.p0 = 0.0f;
   e.scale = 0.0f;
@@ -316,42 +322,50 @@ __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast
 // K1.  grid = (tiles, grid-level splits of the chunk schedule, column super-groups), block = 256 threads:
 // wave w = samples [64 w, 64 w + 64) of the workgroup's 256-sample tile.
 //
-// A chunk of 32 list slots is up to three STEPS, each between two workgroup barriers: the line step (inputs split,
-// 72 MFMAs per 48 columns), then — where the chunk has them — the forward and the backward kink step (36 each; a wave
-// skips those that cannot reach its samples).  The vector-memory counter is in order, so everything a chunk needs from
-// memory is requested in ONE place, the line step of the chunk before: first the gain rows of the next chunk (four rows
-// per slot: the points kc - 2 .. kc + 1 cover its line and both its kinks), then the inputs of the next chunk into
-// the registers the split has just freed (one chunk ahead: two sets of inputs do not fit the register file beside
-// the 96 accumulators, the operand pieces the kink steps need, and the rows on their way).  The rows go through a wave-private piece of LDS; the kink steps request
-// nothing.  Operand fragments: the line's alternate between two buffers, the kinks' have their own (written during
-// the line step of their chunk); the scaled high piece (h 2^-11, gain_h2.h) is made from h where it is used.
+// A chunk of 32 list slots is ONE step between two workgroup barriers: the line (inputs split, 72 MFMAs per 48 columns),
+// then — where the chunk has them — its forward and its backward kinks (36 each; a wave skips those that cannot reach
+// its samples).  The vector-memory counter is in order, so everything is requested in one place, at the start of a
+// step: first the gain rows of the chunk after next (four rows per slot: the points kc - 2 .. kc + 1 cover its line and
+// both its kinks), then the inputs of the next chunk into the registers the split has just freed (one chunk ahead:
+// two sets of inputs do not fit the register file beside the 96 accumulators, the operand pieces the kinks need, and
+// the rows on their way).  The rows go through a wave-private piece of LDS, a chunk's worth at a time: a step first
+// turns the rows staged a step ago into the operand fragments of the NEXT chunk (all three sets; fragments alternate
+// between two buffers), then stages the rows that have arrived meanwhile.  The scaled high piece (h 2^-11, gain_h2.h)
+// is made from h where it is used.
 template <int NCT>
 __global__ void __launch_bounds__(256, 2)
 k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, unsigned *wide_next) {
   constexpr int NW = 4, NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = kHingeTile;
   constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
-  constexpr int RING = 8;
-  constexpr int RS = 4 * NCT;        // 16-byte slots per gain row
-  constexpr int NG = (4 * NQ * RS + 63) / 64;  // 1 KB pieces of a wave's staged gain rows
+  constexpr int RING = 4;
   constexpr int OP = TS + 4;
-  // fragments (1 KB each: 64 lanes x 8 f16): line of even / odd chunks {B0, B1} x column tiles x {h, l}, forward kinks,
-  // backward kinks (column tiles x {h, l}), and two nobody reads (the lanes without a column write there)
-  constexpr int FL = 4 * NCT, FH0 = 2 * FL, FH = 2 * NCT, FDUMMY = FH0 + 2 * FH, NFRAGS = FDUMMY + 2;
+  // fragments (1 KB each: 64 lanes x 8 f16), two sets (even / odd chunks) of: the line {B0, B1} x column tiles x {h, l}, the
+  // forward kinks and the backward kinks (column tiles x {h, l})
+  constexpr int FL = 4 * NCT, FH = 2 * NCT, FSET = FL + 2 * FH, NFRAGS = 2 * FSET;
   constexpr size_t kFragBytes = sizeof(u32x4) * NFRAGS * 64, kTileBytes = sizeof(float) * NW * 16 * OP;
   __shared__ __attribute__((aligned(16))) unsigned char fmem[kFragBytes > kTileBytes ? kFragBytes : kTileBytes];  // (the waves' output
                                                                                             // tiles, once the last step is through)
   auto frag = reinterpret_cast<u32x4(*)[64]>(fmem);
   __shared__ float inv_gcol[16 * NCT];
-  __shared__ __attribute__((aligned(16))) uint64_t ring[RING][CH];   // byte offsets of the slots' input rows
+  __shared__ __attribute__((aligned(16))) u32x4 fdummy[1];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[RING][CH];   // byte offsets of the slots' input rows (below 4 GB: api_core.hip checks)
   __shared__ __attribute__((aligned(16))) u32x4 ringe[RING][2 * CH];  // the LinEntries [0, 32) and the HingeEntries [32, 64)
   __shared__ __attribute__((aligned(16))) uint32_t ringf[RING][2][CH];  // ... their factor words, packed for the lanes
   __shared__ uint32_t ringc[RING];                                    // chunk flags
-  __shared__ __attribute__((aligned(16))) f32x4 stage[NW][NG * 64];  // a wave's gain rows: [slot][4 rows][16 NCT columns]
+  __shared__ __attribute__((aligned(16))) float stage[NW][NQ * 4 * 16 * NCT];  // a wave's gain rows: [slot][4 rows][16 NCT columns]
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
-  const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
+  // workgroups k and k + 32 of an XCD — the two a CU holds when the dispatcher goes round the XCD's 32 CUs — take adjacent
+  // tiles: most of the gain rows one of them asks for the other has just fetched or is fetching (L2 -> L1 requests are
+  // what this kernel is short of: 2 % of its time, measured; any mapping is correct)
+  const int wgtile = [&] {
+    const int b = blockIdx.x, n = gridDim.x, per = n >> 3;
+    if (b >= per * 8 || (per & 63)) return xcd_tile(b, n);
+    const int k = b >> 3;
+    return (b & 7) * per + (((k >> 6) << 6) | ((k & 31) << 1) | ((k >> 5) & 1));
+  }();
   // gains are scaled to HALF the range the other split kernels use (T x slope of a ramp of T / 2 samples or more is at
   // most twice the gains' range; differences of two such slopes stay inside the f16 range for gains of one sign, and
   // what does not shows as non-finite totals: exact redo below)
@@ -444,10 +458,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
     const int c_lo = (int)(((int64_t)total * part) / nparts), c_hi = (int)(((int64_t)total * (part + 1)) / nparts);
     if (c_hi > c_lo) {
       const int nvec = (P.nsamples + 3) & ~3;
-      const uint64_t rstride = P.in_stride * sizeof(float);
+      const uint32_t rstride = (uint32_t)(P.in_stride * sizeof(float));
       const float g_scale = 0.5f * gcol[col0 + min(lane, 16 * NCT - 1)];  // the scale of the lane's gain column
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
       typedef float f32x3 __attribute__((ext_vector_type(3)));
       typedef const uint32_t __attribute__((address_space(4))) *ConstWords;  // (K0 wrote them, this kernel only reads: scalar loads)
       // What a step needs to know about its lane.  Made anew from the lane number in every chunk (through an opaque
@@ -457,7 +470,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       struct LaneCtx {
         int lane, li, kg;
         unsigned xlane;      // byte offset of the lane's float4 inside an input row
-        const float *glane;  // the lane's 12 bytes of a gain row (less the row)
+        unsigned glane;      // byte offset of the lane's 12 bytes inside a gain row
         int rsh;             // where the place of the lane's row (R_kg) is in a LinEntry's first word
         float *sw;           // where the lane's 12 bytes of slot 0 go in the wave's staged rows
         const float *sf;     // the lane's column in them
@@ -472,7 +485,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         L.li = L.lane & 15;
         L.kg = L.lane >> 4;
         L.xlane = (unsigned)min(tile_s0 + L.li * NRT, nvec - 4) * 4u;
-        L.glane = gain + col0 + NCT * L.li;
+        L.glane = (unsigned)(col0 + NCT * L.li) * 4u;
         L.rsh = kLinRowShift + 2 * L.kg;
         L.sw = reinterpret_cast<float *>(&stage[w][0]) + L.kg * (16 * NCT) + NCT * L.li;
         L.sf = reinterpret_cast<const float *>(&stage[w][0]) + min(L.lane, 16 * NCT - 1);
@@ -498,7 +511,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         const int sl = c & (RING - 1);
         ringe[sl][L.lane] = ring_next;
         if (L.lane < 32) {
-          ring[sl][L.lane] = (uint64_t)(ring_next[0] & kLinObjMask) * rstride;
+          ring[sl][L.lane] = (ring_next[0] & kLinObjMask) * rstride;
           if (L.lane == 0) ringc[sl] = ring_next_cf;
         } else {
           ringf[sl][0][L.lane - 32] = ring_next[0];
@@ -507,12 +520,12 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       };
       // ---- inputs of chunk c: 8 requests of 16 bytes per lane (slots 8 kg .. 8 kg + 7, the lane's 4 samples)
       auto load_x = [&](const LaneCtx &L, int c, f32x4 (&x)[8]) {
-        const char *bp = reinterpret_cast<const char *>(P.in) + L.xlane;
+        const char *bp = reinterpret_cast<const char *>(P.in);
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          const u64x2 mw = *reinterpret_cast<const u64x2 *>(&ring[c & (RING - 1)][L.kg * 8 + q]);
-          x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + mw[0]));
-          x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + mw[1]));
+        for (int q = 0; q < 8; q += 4) {
+          const u32x4 mw = *reinterpret_cast<const u32x4 *>(&ring[c & (RING - 1)][L.kg * 8 + q]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) x[q + i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (mw[i] + L.xlane)));
         }
       };
       // ---- gain rows of the slots NQ w .. NQ w + NQ - 1 of chunk c, four rows each (R0 .. R3 of its LinEntry): request q
@@ -523,7 +536,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         for (int q = 0; q < NQ; q++) {
           const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringe[c & (RING - 1)][w * NQ + q]);  // (m | rows' places, row R1)
           const unsigned row = mr[1] + ((mr[0] >> L.rsh) & 3u) - 1u;
-          const float *gp = L.glane + (size_t)row * rowlen;
+          // (uniform base + 32-bit lane offset: the image of the curves is below 4 GB, api_core.hip checks)
+          const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(gain) + (row * (rowlen * 4u) + L.glane));
           if constexpr (NCT == 3) G[q] = *reinterpret_cast<const f32x3 *>(gp);
           else if constexpr (NCT == 2) G[q] = f32x3{gp[0], gp[1], 0.0f};
           else G[q] = f32x3{gp[0], 0.0f, 0.0f};
@@ -547,9 +561,10 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           h[i] = H;
           l[i] = pack_f16(v[2 * i] - f16_lo(H), v[2 * i + 1] - f16_hi(H));  // residuals: exact in fp32
         }
-        f = L.fpair >= 0 ? f + L.fpair : FDUMMY;
-        frag[f][L.fe] = u32x4{h[0], h[1], h[2], h[3]};
-        frag[f + 1][L.fe] = u32x4{l[0], l[1], l[2], l[3]};
+        if (L.fpair >= 0) {  // (lanes 48 .. 63 have no column)
+          frag[f + L.fpair][L.fe] = u32x4{h[0], h[1], h[2], h[3]};
+          frag[f + L.fpair + 1][L.fe] = u32x4{l[0], l[1], l[2], l[3]};
+        }
       };
       // the line of chunk c from the staged rows -> its fragment set
       auto convert_lin = [&](const LaneCtx &L, int c) {
@@ -562,7 +577,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           b0[q] = __builtin_fmaf(p0, dC, R1) * g_scale;  // the line at the tile start: S + p (E - S) (gain_interpolator.hpp:272-274)
           b1[q] = (sc * dC) * g_scale;                   // its slope per sample
         }
-        const int f0 = (c & 1) * FL;
+        const int f0 = (c & 1) * FSET;
         store_frag(L, b0, f0);
         store_frag(L, b1, f0 + 2 * NCT);
       };
@@ -579,11 +594,12 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           dF[q] = (mb - mc) * (g_scale * (float)T);
           dB[q] = (mc - ma) * (g_scale * (float)T);
         }
-        if (cf & 1u) store_frag(L, dF, FH0);
-        if (cf & 2u) store_frag(L, dB, FH0 + FH);
+        const int f0 = (c & 1) * FSET + FL;
+        if (cf & 1u) store_frag(L, dF, f0);
+        if (cf & 2u) store_frag(L, dB, f0 + FH);
       };
 
-      // ---- prologue
+      // ---- prologue: ring slots of the first chunks; fragments of the first chunk; rows of the second one staged
       f32x4 X0[8];
       u32x4 ah[NRT], al[NRT];
       {
@@ -598,38 +614,73 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         __syncthreads();
         f32x3 G[NQ];
         load_gains(L, c_lo, G);
-        load_x(L, c_lo, X0);
         stage_gains(L, G);
+        load_gains(L, c_lo + 1, G);
+        load_x(L, c_lo, X0);
         convert_lin(L, c_lo);
+        const uint32_t cf0 = ringc[c_lo & (RING - 1)];
+        if (cf0 & 3u) convert_hinges(L, c_lo, cf0);
+        stage_gains(L, G);
       }
 
-      // 12 MFMAs of one operand against the fragment pair at f: the three partial products of split operands, small ones first
-      auto mfma12 = [&](int ln, const u32x4 (&Ah)[NRT], const u32x4 (&Al)[NRT], int f, f32x4 (&tt)[NRT][NCT], int ct) {
-        const u32x4 bh = frag[f][ln];
-        u32x4 bs;
+      // the conversions in half-slices (slots 4 hf .. 4 hf + 3 of the wave's eight), so that they can be woven between the MFMAs
+      auto store_half = [&](const LaneCtx &L, const float (&v)[4], int f, int hf) {
+        const uint32_t H0 = pack_f16(v[0], v[1]), H1 = pack_f16(v[2], v[3]);
+        const uint32_t L0 = pack_f16(v[0] - f16_lo(H0), v[1] - f16_hi(H0)), L1 = pack_f16(v[2] - f16_lo(H1), v[3] - f16_hi(H1));
+        // (lanes 48 .. 63 have no column: they all write the same 8 bytes nobody reads — no branch, the slices stay inside
+        // the MFMA blocks' basic block, where the scheduler can weave them between the MFMAs)
+        u32x2 *ph = L.fpair >= 0 ? reinterpret_cast<u32x2 *>(&frag[f + L.fpair][L.fe]) + hf : reinterpret_cast<u32x2 *>(&fdummy[0]);
+        u32x2 *pl = L.fpair >= 0 ? reinterpret_cast<u32x2 *>(&frag[f + L.fpair + 1][L.fe]) + hf : reinterpret_cast<u32x2 *>(&fdummy[0]) + 1;
+        *ph = u32x2{H0, H1};
+        *pl = u32x2{L0, L1};
+      };
+      auto convert_lin_half = [&](const LaneCtx &L, int c, int hf) {
+        float b0[4], b1[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(bh[i]);  // h 2^-11: partner of the inputs' scaled low piece
+        for (int i = 0; i < 4; i++) {
+          const int q = 4 * hf + i;
+          const float R1 = L.sf[(4 * q + 1) * (16 * NCT)], dC = L.sf[(4 * q + 2) * (16 * NCT)] - R1;
+          const u32x2 ps2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][w * NQ + q]) + 8);
+          const float p0 = __uint_as_float(ps2[0]), sc = __uint_as_float(ps2[1]);
+          b0[i] = __builtin_fmaf(p0, dC, R1) * g_scale;
+          b1[i] = (sc * dC) * g_scale;
+        }
+        const int f0 = (c & 1) * FSET;
+        store_half(L, b0, f0, hf);
+        store_half(L, b1, f0 + 2 * NCT, hf);
+      };
+      auto convert_hinges_half = [&](const LaneCtx &L, int c, int hf) {
+        float dF[4], dB[4];
 #pragma unroll
-        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(Al[r], bs, tt[r][ct]);
-        const u32x4 bl = frag[f + 1][ln];
-#pragma unroll
-        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(Ah[r], bl, tt[r][ct]);
-#pragma unroll
-        for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(Ah[r], bh, tt[r][ct]);
+        for (int i = 0; i < 4; i++) {
+          const int q = 4 * hf + i;
+          const float R0 = L.sf[(4 * q) * (16 * NCT)], R1 = L.sf[(4 * q + 1) * (16 * NCT)], R2 = L.sf[(4 * q + 2) * (16 * NCT)],
+                      R3 = L.sf[(4 * q + 3) * (16 * NCT)];
+          const float sc = __uint_as_float(ringe[c & (RING - 1)][w * NQ + q][3]);
+          const u32x2 s2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][32 + w * NQ + q]) + 8);
+          const float mc = sc * (R2 - R1), ma = __uint_as_float(s2[0]) * (R1 - R0), mb = __uint_as_float(s2[1]) * (R3 - R2);
+          dF[i] = (mb - mc) * (g_scale * (float)T);
+          dB[i] = (mc - ma) * (g_scale * (float)T);
+        }
+        const int f0 = (c & 1) * FSET + FL;
+        store_half(L, dF, f0, hf);
+        store_half(L, dB, f0 + FH, hf);
+      };
+      auto load_x_part = [&](const LaneCtx &L, int c, f32x4 (&x)[8], int q0) {  // requests q0, q0 + 1
+        const char *bp = reinterpret_cast<const char *>(P.in);
+        const u32x2 mw = *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][L.kg * 8 + q0]);
+        x[q0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (mw[0] + L.xlane)));
+        x[q0 + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (mw[1] + L.xlane)));
       };
 
       auto chunk_body = [&](int c, f32x4 (&X)[8]) __attribute__((always_inline)) {
-        // ======== the line step of chunk c
-        __syncthreads();  // its fragments are in place; ring slots up to c + RD - 1 are visible
+        __syncthreads();  // the fragments of chunk c are in place; ring slots up to c + RD - 1 are visible
         const LaneCtx L = lane_ctx(true);
         const uint32_t cf = ringc[c & (RING - 1)];
         f32x3 G[NQ];
-        load_gains(L, c + 1, G);  // (past the schedule: the clamped last chunk's, never used)
+        load_gains(L, c + 2, G);  // (past the schedule: the clamped last chunk's, never used)
+        if (w == 0) ring_load(L, c + RD);  // (stored behind the line's MFMAs)
         __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
-        // this chunk's kink operands from the rows staged a chunk ago (before the split: the registers are free now)
-        if (cf & 3u) convert_hinges(L, c, cf);
-        __builtin_amdgcn_sched_barrier(0);
-        if (w == 0) ring_load(L, c + RD);  // (stored at the end of this step)
         // operand split of the inputs (gain_h2.h, wide form): 2 x 2 blocks, an f16 pair packs two SLOTS of one row tile
 #pragma unroll
         for (int qp = 0; qp < 4; qp++)
@@ -645,82 +696,138 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             al[rp][qp] = pack_f16(r0[0], r1[0]);
             al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
           }
-        __builtin_amdgcn_sched_barrier(0);
-        load_x(L, min(c + 1, c_hi - 1), X);  // the inputs of the next chunk, into the registers just freed
-        const int f0 = (c & 1) * FL;
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
+        // ======== the line: 2 NCT blocks of 12 MFMAs (operand B0 / B1 of a column tile: the three partial products, small
+        // ones first).  Between them, in this order: the requests of the next chunk's inputs (into the registers the
+        // split has just freed), then the next chunk's operands from the rows staged a step ago — MFMA and VALU
+        // instructions of one wave overlap only when they alternate (gain_h2.h).  (h, l) of a block are read a block ahead.
+        const int f0 = (c & 1) * FSET;
+        constexpr int NBLK = 2 * NCT;
+        const int cx = min(c + 1, c_hi - 1);
+        u32x4 bh[2];
+        auto frag_of = [&](int blk) { return f0 + (blk & 1) * 2 * NCT + 2 * (blk >> 1); };
+        bh[0] = frag[frag_of(0)][L.lane];
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        auto block = [&](auto blk_tag) __attribute__((always_inline)) {
+          constexpr int blk = decltype(blk_tag)::value;
+          constexpr int ct = blk >> 1;
+          // the items of this block: it0 .. it1 - 1 of: 4 pairs of input requests, 2 half-slices of the line's conversion,
+          // 2 of the kinks'
+          constexpr int it0 = NBLK == 6 ? (blk < 2 ? 2 * blk : blk + 2) : NBLK == 4 ? (blk == 0 ? 0 : blk == 1 ? 4 : blk + 4) : 6 * blk;
+          constexpr int it1 = NBLK == 6 ? (blk < 2 ? 2 * blk + 2 : blk + 3) : NBLK == 4 ? (blk == 0 ? 4 : blk == 1 ? 6 : blk + 5) : 6 + 2 * blk;
+          constexpr int nx = (it1 < 4 ? it1 : 4) - (it0 < 4 ? it0 : 4), nconv = (it1 - it0) - nx;
+          f32x4(&tt)[NRT][NCT] = (blk & 1) ? tot1 : tot0;
+          // (h of a block is read a block ahead, l as the block starts, behind the four MFMAs that do not need it: registers)
+          const u32x4 ch = bh[blk & 1];
+          const u32x4 cl = frag[frag_of(blk) + 1][L.lane];
+          if constexpr (blk + 1 < NBLK) bh[(blk + 1) & 1] = frag[frag_of(blk + 1)][L.lane];
+          u32x4 bs;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-          mfma12(L.lane, ah, al, f0 + 2 * ct, tot0, ct);
-          __builtin_amdgcn_sched_barrier(0);
-          mfma12(L.lane, ah, al, f0 + 2 * NCT + 2 * ct, tot1, ct);
-          __builtin_amdgcn_sched_barrier(0);
-          if (ct == (NCT - 1) / 2) {
-            stage_gains(L, G);  // the next chunk's rows replace this chunk's (same wave: in order)
-            __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(ch[i]);  // h 2^-11: partner of the inputs' scaled low piece
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(al[r], bs, tt[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(ah[r], cl, tt[r][ct]);
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(ah[r], ch, tt[r][ct]);
+#pragma unroll
+          for (int it = it0; it < it1; it++) {
+            if (it < 4) {
+              load_x_part(L, cx, X, 2 * it);
+            } else if (it < 6) {
+              convert_lin_half(L, c + 1, it - 4);
+            } else {
+              convert_hinges_half(L, c + 1, it - 6);  // (whether the next chunk has kinks or not: no branch inside the blocks)
+            }
           }
+          // issue order: the LDS reads of the next block first, then the MFMAs with the other work between them
+          if constexpr (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if constexpr (nconv > 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+          } else if constexpr (nx > 0) {
+#pragma unroll
+            for (int k = 0; k < nx; k++) {  // MFMAs, then a pair of requests (address arithmetic + loads)
+              __builtin_amdgcn_sched_group_barrier(0x008, 12 / nx, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+          }
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
+        if constexpr (NBLK > 2) {
+          block(std::integral_constant<int, 2>{});
+          block(std::integral_constant<int, 3>{});
         }
+        if constexpr (NBLK > 4) {
+          block(std::integral_constant<int, 4>{});
+          block(std::integral_constant<int, 5>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage_gains(L, G);  // the rows of the chunk after next replace the next chunk's (same wave: in order)
         if (w == 0) ring_store(L, c + RD);
-        if (!(cf & 3u)) convert_lin(L, c + 1);
-        // ======== its kink steps: forward, then backward
+        // ======== its kinks: forward, then backward
 #pragma unroll 1
-        for (int g = (cf & 1u) ? 0 : 1; g < 2 && ((cf >> g) & 1u); g++) {
-          __syncthreads();
-          const LaneCtx H = lane_ctx(true);
-          if ((cf >> (8 + 4 * g + w)) & 1u) {  // (wave-uniform) can these kinks reach this wave's samples?
-            // the lane's 8 factor words -> (slope, slope) and (offset, offset) pairs of its slot pairs
-            const u32x4 fa = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][H.kg * 8]);
-            const u32x4 fb = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][H.kg * 8 + 4]);
-            uint32_t SC[4], P0[4];
+        for (int g = 0; g < 2; g++) {
+          if (!((cf >> (8 + 4 * g + w)) & 1u)) continue;  // (wave-uniform) no such kinks, or none that reach this wave's samples
+          // the lane's 8 factor words -> (slope, slope) and (offset, offset) pairs of its slot pairs
+          const u32x4 fa = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][L.kg * 8]);
+          const u32x4 fb = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][L.kg * 8 + 4]);
+          uint32_t SC[4], P0[4];
 #pragma unroll
-            for (int qp = 0; qp < 4; qp++) {
-              const uint32_t w0 = qp < 2 ? fa[2 * qp] : fb[2 * qp - 4], w1 = qp < 2 ? fa[2 * qp + 1] : fb[2 * qp - 3];
-              SC[qp] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // (lo16 of w0, lo16 of w1)
-              P0[qp] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // (hi16 of w0, hi16 of w1)
-            }
-            const int fh = FH0 + g * FH;
-            // the lane's samples as f16 pairs (s, s), s counted from the start of the workgroup tile: the factor of a kink
-            // is F = clamp(s * slope + offset) in packed f16 arithmetic (exact: 8 bits)
-            uint32_t SS[NRT];
+          for (int qp = 0; qp < 4; qp++) {
+            const uint32_t w0 = qp < 2 ? fa[2 * qp] : fb[2 * qp - 4], w1 = qp < 2 ? fa[2 * qp + 1] : fb[2 * qp - 3];
+            SC[qp] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // (lo16 of w0, lo16 of w1)
+            P0[qp] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // (hi16 of w0, hi16 of w1)
+          }
+          const int fh = f0 + FL + g * FH;
+          // the lane's samples as f16 pairs (s, s), s counted from the start of the workgroup tile: the factor of a kink
+          // is F = clamp(s * slope + offset) in packed f16 arithmetic (exact: 8 bits)
+          uint32_t SS[NRT];
 #pragma unroll
-            for (int r = 0; r < NRT; r++) SS[r] = f16_bits((float)(wave_s0 + H.li * NRT + r)) * 0x10001u;
+          for (int r = 0; r < NRT; r++) SS[r] = f16_bits((float)(wave_s0 + L.li * NRT + r)) * 0x10001u;
 #pragma unroll
-            for (int rh = 0; rh < NRT; rh += 2) {  // two row tiles at a time (registers)
-              u32x4 Fh[2], Fl[2];
+          for (int rh = 0; rh < NRT; rh += 2) {  // two row tiles at a time (registers)
+            u32x4 Fh[2], Fl[2];
 #pragma unroll
-              for (int r2 = 0; r2 < 2; r2++)
+            for (int r2 = 0; r2 < 2; r2++)
 #pragma unroll
-                for (int qp = 0; qp < 4; qp++) {
-                  const int r = rh + r2;
-                  const hg_h2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
-                  const hg_h2 k2048 = {(_Float16)kLowPieceScale, (_Float16)kLowPieceScale};
-                  const hg_h2 F = __builtin_elementwise_min(
-                      __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero), one);
-                  const hg_h2 xh = as_h2(ah[r][qp]), xl = as_h2(al[r][qp]);
-                  const hg_h2 Ah = F * xh;                                         // rn(F xh)
-                  const hg_h2 res = __builtin_elementwise_fma(F, xh, -Ah);         // ... its residual: exact
-                  const hg_h2 Al = __builtin_elementwise_fma(res, k2048, F * xl);  // low piece, in the scaled units of xl
-                  Fh[r2][qp] = h2_bits(Ah);
-                  Fl[r2][qp] = h2_bits(Al);
-                }
-#pragma unroll
-              for (int ct = 0; ct < NCT; ct++) {
-                const u32x4 bh = frag[fh + 2 * ct][H.lane];
-                u32x4 bs;
-#pragma unroll
-                for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(bh[i]);
-#pragma unroll
-                for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fl[r2], bs, tot0[rh + r2][ct]);
-                const u32x4 bl = frag[fh + 2 * ct + 1][H.lane];
-#pragma unroll
-                for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fh[r2], bl, tot0[rh + r2][ct]);
-#pragma unroll
-                for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fh[r2], bh, tot0[rh + r2][ct]);
-                __builtin_amdgcn_sched_barrier(0);
+              for (int qp = 0; qp < 4; qp++) {
+                const int r = rh + r2;
+                const hg_h2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+                const hg_h2 k2048 = {(_Float16)kLowPieceScale, (_Float16)kLowPieceScale};
+                const hg_h2 F = __builtin_elementwise_min(
+                    __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero), one);
+                const hg_h2 xh = as_h2(ah[r][qp]), xl = as_h2(al[r][qp]);
+                const hg_h2 Ah = F * xh;                                         // rn(F xh)
+                const hg_h2 res = __builtin_elementwise_fma(F, xh, -Ah);         // ... its residual: exact
+                const hg_h2 Al = __builtin_elementwise_fma(res, k2048, F * xl);  // low piece, in the scaled units of xl
+                Fh[r2][qp] = h2_bits(Ah);
+                Fl[r2][qp] = h2_bits(Al);
               }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) {
+              const u32x4 bh = frag[fh + 2 * ct][L.lane];
+              u32x4 bs;
+#pragma unroll
+              for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(bh[i]);
+#pragma unroll
+              for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fl[r2], bs, tot0[rh + r2][ct]);
+              const u32x4 bl = frag[fh + 2 * ct + 1][L.lane];
+#pragma unroll
+              for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fh[r2], bl, tot0[rh + r2][ct]);
+#pragma unroll
+              for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fh[r2], bh, tot0[rh + r2][ct]);
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
-          if (g == 1 || !(cf & 2u)) convert_lin(H, c + 1);  // the chunk's last step: the next line's operands
         }
       };
 #pragma unroll 1
