@@ -483,6 +483,7 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     L.hinge = M <= kMaxHingeCached && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps;
     if (const char *e = getenv("EARHIP_HINGE")) L.hinge = atoi(e) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
+    if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
     if (L.hinge) L.pieces = false;
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to

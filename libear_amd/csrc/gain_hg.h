@@ -46,7 +46,14 @@ namespace earhip {
 
 constexpr int kHingeTile = 256;     // samples per workgroup tile (4 waves)
 constexpr int kHingeMinLen = 128;   // ramps that meet a kink are at least this long (T / 2)
-constexpr int kMaxHingeCached = 12288;  // (object, tile) pairs a list-building workgroup keeps between its two passes
+constexpr int kMaxHingeCached = 12288;
+// The factor of a kink is kept as 16 (s - r) / T, its gain operand as T D / 16: with F in [1 / 256, 1] the product F x of a quiet
+// object's input would be a subnormal f16 (x sits 2^-10 below the call's level at -100 dB; the packed-f16 products have no
+// wider intermediate), 16 F x stays normal — and its residual exactly representable — down to 17 binades below the level.
+// Quieter objects take the exact path (kHingeQuietBinades; the other split kernels: 20).  The price: inputs more than
+// 24 dB above the probed level (instead of 48) overflow the operands and send their tile through the exact redo.
+constexpr float kHingeFactorScale = 16.0f;
+constexpr int kHingeQuietBinades = 16;  // (object, tile) pairs a list-building workgroup keeps between its two passes
 
 struct LinEntry {
   uint32_t m;   // object | the rows' places (kLinRowShift) | kLinNull
@@ -58,8 +65,8 @@ struct LinEntry {
   float scale;  // 1.0f / (float)(end - start) of the centre segment; 0: constant
 };
 struct HingeEntry {
-  uint32_t fac_f, fac_b;  // forward / backward kink: f16 pair (slope of F: +-1/T, offset of F: -+(r - s0)/T), F(s) = clamp(s * slope +
-                          // offset, 0, 1), s counted from the tile start; 0: no such kink (F = 0)
+  uint32_t fac_f, fac_b;  // forward / backward kink: f16 pair (slope of F: +-16/T, offset of F: -+16 (r - s0)/T), F(s) = max(s * slope +
+                          // offset, 0), s counted from the tile start; 0: no such kink (F = 0)
   float s_before, s_after;  // 1 / length of the ramp before the centre segment (points kc - 2, kc - 1) and behind it (kc, kc + 1); 0: constant
 };
 static_assert(sizeof(LinEntry) == 16 && sizeof(HingeEntry) == 16, "list entries are loaded as one dwordx4");
@@ -165,7 +172,7 @@ __device__ __forceinline__ void hinge_entries(const PointStore &ps, const HingeR
     e.scale = R.r[2].scale;
     e.p0 = (float)(int32_t)(t0 - R.r[1].time) * R.r[2].scale;
   }
-  const float slope = 1.0f / kHingeTile;
+  const float slope = kHingeFactorScale / kHingeTile;
   h.fac_f = h.fac_b = 0u;
   if (fwd) h.fac_f = f16_bits(slope) | f16_bits(-(float)(int)(R.r[2].time - t0) * slope) << 16;
   if (bwd) h.fac_b = f16_bits(-slope) | f16_bits((float)(int)(R.r[1].time - t0) * slope) << 16;
@@ -210,7 +217,8 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       const HingeRecs R = hinge_load(ps, base, n, kc);
       bool fwd, bwd;
       int cls = hinge_classify(ps, R, t0, t1, fwd, bwd);
-      if (obj_level && level_is_quiet(obj_level[m], call_level)) cls = kHgExact;
+      if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - kHingeQuietBinades)
+        cls = kHgExact;
       hg_cache[(size_t)m * TPW + j] = kc << 3 | cls;
       atomicAdd(&cnt[j][cls], 1);
     }
@@ -591,8 +599,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           const float sc = __uint_as_float(ringe[c & (RING - 1)][w * NQ + q][3]);
           const u32x2 s2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][32 + w * NQ + q]) + 8);
           const float mc = sc * (R2 - R1), ma = __uint_as_float(s2[0]) * (R1 - R0), mb = __uint_as_float(s2[1]) * (R3 - R2);
-          dF[q] = (mb - mc) * (g_scale * (float)T);
-          dB[q] = (mc - ma) * (g_scale * (float)T);
+          dF[q] = (mb - mc) * (g_scale * ((float)T / kHingeFactorScale));
+          dB[q] = (mc - ma) * (g_scale * ((float)T / kHingeFactorScale));
         }
         const int f0 = (c & 1) * FSET + FL;
         if (cf & 1u) store_frag(L, dF, f0);
@@ -659,8 +667,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           const float sc = __uint_as_float(ringe[c & (RING - 1)][w * NQ + q][3]);
           const u32x2 s2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][32 + w * NQ + q]) + 8);
           const float mc = sc * (R2 - R1), ma = __uint_as_float(s2[0]) * (R1 - R0), mb = __uint_as_float(s2[1]) * (R3 - R2);
-          dF[i] = (mb - mc) * (g_scale * (float)T);
-          dB[i] = (mc - ma) * (g_scale * (float)T);
+          dF[i] = (mb - mc) * (g_scale * ((float)T / kHingeFactorScale));
+          dB[i] = (mc - ma) * (g_scale * ((float)T / kHingeFactorScale));
         }
         const int f0 = (c & 1) * FSET + FL;
         store_half(L, dF, f0, hf);
@@ -789,7 +797,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           }
           const int fh = f0 + FL + g * FH;
           // the lane's samples as f16 pairs (s, s), s counted from the start of the workgroup tile: the factor of a kink
-          // is F = clamp(s * slope + offset) in packed f16 arithmetic (exact: 8 bits)
+          // is F = max(s * slope + offset, 0) in packed f16 arithmetic (exact: 8 bits; at most 16: kHingeFactorScale)
           uint32_t SS[NRT];
 #pragma unroll
           for (int r = 0; r < NRT; r++) SS[r] = f16_bits((float)(wave_s0 + L.li * NRT + r)) * 0x10001u;
@@ -801,10 +809,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
 #pragma unroll
               for (int qp = 0; qp < 4; qp++) {
                 const int r = rh + r2;
-                const hg_h2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+                const hg_h2 zero = {(_Float16)0.0f, (_Float16)0.0f};
                 const hg_h2 k2048 = {(_Float16)kLowPieceScale, (_Float16)kLowPieceScale};
-                const hg_h2 F = __builtin_elementwise_min(
-                    __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero), one);
+                const hg_h2 F = __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero);
                 const hg_h2 xh = as_h2(ah[r][qp]), xl = as_h2(al[r][qp]);
                 const hg_h2 Ah = F * xh;                                         // rn(F xh)
                 const hg_h2 res = __builtin_elementwise_fma(F, xh, -Ah);         // ... its residual: exact

@@ -120,8 +120,9 @@ def test_full_chain_vs_oracle(m, layout, block, nblocks, kind):
     want = run_oracle(curves, x, n, block, dec, 255)
     got = run_hip(curves, x, n, block, dec, 255, [nblocks])
     assert scenes.rel_rms(got, want) <= 1e-6
-    if m == 1:  # config 1: the gain stage alone is libear's LinearInterpVector, bit for bit
-        direct = run_hip(curves, x, n, block, None, 0, [nblocks])
+    if m == 1:  # config 1: the gain stage alone is libear's LinearInterpVector — bit for bit in strict mode (the default
+        # kernel for fewer than 32 objects contracts the ramp into fused multiply-adds: within 1e-6, above)
+        direct = run_hip(curves, x, n, block, None, 0, [nblocks], strict=True)
         assert np.array_equal(direct, run_oracle(curves, x, n, block, None, 0))
     step = run_hip(curves, x, n, block, dec, 255, [1] * nblocks)
     assert scenes.rel_rms(step, want) <= 1e-6
@@ -676,9 +677,9 @@ def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
 
 
 def test_gain_kernel_choice_follows_the_curves():
-    """f16x2 kernel (3) for curves without points inside the tiles (block-aligned ramps, static gains),
-    f16x2 piece-list kernel (4) for curves that ignore the tile grid, VALU kernel (0) in strict mode; fewer than
-    32 objects: f32 slot kernel (1)."""
+    """f16x2 kernel (3) for curves without points inside the tiles (block-aligned ramps, static gains), hinge kernel (5)
+    for curves that ramp all the time off the tile grid, f16x2 piece-list kernel (4) for the other curves that ignore
+    it (ramp, then hold), VALU kernel (0) in strict mode; fewer than 32 objects: f32 slot kernel (1)."""
     from libear_amd import capi
     layout, block, nblocks = "0+5+0", 512, 4
     n = len(LAYOUTS[layout])
@@ -699,11 +700,11 @@ def test_gain_kernel_choice_follows_the_curves():
         return k
 
     forced = os.environ.get("EARHIP_MFMA")
-    if forced not in (None, "3"):
-        pytest.skip("kernel forced by EARHIP_MFMA")
+    if forced not in (None, "3") or os.environ.get("EARHIP_HINGE") is not None:
+        pytest.skip("kernel forced by EARHIP_MFMA / EARHIP_HINGE")
     dense = scenes.dense_curves(64, n, block, nblocks)
     assert kernel_for(64, dense) == 3
-    assert kernel_for(64, dense, t0=17) == 4          # same curves, call grid shifted off the points
+    assert kernel_for(64, dense, t0=17) == 5          # same curves, call grid shifted off the points: always ramping
     assert kernel_for(64, dense, strict=True) == 0
     assert kernel_for(16, scenes.dense_curves(16, n, block, nblocks)) == 1   # fewer than 32 objects
     assert kernel_for(64, scenes.adm_curves(64, n, total, seed=1)) == 4

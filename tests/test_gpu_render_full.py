@@ -70,6 +70,20 @@ def render_device(curves, x_dev, n_out, block, dec, delay, calls, t0=0):
     return out, plan
 
 
+def _with_hinge(value, fn):
+    """run fn with EARHIP_HINGE set to value (None: as the environment has it): the launch plan reads it at every call"""
+    if value is None:
+        return fn()
+    keep = os.environ.get("EARHIP_HINGE")
+    os.environ["EARHIP_HINGE"] = value
+    try:
+        return fn()
+    finally:
+        os.environ.pop("EARHIP_HINGE", None)
+        if keep is not None:
+            os.environ["EARHIP_HINGE"] = keep
+
+
 def check_windows(curves, x_dev, out_dev, n_out, block, dec, delay, windows, two_bus=True, tol=TOL):
     worst = 0.0
     for b0, nb in windows:
@@ -166,7 +180,7 @@ def test_levels_spread_over_100_db_every_channel_within_tolerance(what, m, nbloc
     print(f"levels over 100 dB ({what}, {m} objects): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
 
-@pytest.mark.parametrize("kind", ["dense", "adm"])
+@pytest.mark.parametrize("kind", ["dense", "adm", "moving"])
 def test_levels_scene_at_the_headline_size(kind):
     """bench.py --scene levels / levels-adm at 1024 objects: signal levels log-uniform over 0 .. -90 dB and 30 % of
     the objects silent for the first half of the call, on dense gains (every loudspeaker carries every object) —
@@ -176,14 +190,15 @@ def test_levels_scene_at_the_headline_size(kind):
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
     total = block * nblocks
-    curves = scenes.dense_curves(m, n, block, nblocks) if kind == "dense" else scenes.adm_curves(m, n, total)
+    curves = (scenes.dense_curves(m, n, block, nblocks) if kind == "dense" else scenes.adm_curves(m, n, total) if kind == "adm"
+              else scenes.adm_curves(m, n, total, period=240, ramp=240))  # (moving: always ramping off the grid, the hinge kernel)
     lv, late = scenes.object_levels(m)
     x = device_audio(m, total, 99, scale=lv)
     import torch
     x[torch.as_tensor(late, device="cuda"), :total // 2] = 0.0
     out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
     if os.environ.get("EARHIP_MFMA") in (None, "3"):
-        assert plan["kernel"] == (3 if kind == "dense" else 4), plan
+        assert plan["kernel"] == {"dense": 3, "adm": 4, "moving": 5}[kind], plan
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks // 2 - 1, 3), (nblocks - 2, 2)])
     print(f"levels scene ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
@@ -259,7 +274,7 @@ def test_native_decorrelators_equal_the_oracles():
         assert np.max(np.abs(got - want)) <= 2e-9
 
 
-@pytest.mark.parametrize("kind", ["aligned", "adm"])
+@pytest.mark.parametrize("kind", ["aligned", "adm", "adm-lists"])
 @pytest.mark.parametrize("gain_db", [-100.0, -120.0, -160.0])
 def test_objects_with_small_gains_alone_on_their_loudspeakers(kind, gain_db):
     """The same with the level difference in the GAINS: full-scale signals, but the objects on the second half of
@@ -278,7 +293,7 @@ def test_objects_with_small_gains_alone_on_their_loudspeakers(kind, gain_db):
     rng = np.random.default_rng(int(-gain_db))
     if kind == "aligned":
         times = [block * np.arange(nblocks + 1, dtype=np.int64)] * m
-    else:
+    else:  # adm, adm-lists
         times = [c[0] for c in scenes.adm_curves(m, n, total, seed=3)]
     small = np.arange(m) % 4 == 1
     curves = []
@@ -297,14 +312,16 @@ def test_objects_with_small_gains_alone_on_their_loudspeakers(kind, gain_db):
             f[j, idx] = g * np.sqrt(diff) * scale
         curves.append((times[i], d, f))
     x = device_audio(m, total, 12)
-    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
-    if os.environ.get("EARHIP_MFMA") in (None, "3"):
-        assert plan["kernel"] == (3 if kind == "aligned" else 4), plan
+    # (these curves take a new random target at every point of the ADM times: ramping all the time off the grid, the hinge
+    # kernel's case; adm-lists forces them onto the piece lists)
+    out, plan = _with_hinge("0" if kind == "adm-lists" else None, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
+    if os.environ.get("EARHIP_MFMA") in (None, "3") and os.environ.get("EARHIP_HINGE") is None:
+        assert plan["kernel"] == {"aligned": 3, "adm": 5, "adm-lists": 4}[kind], plan
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (7, 2), (nblocks - 2, 2)])
     print(f"small gains at {gain_db} dB ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
 
-@pytest.mark.parametrize("kind", ["aligned", "adm"])
+@pytest.mark.parametrize("kind", ["aligned", "adm", "adm-lists"])
 @pytest.mark.parametrize("quiet_db", [-70.0, -100.0, -130.0])
 def test_quiet_objects_alone_on_their_loudspeakers(kind, quiet_db):
     """Full-scale objects on one half of the loudspeakers, objects `quiet_db` below them on the other half,
@@ -343,8 +360,10 @@ def test_quiet_objects_alone_on_their_loudspeakers(kind, quiet_db):
             f[j, idx] = g * np.sqrt(diff)
         curves.append((times[i], d, f))
     x = device_audio(m, total, 11, scale=level)
-    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
-    if os.environ.get("EARHIP_MFMA") in (None, "3"):
-        assert plan["kernel"] == (3 if kind == "aligned" else 4), plan
+    # (these curves take a new random target at every point of the ADM times: ramping all the time off the grid, the hinge
+    # kernel's case; adm-lists forces them onto the piece lists)
+    out, plan = _with_hinge("0" if kind == "adm-lists" else None, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
+    if os.environ.get("EARHIP_MFMA") in (None, "3") and os.environ.get("EARHIP_HINGE") is None:
+        assert plan["kernel"] == {"aligned": 3, "adm": 5, "adm-lists": 4}[kind], plan
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (7, 2), (nblocks - 2, 2)])
     print(f"quiet objects at {quiet_db} dB ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
