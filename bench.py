@@ -299,7 +299,8 @@ def main():
                          "(steps measured right after start-up are ~9 %% slower)")
     ap.add_argument("--cpu-blocks", type=int, default=160, help="blocks of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--strict", action="store_true", help="bit-exact gain arithmetic (slower)")
-    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed", "panned", "panned-adm", "levels", "levels-adm"),
+    ap.add_argument("--scene", choices=("dense", "adm", "static", "moving", "mixed", "panned", "panned-adm", "levels", "levels-adm",
+                                        "bursty", "bursty-adm", "bursty-moving"),
                     default="dense",
                     help="dense: block-aligned full-length ramps (headline, SURVEY 8d); adm: metadata blocks of "
                          "960 samples at a random phase per object, 240-sample ramps then constant (not block-aligned); "
@@ -307,7 +308,10 @@ def main():
                          "I: real 3-sparse VBAP gains, sqrt(1-d)/sqrt(d) split, zero LFE columns), a new position every "
                          "block / every 960 samples at a per-object phase; levels / levels-adm: the dense / adm scene with the "
                          "objects' SIGNAL levels log-uniform over 0 .. -90 dB and 30 %% of the objects digitally silent for the "
-                         "first half of the call (real mixes: pauses, tails, entries)")
+                         "first half of the call (real mixes: pauses, tails, entries); bursty / bursty-adm / bursty-moving: the "
+                         "dense / adm / moving scene with NON-STATIONARY signals (per object and block: holds, fades of 3 dB per "
+                         "block to -90 dB, digital silence, gated bursts, single blocks 40 dB above their surroundings), eight "
+                         "objects alone on a loudspeaker each and 80 dB down for most of the call")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE config 4): --objects in total, split over the GPUs; "
                          "weak: --objects per GPU")
@@ -419,9 +423,9 @@ def main():
             self.M_hoa = hoa if (rank == 0 or scaling == "weak") else 0  # the bed goes to one rank
             self.M = self.M_obj + self.M_hoa
             m, seed = max(self.M_obj, 1), seed_base + rank
-            if args.scene in ("adm", "levels-adm"):
+            if args.scene in ("adm", "levels-adm", "bursty-adm"):
                 curves = scenes.adm_curves(m, N, total, seed=11 + seed)
-            elif args.scene == "moving":  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
+            elif args.scene in ("moving", "bursty-moving"):  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
                 curves = scenes.adm_curves(m, N, total, period=240, ramp=240, seed=12 + seed)
             elif args.scene == "static":  # one gain vector per object and bus, never changing
                 curves = scenes.constant_curves(m, N, seed=8 + seed)
@@ -448,6 +452,11 @@ def main():
             else:
                 curves = scenes.dense_curves(m, N, B, T, seed=7 + seed)
             curves = curves[:self.M_obj]
+            self.solo = 0
+            if args.scene.startswith("bursty") and self.M_obj >= 64:
+                self.solo = 8
+                spk = [c for c in range(N) if not names[c].startswith("LFE")]
+                curves = scenes.solo_curves(curves, N, spk[-self.solo:])
             if self.M_hoa:  # constant decode matrix: one gain point on the direct bus, nothing on the diffuse bus
                 decode = np.random.default_rng(55).uniform(-0.5, 0.5, (self.M_hoa, N)).astype(np.float32)
                 curves = [(np.zeros(1, np.int64), decode[c:c + 1], np.zeros((1, N), np.float32))
@@ -459,6 +468,9 @@ def main():
             rows = max(self.M, 1)
             self.x_full = torch.rand((rows, self.in_stride), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
             self.x = self.x_full[:, :total]  # planar rows, in_stride floats apart
+            if args.scene.startswith("bursty"):
+                blv = scenes.bursty_levels(rows, T, self.solo, seed=91 + seed)
+                self.x_full[:, :total].unflatten(1, (T, B)).mul_(torch.as_tensor(blv, device=dev)[:, :, None])
             if args.scene in ("levels", "levels-adm"):
                 lv, late = scenes.object_levels(rows, seed=77 + seed)
                 self.x_full *= torch.as_tensor(lv, device=dev, dtype=torch.float32)[:, None]
@@ -683,6 +695,9 @@ def main():
                       "mixed": "the dense scene with 8 of every 1024 objects on ADM-like metadata off the block grid",
                       "levels": "the dense scene; signal levels log-uniform 0 .. -90 dB, 30 % of the objects silent for the first half",
                       "levels-adm": "the adm scene; signal levels log-uniform 0 .. -90 dB, 30 % of the objects silent for the first half",
+                      "bursty": "the dense scene; non-stationary signals (fades to -90 dB, silence, gated bursts, +40 dB blocks), 8 objects alone on a loudspeaker and 80 dB down most of the call",
+                      "bursty-adm": "the adm scene; non-stationary signals as in `bursty`",
+                      "bursty-moving": "the moving scene; non-stationary signals as in `bursty`",
                       "panned": "moving point sources, a new position every block: gains from the device panner "
                                 "(3-sparse VBAP gains, diffuse split, zero LFE columns)",
                       "panned-adm": "moving point sources, a new position every 960 samples at a per-object phase: "
@@ -860,8 +875,15 @@ def main():
                                 "max_channel_gpu_rel_rms_vs_float64": float(f"{scenes.rel_rms_per_channel(got, truth):.3e}"),
                                 "max_abs": float(f"{np.max(np.abs(got - want)):.3e}"), "blocks": nb,
                                 "tolerance": 1e-6}
-            # per channel, against the CPU path: a run whose timed output is off is not a measurement
-            result["parity"]["pass"] = bool(result["parity"]["max_channel_rel_rms_vs_cpu"] <= 1e-6)
+            # per channel, against the CPU path: a run whose timed output is off is not a measurement.  And the claim that most
+            # of that distance is the CPU path's own sequential float32 sum is checked, not narrated: the GPU output must be
+            # no further from a float64 render than the CPU path is (headline kernel; the others within 1.25 x: their chains of
+            # MFMAs on one accumulator are longer)
+            par = result["parity"]
+            par["gpu_closer_to_float64_than_cpu"] = bool(par["gpu_rel_rms_vs_float64"] <= par["cpu_rel_rms_vs_float64"])
+            f64_ok = par["gpu_rel_rms_vs_float64"] <= (1.0 if parity_plan["kernel"] == 3 else 1.25) * par["cpu_rel_rms_vs_float64"] \
+                or par["gpu_rel_rms_vs_float64"] <= 2e-7 or args.strict or M < 64
+            par["pass"] = bool(par["max_channel_rel_rms_vs_cpu"] <= 1e-6 and f64_ok)
 
         # ---- CPU baseline: the scalar restatement on this host, bounded sample -----------------
         if world == 1 and args.cpu_blocks > 0 and not args.stream_only:

@@ -54,9 +54,9 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // the segments itself and the descriptor pass is skipped; with long curves the 16-lanes-per-
   // object search of k_seg_prep is the faster one (measured both ways)
   const bool fused_prep = slots && (size_t)ps.zero_row <= (size_t)8 * M;
-  // f16x2 kernel: K0 also probes the level of the call's inputs (one float4 per object at the start
-  // and in the middle of the call; rows must allow 16-byte loads).  The two level words alternate between calls: this call's
-  // K0 raises word `li` (zero since the last f16x2 call cleared it), its K1 reads it and clears the other.
+  // split-operand kernels: K0 starts with the level probe of the call's inputs (k_level_probe: 64 instants per object; rows
+  // must allow 16-byte loads).  The two level words alternate between calls: this call's probe raises word `li` (zero since
+  // the last such call cleared it), its K1 reads it and clears the other.
   LevelProbe probe;
   unsigned *level_cur = nullptr, *level_next = nullptr;
   unsigned *wide_cur = nullptr, *wide_next = nullptr;  // f16x2 kernel: "run this call in wide mode" (gain_h2.h)
@@ -70,23 +70,17 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if ((size_t)ml.ntiles * ml.gsplit >= 2 * (size_t)ctx->num_cus) wide_cur = ctx->level.p + 2 + ctx->level_idx;
     wide_next = ctx->level.p + 2 + (ctx->level_idx ^ 1);
     ctx->level_idx ^= 1;
-    probe.in = in_dev;
-    probe.in_stride = in_stride;
-    probe.nsamples = nsamples;
-    probe.every = std::max(1, (ml.ntiles + 1) / 2);  // two instants per object at most: every probe is a page walk
-                                                     // (2.5 ns each in K0; eight instants cost 20 us)
-    probe.level = level_cur;
-    // per-object levels: raised by K0; k_mark_quiet flags the quiet objects' descriptors and clears them
-    // again (all zero between calls)
-    // (two buffers: k_seg_prep's form of the probe raises its words with atomicMax and k_mark_quiet clears them again —
-    // all zero between calls —, the list builders' probe stores every object's word plainly.  Both grow with the
-    // largest M this context has seen: contexts are shared by gain stages of different sizes.)
-    DevBuf<unsigned> &lv = (ml.pieces || ml.hinge ? ctx->obj_level_lists : ctx->obj_level);
-    if (lv.n < (size_t)M) {
+    // per-object levels (k_level_probe, gain_kernels.h): grown with the largest M this context has seen — contexts are
+    // shared by gain stages of different sizes
+    if (ctx->obj_level_cap < M) {
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      lv.alloc_zero((size_t)M + M / 2 + 64, ctx->stream);
+      ctx->obj_level_cap = M + M / 2 + 64;
+      ctx->obj_level.alloc_zero(2 * (size_t)ctx->obj_level_cap, ctx->stream);
     }
-    probe.obj_level = lv.p;
+    probe.obj_level = ctx->obj_level.p;
+    probe.level = level_cur;
+    hipLaunchKernelGGL(k_level_probe, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M, level_cur,
+                       ctx->obj_level.p, ctx->obj_level_cap);
   }
   // (piece lists: K0 also counts every object's ramps per tile, into the list builder's count words)
   PieceLists pl;
@@ -113,12 +107,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (M > kMaxHingeCached || ml.tile() != kHingeTile) fail_internal("hinge lists: object count or tile out of range");
     // (the kernel addresses input rows and gain rows with 32-bit byte offsets; plan_mix only picks it within these limits)
     if (!hinge_addressable(M, in_stride, nsamples, ps.zero_row + 2, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
-    unsigned *obj_lv = nullptr;
-    if (probe.obj_level) {
-      obj_lv = probe.obj_level;
-      hipLaunchKernelGGL(k_level_probe, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M,
-                         ml.ntiles, ml.tile(), probe.every, level_cur, obj_lv);
-    }
+    unsigned *obj_lv = probe.obj_level;
     int tpw = 1;
     while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
@@ -134,12 +123,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const bool one_pass = ml.pieces || ml.hinge;
   if (ml.pieces) {
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
-    unsigned *obj_lv = nullptr;
-    if (probe.obj_level) {
-      obj_lv = probe.obj_level;  // (ctx->obj_level_lists: its own buffer, see above)
-      hipLaunchKernelGGL(k_level_probe, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M,
-                         ml.ntiles, ml.tile(), probe.every, level_cur, obj_lv);
-    }
+    unsigned *obj_lv = probe.obj_level;
     // tiles per workgroup: as many as leave one workgroup per CU (eight tiles = eight lanes per object reading
     // neighbouring points beat four tiles and two workgroups per CU: 0.084 vs 0.096 ms on the ADM scene)
     int tpw = 1;
@@ -175,7 +159,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
   if (probe.obj_level && !one_pass)
     hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
-                       level_cur, slow_cur, ml.split ? wide_cur : nullptr);
+                       ctx->obj_level_cap, level_cur, slow_cur, ml.split ? wide_cur : nullptr);
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
   P.sl = sl;

@@ -135,8 +135,9 @@ struct earhip_ctx {
   earhip::DevBuf<unsigned> tile_slow;
   size_t tile_slow_cap = 0;
   int tile_slow_idx = 0;
-  earhip::DevBuf<unsigned> obj_level;  // [objects] per-object input levels of the current call (float bits); all zero between calls
-  earhip::DevBuf<unsigned> obj_level_lists;  // [objects] the same for the list-building kernels (plain stores: no state between calls)
+  earhip::DevBuf<unsigned> obj_level;  // [2][obj_level_cap] per-object input levels of the current call (float bits): the largest and the
+                                       // smallest non-zero magnitude the level probe saw (k_level_probe: plain stores, no state between calls)
+  int obj_level_cap = 0;
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
   bool tiles_per_wg_forced = false;  // (EARHIP_TPW: taken as given)

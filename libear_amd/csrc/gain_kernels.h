@@ -178,6 +178,42 @@ constexpr int kPlainBinades = 8;
 __host__ __device__ __forceinline__ bool level_is_quiet(unsigned obj_level, unsigned call_level) {
   return obj_level != 0u && call_level != 0u && (int)(obj_level >> 23) < (int)(call_level >> 23) - kQuietBinades;
 }
+// The level probe of the split-operand kernels, a small launch ahead of everything that needs it: a WAVE per object
+// looks at kProbeInstants instants spread over the whole call (one float4 each, jittered per object and instant; rounds 2
+// and 3 looked at two instants per object from inside the list builders — a decision for 11 s of audio from 8 samples).
+// Left behind: obj_level[m] = the object's largest magnitude probed (float bits; plain store: every object is written by
+// every call), obj_level[cap + m] = the smallest NON-ZERO one among its instants (how far the object falls below its own
+// peaks: fades, tails, pauses in noise; digital silence needs no precision), and *level raised to the call's maximum (zero
+// before the launch: the words alternate between calls, gain_h2.h).  Costs ~5 us whatever the length of the call.
+constexpr int kProbeInstants = 64;
+static __global__ void __launch_bounds__(256)
+k_level_probe(const float *in, size_t in_stride, int nsamples, int M, unsigned *level, unsigned *obj_level, int cap) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;  // (whole waves)
+  const int nvec = nsamples >> 2, ninst = min(kProbeInstants, nvec);
+  unsigned v = 0u;
+  if (lane < ninst) {
+    // instant `lane` of ninst: somewhere in its own stretch of the call, at a place that differs from object to object
+    const int lo = (int)(((int64_t)lane * nvec) / ninst), hi = (int)(((int64_t)(lane + 1) * nvec) / ninst);
+    const unsigned h = ((unsigned)m * 2654435761u) ^ ((unsigned)lane * 40503u);
+    const int at = lo + (int)((h >> 8) % (unsigned)max(hi - lo, 1));
+    const float4 px = *reinterpret_cast<const float4 *>(in + (size_t)m * in_stride + 4 * (size_t)at);
+    v = max(max(__float_as_uint(px.x) & 0x7fffffffu, __float_as_uint(px.y) & 0x7fffffffu),
+            max(__float_as_uint(px.z) & 0x7fffffffu, __float_as_uint(px.w) & 0x7fffffffu));
+  }
+  unsigned hi_v = v, lo_v = v ? v : 0xffffffffu;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    hi_v = max(hi_v, (unsigned)__shfl_xor((int)hi_v, d));
+    lo_v = min(lo_v, (unsigned)__shfl_xor((int)lo_v, d));
+  }
+  if (lane == 0) {
+    obj_level[m] = hi_v;
+    obj_level[cap + m] = lo_v == 0xffffffffu ? 0u : lo_v;
+    if (hi_v != 0 && hi_v > __atomic_load_n(level, __ATOMIC_RELAXED)) atomicMax(level, hi_v);
+  }
+}
+
 // kPrepRun consecutive tiles per thread: 2 for up to 2047 tiles (headline: K0 0.020 -> 0.018 ms), 4 beyond
 // (ADM scene, 4096 tiles of 128 samples: K0 + K0s 0.112 -> 0.092 ms)
 template <int kPrepRun>
@@ -254,14 +290,14 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
 // k_seg_prep's last workgroup instead needs a device-scope fence per workgroup — an L2 write-back on this
 // chip — and made K0 ten times slower.)
 static __global__ void __launch_bounds__(256)
-k_mark_quiet(SegDesc *desc, int M, int ntiles, unsigned *obj_level, const unsigned *level_cur, unsigned *tile_slow,
+k_mark_quiet(SegDesc *desc, int M, int ntiles, const unsigned *obj_level, int cap, const unsigned *level_cur, unsigned *tile_slow,
              unsigned *wide) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
-  const unsigned lv = obj_level[m];
-  obj_level[m] = 0u;
-  // (wide: zero before the launch; every writer writes 1)
-  if (wide && lv != 0u && *level_cur != 0u && (int)(lv >> 23) < (int)(*level_cur >> 23) - kPlainBinades) *wide = 1u;
+  const unsigned lv = obj_level[m], lo = obj_level[cap + m];
+  // (wide: zero before the launch; every writer writes 1.  The decision looks at how far any object FALLS, not only at
+  // how loud it gets: an object that is loud at some instants and 60 dB down at others needs the scaled low pieces there)
+  if (wide && lo != 0u && *level_cur != 0u && (int)(lo >> 23) < (int)(*level_cur >> 23) - kPlainBinades) *wide = 1u;
   if (!level_is_quiet(lv, *level_cur)) return;
   for (int t = 0; t < ntiles; t++) {
     desc[(size_t)t * M + m].info |= kSegQuiet;

@@ -204,38 +204,6 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
   return nd > kPieceMaxPerObject ? -1 : nd;
 }
 
-// The level of the call's inputs for the split-operand kernels, as its own small launch ahead of the list builder
-// (which needs the CALL's level to tell which objects are quiet): a thread per object looks at one float4 at the
-// start and one in the middle of the call (every probe is a page walk: two instants), leaves the object's largest
-// magnitude in obj_level[m] (float bits; plain store: every object is written by every call) and raises *level
-// (zero before the launch: the words alternate between calls, gain_h2.h).
-static __global__ void __launch_bounds__(256)
-k_level_probe(const float *in, size_t in_stride, int nsamples, int M, int ntiles, int tile_samples, int every, unsigned *level,
-              unsigned *obj_level) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  unsigned v = 0u;
-  if (m < M) {
-    float4 px[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int tile = i * every;
-      const int s = tile * tile_samples + 4 * ((m + 5 * tile) & 15);
-      px[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if ((i == 0 || every < ntiles) && tile < ntiles && s + 3 < nsamples)
-        px[i] = *reinterpret_cast<const float4 *>(in + (size_t)m * in_stride + s);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-      v = max(v, max(max(__float_as_uint(px[i].x) & 0x7fffffffu, __float_as_uint(px[i].y) & 0x7fffffffu),
-                     max(__float_as_uint(px[i].z) & 0x7fffffffu, __float_as_uint(px[i].w) & 0x7fffffffu)));
-    obj_level[m] = v;
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
-  if ((threadIdx.x & 63) == 0 && v != 0)
-    if (v > __atomic_load_n(level, __ATOMIC_RELAXED)) atomicMax(level, v);
-}
-
 constexpr int kBuildThreads = 1024;
 // grid = ceil(ntiles / TPW) workgroups of 1024 threads; a thread = one (object, tile) pair of a batch of 1024 / TPW
 // objects, the TILE index fastest: the TPW lanes of an object read neighbouring points of its curve (the same

@@ -241,3 +241,74 @@ def moving_sources(n_obj, total, period=960, seed=31, phase=None, ramp=None):
         idx[1::2] = np.arange(len(starts)) + 1  # end of the ramp: the new target
         az.append(a[idx]); el.append(e[idx]); df.append(d[idx]); times.append(t)
     return az, el, df, times
+
+
+def bursty_levels(n_obj, n_blocks, solo=8, seed=91):
+    """Per-object, per-block signal LEVELS (linear factors, [n_obj][n_blocks]) of non-stationary audio: holds at
+    0 .. -30 dB, fades of 3 dB per block down to -90 dB, exact silence, gated bursts (every other block digitally
+    silent), single blocks 40 dB ABOVE the level around them.  The first `solo` objects follow a fixed programme that is
+    loud at the start of a call and then spends most of it 80 dB down: loud for 16 blocks, -80 dB up to the middle,
+    one block at +40 dB, 24 blocks of exact silence, a fade from 0 dB to -90 dB, -90 dB to the end (with solo_curves()
+    each of them has a loudspeaker to itself: whatever a level decision gets wrong shows there, in the quiet stretches)."""
+    rng = np.random.default_rng(seed)
+    lv = np.zeros((n_obj, n_blocks), np.float32)
+    db = lambda v: np.float32(10.0 ** (v / 20.0))
+    for m in range(n_obj):
+        if m < solo:
+            mid = n_blocks // 2
+            prog = np.full(n_blocks, db(-80.0), np.float32)
+            prog[:16] = 1.0
+            prog[mid] = db(40.0)
+            prog[mid + 1:mid + 25] = 0.0
+            fade = np.arange(max(n_blocks - (mid + 25), 0), dtype=np.float64)
+            prog[mid + 25:] = np.maximum(10.0 ** (-3.0 * fade / 20.0), 10.0 ** (-90.0 / 20.0)).astype(np.float32)
+            lv[m] = prog
+            continue
+        b = 0
+        level = -rng.uniform(0.0, 30.0)
+        while b < n_blocks:
+            kind = rng.integers(0, 5)
+            if kind == 0:  # hold
+                n = int(rng.integers(8, 40))
+                lv[m, b:b + n] = db(level)
+            elif kind == 1:  # fade to -90 dB, then silence
+                n = int(np.ceil((90.0 + level) / 3.0))
+                steps = level - 3.0 * np.arange(n)
+                k = min(n, n_blocks - b)
+                lv[m, b:b + k] = (10.0 ** (steps[:k] / 20.0)).astype(np.float32)
+                n += int(rng.integers(4, 20))  # (the rest stays exactly zero)
+                level = -rng.uniform(0.0, 30.0)
+            elif kind == 2:  # gated bursts
+                n = 2 * int(rng.integers(5, 12))
+                seg = lv[m, b:b + n]
+                seg[0::2] = db(level)
+            elif kind == 3:  # silence
+                n = int(rng.integers(4, 30))
+            else:  # one block 40 dB above, then back
+                n = int(rng.integers(4, 12))
+                lv[m, b:b + n] = db(level)
+                lv[m, b] = db(level + 40.0)
+            b += n
+    return lv
+
+
+def solo_curves(curves, n_out, solo_speakers, seed=92):
+    """give the first len(solo_speakers) objects of a scene a loudspeaker each to themselves: their gains live on that
+    column only (both buses), everybody else's gains on those columns are zero; the point times stay the scene's"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for m, (t, d, f) in enumerate(curves):
+        d, f = d.copy(), (None if f is None else f.copy())
+        if m < len(solo_speakers):
+            g = rng.uniform(0.5, 1.0, (len(t), 2)).astype(np.float32)
+            d[:] = 0.0
+            d[:, solo_speakers[m]] = g[:, 0]
+            if f is not None:
+                f[:] = 0.0
+                f[:, solo_speakers[m]] = g[:, 1]
+        else:
+            d[:, solo_speakers] = 0.0
+            if f is not None:
+                f[:, solo_speakers] = 0.0
+        out.append((t, d, f))
+    return out
