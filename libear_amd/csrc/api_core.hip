@@ -60,6 +60,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   LevelProbe probe;
   unsigned *level_cur = nullptr, *level_next = nullptr;
   unsigned *wide_cur = nullptr, *wide_next = nullptr;  // f16x2 kernel: "run this call in wide mode" (gain_h2.h)
+  unsigned *gate = nullptr;                            // hinge kernel: "this call is the piece lists'" (k_hinge_gate)
   if ((ml.split || ml.pieces || ml.hinge) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
     if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);  // [0..1] level words, [2..3] wide-mode words
     level_cur = ctx->level.p + ctx->level_idx;
@@ -69,6 +70,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // (every call clears the word the NEXT call decides with, whether it decides itself or not)
     if ((size_t)ml.ntiles * ml.gsplit >= 2 * (size_t)ctx->num_cus) wide_cur = ctx->level.p + 2 + ctx->level_idx;
     wide_next = ctx->level.p + 2 + (ctx->level_idx ^ 1);
+    gate = ctx->level.p + 2 + ctx->level_idx;  // (the same word: bit 0 the grid kernel's wide mode, bit 1 "not the hinge kernel")
     ctx->level_idx ^= 1;
     // per-object levels (k_level_probe, gain_kernels.h): grown with the largest M this context has seen — contexts are
     // shared by gain stages of different sizes
@@ -79,8 +81,13 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     }
     probe.obj_level = ctx->obj_level.p;
     probe.level = level_cur;
-    hipLaunchKernelGGL(k_level_probe, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, in_dev, in_stride, nsamples, M, level_cur,
-                       ctx->obj_level.p, ctx->obj_level_cap);
+    static const int probe_runs = [] {  // tuning knob: runs of consecutive samples per object (1 .. 64)
+      const char *e = getenv("EARHIP_PROBE_RUNS");
+      const int v = e ? atoi(e) : 0;
+      return v >= 1 && v <= 64 && (v & (v - 1)) == 0 ? v : 16;
+    }();
+    hipLaunchKernelGGL(k_level_probe, dim3((M + kProbeObjects - 1) / kProbeObjects), dim3(64 * kProbeObjects), 0, ctx->stream, in_dev,
+                       in_stride, nsamples, M, level_cur, ctx->obj_level.p, ctx->obj_level_cap, probe_runs);
   }
   // (piece lists: K0 also counts every object's ramps per tile, into the list builder's count words)
   PieceLists pl;
@@ -108,6 +115,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // (the kernel addresses input rows and gain rows with 32-bit byte offsets; plan_mix only picks it within these limits)
     if (!hinge_addressable(M, in_stride, nsamples, ps.zero_row + 2, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
     unsigned *obj_lv = probe.obj_level;
+    // with a probe: does the hinge kernel's span of levels cover this call?  (decided on the device: k_hinge_gate)
+    if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate);
     int tpw = 1;
     while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
@@ -115,13 +124,13 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #define EARHIP_HBUILD_CASE(T_)                                                                                        \
   if (tpw == T_)                                                                                                      \
     hipLaunchKernelGGL(k_hinge_build<T_>, bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                       t_call + nsamples, hl, obj_lv, level_cur);
+                       t_call + nsamples, hl, obj_lv, level_cur, gate);
     EARHIP_HBUILD_CASE(1) EARHIP_HBUILD_CASE(2) EARHIP_HBUILD_CASE(4) EARHIP_HBUILD_CASE(8)
 #undef EARHIP_HBUILD_CASE
   }
   // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch
   const bool one_pass = ml.pieces || ml.hinge;
-  if (ml.pieces) {
+  if (ml.pieces || (ml.hinge && gate)) {  // (behind the hinge kernel's builder: the lists of the call it may not take)
     if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     unsigned *obj_lv = probe.obj_level;
     // tiles per workgroup: as many as leave one workgroup per CU (eight tiles = eight lanes per object reading
@@ -136,7 +145,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #define EARHIP_BUILD_CASE(T_)                                                                                          \
   if (tpw == T_)                                                                                                       \
     hipLaunchKernelGGL(k_piece_build<T_>, bgrid, dim3(kBuildThreads), 0, ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, \
-                       t_call + nsamples, pl, obj_lv, level_cur);
+                       t_call + nsamples, pl, obj_lv, level_cur, ml.hinge ? gate : nullptr);
     EARHIP_BUILD_CASE(1) EARHIP_BUILD_CASE(2) EARHIP_BUILD_CASE(4) EARHIP_BUILD_CASE(8)
 #undef EARHIP_BUILD_CASE
   }
@@ -194,11 +203,12 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const float *gs = cs.column_scales();
 #define EARHIP_HG_CASE(NCT_)                                                                                          \
   if (cp.nct == NCT_)                                                                                                 \
-    hipLaunchKernelGGL((k_gain_mix_hg<NCT_>), bgrid, dim3(256), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next);
+    hipLaunchKernelGGL((k_gain_mix_hg<NCT_>), bgrid, dim3(256), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next, gate);
     EARHIP_HG_CASE(1) EARHIP_HG_CASE(2) EARHIP_HG_CASE(3)
 #undef EARHIP_HG_CASE
     launched = true;
-  } else if (ml.pieces) {
+  }
+  if (ml.pieces || (ml.hinge && gate)) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
@@ -206,16 +216,17 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (cp.nct == NCT_ && ml.paired == PR_) {                                                                         \
     if (ml.pw == 4)                                                                                                 \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4, PR_>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next, wide_next);                                                                     \
+                         level_next, wide_next, ml.hinge ? gate : nullptr);                                          \
     else                                                                                                            \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8, PR_>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next, wide_next);                                                                     \
+                         level_next, wide_next, ml.hinge ? gate : nullptr);                                          \
   }
     EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
     EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)
 #undef EARHIP_P2_CASE
     launched = true;
-  } else if (ml.split) {
+  }
+  if (ml.split) {
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();

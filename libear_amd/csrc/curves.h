@@ -484,7 +484,7 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     if (const char *e = getenv("EARHIP_HINGE")) L.hinge = atoi(e) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
-    if (L.hinge) L.pieces = false;
+    if (L.hinge) L.pieces = false, L.pw = 4;  // (the piece lists stand by on the same 256-sample tiles: k_hinge_gate)
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
   // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments

@@ -108,7 +108,7 @@ template <int NCT, int NW, bool WIDE>
 __global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 4 : (NW == 4 ? 2 : 1))
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next, const unsigned *wide_cur, unsigned *wide_next) {
-  if (wide_cur && (*wide_cur != 0u) != WIDE) return;  // the other form of this kernel works on this call
+  if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
   constexpr int NFRAG = 2 * NCT * 3;  // {B0,B1} x column tiles x {h, l, h 2^-11 (wide mode)}

@@ -53,7 +53,7 @@ constexpr int kMaxHingeCached = 12288;
 // Quieter objects take the exact path (kHingeQuietBinades; the other split kernels: 20).  The price: inputs more than
 // 24 dB above the probed level (instead of 48) overflow the operands and send their tile through the exact redo.
 constexpr float kHingeFactorScale = 16.0f;
-constexpr int kHingeQuietBinades = 16;  // (object, tile) pairs a list-building workgroup keeps between its two passes
+constexpr int kHingeQuietBinades = kHingeSpreadBinades;  // (gain_kernels.h: the same span decides which calls this kernel takes at all)  // (object, tile) pairs a list-building workgroup keeps between its two passes
 
 struct LinEntry {
   uint32_t m;   // object | the rows' places (kLinRowShift) | kLinNull
@@ -190,7 +190,8 @@ constexpr int kHingeBuildThreads = 1024;
 template <int TPW>
 __global__ void __launch_bounds__(kHingeBuildThreads)
 k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
-              const unsigned *level_cur) {
+              const unsigned *level_cur, const unsigned *gate) {
+  if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate)
   constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
   constexpr int NWV = kHingeBuildThreads / 64;
   constexpr int T = kHingeTile;
@@ -343,7 +344,8 @@ __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast
 template <int NCT>
 __global__ void __launch_bounds__(256, 2)
 k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next, unsigned *wide_next) {
+              unsigned *level_next, unsigned *wide_next, const unsigned *gate) {
+  if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate); they clear the words of the next
   constexpr int NW = 4, NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = kHingeTile;
   constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
   constexpr int RING = 4;

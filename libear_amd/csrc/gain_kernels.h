@@ -179,24 +179,28 @@ __host__ __device__ __forceinline__ bool level_is_quiet(unsigned obj_level, unsi
   return obj_level != 0u && call_level != 0u && (int)(obj_level >> 23) < (int)(call_level >> 23) - kQuietBinades;
 }
 // The level probe of the split-operand kernels, a small launch ahead of everything that needs it: a WAVE per object
-// looks at kProbeInstants instants spread over the whole call (one float4 each, jittered per object and instant; rounds 2
+// looks at kProbeInstants float4s spread over the whole call (16 jittered runs of 16 consecutive samples; rounds 2
 // and 3 looked at two instants per object from inside the list builders — a decision for 11 s of audio from 8 samples).
 // Left behind: obj_level[m] = the object's largest magnitude probed (float bits; plain store: every object is written by
 // every call), obj_level[cap + m] = the smallest NON-ZERO one among its instants (how far the object falls below its own
 // peaks: fades, tails, pauses in noise; digital silence needs no precision), and *level raised to the call's maximum (zero
 // before the launch: the words alternate between calls, gain_h2.h).  Costs ~5 us whatever the length of the call.
-constexpr int kProbeInstants = 64;
-static __global__ void __launch_bounds__(256)
-k_level_probe(const float *in, size_t in_stride, int nsamples, int M, unsigned *level, unsigned *obj_level, int cap) {
-  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;  // (whole waves)
+constexpr int kProbeInstants = 64, kProbeObjects = 16;  // float4s per object; objects (waves) per workgroup
+static __global__ void __launch_bounds__(64 * kProbeObjects)
+k_level_probe(const float *in, size_t in_stride, int nsamples, int M, unsigned *level, unsigned *obj_level, int cap, int nruns) {
+  __shared__ unsigned wmax[kProbeObjects];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = blockIdx.x * kProbeObjects + wv;
   const int nvec = nsamples >> 2, ninst = min(kProbeInstants, nvec);
   unsigned v = 0u;
-  if (lane < ninst) {
-    // instant `lane` of ninst: somewhere in its own stretch of the call, at a place that differs from object to object
-    const int lo = (int)(((int64_t)lane * nvec) / ninst), hi = (int)(((int64_t)(lane + 1) * nvec) / ninst);
-    const unsigned h = ((unsigned)m * 2654435761u) ^ ((unsigned)lane * 40503u);
-    const int at = lo + (int)((h >> 8) % (unsigned)max(hi - lo, 1));
+  if (m < M && lane < ninst) {
+    // The instants come in nruns runs of consecutive float4s (a power of two up to 64; 16: runs of 16 samples).  Run g:
+    // somewhere in its own stretch of the call, at a place that differs from object to object.
+    const unsigned sh = (unsigned)__builtin_ctz((unsigned)nruns), per = 64u >> sh;  // float4s per run
+    const unsigned nrun = max((unsigned)ninst / per, 1u), g = min((unsigned)lane / per, nrun - 1u), sub = (unsigned)lane & (per - 1u);
+    const unsigned stretch = (unsigned)nvec / nrun;  // float4s of the call per run
+    const unsigned h = ((unsigned)m * 2654435761u) ^ (g * 40503u);
+    const unsigned room = stretch > per ? stretch - per + 1u : 1u;
+    const int at = (int)min(g * stretch + __umulhi(h, room) + sub, (unsigned)nvec - 1u);
     const float4 px = *reinterpret_cast<const float4 *>(in + (size_t)m * in_stride + 4 * (size_t)at);
     v = max(max(__float_as_uint(px.x) & 0x7fffffffu, __float_as_uint(px.y) & 0x7fffffffu),
             max(__float_as_uint(px.z) & 0x7fffffffu, __float_as_uint(px.w) & 0x7fffffffu));
@@ -208,10 +212,41 @@ k_level_probe(const float *in, size_t in_stride, int nsamples, int M, unsigned *
     lo_v = min(lo_v, (unsigned)__shfl_xor((int)lo_v, d));
   }
   if (lane == 0) {
-    obj_level[m] = hi_v;
-    obj_level[cap + m] = lo_v == 0xffffffffu ? 0u : lo_v;
-    if (hi_v != 0 && hi_v > __atomic_load_n(level, __ATOMIC_RELAXED)) atomicMax(level, hi_v);
+    wmax[wv] = hi_v;
+    if (m < M) {
+      obj_level[m] = hi_v;
+      obj_level[cap + m] = lo_v == 0xffffffffu ? 0u : lo_v;
+    }
   }
+  __syncthreads();
+  // the call's level: one word for everybody behind this kernel.  Same-address traffic is what it costs — a thousand
+  // waves that only LOOK at the word (a coherent load each) took 11 of this kernel's 16 us — so a workgroup's 16 objects
+  // go there once, and with the mantissa cleared (only the exponent is ever used), so that most find the word there already
+  if (threadIdx.x == 0) {
+    unsigned he = 0u;
+#pragma unroll
+    for (int i = 0; i < kProbeObjects; i++) he = max(he, wmax[i]);
+    he &= 0x7f800000u;
+    if (he != 0 && he > __atomic_load_n(level, __ATOMIC_RELAXED)) atomicMax(level, he);
+  }
+}
+
+// The hinge kernel (gain_hg.h) keeps 1e-6 for inputs down to kHingeSpreadBinades below the level the prescale aims at (the
+// piece-list kernel: 21).  Behind the probe: bit 1 of *gate is raised when some object that does not take the exact path anyway
+// FALLS further than that at some probed instant — the hinge kernel and its list builder then return at once and the piece
+// lists, launched behind them, do the call (each pair of launches looks at the word: the ones that do not work cost ~3 us).
+constexpr int kHingeSpreadBinades = 16;
+constexpr unsigned kGateHingeUnsafe = 2u;
+static __global__ void __launch_bounds__(256)
+k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cur, unsigned *gate) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  bool unsafe = false;
+  if (m < M) {
+    const unsigned hi = obj_level[m], lo = obj_level[cap + m], call = *level_cur;
+    const bool exact_anyway = hi != 0u && call != 0u && (int)(hi >> 23) < (int)(call >> 23) - kHingeSpreadBinades;
+    unsafe = !exact_anyway && lo != 0u && call != 0u && (int)(lo >> 23) < (int)(call >> 23) - kHingeSpreadBinades;
+  }
+  if (__syncthreads_or(unsafe ? 1 : 0) && threadIdx.x == 0) atomicOr(gate, kGateHingeUnsafe);
 }
 
 // kPrepRun consecutive tiles per thread: 2 for up to 2047 tiles (headline: K0 0.020 -> 0.018 ms), 4 beyond
@@ -297,7 +332,7 @@ k_mark_quiet(SegDesc *desc, int M, int ntiles, const unsigned *obj_level, int ca
   const unsigned lv = obj_level[m], lo = obj_level[cap + m];
   // (wide: zero before the launch; every writer writes 1.  The decision looks at how far any object FALLS, not only at
   // how loud it gets: an object that is loud at some instants and 60 dB down at others needs the scaled low pieces there)
-  if (wide && lo != 0u && *level_cur != 0u && (int)(lo >> 23) < (int)(*level_cur >> 23) - kPlainBinades) *wide = 1u;
+  if (wide && lo != 0u && *level_cur != 0u && (int)(lo >> 23) < (int)(*level_cur >> 23) - kPlainBinades) atomicOr(wide, 1u);
   if (!level_is_quiet(lv, *level_cur)) return;
   for (int t = 0; t < ntiles; t++) {
     desc[(size_t)t * M + m].info |= kSegQuiet;

@@ -220,7 +220,8 @@ constexpr int kBuildThreads = 1024;
 template <int TPW>
 __global__ void __launch_bounds__(kBuildThreads)
 k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end, PieceLists pl,
-              const unsigned *obj_level, const unsigned *level_cur) {
+              const unsigned *obj_level, const unsigned *level_cur, const unsigned *gate = nullptr) {
+  if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel's builder, which does this call (k_hinge_gate)
   constexpr int OB = kBuildThreads / TPW;  // objects per batch
   constexpr int WPT = OB / 64;             // waves that scan one tile's objects
   static_assert(OB % 64 == 0, "a tile's objects of a batch are whole waves of the scan");
@@ -366,7 +367,8 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 template <int NCT, int NW, bool PAIRED>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next, unsigned *wide_next) {
+              unsigned *level_next, unsigned *wide_next, const unsigned *gate = nullptr) {
+  if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel, which did this call (k_hinge_gate)
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
   constexpr int NFRAG = NCT * 3;  // column tiles x {h, l, h 2^-11}

@@ -301,6 +301,9 @@ def solo_curves(curves, n_out, solo_speakers, seed=92):
         d, f = d.copy(), (None if f is None else f.copy())
         if m < len(solo_speakers):
             g = rng.uniform(0.5, 1.0, (len(t), 2)).astype(np.float32)
+            for k in range(1, len(t)):  # (metadata that restates a point — same time — restates its gains: no steps)
+                if t[k] == t[k - 1]:
+                    g[k] = g[k - 1]
             d[:] = 0.0
             d[:, solo_speakers[m]] = g[:, 0]
             if f is not None:
