@@ -386,9 +386,16 @@ int earhip_render_get_timing(earhip_render *r, double out[6]);
 /* Which gain kernel the last process call used: 0 = VALU with libear's exact
  * arithmetic (strict mode), 1 = f32 MFMA over slot lists, 3 = f16x2-split MFMA (all
  * curve points on the kernel's tile boundaries), 4 = f16x2-split MFMA over piece lists
- * (metadata that ignores the tile grid); -1 before the first call.  (2 was the bf16x3
- * kernel of the first round: removed.) */
+ * (metadata that ignores the tile grid), 5 = f16x2-split MFMA with hinges (curves that ramp
+ * all the time off the tile grid; the piece lists stand by: see below); -1 before the first
+ * call.  (2 was the bf16x3 kernel of the first round: removed.) */
 int earhip_render_gain_kernel(const earhip_render *r, int *kind);
+/* Kernel 5 keeps 1e-6 for inputs down to 16 binades below the call's level (kernel 4: 21), so a
+ * call it is planned for is decided ON THE DEVICE, from the level probe of the call's inputs: the
+ * hinge kernel or the piece lists launched behind it.  *standby = 1 when the last call of this
+ * context was planned for kernel 5 and the piece lists did it, else 0.  Synchronises the stream
+ * (for benchmarks and tests that must name the kernel they measured). */
+int earhip_render_hinge_standby(earhip_render *r, int *standby);
 /* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
  * For tests and benchmarks that must know which kernel instantiation they measured. */

@@ -611,6 +611,13 @@ class Renderer:
         check(load().earhip_render_gain_kernel(self.h, C.byref(kind)))
         return kind.value
 
+    def hinge_standby(self):
+        """True when the last call was planned for the hinge kernel (5) and the device handed it to the piece lists standing
+        by (its inputs' levels spread further than the hinge kernel's span); synchronises the stream"""
+        flag = C.c_int(0)
+        check(load().earhip_render_hinge_standby(self.h, C.byref(flag)))
+        return bool(flag.value)
+
     def last_plan(self):
         """launch plan of the last call: gain kernel, samples per workgroup tile, tiles, object splits"""
         out = (C.c_int * 4)()

@@ -653,6 +653,20 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind) {
   });
 }
 
+int earhip_render_hinge_standby(earhip_render *r, int *standby) {
+  return guarded([&] {
+    require(r != nullptr && standby != nullptr, "NULL argument");
+    *standby = 0;
+    earhip_ctx *ctx = r->ctx;
+    if (r->last_kind != 5 || ctx->last_gate_idx < 0 || !ctx->level.p) return;
+    ctx->use();
+    unsigned word = 0;
+    EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + ctx->last_gate_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    *standby = (word & kGateHingeUnsafe) ? 1 : 0;
+  });
+}
+
 int earhip_render_last_plan(const earhip_render *r, int out[4]) {
   return guarded([&] {
     require(r != nullptr && out != nullptr, "NULL argument");

@@ -131,3 +131,20 @@ def test_producer_line():
     assert line["unit"] == "Mpositions/s" and line["value"] > 0
     assert line["parity"]["pass"] and line["parity"]["max_rel_norm"] <= 1e-5
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+
+
+def test_default_line_carries_the_other_workloads():
+    """`python bench.py` as the driver runs it (fewer steps here): the headline line carries a `secondary` array — the other
+    BASELINE configurations and the scenes of the other gain kernels, each timed in a process of its own with the parity gate
+    on its own timed buffer"""
+    if any(os.environ.get(k) is not None for k in ("EARHIP_P2_PAIRS", "EARHIP_P2_TILE", "EARHIP_H2_TILE", "EARHIP_MFMA", "EARHIP_HINGE")):
+        pytest.skip("kernel forced")
+    line = run_bench(["--steps", "6", "--warmup", "2", "--cpu-blocks", "4"])
+    sec = {e["workload"]: e for e in line["secondary"]}
+    assert {"C2", "C3", "C5", "C4 adm", "C4 moving", "C4 bursty"} <= set(sec), sorted(sec)
+    for name, e in sec.items():
+        assert "error" not in e, (name, e.get("error"))
+        assert e["value"] > 0 and e["steps"] >= 5 and 0 < e["roofline"]["frac"] < 1.0, (name, e)
+        assert e["parity"]["pass"] and e["parity"]["same_plan_as_timed"] and e["parity"]["max_channel_rel_rms_vs_cpu"] <= 1e-6, (name, e)
+    assert "k_gain_mix_hg" in sec["C4 moving"]["roofline"]["kernel"] and "k_gain_mix_p2" in sec["C4 adm"]["roofline"]["kernel"]
+    assert "k_gain_mix_h2" in sec["C4 bursty"]["roofline"]["kernel"]
