@@ -53,7 +53,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // short curves (static or nearly static gains, <= 8 points per object on average): K0s finds
   // the segments itself and the descriptor pass is skipped; with long curves the 16-lanes-per-
   // object search of k_seg_prep is the faster one (measured both ways)
-  const bool fused_prep = slots && (size_t)ps.zero_row <= (size_t)8 * M;
+  const bool fused_prep = slots && (size_t)ps.npoints <= (size_t)8 * M;
   // split-operand kernels: K0 starts with the level probe of the call's inputs (k_level_probe: 64 instants per object; rows
   // must allow 16-byte loads).  The two level words alternate between calls: this call's probe raises word `li` (zero since
   // the last such call cleared it), its K1 reads it and clears the other.
@@ -115,7 +115,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (ml.hinge) {
     if (M > kMaxHingeCached || ml.tile() != kHingeTile) fail_internal("hinge lists: object count or tile out of range");
     // (the kernel addresses input rows and gain rows with 32-bit byte offsets; plan_mix only picks it within these limits)
-    if (!hinge_addressable(M, in_stride, nsamples, ps.zero_row + 2, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
+    if (!hinge_addressable(M, in_stride, nsamples, ps.rows, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
     unsigned *obj_lv = probe.obj_level;
     // with a probe: does the hinge kernel's span of levels cover this call?  (decided on the device: k_hinge_gate)
     if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate);

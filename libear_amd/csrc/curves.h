@@ -45,22 +45,63 @@ struct ColumnPlan {
   }
 };
 
+// k_curve_upload: the changed objects' regions of the curve image, host mirror (pinned, device-visible) -> device, in ONE
+// launch: a commit that touches 16 of 1024 objects costs the host one kernel launch, not 64 copy calls, and the device
+// what those objects' points weigh (CurveSet::commit).  grid = changed objects, block = 256 threads.
+struct CurveImage {
+  int32_t *off, *cnt;
+  int64_t *time;
+  uint8_t *flat;
+  PointRec *rec;
+  float *gain;
+};
+static __global__ void __launch_bounds__(256)
+k_curve_upload(CurveImage src, CurveImage dst, const int32_t *changed, int row) {
+  const int m = changed[blockIdx.x];
+  const int off = src.off[m], n = src.cnt[m];
+  if (threadIdx.x == 0) dst.off[m] = off, dst.cnt[m] = n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    dst.time[off + i] = src.time[off + i];
+    dst.flat[off + i] = src.flat[off + i];
+    dst.rec[off + i] = src.rec[off + i];
+  }
+  const size_t g0 = (size_t)off * row, gn = (size_t)n * row;  // (row is a multiple of 4: float4 copies)
+  const float4 *sg = reinterpret_cast<const float4 *>(src.gain + g0);
+  float4 *dg = reinterpret_cast<float4 *>(dst.gain + g0);
+  for (size_t i = threadIdx.x; i < gn / 4; i += 256) dg[i] = sg[i];
+}
+
+// The gain curves of M objects: libear's GainInterpolator::interp_points per object (gain_interpolator.hpp:42-43: a
+// public vector the caller changes freely), as a device image the kernels read and a host mirror of it.
+//
+// Image: an ARENA of curve points — rows 0 and 1 are all zero (the row objects to skip point at, and the row behind it
+// that a null ramp reads as its end point), every object owns a region [off, off + cap) of which cnt points are live;
+// per point its time, the packed record of the segment that ends there, the per-bus "equals the previous point"
+// bits and the gain row.  An object that outgrows its region moves to the end of the arena (regions grow by half;
+// the arena is re-packed when more than half of it is abandoned).
+//
+// commit() costs what CHANGED: the changed objects' points are written to the mirror, their statistics (time grid, ramp
+// share, hinge / pair statistics, column maxima) replace their old contributions to the set's, and their regions go
+// to the device in one launch of k_curve_upload (more than a quarter of the objects changed, or buffers grown: plain
+// copies of the whole arrays).  1024 objects x 64-point windows, 16 objects replaced per block: tools/commit_cost.py.
 class CurveSet {
  public:
   // ncols = nbus * bus_cols; each bus is one libear GainInterpolator per object
   CurveSet(int M, int ncols, int nbus = 1, bool force_ramp = false)
-      : M_(M), ncols_(ncols), nbus_(nbus), force_ramp_(force_ramp),
-        plan_(ColumnPlan::make(ncols)) {
-    times_.resize(M);
-    gains_.resize(M);
-    flat_.resize(M);
+      : M_(M), ncols_(ncols), nbus_(nbus), force_ramp_(force_ramp), plan_(ColumnPlan::make(ncols)), obj_(M) {
     // an object without a curve is silent: one all-zero point
     for (int m = 0; m < M; m++) {
-      times_[m].assign(1, 0);
-      gains_[m].assign(plan_.row, 0.0f);
-      flat_[m].assign(1, 0);
+      obj_[m].t.assign(1, 0);
+      obj_[m].g.assign(plan_.row, 0.0f);
+      obj_[m].flat.assign(1, 0);
+      obj_[m].dirty = true;
+      dirty_list_.push_back(m);
     }
-    dirty_ = true;
+    cmax_.assign(plan_.row, 0.0f);
+    obj_cmax_.assign((size_t)M * plan_.row, 0.0f);
+    cm_scratch_.assign(plan_.row, 0.0f);
+    dirty_list_.reserve(M);
+    for (auto &p : phases_) p.items.reserve(M);
   }
   ~CurveSet() {
     if (staged_) (void)hipEventDestroy(staged_);
@@ -82,16 +123,17 @@ class CurveSet {
       if (times[k] - times[k - 1] > (int64_t)0x7fffffff)
         fail_invalid("interpolation ramp longer than 2^31-1 samples is not supported");
     }
-    times_[m].assign(times, times + npoints);
-    gains_[m].assign((size_t)npoints * plan_.row, 0.0f);
+    Obj &o = obj_[m];
+    const size_t row = (size_t)plan_.row;
+    o.t.assign(times, times + npoints);
+    o.g.assign((size_t)npoints * row, 0.0f);
     for (int k = 0; k < npoints; k++)
-      std::memcpy(&gains_[m][(size_t)k * plan_.row], rows + (size_t)k * ncols_,
-                  sizeof(float) * ncols_);
-    flat_[m].assign(npoints, 0);
+      std::memcpy(&o.g[(size_t)k * row], rows + (size_t)k * ncols_, sizeof(float) * ncols_);
+    o.flat.assign(npoints, 0);
     const int bc = ncols_ / nbus_;
     for (int k = 1; k < npoints; k++) {
       if (flat_override) {
-        flat_[m][k] = flat_override[k];
+        o.flat[k] = flat_override[k];
         continue;
       }
       // InterpType::constant_interp: a == b on every component
@@ -100,7 +142,7 @@ class CurveSet {
         bool same = true;
         for (int c = b * bc; same && c < (b + 1) * bc; c++)
           same = rows[(size_t)(k - 1) * ncols_ + c] == rows[(size_t)k * ncols_ + c];
-        if (same) flat_[m][k] |= (uint8_t)(1 << b);
+        if (same) o.flat[k] |= (uint8_t)(1 << b);
       }
     }
     // A point that repeats its predecessor — the same time and bit for bit the same gains — is an empty segment
@@ -110,215 +152,160 @@ class CurveSet {
     // of one tile and the start row of the next are two rows in memory instead of one fetched once (the panned
     // scene's gain kernel: 0.43 -> 0.40 ms), and the curve takes twice the space.
     {
-      const size_t row = (size_t)plan_.row;
       int w = 1;
       for (int k = 1; k < npoints; k++) {
-        const bool repeat = times_[m][k] == times_[m][w - 1] &&
-                            std::memcmp(&gains_[m][(size_t)k * row], &gains_[m][(size_t)(w - 1) * row], sizeof(float) * row) == 0;
+        const bool repeat = o.t[k] == o.t[w - 1] && std::memcmp(&o.g[(size_t)k * row], &o.g[(size_t)(w - 1) * row], sizeof(float) * row) == 0;
         if (repeat) continue;
         if (w != k) {
-          times_[m][w] = times_[m][k];
-          flat_[m][w] = flat_[m][k];
-          std::memmove(&gains_[m][(size_t)w * row], &gains_[m][(size_t)k * row], sizeof(float) * row);
+          o.t[w] = o.t[k];
+          o.flat[w] = o.flat[k];
+          std::memmove(&o.g[(size_t)w * row], &o.g[(size_t)k * row], sizeof(float) * row);
         }
         w++;
       }
-      times_[m].resize(w);
-      flat_[m].resize(w);
-      gains_[m].resize((size_t)w * row);
+      o.t.resize(w);
+      o.flat.resize(w);
+      o.g.resize((size_t)w * row);
     }
-    dirty_ = true;
+    if (!o.dirty) o.dirty = true, dirty_list_.push_back(m);
   }
 
-  // Flatten and upload.  The image is staged in pinned memory and copied on the
-  // context's stream: kernels already enqueued still see the old image (stream order),
-  // the caller does not wait for the GPU.  Only growing a device buffer, or re-using
-  // the staging buffers while their last copy is still in flight, synchronises.
+  // Bring the device image up to date.  Uploads run on the context's stream: kernels already enqueued still see the old
+  // image (stream order), the caller does not wait for the GPU.  Only growing a device buffer, or touching the
+  // mirror while its last upload is still in flight, synchronises.
   void commit(earhip_ctx *ctx) {
-    if (!dirty_) return;
-    size_t P = 0;
-    for (int m = 0; m < M_; m++) P += times_[m].size();
+    if (dirty_list_.empty()) return;
     const size_t row = (size_t)plan_.row;
-    if (staged_) EARHIP_HIP(hipEventSynchronize(staged_));  // staging buffers free again
-    if (M_ + 1 > (int)h_off_.n || P > h_time_.n || P > h_rec_.n || (P + 2) * row > h_gain_.n) {
-      const size_t cap = P + P / 2 + 16;  // grow with headroom: appending points stays cheap
-      h_off_.reserve(M_ + 1);
-      h_time_.reserve(cap);
-      h_flat_.reserve(cap);
-      h_rec_.reserve(cap);
-      h_gain_.reserve((cap + 2) * row);
+    if (staged_) EARHIP_HIP(hipEventSynchronize(staged_));  // the mirror is free again
+    // ---- regions: an object that outgrew its region moves to the end of the arena
+    bool full_upload = !uploaded_once_;
+    for (int m : dirty_list_) {
+      Obj &o = obj_[m];
+      const int n = (int)o.t.size();
+      if (n > o.cap) {
+        abandoned_ += (size_t)o.cap;
+        o.cap = std::max(16, n + n / 2);
+        o.off = (int)arena_used_;
+        arena_used_ += (size_t)o.cap;
+      }
     }
-    if (P > d_time_.n || P > d_rec_.n || (P + 2) * row > d_gain_.n || (size_t)M_ + 1 > d_off_.n) {
+    if (abandoned_ > arena_used_ / 2 && abandoned_ > 4096) {  // re-pack: every object into a fresh region, in order
+      arena_used_ = 2;
+      abandoned_ = 0;
+      for (int m = 0; m < M_; m++) {
+        Obj &o = obj_[m];
+        o.cap = std::max(16, (int)o.t.size() + (int)o.t.size() / 2);
+        o.off = (int)arena_used_;
+        arena_used_ += (size_t)o.cap;
+        if (!o.dirty) o.dirty = true, dirty_list_.push_back(m);
+      }
+      full_upload = true;
+    }
+    if (arena_used_ >= ((size_t)1 << 31)) fail_invalid("too many interpolation points");
+    if (arena_used_ > arena_cap_) {  // grow the buffers (host mirror and device image): everything is copied again
+      const size_t cap = arena_used_ + arena_used_ / 2 + 64;
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // the old image may still be in use
-      d_off_.reserve(M_ + 1);
-      d_time_.reserve(h_time_.n);
-      d_flat_.reserve(h_flat_.n);
-      d_rec_.reserve(h_rec_.n);
-      d_gain_.reserve(h_gain_.n);
+      PinBuf<int64_t> nt;
+      PinBuf<uint8_t> nf;
+      PinBuf<PointRec> nr;
+      PinBuf<float> ng;
+      nt.reserve(cap), nf.reserve(cap), nr.reserve(cap), ng.reserve(cap * row);
+      if (arena_cap_) {
+        std::memcpy(nt.p, h_time_.p, arena_cap_ * sizeof(int64_t));
+        std::memcpy(nf.p, h_flat_.p, arena_cap_);
+        std::memcpy(nr.p, h_rec_.p, arena_cap_ * sizeof(PointRec));
+        std::memcpy(ng.p, h_gain_.p, arena_cap_ * row * sizeof(float));
+      } else {
+        std::memset(ng.p, 0, 2 * row * sizeof(float));  // rows 0, 1: all zero
+        std::memset(nt.p, 0, 2 * sizeof(int64_t));
+        std::memset(nf.p, 0, 2);
+        std::memset(nr.p, 0, 2 * sizeof(PointRec));
+      }
+      std::swap(h_time_.p, nt.p), std::swap(h_time_.n, nt.n);  // (the old buffers are released with nt .. ng)
+      std::swap(h_flat_.p, nf.p), std::swap(h_flat_.n, nf.n);
+      std::swap(h_rec_.p, nr.p), std::swap(h_rec_.n, nr.n);
+      std::swap(h_gain_.p, ng.p), std::swap(h_gain_.n, ng.n);
+      d_time_.alloc(cap), d_flat_.alloc(cap), d_rec_.alloc(cap), d_gain_.alloc(cap * row);
+      arena_cap_ = cap;
+      full_upload = true;
     }
-    size_t at = 0;
-    for (int m = 0; m < M_; m++) {
-      h_off_.p[m] = (int32_t)at;
-      const size_t n = times_[m].size();
-      std::memcpy(h_time_.p + at, times_[m].data(), n * sizeof(int64_t));
-      std::memcpy(h_gain_.p + at * row, gains_[m].data(), n * row * sizeof(float));
-      std::memcpy(h_flat_.p + at, flat_[m].data(), n);
-      for (size_t k = 0; k < n; k++) {
-        PointRec &r = h_rec_.p[at + k];
-        r.time = times_[m][k];
-        const int64_t len = k ? times_[m][k] - times_[m][k - 1] : 0;
+    if (!h_off_.p) {
+      h_off_.reserve(M_), h_cnt_.reserve(M_), h_changed_.reserve(M_), h_gcol_.reserve(row);
+      d_off_.alloc(M_), d_cnt_.alloc(M_), d_gcol_.alloc(row);
+    }
+    // ---- the changed objects: mirror, statistics
+    const float old_scale = gain_scale();
+    bool cmax_shrunk = false;
+    for (int m : dirty_list_) {
+      Obj &o = obj_[m];
+      const int n = (int)o.t.size();
+      h_off_.p[m] = o.off;
+      h_cnt_.p[m] = n;
+      std::memcpy(h_time_.p + o.off, o.t.data(), (size_t)n * sizeof(int64_t));
+      std::memcpy(h_flat_.p + o.off, o.flat.data(), (size_t)n);
+      std::memcpy(h_gain_.p + (size_t)o.off * row, o.g.data(), (size_t)n * row * sizeof(float));
+      for (int k = 0; k < n; k++) {
+        PointRec &r = h_rec_.p[o.off + k];
+        r.time = o.t[k];
+        const int64_t len = k ? o.t[k] - o.t[k - 1] : 0;
         r.scale = len > 0 ? 1.0f / (float)len : 0.0f;  // describe_segment's own expression (gain_kernels.h)
-        r.flat = flat_[m][k];
+        r.flat = o.flat[k];
       }
-      at += n;
+      float *cm = obj_cmax_.data() + (size_t)m * row;
+      if (o.has_stats) cmax_shrunk = retire(o.st, cm) || cmax_shrunk;
+      o.st = stats_of(o, cm);
+      admit(o.st, cm);
+      o.has_stats = true;
     }
-    h_off_.p[M_] = (int32_t)at;
-    // two all-zero rows (split-operand kernels: the row objects to skip point at, and the row behind it that a
-    // null RAMP piece of the piece-list kernel reads as its end point)
-    std::memset(h_gain_.p + P * row, 0, 2 * row * sizeof(float));
-    npoints_ = (int)P;
-    // common grid of all point times: every time is t_ref_ + k * grid_ (grid_ = 0: all equal)
-    t_ref_ = P ? times_[0][0] : 0;
-    uint64_t g = 0;
-    for (int m = 0; m < M_; m++)
-      for (int64_t t : times_[m]) {
-        uint64_t a = (uint64_t)(t >= t_ref_ ? t - t_ref_ : t_ref_ - t), b = g;
-        while (a) {
-          const uint64_t r = b % a;
-          b = a;
-          a = r;
-        }
-        g = b;
-      }
-    grid_ = g;
-    // The same per grid size of the split-operand kernels, tolerant of a few objects: an object is ON the
-    // grid G when all its points are congruent modulo G to the phase most objects share.  Objects off the
-    // grid only cost their own slow path in the tiles where their points fall.
-    const int grids[2] = {512, 256};
-    for (int gi = 0; gi < 2; gi++) {
-      const int64_t G = grids[gi];
-      std::vector<int64_t> &phase = scratch_phase_;  // (members: commit runs inside process calls of the policies)
-      phase.assign(M_, -1);  // -1: the object's points do not share a phase
-      for (int m = 0; m < M_; m++) {
-        const auto &t = times_[m];
-        if (t.empty()) continue;
-        const int64_t p0 = ((t[0] % G) + G) % G;
-        bool same = true;
-        for (int64_t v : t) same = same && (((v % G) + G) % G) == p0;
-        if (same) phase[m] = p0;
-      }
-      std::vector<int64_t> &sorted = scratch_sorted_;
-      sorted.clear();
+    // A column's largest gain went away with an old curve: the set's maxima may be smaller now.  They only set the
+    // columns' scales (powers of two): a maximum that stays too large for a while costs the small gains of that column
+    // a bit of precision each binade, nothing else — so everybody's maxima are looked at again (O(M x columns)) when
+    // everything is uploaded anyway, and otherwise every 256th commit that could have shrunk one.
+    if (cmax_shrunk && (full_upload || ++shrink_pending_ >= 256)) {
+      shrink_pending_ = 0;
+      cmax_.assign(row, 0.0f);
       for (int m = 0; m < M_; m++)
-        if (phase[m] >= 0) sorted.push_back(phase[m]);
-      std::sort(sorted.begin(), sorted.end());
-      int64_t best = 0;
-      size_t best_n = 0;
-      for (size_t i = 0; i < sorted.size();) {
-        size_t j = i;
-        while (j < sorted.size() && sorted[j] == sorted[i]) j++;
-        if (j - i > best_n) best_n = j - i, best = sorted[i];
-        i = j;
-      }
-      grid_phase_[gi] = best;
-      int empty = 0;
-      for (int m = 0; m < M_; m++) empty += times_[m].empty() ? 1 : 0;
-      grid_off_[gi] = M_ - empty - (int)best_n;
-    }
-    // share of the curves' time spans spent in ramps (the rest is constant)
-    double span = 0, ramp = 0;
-    const int allflat = (1 << nbus_) - 1;
-    for (int m = 0; m < M_; m++) {
-      const auto &t = times_[m];
-      for (size_t k = 1; k < t.size(); k++) {
-        span += (double)(t[k] - t[k - 1]);
-        if ((flat_[m][k] & allflat) != allflat) ramp += (double)(t[k] - t[k - 1]);
-      }
-    }
-    ramp_share_ = span > 0 ? ramp / span : 0.0;
-    // What the hinge kernel (gain_hg.h) would have to send through its exact path: (object, tile) pairs with a ramp
-    // shorter than kHingeMinLen (a step: a ramp of no length) or with curve points closer together than that — as a share
-    // of all pairs on 256-sample tiles.  A short ramp spoils the tiles it touches, two close points on a constant stretch
-    // the tile they share about every other time.
-    {
-      double bad = 0;
-      for (int m = 0; m < M_; m++) {
-        const auto &t = times_[m];
-        for (size_t k = 1; k < t.size(); k++) {
-          const int64_t len = t[k] - t[k - 1];
-          if (len >= kHingeMinLen) continue;
-          bad += (flat_[m][k] & allflat) != allflat ? 1.0 + (double)len / kHingeTile : 0.5;
+        for (size_t c = 0; c < row; c++) {
+          const float v = obj_cmax_[(size_t)m * row + c];
+          cmax_[c] = v <= cmax_[c] ? cmax_[c] : v;
         }
-      }
-      hinge_exact_share_ = span > 0 ? std::min(1.0, bad / std::max(1.0, span / kHingeTile)) : 0.0;
     }
-    // curve points per sample and object over the time the curves span (the piece kernel picks its tile from it)
-    double npts = 0;
-    for (int m = 0; m < M_; m++)
-      if (times_[m].size() > 1) npts += (double)(times_[m].size() - 1);
-    point_density_ = span > 0 ? npts / span : 0.0;
-    // The piece-list kernel's paired layout spends two slots on every delta piece (gain_p2.h): an object with k > 1
-    // ramps in one tile costs k - 1 slots more than in the packed layout.  Share of such extra slots among the slots
-    // of the packed layout, over the curves' whole span, on grids of 256- and of 512-sample tiles from time 0 (a
-    // call's grid starts at its own first sample: same statistics).
-    for (int gi = 0; gi < 2; gi++) {
-      const int64_t T = gi ? 512 : 256;
-      auto tile_of = [T](int64_t a) { return a >= 0 ? a / T : -((-a + T - 1) / T); };
-      double incid = 0, touched = 0, tiles = 0;
-      for (int m = 0; m < M_; m++) {
-        const auto &t = times_[m];
-        if (t.size() > 1) tiles += (double)(t.back() - t.front()) / (double)T;
-        int64_t last_tile = INT64_MIN;
-        for (size_t k = 1; k < t.size(); k++) {
-          if ((flat_[m][k] & allflat) == allflat) continue;
-          // a step (two equal times) is a ramp of length one ending at the time
-          const int64_t a = t[k] > t[k - 1] ? t[k - 1] : t[k] - 1, b = t[k];  // the ramp covers samples [a, b)
-          const int64_t ta = tile_of(a), tb = tile_of(b - 1);
-          incid += (double)(tb - ta + 1);
-          touched += (double)(tb - ta + 1) - (ta == last_tile ? 1.0 : 0.0);
-          last_tile = tb;
-        }
-      }
-      pair_waste_[gi] = (incid - touched) / std::max(1.0, tiles + incid);
-    }
-    // largest |gain| (k_gain_mix_h2 scales the gains to the top of the f16 range); NaN / inf count as huge
-    // ... and per COLUMN (the split-operand kernels scale every output column's gains by its own power of two:
-    // a loudspeaker that only ever gets small gains — an object 120 dB down alone on it — keeps both f16 pieces of
-    // its gains normal; the inverse is applied to the column's output).  Columns without any gain: the set's scale.
-    // One row-major sweep for both (commit runs inside process calls: no strided passes over the image).
-    scratch_cmax_.assign(row, 0.0f);
-    float gmax = 0.0f;
-    for (size_t k = 0; k < P; k++) {
-      const float *g = h_gain_.p + k * row;
-      for (size_t c = 0; c < row; c++) {
-        const float a = std::fabs(g[c]);
-        float &cm = scratch_cmax_[c];
-        cm = a <= cm ? cm : a;  // (a NaN replaces the maximum)
-      }
-    }
-    for (size_t c = 0; c < row; c++) gmax = scratch_cmax_[c] <= gmax ? gmax : scratch_cmax_[c];
-    gain_max_ = gmax;
-    h_gcol_.reserve(row);
+    finish_stats();
+    // per-column gain scales (the split-operand kernels scale every output column's gains by its own power of two: a
+    // loudspeaker that only ever gets small gains — an object 120 dB down alone on it — keeps both f16 pieces of its
+    // gains normal; the inverse is applied to the column's output).  Columns without any gain: the set's scale.
     const float set_scale = gain_scale();
+    bool gcol_changed = !uploaded_once_ || set_scale != old_scale;
     for (size_t c = 0; c < row; c++) {
-      const float cm = scratch_cmax_[c];
+      const float cm = cmax_[c];
       int e;
       std::frexp(cm, &e);
-      h_gcol_.p[c] = (cm >= 1e-30f && cm < 1e30f) ? std::ldexp(1.0f, 14 - e) : (set_scale > 0.0f ? set_scale : 1.0f);
+      const float v = (cm >= 1e-30f && cm < 1e30f) ? std::ldexp(1.0f, 14 - e) : (set_scale > 0.0f ? set_scale : 1.0f);
+      gcol_changed = gcol_changed || v != h_gcol_.p[c];
+      h_gcol_.p[c] = v;
     }
-    if (d_gcol_.n < row) {
-      EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-      d_gcol_.reserve(row);
+    // ---- upload
+    if (gcol_changed) EARHIP_HIP(hipMemcpyAsync(d_gcol_.p, h_gcol_.p, row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (full_upload || dirty_list_.size() > (size_t)M_ / 4) {
+      EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, M_ * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      EARHIP_HIP(hipMemcpyAsync(d_cnt_.p, h_cnt_.p, M_ * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, arena_used_ * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+      EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, arena_used_, hipMemcpyHostToDevice, ctx->stream));
+      EARHIP_HIP(hipMemcpyAsync(d_rec_.p, h_rec_.p, arena_used_ * sizeof(PointRec), hipMemcpyHostToDevice, ctx->stream));
+      EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, arena_used_ * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      for (size_t i = 0; i < dirty_list_.size(); i++) h_changed_.p[i] = dirty_list_[i];
+      CurveImage src{h_off_.p, h_cnt_.p, h_time_.p, h_flat_.p, h_rec_.p, h_gain_.p};
+      CurveImage dst{d_off_.p, d_cnt_.p, d_time_.p, d_flat_.p, d_rec_.p, d_gain_.p};
+      hipLaunchKernelGGL(k_curve_upload, dim3((unsigned)dirty_list_.size()), dim3(256), 0, ctx->stream, src, dst, h_changed_.p,
+                         (int)row);
+      EARHIP_HIP(hipGetLastError());
     }
-    EARHIP_HIP(hipMemcpyAsync(d_gcol_.p, h_gcol_.p, row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, (M_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, P * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, P, hipMemcpyHostToDevice, ctx->stream));
-    EARHIP_HIP(hipMemcpyAsync(d_rec_.p, h_rec_.p, P * sizeof(PointRec), hipMemcpyHostToDevice, ctx->stream));
-    EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, (P + 2) * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (!staged_) EARHIP_HIP(hipEventCreateWithFlags(&staged_, hipEventDisableTiming));
     EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
-    dirty_ = false;
+    for (int m : dirty_list_) obj_[m].dirty = false;
+    dirty_list_.clear();
+    uploaded_once_ = true;
   }
 
   // true when no curve point can fall strictly inside a tile of `tile` samples of a
@@ -343,14 +330,25 @@ class CurveSet {
   }
 
   // fraction of the curves' time in ramps; 0 for static gains
-  double ramp_share() const { return ramp_share_; }
+  double ramp_share() const { return tot_.span > 0 ? tot_.ramp / tot_.span : 0.0; }
   // curve points per sample and object (0 for static gains)
-  double point_density() const { return point_density_; }
-  double pair_waste(int tile) const { return pair_waste_[tile >= 512 ? 1 : 0]; }
-  // share of the (object, tile) pairs the hinge kernel would send through its exact path; > 1: not a curve set for it
+  double point_density() const { return tot_.span > 0 ? tot_.npts / tot_.span : 0.0; }
+  // The piece-list kernel's paired layout spends two slots on every delta piece (gain_p2.h): an object with k > 1
+  // ramps in one tile costs k - 1 slots more than in the packed layout.  Share of such extra slots among the slots
+  // of the packed layout, over the curves' whole span, on grids of 256- and of 512-sample tiles from time 0 (a
+  // call's grid starts at its own first sample: same statistics).
+  double pair_waste(int tile) const {
+    const int gi = tile >= 512 ? 1 : 0;
+    return (tot_.incid[gi] - tot_.touched[gi]) / std::max(1.0, tot_.tiles[gi] + tot_.incid[gi]);
+  }
+  // What the hinge kernel (gain_hg.h) would have to send through its exact path: (object, tile) pairs with a ramp
+  // shorter than kHingeMinLen (a step: a ramp of no length) or with curve points closer together than that — as a share
+  // of all pairs on 256-sample tiles (a short ramp spoils the tiles it touches, two close points on a constant stretch
+  // the tile they share about every other time); > 1: not a curve set for it.
   // (in_stride, nsamples: the input rows of the call — the kernel addresses them, and the gain rows, with 32-bit offsets)
   double hinge_exact_share(size_t in_stride, size_t nsamples) const {
-    return force_ramp_ || !hinge_addressable((size_t)M_, in_stride, nsamples, (size_t)npoints_ + 2, (size_t)plan_.row) ? 2.0 : hinge_exact_share_;
+    if (force_ramp_ || !hinge_addressable((size_t)M_, in_stride, nsamples, arena_used_, (size_t)plan_.row)) return 2.0;
+    return tot_.span > 0 ? std::min(1.0, tot_.bad / std::max(1.0, tot_.span / kHingeTile)) : 0.0;
   }
 
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
@@ -369,6 +367,7 @@ class CurveSet {
   PointStore device() const {
     PointStore ps;
     ps.off = d_off_.p;
+    ps.cnt = d_cnt_.p;
     ps.time = d_time_.p;
     ps.flat = d_flat_.p;
     ps.rec = d_rec_.p;
@@ -376,44 +375,196 @@ class CurveSet {
     ps.row = plan_.row;
     ps.bus_cols = ncols_ / nbus_;
     ps.nbus = nbus_;
-    ps.zero_row = npoints_;
+    ps.zero_row = 0;
+    ps.npoints = (int)tot_.points;
+    ps.rows = (int)arena_used_;
     ps.force_ramp = force_ramp_ ? 1 : 0;
     return ps;
   }
 
  private:
+  // what ONE object's curve contributes to the statistics of the set
+  struct ObjStats {
+    uint64_t gcd = 0;        // of the differences of its point times
+    int64_t first = 0;       // its first point's time
+    int64_t phase[2] = {-1, -1};  // modulo 512 / 256 when all its points share one; -1: they do not
+    double span = 0, ramp = 0, npts = 0, bad = 0, points = 0;
+    double incid[2] = {0, 0}, touched[2] = {0, 0}, tiles[2] = {0, 0};
+    // (its column maxima: obj_cmax_[m][row] — commit() runs inside process calls and must not allocate)
+  };
+  struct Obj {
+    std::vector<int64_t> t;
+    std::vector<float> g;
+    std::vector<uint8_t> flat;
+    int off = 0, cap = 0;  // region of the arena
+    bool dirty = false, has_stats = false;
+    ObjStats st;
+  };
+
+  // cm: [row], the object's column maxima (largest |gain| per column; NaN / inf count as huge)
+  ObjStats stats_of(const Obj &o, float *cm) const {
+    ObjStats s;
+    const auto &t = o.t;
+    const size_t row = (size_t)plan_.row, n = t.size();
+    const int allflat = (1 << nbus_) - 1;
+    s.first = t[0];
+    s.points = (double)n;
+    for (size_t k = 1; k < n && s.gcd != 1; k++) {
+      uint64_t a = (uint64_t)(t[k] - t[k - 1]), b = s.gcd;
+      while (a) {
+        const uint64_t r = b % a;
+        b = a;
+        a = r;
+      }
+      s.gcd = b;
+    }
+    const int64_t grids[2] = {512, 256};
+    for (int gi = 0; gi < 2; gi++) {
+      const int64_t G = grids[gi];
+      const int64_t p0 = ((t[0] % G) + G) % G;
+      bool same = s.gcd % (uint64_t)G == 0;  // (all differences multiples of G: one phase)
+      s.phase[gi] = same ? p0 : -1;
+    }
+    for (size_t k = 1; k < n; k++) {
+      const int64_t len = t[k] - t[k - 1];
+      const bool is_ramp = (o.flat[k] & allflat) != allflat;
+      s.span += (double)len;
+      if (is_ramp) s.ramp += (double)len;
+      if (len < kHingeMinLen) s.bad += is_ramp ? 1.0 + (double)len / kHingeTile : 0.5;
+    }
+    if (n > 1) s.npts = (double)(n - 1);
+    for (int gi = 0; gi < 2; gi++) {
+      const int64_t T = gi ? 512 : 256;
+      auto tile_of = [T](int64_t a) { return a >= 0 ? a / T : -((-a + T - 1) / T); };
+      if (n > 1) s.tiles[gi] = (double)(t.back() - t.front()) / (double)T;
+      int64_t last_tile = INT64_MIN;
+      for (size_t k = 1; k < n; k++) {
+        if ((o.flat[k] & allflat) == allflat) continue;
+        // a step (two equal times) is a ramp of length one ending at the time
+        const int64_t a = t[k] > t[k - 1] ? t[k - 1] : t[k] - 1, b = t[k];  // the ramp covers samples [a, b)
+        const int64_t ta = tile_of(a), tb = tile_of(b - 1);
+        s.incid[gi] += (double)(tb - ta + 1);
+        s.touched[gi] += (double)(tb - ta + 1) - (ta == last_tile ? 1.0 : 0.0);
+        last_tile = tb;
+      }
+    }
+    for (size_t c = 0; c < row; c++) cm[c] = 0.0f;
+    for (size_t k = 0; k < n; k++) {
+      const float *g = o.g.data() + k * row;
+      for (size_t c = 0; c < row; c++) {
+        const float a = std::fabs(g[c]);
+        cm[c] = a <= cm[c] ? cm[c] : a;  // (a NaN replaces the maximum)
+      }
+    }
+    return s;
+  }
+  // take an object's old contribution out of the totals; true when one of its column maxima was the set's
+  bool retire(const ObjStats &s, const float *cm) {
+    tot_.span -= s.span, tot_.ramp -= s.ramp, tot_.npts -= s.npts, tot_.bad -= s.bad, tot_.points -= s.points;
+    for (int gi = 0; gi < 2; gi++) {
+      tot_.incid[gi] -= s.incid[gi], tot_.touched[gi] -= s.touched[gi], tot_.tiles[gi] -= s.tiles[gi];
+      if (s.phase[gi] >= 0) phases_[gi].add(s.phase[gi], -1);
+    }
+    grid_stale_ = true;  // (a gcd cannot be un-done: recomputed over the objects' own, finish_stats)
+    bool shrunk = false;
+    for (size_t c = 0; c < cmax_.size(); c++) shrunk = shrunk || (cm[c] > 0.0f && !(cm[c] < cmax_[c]));
+    return shrunk;
+  }
+  void admit(const ObjStats &s, const float *cm) {
+    tot_.span += s.span, tot_.ramp += s.ramp, tot_.npts += s.npts, tot_.bad += s.bad, tot_.points += s.points;
+    for (int gi = 0; gi < 2; gi++) {
+      tot_.incid[gi] += s.incid[gi], tot_.touched[gi] += s.touched[gi], tot_.tiles[gi] += s.tiles[gi];
+      if (s.phase[gi] >= 0) phases_[gi].add(s.phase[gi], +1);
+    }
+    grid_stale_ = true;
+    for (size_t c = 0; c < cmax_.size(); c++) cmax_[c] = cm[c] <= cmax_[c] ? cmax_[c] : cm[c];
+  }
+  void finish_stats() {
+    // common grid of all point times: every time is t_ref_ + k * grid_ (grid_ = 0: all equal) — from the objects' own
+    // gcds and first points: O(M) small steps, only when some object changed
+    if (grid_stale_) {
+      t_ref_ = obj_[0].st.first;
+      uint64_t g = 0;
+      auto fold = [&g](uint64_t a) {
+        uint64_t b = g;
+        while (a) {
+          const uint64_t r = b % a;
+          b = a;
+          a = r;
+        }
+        g = b;
+      };
+      for (int m = 0; m < M_ && g != 1; m++) {
+        const ObjStats &s = obj_[m].st;
+        fold(s.gcd);
+        fold((uint64_t)(s.first >= t_ref_ ? s.first - t_ref_ : t_ref_ - s.first));
+      }
+      grid_ = g;
+      grid_stale_ = false;
+    }
+    // per grid size of the split-operand kernels, tolerant of a few objects: an object is ON the grid G when all its
+    // points are congruent modulo G to the phase most objects share (objects off the grid only cost their own slow
+    // path in the tiles where their points fall)
+    for (int gi = 0; gi < 2; gi++) {
+      int64_t best = 0;
+      int best_n = 0;
+      for (const auto &kv : phases_[gi].items)
+        if (kv.second > best_n) best_n = kv.second, best = kv.first;
+      grid_phase_[gi] = best;
+      grid_off_[gi] = M_ - best_n;
+    }
+    float gmax = 0.0f;
+    for (float v : cmax_) gmax = v <= gmax ? gmax : v;
+    gain_max_ = gmax;
+  }
+
   int M_, ncols_, nbus_;
   bool force_ramp_;
   ColumnPlan plan_;
-  std::vector<std::vector<int64_t>> times_;
-  std::vector<std::vector<float>> gains_;
-  std::vector<std::vector<uint8_t>> flat_;
-  bool dirty_ = true;
-  int npoints_ = 0;
+  std::vector<Obj> obj_;
+  std::vector<int> dirty_list_;
+  bool uploaded_once_ = false;
+  size_t arena_used_ = 2, arena_cap_ = 0, abandoned_ = 0;  // in points (rows 0, 1: the all-zero rows)
+  int shrink_pending_ = 0;
+  // statistics of the set
+  struct Totals {
+    double span = 0, ramp = 0, npts = 0, bad = 0, points = 0;
+    double incid[2] = {0, 0}, touched[2] = {0, 0}, tiles[2] = {0, 0};
+  } tot_;
+  // [512, 256]: how many objects have all their points on that phase (at most M distinct ones: room for them from the
+  // start — commit() must not allocate)
+  struct PhaseCounts {
+    std::vector<std::pair<int64_t, int>> items;
+    void add(int64_t phase, int d) {
+      for (size_t i = 0; i < items.size(); i++)
+        if (items[i].first == phase) {
+          items[i].second += d;
+          if (items[i].second <= 0) items[i] = items.back(), items.pop_back();
+          return;
+        }
+      if (d > 0) items.emplace_back(phase, d);
+    }
+  } phases_[2];
+  std::vector<float> obj_cmax_;  // [M][row] the objects' column maxima
+  std::vector<float> cm_scratch_;  // [row]
+  bool grid_stale_ = true;
   int64_t t_ref_ = 0;
   uint64_t grid_ = 0;
   int64_t grid_phase_[2] = {0, 0};  // [512, 256]: the phase most objects' points share
   int grid_off_[2] = {0, 0};        // objects whose points are not all on that phase
-  double ramp_share_ = 0;
-  double point_density_ = 0;
-  double pair_waste_[2] = {0, 0};  // on 256- and 512-sample tiles
-  double hinge_exact_share_ = 1.0;
+  std::vector<float> cmax_;         // [row] largest |gain| per column over the set
   float gain_max_ = 0;
-  DevBuf<int32_t> d_off_;
+  DevBuf<int32_t> d_off_, d_cnt_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
   DevBuf<PointRec> d_rec_;
-  DevBuf<float> d_gcol_;
-  PinBuf<float> h_gcol_;
-  DevBuf<float> d_gain_;
-  PinBuf<int32_t> h_off_;
+  DevBuf<float> d_gcol_, d_gain_;
+  PinBuf<float> h_gcol_, h_gain_;
+  PinBuf<int32_t> h_off_, h_cnt_, h_changed_;
   PinBuf<int64_t> h_time_;
   PinBuf<uint8_t> h_flat_;
   PinBuf<PointRec> h_rec_;
-  PinBuf<float> h_gain_;
   hipEvent_t staged_ = nullptr;
-  std::vector<int64_t> scratch_phase_, scratch_sorted_;
-  std::vector<float> scratch_cmax_;
 };
 
 // How K1 is spread over the chip for one call.

@@ -180,7 +180,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
-    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const int base = P.ps.off[m], n = P.ps.cnt[m];
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;

@@ -213,7 +213,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   for (int mb = 0; mb < M; mb += OB) {
     const int m = mb + oi;
     if (m < M && tile < ntiles) {
-      const int base = ps.off[m], n = ps.off[m + 1] - base;
+      const int base = ps.off[m], n = ps.cnt[m];
       const int kc = upper_bound_time_window(ps.time + base, n, t0 + T / 2);
       const HingeRecs R = hinge_load(ps, base, n, kc);
       bool fwd, bwd;
@@ -278,7 +278,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
         hl.ovf[(size_t)tile * M + at] = m;
       } else {
         const int slot = start[j][cls] + at;
-        const int base = ps.off[m], n = ps.off[m + 1] - base;
+        const int base = ps.off[m], n = ps.cnt[m];
         const HingeRecs R = hinge_load(ps, base, n, kc);
         const bool fwd = cls == kHgF3 || cls == kHgF2 || cls == kHgBoth, bwd = cls == kHgB1 || cls == kHgB0 || cls == kHgBoth;
         LinEntry e;
@@ -419,7 +419,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? 0.5f * gcol[col0 + c * 16 + li] : 1.0f;
-    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const int base = P.ps.off[m], n = P.ps.cnt[m];
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;

@@ -42,7 +42,8 @@ static_assert(sizeof(PointRec) == 16, "PointRec is loaded as one dwordx4");
 
 // Flattened gain curves of all objects (device pointers).
 struct PointStore {
-  const int32_t *off;    // [M+1] first point of each object
+  const int32_t *off;    // [M] first point of each object (its region of the arena: curves.h)
+  const int32_t *cnt;    // [M] its points
   const int64_t *time;   // [P]   point times, sorted per object
   const uint8_t *flat;   // [P]   bit b: bus b's gain vector at point k equals point k-1
   const PointRec *rec;   // [P]   the same three facts per point, packed (time, 1 / segment length, flat bits)
@@ -50,7 +51,9 @@ struct PointStore {
   int row;               // floats per row (multiple of 4)
   int bus_cols;          // columns per bus (columns [b*bus_cols, (b+1)*bus_cols) = bus b)
   int nbus;              // 1 or 2; each bus is one libear GainInterpolator
-  int zero_row;          // index of an all-zero gain row (after the last point)
+  int zero_row;          // index of an all-zero gain row (the row behind it is all zero as well)
+  int npoints;           // points of all objects together
+  int rows;              // rows of the gain image (the arena: all regions, live or not)
   int force_ramp;        // policy mode: every object is ONE ramp through its 2 points,
                          // extrapolated outside (LinearInterp*::apply_interp as called directly)
 };
@@ -273,7 +276,7 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
     }
   }
   if (tile0 < ntiles && m < M) {
-    const int base = ps.off[m], n = ps.off[m + 1] - base;
+    const int base = ps.off[m], n = ps.cnt[m];
     int k = 0;
 #pragma unroll
     for (int j = 0; j < kPrepRun; j++) {
@@ -403,7 +406,7 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
     int base = 0, n = 0;
     if (dk.info & kSegMulti) {
       base = ps.off[m];
-      n = ps.off[m + 1] - base;
+      n = ps.cnt[m];
     }
     int k = seg_k(dk.info), cur = 0, step = 0;
     cp = 0;
@@ -473,7 +476,7 @@ k_slot_list(PointStore ps, int M, int tile_samples, int64_t t_call, int64_t t_ca
       if (desc) {
         d = desc[(size_t)tile * M + m];
       } else {  // no descriptor pass: find the segment here
-        const int base = ps.off[m], n = ps.off[m + 1] - base;
+        const int base = ps.off[m], n = ps.cnt[m];
         d = describe_segment(ps, base, n, upper_bound_time_window(ps.time + base, n, t0), t0, t_end);
       }
       walk(m, d, nullptr, nullptr, cp, cm, nx, true);
@@ -665,7 +668,7 @@ __global__ void __launch_bounds__(512) k_gain_mix(GainMixParams P) {
                                             P.ps.row, lane, col0, P.ps.bus_cols);
       if (!(d.info & kSegMulti)) break;
       cur = seg_end;
-      const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+      const int base = P.ps.off[m], n = P.ps.cnt[m];
       d = describe_segment(P.ps, base, n, seg_k(d.info) + 1, tile_t0, tile_t1);
     }
   }

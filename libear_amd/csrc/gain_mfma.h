@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(512) k_gain_mix_mfma(GainMixParams P) {
   // GainInterpolator::process (gain_interpolator.hpp:58-86).  Used for unaligned
   // buffers and for objects whose slots did not fit the tile's list.
   auto single_object = [&](int m) {
-    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const int base = P.ps.off[m], n = P.ps.cnt[m];
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     int k = upper_bound_time(P.ps.time + base, n, tile_t0);
     int cur = 0;

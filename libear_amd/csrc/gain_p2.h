@@ -252,7 +252,7 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
     Piece keep[kKeepPieces];
     if (in) {
       base = ps.off[m];
-      n = ps.off[m + 1] - base;
+      n = ps.cnt[m];
       kst = upper_bound_time_window(ps.time + base, n, t0);
       int k = kst;
       cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr, keep);
@@ -433,7 +433,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
-    const int base = P.ps.off[m], n = P.ps.off[m + 1] - base;
+    const int base = P.ps.off[m], n = P.ps.cnt[m];
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;

@@ -1034,3 +1034,52 @@ def test_hinge_kernel_is_chosen_for_always_ramping_curves_off_the_grid():
         r.close()
         assert plan["kernel"] == kernel, plan
         assert scenes.rel_rms_per_channel(got, run_oracle(curves, x, n, block, dec, 255)) <= 1e-6
+
+
+def test_curves_updated_object_by_object_between_block_mode_calls():
+    """interp_points is a per-object vector the caller changes freely (gain_interpolator.hpp:42-43): between block-mode
+    calls a few objects get a new window of curve points (longer ones too: their region of the curve image moves), most
+    keep theirs — the device image follows object by object (CurveSet::commit uploads what changed), the stream equals
+    the oracle's with the same updates, and a renderer whose objects are ALL set again gives the same output bit for bit."""
+    from libear_amd import capi
+    layout, block, nblocks, m = "4+5+0", 256, 14, 96
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    x = scenes.audio(m, total, seed=5)
+    rng = np.random.default_rng(17)
+
+    def window(first_block, length, shift):
+        t = (first_block + np.arange(length, dtype=np.int64)) * block + shift
+        return t, rng.uniform(0, 1, (length, n)).astype(np.float32), rng.uniform(0, 1, (length, n)).astype(np.float32)
+
+    cur = [window(0, 6, 13 * (i % 3)) for i in range(m)]  # a third of the objects on the block grid, the others off it
+    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=1)
+    full = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=1)
+    o = _oracle.ObjectsRenderer(m, n, block, dec, 255)
+    for i, (t, d, f) in enumerate(cur):
+        r.set_object_points(i, t, d, f)
+        o.set_points(i, 0, t, d)
+        o.set_points(i, 1, t, f)
+    got = np.zeros((n, total), np.float32)
+    got_full = np.zeros_like(got)
+    want = np.zeros_like(got)
+    for b in range(nblocks):
+        if b > 0:  # replace 5 objects' windows: same length, longer (the region moves), shorter
+            for j in range(5):
+                i = (7 * b + 11 * j) % m
+                cur[i] = window(b, [6, 40, 3, 9, 6][j], 13 * (i % 3))
+                t, d, f = cur[i]
+                r.set_object_points(i, t, d, f)
+                o.set_points(i, 0, t, d)
+                o.set_points(i, 1, t, f)
+        for i, (t, d, f) in enumerate(cur):
+            full.set_object_points(i, t, d, f)
+        sl = slice(b * block, (b + 1) * block)
+        got[:, sl] = r.process(x[:, sl])
+        got_full[:, sl] = full.process(x[:, sl])
+        want[:, sl] = o.process(x[:, sl])
+    r.close()
+    full.close()
+    assert np.array_equal(got, got_full)
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
