@@ -400,6 +400,10 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby);
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
  * For tests and benchmarks that must know which kernel instantiation they measured. */
 int earhip_render_last_plan(const earhip_render *r, int out[4]);
+/* Bytes of device scratch (segment descriptors, slot / piece / hinge lists) the last process call needed: sized per call
+ * from its launch plan and the curves (the piece lists from the most ramps any window of a tile's length overlaps, per
+ * object), not for the worst case. */
+int earhip_render_scratch_bytes(const earhip_render *r, size_t *bytes);
 
 /* ------------------------------------------------------------------------
  * (J) Multi-GPU exchange — no libear counterpart (libear is single-device).  Objects are

@@ -618,6 +618,12 @@ class Renderer:
         check(load().earhip_render_hinge_standby(self.h, C.byref(flag)))
         return bool(flag.value)
 
+    def scratch_bytes(self):
+        """device scratch (descriptors, lists) the last call needed"""
+        v = C.c_size_t(0)
+        check(load().earhip_render_scratch_bytes(self.h, C.byref(v)))
+        return v.value
+
     def last_plan(self):
         """launch plan of the last call: gain kernel, samples per workgroup tile, tiles, object splits"""
         out = (C.c_int * 4)()

@@ -93,9 +93,10 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   }
   // (piece lists: K0 also counts every object's ramps per tile, into the list builder's count words)
   PieceLists pl;
-  pl.pieces = reinterpret_cast<Piece *>(desc + (size_t)M * ml.ntiles);
+  pl.pieces = reinterpret_cast<Piece *>(desc);  // (the list builders need no descriptors)
   pl.M = M;
   pl.paired = ml.paired ? 1 : 0;
+  pl.slots = cs.piece_cap(ml.tile(), ml.paired);
   pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
   pl.ovf = pl.count + (size_t)8 * ml.ntiles;
   // f16x2 gain kernel: a word per tile, "some object needs the exact path here" (see gain_h2.h)
@@ -301,7 +302,7 @@ struct GainStage {
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
                             curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
                             curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share(in_stride, (size_t)nsamples));
-    desc.reserve(std::max(std::max(desc_units(n_in, ml.ntiles), piece_units(n_in, ml.ntiles)), hinge_units(n_in, ml.ntiles)));
+    desc.reserve(scratch_units(curves, ml, n_in));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,
                       out_stride, 0, desc.p, nullptr);

@@ -185,6 +185,7 @@ struct earhip_render {
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
+  size_t last_scratch_bytes = 0;  // K0 / K1 scratch the last call needed
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
                        // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
@@ -268,6 +269,16 @@ struct earhip_render {
     MixLaunch ml = plan_call(nblocks, in_stride);
 
     last_kind = ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
+    {
+      // K0 / K1 scratch for THIS plan and THESE curves (round 3: 537 MB at the headline's size for any curves).  Grows
+      // when a call needs more than any before it (a synchronising hipMalloc: curves or call lengths that change the plan)
+      const size_t need = scratch_units(*curves, ml, M);
+      if (need > desc.n) {
+        EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+        desc.reserve(need + need / 8);
+      }
+      last_scratch_bytes = need * 16;
+    }
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     const size_t part_stride = bus_stride * K * N;
     // (the bus is sized for every plan plan_mix can make, earhip_render_create; should a tuning knob push a plan
@@ -407,8 +418,10 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // smallest tile any gain kernel of this context uses (f32 MFMA: 16 * nrt samples)
     const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
     const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
-    r->desc.alloc(std::max(std::max(desc_units(r->M, max_tiles), piece_units(r->M, (max_samples + 255) / 256)),
-                           hinge_units(r->M, (max_samples + 255) / 256)));  // (the piece-list kernel's tiles: 256 or 512 samples)
+    // (the scratch of K0 / K1 — descriptors, slot, piece or hinge lists — is sized per call from the plan and the curves:
+    // process_device; here only what the grid kernel needs for the longest call)
+    r->desc.alloc((size_t)r->M * ((max_samples + 255) / 256) + 1);
+    (void)max_tiles;  // (the piece-list kernel's tiles: 256 or 512 samples)
     // Buses: [gsplit][K*N][pad4(nsamples)] per call.  Grid-level object splits (gsplit > 1) are only
     // chosen for calls with few tiles: plan_mix doubles gsplit while gsplit * (ntiles / tpw) stays below
     // 2 * num_cus, so gsplit * ntiles < (4 * num_cus + gsplit) * tpw with tiles of at most 256 samples
@@ -664,6 +677,13 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby) {
     EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + ctx->last_gate_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     *standby = (word & kGateHingeUnsafe) ? 1 : 0;
+  });
+}
+
+int earhip_render_scratch_bytes(const earhip_render *r, size_t *bytes) {
+  return guarded([&] {
+    require(r != nullptr && bytes != nullptr, "NULL argument");
+    *bytes = r->last_scratch_bytes;
   });
 }
 

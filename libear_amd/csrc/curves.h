@@ -351,6 +351,16 @@ class CurveSet {
     return tot_.span > 0 ? std::min(1.0, tot_.bad / std::max(1.0, tot_.span / kHingeTile)) : 0.0;
   }
 
+  // Slots of ONE tile's piece list (gain_p2.h) that hold it whatever the tile: every object's base piece and as many delta
+  // pieces as its curve can have ramps in one window of `tile` samples (objects beyond the per-object limits take the exact
+  // path and have none), in either layout, padding included.  (Round 3 sized the lists for 15 ramps per object and tile:
+  // 537 MB at the headline's size whatever the curves.)
+  int piece_cap(int tile, bool paired) const {
+    const int gi = tile >= 512 ? 1 : 0;
+    const long slots = paired ? (long)((M_ + 63) & ~63) + 2 * tot_.sum_r7[gi] : (long)M_ + tot_.sum_r15[gi];
+    return (int)std::min<long>(slots + 128, (long)kPieceCapPerObject * M_ + 128);
+  }
+
   // 2^k with 2^k * |gain| <= 2^14 for every gain of the set (slopes and differences of two gains stay
   // below the f16 limit 65504); 0 when the gains are not finite or beyond what a scale can fix
   float gain_scale() const {
@@ -390,6 +400,7 @@ class CurveSet {
     int64_t phase[2] = {-1, -1};  // modulo 512 / 256 when all its points share one; -1: they do not
     double span = 0, ramp = 0, npts = 0, bad = 0, points = 0;
     double incid[2] = {0, 0}, touched[2] = {0, 0}, tiles[2] = {0, 0};
+    int maxr[2] = {0, 0};  // the most ramps of this curve that any window of 256 / 512 samples overlaps
     // (its column maxima: obj_cmax_[m][row] — commit() runs inside process calls and must not allocate)
   };
   struct Obj {
@@ -448,6 +459,27 @@ class CurveSet {
         last_tile = tb;
       }
     }
+    // the most ramps any window of T samples overlaps (a bound for the delta pieces of this object in any tile of a
+    // piece list: the lists are sized from the sum of these, piece_cap()); ramp k covers samples [a_k, b_k), a step is
+    // a ramp of length one ending at its time — two pointers over the ramps in time order
+    for (int gi = 0; gi < 2; gi++) {
+      const int64_t T = gi ? 512 : 256;
+      auto is_r = [&](size_t k) { return (o.flat[k] & allflat) != allflat; };
+      auto ra = [&](size_t k) { return t[k] > t[k - 1] ? t[k - 1] : t[k] - 1; };
+      int best = 0, inside = 0;
+      size_t j = 1;
+      for (size_t i = 1; i < n; i++) {  // windows that start on the last sample of ramp i: [b_i - 1, b_i - 1 + T)
+        if (!is_r(i)) continue;
+        if (j < i) j = i, inside = 0;
+        while (j < n && (!is_r(j) || ra(j) < t[i] - 1 + T)) {
+          if (is_r(j)) inside++;
+          j++;
+        }
+        best = std::max(best, inside);
+        inside--;  // ramp i leaves the window before the next one's
+      }
+      s.maxr[gi] = force_ramp_ ? 1 : best;
+    }
     for (size_t c = 0; c < row; c++) cm[c] = 0.0f;
     for (size_t k = 0; k < n; k++) {
       const float *g = o.g.data() + k * row;
@@ -463,6 +495,7 @@ class CurveSet {
     tot_.span -= s.span, tot_.ramp -= s.ramp, tot_.npts -= s.npts, tot_.bad -= s.bad, tot_.points -= s.points;
     for (int gi = 0; gi < 2; gi++) {
       tot_.incid[gi] -= s.incid[gi], tot_.touched[gi] -= s.touched[gi], tot_.tiles[gi] -= s.tiles[gi];
+      tot_.sum_r15[gi] -= std::min(s.maxr[gi], kPieceMaxPerObject), tot_.sum_r7[gi] -= std::min(s.maxr[gi], kPairMaxPerObject);
       if (s.phase[gi] >= 0) phases_[gi].add(s.phase[gi], -1);
     }
     grid_stale_ = true;  // (a gcd cannot be un-done: recomputed over the objects' own, finish_stats)
@@ -474,6 +507,7 @@ class CurveSet {
     tot_.span += s.span, tot_.ramp += s.ramp, tot_.npts += s.npts, tot_.bad += s.bad, tot_.points += s.points;
     for (int gi = 0; gi < 2; gi++) {
       tot_.incid[gi] += s.incid[gi], tot_.touched[gi] += s.touched[gi], tot_.tiles[gi] += s.tiles[gi];
+      tot_.sum_r15[gi] += std::min(s.maxr[gi], kPieceMaxPerObject), tot_.sum_r7[gi] += std::min(s.maxr[gi], kPairMaxPerObject);
       if (s.phase[gi] >= 0) phases_[gi].add(s.phase[gi], +1);
     }
     grid_stale_ = true;
@@ -530,6 +564,7 @@ class CurveSet {
   struct Totals {
     double span = 0, ramp = 0, npts = 0, bad = 0, points = 0;
     double incid[2] = {0, 0}, touched[2] = {0, 0}, tiles[2] = {0, 0};
+    long sum_r15[2] = {0, 0}, sum_r7[2] = {0, 0};  // sums of the objects' maxr, clipped to what a list takes per object (packed / paired)
   } tot_;
   // [512, 256]: how many objects have all their points on that phase (at most M distinct ones: room for them from the
   // start — commit() must not allocate)
@@ -694,6 +729,16 @@ inline size_t bus_samples_bound(const earhip_ctx *ctx, size_t max_samples, int m
 }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml);
+
+// 16-byte units of the scratch buffer launch_gain_mix needs for a plan: descriptors (grid kernel, VALU kernel), + slot lists
+// (f32 kernel), piece lists sized from the curves, hinge lists (+ the piece lists standing by for them)
+inline size_t scratch_units(const CurveSet &cs, const MixLaunch &ml, int M) {
+  const size_t nt = (size_t)ml.ntiles;
+  if (ml.hinge) return std::max(hinge_units((size_t)M, nt), piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired)));
+  if (ml.pieces) return piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired));
+  if (ml.split || !ml.mfma) return (size_t)M * nt + 1;
+  return desc_units((size_t)M, nt);
+}
 
 // Enqueue K0 + K1.  out: [gsplit][ncols][out_stride] (part_stride floats apart)
 void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, bool strict,

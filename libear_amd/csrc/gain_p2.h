@@ -74,8 +74,8 @@ static_assert(sizeof(Piece) == 16, "Piece is loaded as one dwordx4");
 constexpr bool kChunkSums = true;
 constexpr int kPieceMaxPerObject = 15;    // delta pieces of ONE object in one tile (a curve point every 17 samples at 256-sample
                                           // tiles); beyond: the exact path
-constexpr int kPieceCapPerObject = 1 + kPieceMaxPerObject;  // capacity of a tile's list per object: the worst case fits, so a
-                                                            // list cannot overflow (537 MB of lists at 1024 objects x 1024 blocks)
+constexpr int kPieceCapPerObject = 1 + kPieceMaxPerObject;  // most slots of a tile's list per object (the lists are sized from the
+                                                            // curves: CurveSet::piece_cap — a list cannot overflow)
 constexpr int kPieceMaxTile = 512;
 constexpr int kMaxPieceObjects = 1 << 16;
 
@@ -86,7 +86,8 @@ struct PieceLists {
   int *ovf;       // [ntiles][M]: objects that take the exact per-object path
   int M;
   int paired;     // layout of a tile's list (see k_gain_mix_p2): 0 packed, 1 singles + pairs
-  __host__ __device__ int cap() const { return kPieceCapPerObject * M + 4 * 32; }
+  int slots;      // slots of a tile's list: what the curves can need (CurveSet::piece_cap), at most kPieceCapPerObject M + 128
+  __host__ __device__ int cap() const { return slots; }
   // paired layout: the pairs start here (the singles — at most one per object, padded to a chunk — lie in front)
   __host__ __device__ int pair_off() const { return (M + 63) & ~63; }
 };
@@ -94,12 +95,9 @@ struct PieceLists {
 // exact path
 constexpr int kPairMaxPerObject = 7;
 static_assert(2 * kPairMaxPerObject + 1 <= kPieceCapPerObject, "singles + pairs fit the tile's list");
-// 16-byte units of a buffer holding the descriptors (SegDesc[ntiles][M]) and, behind them, the piece lists
-__host__ __device__ inline size_t piece_units(size_t M, size_t ntiles) {
-  PieceLists pl;
-  pl.M = (int)M;
-  pl.paired = 0;
-  return M * ntiles + (size_t)pl.cap() * ntiles + (32 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
+// 16-byte units of a buffer holding the piece lists of `ntiles` tiles (slots each), their counts and exact-path lists
+__host__ __device__ inline size_t piece_units(size_t M, size_t ntiles, size_t slots) {
+  return slots * ntiles + (32 * ntiles + 4 * M * ntiles + 15) / 16 + 1;
 }
 
 // ---------------------------------------------------------------------------
