@@ -52,7 +52,7 @@ def test_every_traffic_entry_cites_a_tracked_file_that_holds_its_counters():
 
 def test_bench_lines_of_the_round_are_tracked_and_parse():
     tracked = tracked_files()
-    lines = sorted(f for f in tracked if re.match(r"profiles/r03_bench_.*\.json$", f))
+    lines = sorted(f for f in tracked if re.match(r"profiles/r04_bench_.*\.json$", f))
     assert len(lines) >= 10, lines
     for f in lines:
         d = json.loads(open(os.path.join(ROOT, f)).read().strip().splitlines()[-1])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the bench lines of every configuration / scene for profiles/ (on the GPU box):
 #   bash tools/collect_round.sh <tag>     -> gpurun_out/<tag>_bench_<name>.json
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT && mkdir -p gpurun_out
 run() { # name, bench args...
@@ -21,4 +21,10 @@ run panned --scene panned
 run panned_adm --scene panned-adm
 run levels --scene levels
 run levels_adm --scene levels-adm
+run bursty --scene bursty
+run bursty_adm --scene bursty-adm
+run bursty_moving --scene bursty-moving
+run obj512 --objects 512 --brief
+run obj256 --objects 256 --brief
+run obj128 --objects 128 --brief
 run refbench --config refbench --steps 50 --warmup 5
