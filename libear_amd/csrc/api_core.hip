@@ -10,6 +10,7 @@
 #include "gain_kernels.h"
 #include "gain_mfma.h"
 #include "gain_h2.h"
+#include "gain_h2_t1.h"
 #include "gain_p2.h"
 #include "gain_hg.h"
 
@@ -230,7 +231,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     launched = true;
   }
   if (ml.split) {
-    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+    // as many workgroups as are resident at once (a multiple of 8: a workgroup's tiles stay on its XCD), each working
+    // through its share of the tiles in one software pipeline (gain_h2.h)
+    const int per_cu = ml.tile() == 512 ? (cp.nct == 1 ? 2 : 1) : (cp.nct == 1 ? 3 : 2);
+    int wgs = std::max(8, (ctx->num_cus * per_cu / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
+    if (const char *e = getenv("EARHIP_H2_WGS")) wgs = std::max(1, atoi(e));  // tuning knob
+    wgs = std::max(wgs, ((ml.ntiles + 63) / 64 + 7) & ~7);  // (at most 64 tiles per workgroup: its redo mask)
+    if (!h2_persistent(cp.nct, ml.tile() == 512 ? 8 : 4)) wgs = ml.ntiles;  // (a tile per workgroup)
+    const dim3 bgrid(std::min(ml.ntiles, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
     // two forms of the kernel, back to back: the one the device-side mode word names runs, the other returns at once
@@ -238,19 +246,26 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #define EARHIP_H2_LAUNCH(NCT_, NW_, WIDE_)                                                                          \
   hipLaunchKernelGGL((k_gain_mix_h2<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, ps.zero_row, xs,  \
                      gs, level_cur, level_next, slow_cur, slow_next, wide_cur, wide_next);
+#define EARHIP_H2T1_LAUNCH(NCT_, NW_, WIDE_)                                                                        \
+  hipLaunchKernelGGL((k_gain_mix_h2_t1<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, ps.zero_row, xs, \
+                     gs, level_cur, level_next, slow_cur, slow_next, wide_cur, wide_next);
 #define EARHIP_H2_CASE(NCT_)                                                                                        \
   if (cp.nct == NCT_) {                                                                                             \
     if (ml.tile() == 512) {                                                                                         \
       if (wide_cur) EARHIP_H2_LAUNCH(NCT_, 8, false)                                                                \
       EARHIP_H2_LAUNCH(NCT_, 8, true)                                                                               \
+    } else if (NCT_ == 1) {                                                                                         \
+      if (wide_cur) EARHIP_H2_LAUNCH(1, 4, false)                                                                   \
+      EARHIP_H2_LAUNCH(1, 4, true)                                                                                  \
     } else {                                                                                                        \
-      if (wide_cur) EARHIP_H2_LAUNCH(NCT_, 4, false)                                                                \
-      EARHIP_H2_LAUNCH(NCT_, 4, true)                                                                               \
+      if (wide_cur) EARHIP_H2T1_LAUNCH(NCT_, 4, false)                                                              \
+      EARHIP_H2T1_LAUNCH(NCT_, 4, true)                                                                             \
     }                                                                                                               \
   }
     EARHIP_H2_CASE(1) EARHIP_H2_CASE(2) EARHIP_H2_CASE(3)
 #undef EARHIP_H2_CASE
 #undef EARHIP_H2_LAUNCH
+#undef EARHIP_H2T1_LAUNCH
     launched = true;
   }
 #define EARHIP_MIX_CASE(NOUT_, SPL_, STRICT_)                                   \

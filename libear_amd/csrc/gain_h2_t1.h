@@ -1,93 +1,13 @@
-// gain_h2.h — K1 on the f16 matrix cores with every fp32 operand split into TWO f16
-// pieces after an exact power-of-two prescale ("f16x2").  The bus-forming contraction of
-// gain_mfma.h,
-//
-//     bus[col][s] = sum_m x_m(s) * g_m,col(s),      g linear in s on a curve segment,
-//
-// with the ramp moved to the gain side.  For a workgroup tile starting at sample s0
-//
-//     g(s) = B0 + (s - s0) * B1,   B0 = (1-p0)*S + p0*E  (libear's gain AT s0,
-//                                  gain_interpolator.hpp:272-274),
-//                                  B1 = scale * (E - S)  (slope per sample)
-//
-// so  bus = sum_m x*B0 + (s - s0) * sum_m x*B1 : two plain products with the SAME left
-// operand x, and (s - s0) is applied to the accumulator rows.  x is split once per sample
-// and object; B0/B1 are split once per workgroup tile and object and shared by the
-// workgroup's waves through LDS.  The f32-in MFMA runs at the vector rate (157 TFLOP/s:
-// 0.70 ms for the headline scene, above its HBM floor of 0.33 ms); the f16 MFMA at 16x that:
-//
-//   * v * 2^k = h + l with f16 pieces (11 + 11 significand bits, RNE, residual exact in
-//     fp32) is good to 2^-22 relative as long as l is a normal f16, i.e. over 2^16 / 2^-3
-//     = 19 binades below the top of the f16 range; below that the error is 2^-25 ABSOLUTE
-//     in scaled units.  The prescale puts the operands at the top of the range: the gains
-//     by 2^14 / (largest |gain| of the curve set, rounded up to a power of two; known at
-//     commit), the inputs of a call by 2^7 / (the level K0 probes in them; EARHIP_XSCALE: a fixed
-//     scale);
-//   * of the four partial products the three of order >= 2^-11 are kept: xl*bh, xh*bl,
-//     xh*bh (relative error of the contraction on the headline scene: 7e-8, see
-//     tests/test_gpu_render.py and DESIGN.md section 4 / NOTES.md);
-//   * products of f16 pairs are exact in the fp32 accumulate of
-//     v_mfma_f32_16x16x32_f16, so the chunks accumulate straight into two running sets of
-//     accumulators (B0 terms and B1 terms: no per-chunk fold), in scaled units; the ramp
-//     factor (s - s0) and the inverse scale are applied once per tile;
-//   * an input outside the f16 range after the prescale (|x| * scale >= 65520, or a
-//     non-finite sample) turns the tile's accumulators non-finite: the wave then
-//     recomputes its tile with the exact f32 MFMA path, unscaled.  Correct for any input,
-//     fast for audio.
-//
-// Fragment layout of v_mfma_f32_16x16x32_f16 (8 f16 = 4 VGPRs per operand):
-//   A: lane l holds row l&15, k = 8*(l>>4) .. +7     B: column l&15, same k
-//   D: lane l holds column l&15, rows 4*(l>>4) + e, e = 0..3
-// k = the 32 objects of a chunk; row i of row tile r = sample 4*i + r of the wave's
-// 64-sample tile (a lane's 4 inputs of one object are one 16-byte load and the D fragments
-// of the 4 row tiles interleave into float4 stores); column j of column tile c = bus column
-// col0 + 16*c + j.
-//
-// Objects with a curve point inside the workgroup tile, unaligned buffers and partial tiles
-// use the exact f32 MFMA on the same accumulators (slow path, same arithmetic as
-// gain_mfma.h).
+// gain_h2_t1.h — the f16x2 grid kernel of gain_h2.h in its form with ONE tile per workgroup, kept for the 4-wave
+// instantiations with two or three column tiles (256-sample tiles, 17-48 output columns): two such workgroups share a
+// CU and cover each other's pipeline ends, and with the tile end inside the chunk loop (gain_h2.h: a workgroup working
+// through several tiles) these instantiations no longer fit the register file (0.50 -> 0.55 ms on the headline scene at
+// 256-sample tiles).  Same arithmetic, same operands, same results; see gain_h2.h for the method.
 #pragma once
 
-#include <hip/hip_runtime.h>
-
-#include <type_traits>
-
-#include "gain_kernels.h"
-#include "gain_mfma.h"
+#include "gain_h2.h"
 
 namespace earhip {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kSplitTile = 256;   // samples per workgroup tile of the 4-wave kernel (descriptor tile)
-constexpr int kSplitChunk = 32;   // objects per MFMA (k)
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-
-// two floats -> packed f16 pair, round to nearest even (v_cvt_pk_f16_f32)
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
-}
-__device__ __forceinline__ float f16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
-__device__ __forceinline__ float f16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
-
-// Wide mode: the low piece of an input is kept as (residual x 2^11) and multiplied with (h x 2^-11) of the gain —
-// both exact scalings, the same product — so that it is a normal f16 over 21 binades below the level the prescale
-// aims at instead of 11 (measured relative RMS of the products: 6.5e-8 down to 2^-18, 1.4e-7 at 2^-20, 5e-7 at
-// 2^-22; with the plain residual 2.5e-7 at 2^-10 and 1e-6 at 2^-12).
-constexpr float kLowPieceScale = 2048.0f;
-__device__ __forceinline__ uint32_t scale_f16x2_down(uint32_t h) {  // both halves x 2^-11 (exact unless subnormal)
-  const f16x2_t k = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2_t, h) * k);
-}
-
-__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
-                                                0, 0, 0);
-}
 
 // P.ntiles / P.desc refer to WORKGROUP tiles of kSplitTile samples.  x_scale: an exact power of two (see
 // above); gcol: [row] per-COLUMN gain scales, powers of two that put the largest gain a column ever gets at 2^14
@@ -104,11 +24,9 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
 // conversion of a chunk's gains is shared by the whole workgroup, so the 512-sample tile halves that
 // work (and the gain rows' L2 traffic) when no curve point falls inside 512-sample tiles.
-// (the 4-wave forms with two or three column tiles: gain_h2_t1.h, a tile per workgroup)
-constexpr bool h2_persistent(int nct, int nw) { return nw == 8 || nct == 1; }
 template <int NCT, int NW, bool WIDE>
-__global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 4 : (NW == 4 ? 2 : 1))
-k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
+__global__ void __launch_bounds__(64 * NW, 2)
+k_gain_mix_h2_t1(GainMixParams P, int zero_row, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next, const unsigned *wide_cur, unsigned *wide_next) {
   if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
@@ -126,13 +44,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
-  // A workgroup works through the tiles vb = blockIdx.x, + gridDim.x, ... (< P.ntiles; the host launches as many
-  // workgroups as are resident at once): ONE software pipeline runs through all of them, so the requests of a
-  // tile's first chunks are in flight while the tile before is finished and stored.  (A workgroup per tile spent
-  // 8-11 us per tile outside its chunk loop — filling the pipeline, draining it, storing — with nothing else on
-  // the CU to cover it: 8 % of the kernel at 32 chunks per tile, a quarter at 4.)  vb % 8 = the XCD for every
-  // tile of a workgroup when gridDim.x is a multiple of 8.
-  const int ntl = P.ntiles, gx = gridDim.x;
+  const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
   if (wide_next && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *wide_next = 0u;
   if (level_cur) {
     // input scale of THIS call from the level K0 probed: the largest magnitude seen, in [2^E, 2^(E+1)),
@@ -147,24 +59,22 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *level_next = 0;
   }
+  // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0 and
+  // k_mark_quiet leave a word per tile; this call clears the words of the call after next (they alternate).
+  const bool any_slow = !slow_cur || slow_cur[wgtile] != 0u;
+  if (slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[wgtile] = 0u;
   const int nparts = gridDim.y;
   const int part = blockIdx.y;
   const int m_lo = (int)(((int64_t)P.M * part) / nparts);
   const int m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
   const int col0 = blockIdx.z * 16 * NCT;
+  const int tile_s0 = wgtile * (TS * NW) + w * TS;  // first sample of this wave's tile
+  const int tile_len = max(0, min(TS, P.nsamples - tile_s0));
+  const int64_t tile_t0 = P.t_call + tile_s0;
+  const int64_t tile_t1 = tile_t0 + tile_len;
+  const SegDesc *__restrict__ dtile = P.desc + (size_t)wgtile * P.M;
   const float *__restrict__ gain = P.ps.gain;
   const unsigned rowlen = (unsigned)P.ps.row;
-  // (per-tile values are made from the tile index where they are needed: wave-uniform, a few scalar instructions,
-  // instead of registers held through the chunk loop)
-  auto tile_first = [&](int t) { return t * (TS * NW) + w * TS; };  // first sample of this wave's part of tile t
-  auto tile_length = [&](int t) { return max(0, min(TS, P.nsamples - tile_first(t))); };
-  // the rare paths below make their lane numbers anew (from a value the compiler cannot see through) so that nothing
-  // of theirs is kept in registers through the chunk loop
-  auto opaque_lane = [&]() __attribute__((always_inline)) {
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    return l;
-  };
 
   // running totals in scaled units: bus = (tot0 + (s - s0) tot1) / (x_scale g_scale)
   f32x4 tot0[NRT][NCT], tot1[NRT][NCT];
@@ -185,11 +95,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   // khint >= 0: the segment index K0 found at the start of the WORKGROUP tile (the search then only
   // walks on from there: a few steps instead of log2 n dependent loads per object and wave)
   // (sg: the gains are scaled by their column's scale, like the split operands — or not at all)
-  auto single_object = [&](int t, int m, float sx, bool sg, int khint = -1) __attribute__((always_inline)) {
-    const int tile_s0 = tile_first(t), tile_len = tile_length(t);
+  auto single_object = [&](int m, float sx, bool sg, int khint = -1) {
     if (tile_len <= 0) return;
-    const int64_t tile_t0 = P.t_call + tile_s0, tile_t1 = tile_t0 + tile_len;
-    const int ol = opaque_lane(), li = ol & 15, kg = ol >> 4;
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
@@ -238,101 +145,17 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
 
   const int nobj = m_hi - m_lo;
   const int nch = (P.vec_ok && nobj >= CH) ? (nobj + CH - 1) / CH : 0;
-  // the tile is done: scale, apply the ramp factor, store (and start the next tile's totals from zero).  inv_x: the
-  // inverse of the input scale the totals carry (exact: a power of two); col_scaled: they are in units of 1 / (the
-  // column's gain scale) as well
-  auto flush_tile = [&](int t, float inv_x, bool col_scaled) __attribute__((always_inline)) {
-    const int tile_s0 = tile_first(t), tile_len = tile_length(t);
-    if (tile_len > 0) {
-      const int ol = opaque_lane(), li = ol & 15, kg = ol >> 4;
-      // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
-      // four row tiles are 4 consecutive samples.  (s - s0) of the rows: sample 64w + 16kg + 4e + r.
-      const float wf0 = (float)(w * TS + kg * 16);
-      float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
-#pragma unroll
-      for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
-      float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
-      const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
-#pragma unroll
-      for (int c = 0; c < NCT; c++) {
-        if (whole) {
-          // Through wave-private LDS: written straight from the fragments, one store instruction covers 4 columns x
-          // 64 bytes in 16-byte pieces (64 scattered pieces per instruction: the stores of the 100 MB of buses cost a
-          // tenth of this kernel's time, a quarter at 256 objects); transposed, it covers 4 whole 256-byte rows.  The
-          // rows are written past the caches (K2 reads them once, much later: headline K1 0.437 -> 0.412 ms).
-          float *ot = otile[w];
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < NRT; r++)
-              v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
-            *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++) {  // lane: column 4 j + (lane >> 4), samples 4 (lane & 15) .. + 3
-            const int cl = 4 * j + kg, col = col0 + c * 16 + cl;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + cl * OP + li * 4);
-            if (col < P.ncols) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(op + (size_t)col * P.out_stride + li * 4));
-          }
-          continue;
-        }
-        const int col = col0 + c * 16 + li;
-        if (col >= P.ncols) continue;
-        float *o = op + (size_t)col * P.out_stride;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int s = kg * 16 + e * 4;
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < NRT; r++)
-            v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
-          if (P.vec_ok && s + 3 < tile_len) {
-            *reinterpret_cast<f32x4 *>(o + s) = v;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-              if (s + i < tile_len) o[s + i] = v[i];
-          }
-        }
-      }
+  float inv_x = 1.0f / x_scale;  // exact: a power of two
+  bool col_scaled = true;        // the totals are in units of 1 / (x_scale x the column's gain scale)
 
-    }
-    clear_totals();
-  };
-
-  // the workgroup's tiles that a wave has to redo exactly (bit k: its k-th tile; at most 64: the host's grid), kept in
-  // LDS: set once in a blue moon, read once
-  __shared__ unsigned long long redo_tiles[NW];
-  if (lane == 0) redo_tiles[w] = 0ull;
   if (nch > 0) {
     // lane-constant part of the input address: byte offset of this lane's float4 (lanes past the
     // end of the call re-read the last vector; never stored).  All loads below are (wave-uniform
     // 64-bit base) + (32-bit lane offset).  The last chunk is moved back to end at m_hi (its objects
     // that the previous chunk already covered get the zero row).
-    // (the tile enters as a wave-uniform offset: the requests of a chunk may belong to the tile after the one
-    // whose totals are being accumulated)
     const int nvec = (P.nsamples + 3) & ~3;
-    const unsigned xrow = (unsigned)(kg * 8) * (unsigned)P.in_stride * 4u;
-    const int xsl = w * TS + li * NRT;  // the lane's first sample within a workgroup tile
-    // where the pipeline stands: stage A = the chunk whose MFMAs run, B = the next one (its gains are requested
-    // and converted during A), C = the one after (its descriptors and inputs are requested during A): tile index
-    // and chunk within the tile of each; `left` = chunks this workgroup still has to do, A included (B is live
-    // while left > 1, C while left > 2; stages past the end stay on the last tile: their requests are never used)
-    struct Stage {
-      int tile, c;
-    };
-    const int my_tiles = (ntl - (int)blockIdx.x + gx - 1) / gx;
-    int left = my_tiles * nch;
-    int vb_c = blockIdx.x;  // stage C's tile counter
-    auto next_stage = [&](const Stage &s) __attribute__((always_inline)) {
-      Stage n;
-      const bool wrap = s.c + 1 == nch;
-      n.c = wrap ? 0 : s.c + 1;
-      if (wrap) vb_c = min(vb_c + gx, ntl - 1);
-      n.tile = wrap ? xcd_tile(vb_c, ntl) : s.tile;
-      return n;
-    };
+    const unsigned xs = (unsigned)min(tile_s0 + li * NRT, nvec - 4);
+    const unsigned xlane = ((unsigned)(kg * 8) * (unsigned)P.in_stride + xs) * 4u;
     const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
     const float g_scale = gcol[bcol_e];                                   // ... and that column's scale (a power of two)
     // fragment this lane fills: B0 pieces at bfr, bfr+1, B1 pieces NCT*2 further
@@ -344,17 +167,17 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     // inputs q0 .. q0 + n - 1 of chunk c.  Past the last chunk (the two-chunks-ahead requests of the
     // last two chunks: never used) every lane of every request reads the same 16 bytes instead of 64
     // lines per wave that would occupy the CU's miss slots for nothing (6 % of the input requests).
-    auto load_x_part = [&](const Stage &st, bool live, f32x4 (&x)[8], int q0, int n) {
-      const int ts0 = st.tile * (TS * NW);
-      const char *bp = reinterpret_cast<const char *>(P.in + (live ? (size_t)chunk_base(st.c) * P.in_stride + ts0 : 0));
+    auto load_x_part = [&](int c, f32x4 (&x)[8], int q0, int n) {
+      const bool live = c < nch;
+      const char *bp = reinterpret_cast<const char *>(P.in + (live ? (size_t)chunk_base(c) * P.in_stride : 0));
       const size_t rstride = live ? P.in_stride * sizeof(float) : 0;
-      const unsigned xo = live ? xrow + 4u * (unsigned)min(xsl, nvec - 4 - ts0) : 0u;
+      const unsigned xo = live ? xlane : 0u;
 #pragma unroll
       for (int q = 0; q < 8; q++)
         if (q >= q0 && q < q0 + n)
           x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (size_t)q * rstride + xo));
     };
-    auto load_x = [&](const Stage &st, bool live, f32x4 (&x)[8]) { load_x_part(st, live, x, 0, 8); };
+    auto load_x = [&](int c, f32x4 (&x)[8]) { load_x_part(c, x, 0, 8); };
     // What this WAVE converts for chunk c: objects chunk_base + NQ w + q.  Their descriptors are
     // wave-uniform: scalar loads (requested one chunk ahead), scalar row arithmetic, and the
     // gain rows come in as (scalar row pointer) + (the lane's column).
@@ -365,8 +188,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     struct ChunkDesc {
       SegDesc d[NQ];
     };
-    auto load_desc = [&](const Stage &st) {
-      ConstDesc dp = (ConstDesc)(P.desc + (size_t)st.tile * P.M + chunk_base(st.c) + w * NQ);
+    auto load_desc = [&](int c) {
+      const int cc = min(c, nch - 1);
+      ConstDesc dp = (ConstDesc)(dtile + chunk_base(cc) + w * NQ);
       ChunkDesc D;
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
@@ -380,7 +204,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     struct ChunkCoef {
       float p0[NQ], scale[NQ];
     };
-    auto load_gains = [&](const ChunkDesc &R, int cc, ChunkCoef &D, float (&S)[NQ], float (&E)[NQ]) {
+    auto load_gains = [&](const ChunkDesc &R, int c, ChunkCoef &D, float (&S)[NQ], float (&E)[NQ]) {
+      const int cc = min(c, nch - 1);
       const int m0 = chunk_base(cc) + w * NQ;
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
@@ -439,30 +264,24 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     // converted while those are in flight.
     f32x4 X0[8], X1[8];
     ChunkDesc L;
-    Stage sa, sb, sc;
-    sa.tile = xcd_tile(vb_c, ntl);
-    sa.c = 0;
-    sb = next_stage(sa);
-    sc = next_stage(sb);
-    int ka = 0;  // stage A's tile is the workgroup's ka-th
     {
       float S[NQ], E[NQ];
       ChunkCoef D;
-      L = load_desc(sa);
+      L = load_desc(0);
       load_gains(L, 0, D, S, E);
-      load_x(sa, true, X0);
-      load_x(sb, left > 1, X1);
+      load_x(0, X0);
+      load_x(1, X1);
       store_b(D, S, E, 0, 0);
       store_b(D, S, E, 0, 1);
-      L = load_desc(sb);
+      L = load_desc(1);
     }
-    // the chunk of stage A: inputs in xc, B fragments in bfrag[buf]
-    auto chunk = [&](int buf, f32x4 (&xc)[8]) __attribute__((always_inline)) {
-      __syncthreads();  // B fragments of this chunk are in bfrag[buf]; bfrag[buf^1] is free
+    // chunk c: inputs in xc, B fragments in bfrag[buf]
+    auto chunk = [&](int c, int buf, f32x4 (&xc)[8]) {
+      __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free
       float S[NQ], E[NQ];
       ChunkCoef D;
-      load_gains(L, sb.c, D, S, E);  // the next chunk (its descriptors were fetched one chunk ago)
-      L = load_desc(sc);
+      load_gains(L, c + 1, D, S, E);  // chunk c+1 (its descriptors were fetched one chunk ago)
+      L = load_desc(c + 2);
       __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input (see above)
 
       // A fragments: row tile r = sample 4*li + r of the 8 objects of this lane.  2 x 2
@@ -528,7 +347,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
         }
 #pragma unroll
         for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(ah[r], bc[0], tt[r][ct]);
-        if (blk < XB) load_x_part(sc, left > 2, xc, blk * (8 / XB), 8 / XB);
+        if (blk < XB) load_x_part(c + 2, xc, blk * (8 / XB), 8 / XB);
         const bool conv0 = blk == NBLK - 2, conv1 = blk == NBLK - 1;
         if (conv0) store_b(D, S, E, buf ^ 1, 0);  // next chunk's gains (after the last chunk:
         if (conv1) store_b(D, S, E, buf ^ 1, 1);  // written, never read)
@@ -557,70 +376,95 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
         }
       }
     };
-    // what follows a chunk: the end of its tile (exact-path objects, the check of the totals, the stores), and
-    // the pipeline moves on
-    auto tile_end = [&](int t) __attribute__((always_inline)) {
-      {
-        // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0 and
-        // k_mark_quiet leave a word per tile; this call clears the words of the call after next (they alternate).
-        // (a scalar load: a vector load here would have to wait for every input request in flight)
-        typedef const unsigned __attribute__((address_space(4))) *ConstWord;
-        const bool any_slow = !slow_cur || ((ConstWord)slow_cur)[t] != 0u;
-        if (slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[t] = 0u;
-        // objects with curve points inside this workgroup tile (zero rows above)
-        for (int b0 = 0; any_slow && b0 < nobj; b0 += 64) {
-          const int ol = opaque_lane();
-          const SegDesc db = (P.desc + (size_t)t * P.M)[min(m_lo + b0 + ol, m_hi - 1)];
-          unsigned long long multi = __ballot((db.info & (kSegMulti | kSegQuiet)) && b0 + ol < nobj);
-          while (multi) {
-            const int j = __builtin_ctzll(multi);
-            multi &= multi - 1;
-            // (the k field of a descriptor is exact for these objects: the piece ends inside the tile)
-            single_object(t, m_lo + b0 + j, x_scale, true, seg_k(__shfl(db.info, j)));
-          }
-        }
-        // an input beyond the f16 range (or not finite) shows as non-finite totals: the wave's tile is redone
-        // exactly, unscaled, behind the chunk loop
-        bool bad = false;
+#pragma unroll 1
+    for (int c = 0; c < nch; c += 2) {
+      chunk(c, 0, X0);
+      if (c + 1 < nch) chunk(c + 1, 1, X1);
+    }
+
+    // objects with curve points inside this workgroup tile (zero rows above)
+    for (int b0 = 0; any_slow && b0 < nobj; b0 += 64) {
+      const SegDesc db = dtile[min(m_lo + b0 + lane, m_hi - 1)];
+      unsigned long long multi = __ballot((db.info & (kSegMulti | kSegQuiet)) && b0 + lane < nobj);
+      while (multi) {
+        const int j = __builtin_ctzll(multi);
+        multi &= multi - 1;
+        // (the k field of a descriptor is exact for these objects: the piece ends inside the tile)
+        single_object(m_lo + b0 + j, x_scale, true, seg_k(__shfl(db.info, j)));
+      }
+    }
+    // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the
+    // wave's tile exactly, unscaled
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < NRT; r++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
+    if (__ballot(bad)) {
+      clear_totals();
+      inv_x = 1.0f;
+      col_scaled = false;
+      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);
+    }
+  } else {
+    inv_x = 1.0f;
+    col_scaled = false;
+    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);  // unaligned rows
+  }
+
+  if (tile_len <= 0) return;
+  // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
+  // four row tiles are 4 consecutive samples.  (s - s0) of the rows: sample 64w + 16kg + 4e + r.
+  const float wf0 = (float)(w * TS + kg * 16);
+  float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
+#pragma unroll
+  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
+  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
+  const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
+#pragma unroll
+  for (int c = 0; c < NCT; c++) {
+    if (whole) {
+      // Through wave-private LDS: written straight from the fragments, one store instruction covers 4 columns x
+      // 64 bytes in 16-byte pieces (64 scattered pieces per instruction: the stores of the 100 MB of buses cost a
+      // tenth of this kernel's time, a quarter at 256 objects); transposed, it covers 4 whole 256-byte rows.  The
+      // rows are written past the caches (K2 reads them once, much later: headline K1 0.437 -> 0.412 ms).
+      float *ot = otile[w];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        f32x4 v;
 #pragma unroll
         for (int r = 0; r < NRT; r++)
-#pragma unroll
-          for (int c = 0; c < NCT; c++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) bad |= !(__builtin_fabsf(tot0[r][c][e]) < INFINITY) || !(__builtin_fabsf(tot1[r][c][e]) < INFINITY);
-        if (__ballot(bad)) {
-          if (lane == 0) redo_tiles[w] |= 1ull << ka;
-          clear_totals();
-        } else {
-          flush_tile(t, 1.0f / x_scale, true);
-        }
-        ka++;
+          v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
+        *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
       }
-    };
-    auto advance = [&]() __attribute__((always_inline)) {
-      if (sa.c == nch - 1) tile_end(sa.tile);
-      sa = sb;
-      sb = sc;
-      sc = next_stage(sc);
-      left--;
-    };
-#pragma unroll 1
-    while (left > 0) {
-      chunk(0, X0);
-      advance();
-      if (left <= 0) break;
-      chunk(1, X1);
-      advance();
+#pragma unroll
+      for (int j = 0; j < 4; j++) {  // lane: column 4 j + (lane >> 4), samples 4 (lane & 15) .. + 3
+        const int cl = 4 * j + kg, col = col0 + c * 16 + cl;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + cl * OP + li * 4);
+        if (col < P.ncols) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(op + (size_t)col * P.out_stride + li * 4));
+      }
+      continue;
     }
-  }
-  // tiles done exactly and unscaled: every tile of unaligned rows or of fewer objects than a chunk, and the tiles
-  // whose totals were not finite
-  for (int k = 0, vb = blockIdx.x; vb < ntl; k++, vb += gx) {
-    if (nch > 0 && !((redo_tiles[w] >> (k & 63)) & 1ull)) continue;
-    const int t = xcd_tile(vb, ntl);
-    if (nch == 0 && slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[t] = 0u;
-    for (int m = m_lo; m < m_hi; m++) single_object(t, m, 1.0f, false);
-    flush_tile(t, 1.0f, false);
+    const int col = col0 + c * 16 + li;
+    if (col >= P.ncols) continue;
+    float *o = op + (size_t)col * P.out_stride;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int s = kg * 16 + e * 4;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < NRT; r++)
+        v[r] = (__builtin_fmaf(wf0 + (float)(4 * e + r), tot1[r][c][e], tot0[r][c][e]) * inv_x) * inv_gc[c];
+      if (P.vec_ok && s + 3 < tile_len) {
+        *reinterpret_cast<f32x4 *>(o + s) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (s + i < tile_len) o[s + i] = v[i];
+      }
+    }
   }
 }
 
