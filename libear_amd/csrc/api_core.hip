@@ -115,20 +115,31 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // hinge kernel: its own list builder (k_hinge_build, gain_hg.h) behind the same probe launch
   HingeLists hl = hinge_lists(desc, M, ml.ntiles);
   if (ml.hinge) {
-    if (M > kMaxHingeCached || ml.tile() != kHingeTile) fail_internal("hinge lists: object count or tile out of range");
+    if (M > kMaxHingeCached || (ml.tile() != 256 && ml.tile() != 512)) fail_internal("hinge lists: object count or tile out of range");
     // (the kernel addresses input rows and gain rows with 32-bit byte offsets; plan_mix only picks it within these limits)
-    if (!hinge_addressable(M, in_stride, nsamples, ps.rows, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
+    if (!ps.kink_row0) fail_internal("hinge kernel: the curve set has no kink rows");
+    if (!hinge_addressable(M, in_stride, nsamples, (size_t)ps.kink_row0 + ps.rows, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
     unsigned *obj_lv = probe.obj_level;
     // with a probe: does the hinge kernel's span of levels cover this call?  (decided on the device: k_hinge_gate)
     if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate);
     int tpw = 1;
     while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
+    if (const char *e = getenv("EARHIP_HBUILD_TPW")) {  // tuning knob
+      const int v = atoi(e);
+      if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)M * v <= (size_t)kMaxHingeCached) tpw = v;
+    }
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
     const size_t lds = sizeof(int) * (size_t)M * tpw;
 #define EARHIP_HBUILD_CASE(T_)                                                                                        \
   if (tpw == T_)                                                                                                      \
-    hipLaunchKernelGGL(k_hinge_build<T_>, bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                       t_call + nsamples, hl, obj_lv, level_cur, gate);
+  {                                                                                                                   \
+    if (ml.tile() == 256)                                                                                             \
+      hipLaunchKernelGGL((k_hinge_build<T_, 4>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
+                         t_call + nsamples, hl, obj_lv, level_cur, gate);                                             \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_hinge_build<T_, 8>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
+                         t_call + nsamples, hl, obj_lv, level_cur, gate);                                             \
+  }
     EARHIP_HBUILD_CASE(1) EARHIP_HBUILD_CASE(2) EARHIP_HBUILD_CASE(4) EARHIP_HBUILD_CASE(8)
 #undef EARHIP_HBUILD_CASE
   }
@@ -206,8 +217,12 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
 #define EARHIP_HG_CASE(NCT_)                                                                                          \
-  if (cp.nct == NCT_)                                                                                                 \
-    hipLaunchKernelGGL((k_gain_mix_hg<NCT_>), bgrid, dim3(256), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next, gate);
+  if (cp.nct == NCT_) {                                                                                               \
+    if (ml.tile() == 256)                                                                                             \
+      hipLaunchKernelGGL((k_gain_mix_hg<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next, gate); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_gain_mix_hg<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next, gate); \
+  }
     EARHIP_HG_CASE(1) EARHIP_HG_CASE(2) EARHIP_HG_CASE(3)
 #undef EARHIP_HG_CASE
     launched = true;
@@ -317,6 +332,7 @@ struct GainStage {
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
                             curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
                             curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share(in_stride, (size_t)nsamples));
+    if (ml.hinge) curves.ensure_kinks(ctx);
     desc.reserve(scratch_units(curves, ml, n_in));
     if (ml.gsplit == 1) {
       launch_gain_mix(ctx, curves, ml, strict, t_call, nsamples, in_dev, in_stride, out_dev,

@@ -267,6 +267,7 @@ struct earhip_render {
     curves->commit(ctx);
     const bool strict = ctx->strict;
     MixLaunch ml = plan_call(nblocks, in_stride);
+    if (ml.hinge) curves->ensure_kinks(ctx);
 
     last_kind = ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     {

@@ -225,7 +225,7 @@ class CurveSet {
       std::swap(h_flat_.p, nf.p), std::swap(h_flat_.n, nf.n);
       std::swap(h_rec_.p, nr.p), std::swap(h_rec_.n, nr.n);
       std::swap(h_gain_.p, ng.p), std::swap(h_gain_.n, ng.n);
-      d_time_.alloc(cap), d_flat_.alloc(cap), d_rec_.alloc(cap), d_gain_.alloc(cap * row);
+      d_time_.alloc(cap), d_flat_.alloc(cap), d_rec_.alloc(cap), d_gain_.alloc(cap * row * (kinks_ ? 2 : 1));
       arena_cap_ = cap;
       full_upload = true;
     }
@@ -301,12 +301,36 @@ class CurveSet {
                          (int)row);
       EARHIP_HIP(hipGetLastError());
     }
+    // kink rows (hinge kernel; once it has been planned for this set): of the changed objects, or of everybody when
+    // everything went up again or a column's scale changed
+    if (kinks_) {
+      const bool all = full_upload || gcol_changed || dirty_list_.size() > (size_t)M_ / 4;
+      if (!all)  // (h_changed_ holds the list: the partial upload above wrote it)
+        for (size_t i = 0; i < dirty_list_.size(); i++) h_changed_.p[i] = dirty_list_[i];
+      derive_kinks(ctx, all ? nullptr : h_changed_.p, all ? M_ : (int)dirty_list_.size());
+    }
     if (!staged_) EARHIP_HIP(hipEventCreateWithFlags(&staged_, hipEventDisableTiming));
     EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
     for (int m : dirty_list_) obj_[m].dirty = false;
     dirty_list_.clear();
     uploaded_once_ = true;
   }
+
+  // The hinge kernel has been planned for this set: from now on it keeps a kink row per point (gain_hg.h) behind the
+  // gain rows, in the same buffer (twice its size; sets that never meet that kernel never pay for it).  Called with
+  // everything committed; the first call re-allocates and sends the gain rows again.
+  void ensure_kinks(earhip_ctx *ctx) {
+    if (kinks_) return;
+    kinks_ = true;
+    const size_t row = (size_t)plan_.row;
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // the old image may still be in use
+    d_gain_.alloc(arena_cap_ * row * 2);
+    EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, arena_used_ * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    derive_kinks(ctx, nullptr, M_);
+    if (!staged_) EARHIP_HIP(hipEventCreateWithFlags(&staged_, hipEventDisableTiming));
+    EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
+  }
+  bool has_kinks() const { return kinks_; }
 
   // true when no curve point can fall strictly inside a tile of `tile` samples of a
   // call that starts at t_call (all point times lie on tile boundaries)
@@ -347,7 +371,7 @@ class CurveSet {
   // the tile they share about every other time); > 1: not a curve set for it.
   // (in_stride, nsamples: the input rows of the call — the kernel addresses them, and the gain rows, with 32-bit offsets)
   double hinge_exact_share(size_t in_stride, size_t nsamples) const {
-    if (force_ramp_ || !hinge_addressable((size_t)M_, in_stride, nsamples, arena_used_, (size_t)plan_.row)) return 2.0;
+    if (force_ramp_ || !hinge_addressable((size_t)M_, in_stride, nsamples, 2 * arena_cap_, (size_t)plan_.row)) return 2.0;
     return tot_.span > 0 ? std::min(1.0, tot_.bad / std::max(1.0, tot_.span / kHingeTile)) : 0.0;
   }
 
@@ -388,11 +412,21 @@ class CurveSet {
     ps.zero_row = 0;
     ps.npoints = (int)tot_.points;
     ps.rows = (int)arena_used_;
+    ps.kink_row0 = kinks_ ? (int)arena_cap_ : 0;
     ps.force_ramp = force_ramp_ ? 1 : 0;
     return ps;
   }
 
  private:
+  void derive_kinks(earhip_ctx *ctx, const int32_t *objects, int count) {
+    const size_t row = (size_t)plan_.row;
+    uint32_t *kink = reinterpret_cast<uint32_t *>(d_gain_.p + arena_cap_ * row);
+    // (rows 0 and 1 of the kink image: all zero, like the gain rows they stand behind)
+    EARHIP_HIP(hipMemsetAsync(kink, 0, 2 * row * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_kink_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_off_.p, d_cnt_.p, d_rec_.p, d_gain_.p, kink,
+                       d_gcol_.p, objects, (int)row, nbus_);
+    EARHIP_HIP(hipGetLastError());
+  }
   // what ONE object's curve contributes to the statistics of the set
   struct ObjStats {
     uint64_t gcd = 0;        // of the differences of its point times
@@ -594,6 +628,7 @@ class CurveSet {
   DevBuf<uint8_t> d_flat_;
   DevBuf<PointRec> d_rec_;
   DevBuf<float> d_gcol_, d_gain_;
+  bool kinks_ = false;  // d_gain_ is twice as long: the kink rows behind the gain rows (ensure_kinks)
   PinBuf<float> h_gcol_, h_gain_;
   PinBuf<int32_t> h_off_, h_cnt_, h_changed_;
   PinBuf<int64_t> h_time_;
@@ -611,11 +646,12 @@ struct MixLaunch {
   int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
   bool paired = false;         // with pieces: the lists' paired layout (gain_p2.h)
   bool hinge = false;          // matrix-core kernel on f16x2 split operands with the curve points inside a tile as hinges (gain_hg.h)
+  int hinge_tile = 512;        // with hinge: 512 (8 waves, up to two kinks on either side of a tile's centre) or 256 (4 waves, one)
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
   int tpw = 1;                 // MFMA: adjacent tiles per workgroup
-  int tile() const { return hinge ? kHingeTile : pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
+  int tile() const { return hinge ? hinge_tile : pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
@@ -670,7 +706,11 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     if (const char *e = getenv("EARHIP_HINGE")) L.hinge = atoi(e) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
-    if (L.hinge) L.pieces = false, L.pw = 4;  // (the piece lists stand by on the same 256-sample tiles: k_hinge_gate)
+    if (L.hinge) {
+      if (const char *e = getenv("EARHIP_HG_TILE")) L.hinge_tile = atoi(e) == 256 ? 256 : 512;  // tuning knob
+      // (the piece lists stand by on the same tiles, packed: k_hinge_gate)
+      L.pieces = false, L.paired = false, L.pw = L.hinge_tile / 64;
+    }
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
   // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments

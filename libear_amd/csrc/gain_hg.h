@@ -17,25 +17,31 @@
 //
 //   * L costs what it costs the grid kernel (gain_h2.h): ONE split of the inputs, two gain operands B0 = L(s0) and
 //     B1 = the slope, and (s - s0) applied to the accumulators of the B1 products at the end of the tile;
-//   * a kink costs no split at all: its factor F(s) = clamp(+-(s - r) / T, 0, 1) is exact in f16 (8 bits), so the
+//   * a kink costs no split at all: its factor F(s) = max(+-(s - r) / 16, 0) is exact in f16 (9 bits), so the
 //     operand pieces of x F come out of the pieces (xh, xl) the line's split left in registers by PACKED f16
 //     arithmetic: Ah = rn(F xh), the exact residual fma(F, xh, -Ah), plus F xl — five v_pk instructions per
 //     register of two operands instead of the ~20 of a position factor and a split from f32;  the gain operand of
-//     the kink is T D, one MFMA set (the line has two);
+//     the kink is 16 D, one MFMA set (the line has two) — a property of the curve POINT, made when the curves are
+//     committed (k_kink_rows: a "kink row" per point beside its gain row, already split into f16 pieces);
 //   * the objects of a tile are ordered by where their kinks lie, so that whole chunks of 32 have their kinks in the
-//     same quarter of the tile, and a wave (= a quarter: 64 samples) skips the kink sets that cannot reach its
-//     samples: a forward kink in the last quarter only costs the wave of that quarter.
+//     same part of the tile, and a wave (64 samples) skips the kink sets that cannot reach its samples: a forward
+//     kink in the last 64 samples only costs the wave of those.
 //
-// What qualifies: an (object, tile) pair whose curve points inside the tile are at most the two ends of the centre
-// segment, with every ramp that meets such a point at least T / 2 long (so that T x slope stays within twice the
-// gains' range: the operands are scaled to half the f16 range the other split kernels use).  Everything else —
-// several points in one half of a tile, short ramps, steps, quiet objects — takes the exact per-object path; curve
-// sets made of such things are the piece-list kernel's (plan_mix decides from the curves).
+// Two forms: 8 waves on 512-sample tiles with up to TWO kinks on either side of the tile's centre (the default), 4
+// waves on 256-sample tiles with one.  Bigger tiles ask for fewer rows per sample (25.7 M instead of 29.2 M L2 -> L1
+// requests on the always-ramping scene) but a kink reaches further (relu runs to the tile's end: twice the kink MFMAs
+// per sample): the two come out even, 0.75-0.77 ms, and the lists of half as many tiles are built faster.
 //
-// Lists (k_hinge_build): per tile the objects in the order  no kink | forward kink in quarter 3 | forward in 2 | both |
-// backward in 1 | backward in 0,  padded to a multiple of 32 at the end only; per slot a LinEntry and, in chunks that
-// have any, a forward and a backward HingeEntry; per chunk a flag word (has forward / backward kinks, and which waves
-// they can reach).
+// What qualifies: an (object, tile) pair whose curve points inside the tile are at most two (one) on either side of
+// the centre, with every ramp that meets such a point at least kHingeMinLen long (so that 16 x slope differences stay
+// within the gains' range: the operands are scaled to half the f16 range the other split kernels use).  Everything
+// else — more points in one half of a tile, short ramps, steps, quiet objects — takes the exact per-object path;
+// curve sets made of such things are the piece-list kernel's (plan_mix decides from the curves).
+//
+// Lists (k_hinge_build): per tile the objects sorted by (first wave their forward kink reaches, last wave their
+// backward kink reaches), those with second kinks behind them, padded to a multiple of 32 at the end only; per slot a
+// LinEntry and, in chunks that have any kinks, a HingeEntry (the factors of its up to four kinks); per chunk a flag
+// word (per kink set the waves it can reach).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -44,8 +50,8 @@
 
 namespace earhip {
 
-constexpr int kHingeTile = 256;     // samples per workgroup tile (4 waves)
-constexpr int kHingeMinLen = 128;   // ramps that meet a kink are at least this long (T / 2)
+constexpr int kHingeTile = 256;     // samples of the smaller form's tile (what the curve statistics count in)
+constexpr int kHingeMinLen = 128;   // ramps that meet a kink are at least this long
 constexpr int kMaxHingeCached = 12288;
 // The factor of a kink is kept as 16 (s - r) / T, its gain operand as T D / 16: with F in [1 / 256, 1] the product F x of a quiet
 // object's input would be a subnormal f16 (x sits 2^-10 below the call's level at -100 dB; the packed-f16 products have no
@@ -56,27 +62,28 @@ constexpr float kHingeFactorScale = 16.0f;
 constexpr int kHingeQuietBinades = kHingeSpreadBinades;  // (gain_kernels.h: the same span decides which calls this kernel takes at all)  // (object, tile) pairs a list-building workgroup keeps between its two passes
 
 struct LinEntry {
-  uint32_t m;   // object | the rows' places (kLinRowShift) | kLinNull
-  int32_t row;  // gain row R1 of the point the centre segment starts at (kc - 1, clipped into the object's points); the rows
-                // around it: R0 = R1 - d0 (point kc - 2), R2 = R1 + d2 (point kc: the segment's end), R3 = R2 + d3 (point kc + 1),
-                // d = 0 where the object has no such point (the clipped row repeats: differences of rows vanish there)
+  uint32_t m;   // object | kLinD2 | which kinks the pair has (kLinF1 ..) | kLinNull
+  int32_t row;  // gain row R1 of the point the centre segment starts at (kc - 1, clipped into the object's points); its end
+                // (point kc) is row R1 + 1 when kLinD2 is set, else R1 again (no such point: constant)
   float p0;     // libear's p at the tile start, (float)(s0 - start) * scale (gain_interpolator.hpp:272); negative when the
                 // segment starts inside the tile; 0: constant
   float scale;  // 1.0f / (float)(end - start) of the centre segment; 0: constant
 };
+// the factors of a pair's kinks: f16 pairs (slope of F: +-1 / kHingeFactorScale, offset of F: -+(r - s0) / kHingeFactorScale),
+// F(s) = max(s * slope + offset, 0), s counted from the tile start; 0: no such kink (F = 0).  fac[0]: the first kink behind
+// the centre (forward), [1]: the first one in front of it (backward), [2], [3]: the second ones (512-sample tiles)
 struct HingeEntry {
-  uint32_t fac_f, fac_b;  // forward / backward kink: f16 pair (slope of F: +-16/T, offset of F: -+16 (r - s0)/T), F(s) = max(s * slope +
-                          // offset, 0), s counted from the tile start; 0: no such kink (F = 0)
-  float s_before, s_after;  // 1 / length of the ramp before the centre segment (points kc - 2, kc - 1) and behind it (kc, kc + 1); 0: constant
+  uint32_t fac[4];
 };
 static_assert(sizeof(LinEntry) == 16 && sizeof(HingeEntry) == 16, "list entries are loaded as one dwordx4");
 constexpr uint32_t kLinNull = 1u << 31, kLinObjMask = 0xffffu;
-constexpr int kLinRowShift = 16;  // bits 16 + 2 i, 17 + 2 i of m: (row R_i) - (row R1) + 1, i = 0..3
+constexpr uint32_t kLinD2 = 1u << 16;
+constexpr int kLinKinkShift = 17;  // bits 17 .. 20: kinks 0 .. 3 (the order of HingeEntry::fac)
 
 struct HingeLists {
   LinEntry *lin;     // [ntiles][cap]
   HingeEntry *hinge; // [ntiles][cap]
-  uint32_t *cflags;  // [ntiles][cap / 32]: bit 0 / 1: the chunk has forward / backward kinks; bits 8-11 / 12-15: the waves they reach
+  uint32_t *cflags;  // [ntiles][cap / 32]: byte g: the waves kink set g of the chunk reaches (0: the chunk has no such kinks)
   int *count;        // [ntiles][4]: chunks, exact-path objects
   int *ovf;          // [ntiles][M]: objects that take the exact per-object path
   int M, cap;
@@ -106,78 +113,152 @@ inline bool hinge_addressable(size_t M, size_t in_stride, size_t nsamples, size_
 __device__ __forceinline__ uint32_t f16_bits(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); }
 
 // ---------------------------------------------------------------------------
-// K0.  What one (object, tile) pair is for the hinge kernel.
-constexpr int kHgNone = 0, kHgF3 = 1, kHgF2 = 2, kHgBoth = 3, kHgB1 = 4, kHgB0 = 5, kHgExact = 6;
-// the four records around the centre: points kc - 2 .. kc + 1 (missing ones: never looked at)
+// K0.  What one (object, tile) pair is for the hinge kernel.  NW = waves of the kernel's workgroup: tiles of 64 NW samples;
+// a pair may have NW / 4 kinks on either side of the centre (one on 256-sample tiles, two on 512).
+constexpr int kHgClasses = 32, kHgSecond = 30, kHgExact = 31;
+// the six records around the centre: points kc - 3 .. kc + 2 (missing ones: never looked at)
 struct HingeRecs {
-  PointRec r[4];
-  bool has[4];
+  PointRec r[6];
+  bool has[6];
 };
 __device__ __forceinline__ HingeRecs hinge_load(const PointStore &ps, int base, int n, int kc) {
   HingeRecs R;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int k = kc - 2 + i;
+  for (int i = 0; i < 6; i++) {
+    const int k = kc - 3 + i;
     R.has[i] = k >= 0 && k < n;
     R.r[i] = ps.rec[base + min(max(k, 0), n - 1)];
   }
   return R;
 }
-// t0, t1: the tile [t0, t1) (t1 clipped to the end of the call); fwd / bwd: is there a kink behind / in front of the centre
-__device__ __forceinline__ int hinge_classify(const PointStore &ps, const HingeRecs &R, int64_t t0, int64_t t1, bool &fwd, bool &bwd) {
+struct HingePair {
+  int cls;          // sort class of the pair: (first wave its forward kink reaches, last wave its backward kink reaches),
+                    // kHgSecond: it has second kinks, kHgExact: not a pair for this kernel
+  uint32_t kinks;   // bit g: kink g (HingeEntry::fac's order)
+  int pos[4];       // their places, samples from the tile start
+};
+// the waves kink set g of a pair of class `cls` can reach (a bound, exact for the classes below kHgSecond)
+template <int NW>
+__host__ __device__ inline uint32_t hinge_class_masks(int cls) {
+  constexpr int H = NW / 2;
+  const uint32_t all = (1u << NW) - 1, upper = all & ~((1u << H) - 1), lower = (1u << H) - 1;
+  if (cls == kHgSecond) return upper | lower << 8 | upper << 16 | lower << 24;
+  const int wf = cls / (H + 1) + H, wb = cls % (H + 1) - 1;  // wf = NW: no forward kink, wb = -1: no backward kink
+  const uint32_t mf = wf < NW ? all & ~((1u << wf) - 1) : 0u, mb = wb >= 0 ? (1u << (wb + 1)) - 1 : 0u;
+  return mf | mb << 8;
+}
+// t0, t1: the tile [t0, t1) (t1 clipped to the end of the call)
+template <int NW>
+__device__ __forceinline__ HingePair hinge_classify(const PointStore &ps, const HingeRecs &R, int64_t t0, int64_t t1) {
+  constexpr int T = 64 * NW, H = NW / 2, KMAX = NW / 4;
   const uint32_t allflat = (1u << ps.nbus) - 1;
-  // the segment ending at point kc - 2 + i (i = 1..3) is flat when the point repeats its predecessor on every bus; the
-  // stretches before the first and behind the last point are constant (gain_interpolator.hpp:68-75)
+  // the segment ending at point i (i = 1..5) is flat when the point repeats its predecessor on every bus; the stretches
+  // before the first and behind the last point are constant (gain_interpolator.hpp:68-75)
   auto seg_flat = [&](int i) { return !R.has[i] || !R.has[i - 1] || (R.r[i].flat & allflat) == allflat; };
   auto seg_len = [&](int i) { return R.r[i].time - R.r[i - 1].time; };
+  HingePair hp;
+  hp.kinks = 0;
   bool simple = true;
-  // a point in (t0, centre]: the start of the centre segment
-  bwd = R.has[1] && R.r[1].time > t0;
-  if (bwd) {
-    if (R.has[0] && R.r[0].time > t0) simple = false;  // a second point in this half (a step: two equal times)
-    const bool bf = seg_flat(1), af = seg_flat(2);
-    if (bf && af) bwd = false;  // constant on both sides: no kink
-    if (!bf && seg_len(1) < kHingeMinLen) simple = false;
-    if (!af && seg_len(2) < kHingeMinLen) simple = false;
+  // a kink at point i (1..4): at least one of the segments that meet there ramps, and ramps that meet a kink are long
+  auto kink_at = [&](int i) {
+    const bool bf = seg_flat(i), af = seg_flat(i + 1);
+    if (bf && af) return false;  // constant on both sides
+    if (!bf && seg_len(i) < kHingeMinLen) simple = false;
+    if (!af && seg_len(i + 1) < kHingeMinLen) simple = false;
+    return true;
+  };
+  // points in (t0, centre]: point 2 (the start of the centre segment), then 1; a third one: not for this kernel
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int i = 2 - j;
+    if (!(R.has[i] && R.r[i].time > t0)) break;
+    if (j >= KMAX) {
+      simple = false;
+      break;
+    }
+    const int pos = (int)(R.r[i].time - t0);
+    // relu(r - s) > 0 up to s = r - 1
+    if (kink_at(i) && pos >= 1) hp.kinks |= 1u << (1 + 2 * j), hp.pos[1 + 2 * j] = pos;
   }
-  // a point in (centre, t1): the end of the centre segment
-  fwd = R.has[2] && R.r[2].time < t1;
-  if (fwd) {
-    if (R.has[3] && R.r[3].time < t1) simple = false;
-    const bool bf = seg_flat(2), af = seg_flat(3);
-    if (bf && af) fwd = false;
-    if (!bf && seg_len(2) < kHingeMinLen) simple = false;
-    if (!af && seg_len(3) < kHingeMinLen) simple = false;
+  // points in (centre, t1): point 3 (the end of the centre segment), then 4
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int i = 3 + j;
+    if (!(R.has[i] && R.r[i].time < t1)) break;
+    if (j >= KMAX) {
+      simple = false;
+      break;
+    }
+    const int pos = (int)(R.r[i].time - t0);
+    // relu(s - r) > 0 from s = r + 1 on
+    if (kink_at(i) && pos + 1 < T) hp.kinks |= 1u << (2 * j), hp.pos[2 * j] = pos;
   }
-  if (!simple) return kHgExact;
-  if (fwd && bwd) return kHgBoth;
-  if (fwd) return (int)(R.r[2].time - t0) >= 191 ? kHgF3 : kHgF2;  // relu(s - r) > 0 from s = r + 1 on: quarter 3 alone from r = 191
-  if (bwd) return (int)(R.r[1].time - t0) <= 64 ? kHgB0 : kHgB1;   // relu(r - s) > 0 up to s = r - 1: quarter 0 alone up to r = 64
-  return kHgNone;
+  if (!simple) {
+    hp.cls = kHgExact;
+  } else if (hp.kinks & 0xcu) {
+    hp.cls = kHgSecond;
+  } else {
+    const int wf = (hp.kinks & 1u) ? (hp.pos[0] + 1) / 64 : NW, wb = (hp.kinks & 2u) ? (hp.pos[1] - 1) / 64 : -1;
+    hp.cls = (max(wf, H) - H) * (H + 1) + (min(wb, H - 1) + 1);
+  }
+  return hp;
 }
-// the two list entries of a pair (fwd, bwd: hinge_classify's)
+// the two list entries of a pair
 __device__ __forceinline__ void hinge_entries(const PointStore &ps, const HingeRecs &R, int base, int n, int kc, int m, int64_t t0,
-                                              bool fwd, bool bwd, LinEntry &e, HingeEntry &h) {
+                                              const HingePair &hp, LinEntry &e, HingeEntry &h) {
   const uint32_t allflat = (1u << ps.nbus) - 1;
-  auto seg_ramp = [&](int i) { return R.has[i] && R.has[i - 1] && (R.r[i].flat & allflat) != allflat; };
   const int k1 = min(max(kc - 1, 0), n - 1);  // the point R1 stands for
-  const uint32_t d0 = kc - 2 >= 0 && kc - 2 < k1 ? 1u : 0u, d2 = kc < n && kc > k1 ? 1u : 0u, d3 = kc + 1 < n ? 1u : 0u;
-  // (a row no kink needs — R0 without a backward, R3 without a forward kink — is asked for as its neighbour R1 / R2: the same
-  // cache lines again instead of another row's, and a difference of rows that vanishes)
-  e.m = (uint32_t)m | (bwd ? 1u - d0 : 1u) << 16 | 1u << 18 | (1u + d2) << 20 | (1u + d2 + (fwd ? d3 : 0u)) << 22;
+  const bool d2 = kc < n && kc > k1;
+  e.m = (uint32_t)m | (d2 ? kLinD2 : 0u) | hp.kinks << kLinKinkShift;
   e.row = base + k1;
   e.p0 = 0.0f;
   e.scale = 0.0f;
-  if (seg_ramp(2)) {  // (constant on every bus: E == S bit for bit, nothing to interpolate)
-    e.scale = R.r[2].scale;
-    e.p0 = (float)(int32_t)(t0 - R.r[1].time) * R.r[2].scale;
+  if (R.has[3] && R.has[2] && (R.r[3].flat & allflat) != allflat) {  // (constant on every bus: E == S bit for bit, nothing to interpolate)
+    e.scale = R.r[3].scale;
+    e.p0 = (float)(int32_t)(t0 - R.r[2].time) * R.r[3].scale;
   }
-  const float slope = kHingeFactorScale / kHingeTile;
-  h.fac_f = h.fac_b = 0u;
-  if (fwd) h.fac_f = f16_bits(slope) | f16_bits(-(float)(int)(R.r[2].time - t0) * slope) << 16;
-  if (bwd) h.fac_b = f16_bits(-slope) | f16_bits((float)(int)(R.r[1].time - t0) * slope) << 16;
-  h.s_before = seg_ramp(1) ? R.r[1].scale : 0.0f;
-  h.s_after = seg_ramp(3) ? R.r[3].scale : 0.0f;
+  const float slope = 1.0f / kHingeFactorScale;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    h.fac[g] = 0u;
+    if (!((hp.kinks >> g) & 1u)) continue;
+    if (g & 1) h.fac[g] = f16_bits(-slope) | f16_bits((float)hp.pos[g] * slope) << 16;  // backward: F = (r - s) slope
+    else h.fac[g] = f16_bits(slope) | f16_bits(-(float)hp.pos[g] * slope) << 16;          // forward: F = (s - r) slope
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Kink rows.  The gain operand of a kink at curve point k is (slope behind it - slope in front of it) of every column —
+// a property of the POINT, not of the tile it is met in — so it is made once per point, when the curves are committed
+// (CurveSet::commit, behind the upload), and kept behind the gain rows in the same buffer: row k of the kink image =
+// for every column the two f16 pieces (low half h, high half l) of
+//     (sA (R[k+1] - R[k]) - sB (R[k] - R[k-1])) x (kink scale of the column),
+// sA / sB = 1 / length of the ramp behind / in front of the point (0: constant there, or no such point).  The hinge
+// kernel asks for it like for a gain row and only regroups the pieces into its fragments (it used to ask for the rows
+// R[k-1], R[k+1] and do this arithmetic and the split per tile and object: a tenth of its time).
+// Kink scale: half the column's gain scale x kHingeFactorScale (the factor of a kink is (s - r) / kHingeFactorScale).
+__host__ __device__ inline float hinge_kink_scale(float gcol) { return 0.5f * gcol * 16.0f; }
+// grid = objects (the listed ones, or all M when `objects` is NULL), block = 256 threads
+static __global__ void __launch_bounds__(256)
+k_kink_rows(const int32_t *off, const int32_t *cnt, const PointRec *rec, const float *gain, uint32_t *kink, const float *gcol,
+            const int32_t *objects, int row, int nbus) {
+  const int m = objects ? objects[blockIdx.x] : (int)blockIdx.x;
+  const int base = off[m], n = cnt[m];
+  const uint32_t allflat = (1u << nbus) - 1;
+  for (int i = threadIdx.x; i < n * row; i += 256) {
+    const int k = i / row, c = i - k * row;
+    // (the ramp that ENDS at point j: rec[j].scale, flat bits of point j)
+    const bool rb = k > 0 && (rec[base + k].flat & allflat) != allflat;
+    const bool ra = k + 1 < n && (rec[base + k + 1].flat & allflat) != allflat;
+    const float sB = rb ? rec[base + k].scale : 0.0f, sA = ra ? rec[base + k + 1].scale : 0.0f;
+    const float R1 = gain[(size_t)(base + k) * row + c];
+    const float R0 = k > 0 ? gain[(size_t)(base + k - 1) * row + c] : R1;
+    const float R2 = k + 1 < n ? gain[(size_t)(base + k + 1) * row + c] : R1;
+    const float v = (sA * (R2 - R1) - sB * (R1 - R0)) * hinge_kink_scale(gcol[c]);
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    kink[(size_t)(base + k) * row + c] = (uint32_t)__builtin_bit_cast(uint16_t, h) | (uint32_t)__builtin_bit_cast(uint16_t, l) << 16;
+  }
 }
 
 constexpr int kHingeBuildThreads = 1024;
@@ -186,26 +267,25 @@ constexpr int kHingeBuildThreads = 1024;
 // passes over the objects: the first finds every pair's centre segment (one search) and class and counts the classes of
 // each tile, the second — the classes' places in the list known — ranks the pairs of a class in object order (ballots:
 // the lists are deterministic) and writes the entries.  What the first pass found is kept in LDS (dynamic: 4 M TPW
-// bytes).
-template <int TPW>
+// bytes).  NW: the waves of the kernel the lists are for (tiles of 64 NW samples).
+template <int TPW, int NW>
 __global__ void __launch_bounds__(kHingeBuildThreads)
 k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
               const unsigned *level_cur, const unsigned *gate) {
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate)
   constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
   constexpr int NWV = kHingeBuildThreads / 64;
-  constexpr int T = kHingeTile;
-  static_assert(7 * TPW <= 64, "one lane per (tile, class) of a wave's counts");
-  extern __shared__ int hg_cache[];         // [M][TPW]: kc << 3 | class
-  __shared__ int cnt[TPW][8];               // objects per class
-  __shared__ int start[TPW][8];             // first slot of a class (classes 0..5), [6]: listed objects, [7]: chunks
-  __shared__ int run[TPW][8];               // objects of a class placed by the batches so far
-  __shared__ int wcnt[NWV][TPW][8];         // ... by the waves of this batch
+  constexpr int T = 64 * NW, NC = kHgClasses;
+  extern __shared__ int hg_cache[];         // [M][TPW]: kc << 5 | class
+  __shared__ int cnt[TPW][NC];              // objects per class
+  __shared__ int start[TPW][NC + 2];        // first slot of a class (the listed ones: all but kHgExact), [NC]: listed objects, [NC + 1]: chunks
+  __shared__ int run[TPW][NC];              // objects of a class placed by the batches so far
+  __shared__ int wcnt[NWV][TPW][NC];        // ... by the waves of this batch
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = tid % TPW, oi = tid / TPW;
   const int tile = blockIdx.x * TPW + j;
   const unsigned call_level = level_cur ? *level_cur : 0u;
-  if (tid < TPW * 8) (&cnt[0][0])[tid] = 0, (&run[0][0])[tid] = 0;
+  for (int i = tid; i < TPW * NC; i += kHingeBuildThreads) (&cnt[0][0])[i] = 0, (&run[0][0])[i] = 0;
   const int64_t t0 = t_call + (int64_t)tile * T;
   const int64_t t1 = t0 + T > t_call_end ? t_call_end : t0 + T;
   __syncthreads();
@@ -216,31 +296,28 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       const int base = ps.off[m], n = ps.cnt[m];
       const int kc = upper_bound_time_window(ps.time + base, n, t0 + T / 2);
       const HingeRecs R = hinge_load(ps, base, n, kc);
-      bool fwd, bwd;
-      int cls = hinge_classify(ps, R, t0, t1, fwd, bwd);
+      int cls = hinge_classify<NW>(ps, R, t0, t1).cls;
       if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - kHingeQuietBinades)
         cls = kHgExact;
-      hg_cache[(size_t)m * TPW + j] = kc << 3 | cls;
+      hg_cache[(size_t)m * TPW + j] = kc << 5 | cls;
       atomicAdd(&cnt[j][cls], 1);
     }
   }
   __syncthreads();
   if (tid < TPW) {
     int at = 0;
-    for (int b = 0; b < 6; b++) start[tid][b] = at, at += cnt[tid][b];
-    start[tid][6] = at;
-    start[tid][7] = (at + 31) >> 5;
+    for (int b = 0; b < NC; b++)
+      if (b != kHgExact) start[tid][b] = at, at += cnt[tid][b];
+    start[tid][kHgExact] = 0;
+    start[tid][NC] = at;
+    start[tid][NC + 1] = (at + 31) >> 5;
   }
   __syncthreads();
-  // flags of the chunk a slot lies in: which classes share the chunk
+  // flags of the chunk a slot lies in: the waves each kink set reaches, over the classes that share the chunk
   auto chunk_flags = [&](int jj, int c) -> uint32_t {
-    auto hits = [&](int b) { return cnt[jj][b] > 0 && start[jj][b] < 32 * c + 32 && start[jj][b] + cnt[jj][b] > 32 * c; };
     uint32_t f = 0;
-    if (hits(kHgF3)) f |= 1u | 0x8u << 8;
-    if (hits(kHgF2)) f |= 1u | 0xcu << 8;
-    if (hits(kHgBoth)) f |= 3u | 0xcu << 8 | 0x3u << 12;
-    if (hits(kHgB1)) f |= 2u | 0x3u << 12;
-    if (hits(kHgB0)) f |= 2u | 0x1u << 12;
+    for (int b = 0; b < NC; b++)
+      if (b != kHgExact && cnt[jj][b] > 0 && start[jj][b] < 32 * c + 32 && start[jj][b] + cnt[jj][b] > 32 * c) f |= hinge_class_masks<NW>(b);
     return f;
   };
   // ---- pass 2
@@ -249,27 +326,23 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
     for (int l = j; l < 64; l += TPW) v |= 1ull << l;
     return v;
   }();
+  const unsigned long long mytile = [&] {  // lane jj < TPW: the lanes of this wave with tile jj
+    unsigned long long v = 0;
+    for (int l = lane % TPW; l < 64; l += TPW) v |= 1ull << l;
+    return v;
+  }();
   for (int mb = 0; mb < M; mb += OB) {
     const int m = mb + oi;
     const bool in = m < M && tile < ntiles;
-    const int code = in ? hg_cache[(size_t)m * TPW + j] : 7;
-    const int cls = code & 7, kc = code >> 3;
-    unsigned long long bal[7];
-#pragma unroll
-    for (int b = 0; b < 7; b++) bal[b] = __ballot(cls == b);
+    const int code = in ? hg_cache[(size_t)m * TPW + j] : -1;
+    const int cls = in ? code & 31 : -1, kc = code >> 5;
     unsigned long long mine = 0;
-#pragma unroll
-    for (int b = 0; b < 7; b++) mine = cls == b ? bal[b] : mine;
-    const int rank = __popcll(mine & samej & ((1ull << lane) - 1));
-    if (lane < 7 * TPW) {  // lane = class * TPW + tile
-      const int b = lane / TPW, jj = lane % TPW;
-      unsigned long long v = 0;
-#pragma unroll
-      for (int q = 0; q < 7; q++) v = b == q ? bal[q] : v;
-      unsigned long long sj = 0;
-      for (int l = jj; l < 64; l += TPW) sj |= 1ull << l;
-      wcnt[wv][jj][b] = __popcll(v & sj);
+    for (int b = 0; b < NC; b++) {
+      const unsigned long long bal = __ballot(cls == b);
+      mine = cls == b ? bal : mine;
+      if (lane < TPW) wcnt[wv][lane][b] = __popcll(bal & mytile);
     }
+    const int rank = __popcll(mine & samej & ((1ull << lane) - 1));
     __syncthreads();
     if (in) {
       int at = run[j][cls] + rank;
@@ -280,20 +353,20 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
         const int slot = start[j][cls] + at;
         const int base = ps.off[m], n = ps.cnt[m];
         const HingeRecs R = hinge_load(ps, base, n, kc);
-        const bool fwd = cls == kHgF3 || cls == kHgF2 || cls == kHgBoth, bwd = cls == kHgB1 || cls == kHgB0 || cls == kHgBoth;
+        const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
         LinEntry e;
         HingeEntry h;
-        hinge_entries(ps, R, base, n, kc, m, t0, fwd, bwd, e, h);
+        hinge_entries(ps, R, base, n, kc, m, t0, hp, e, h);
         hl.lin[(size_t)tile * hl.cap + slot] = e;
-        if (chunk_flags(j, slot >> 5) & 3u) hl.hinge[(size_t)tile * hl.cap + slot] = h;
+        if (chunk_flags(j, slot >> 5)) hl.hinge[(size_t)tile * hl.cap + slot] = h;
       }
     }
     __syncthreads();
-    if (tid < 7 * TPW) {
-      const int b = tid / TPW, jj = tid % TPW;
-      int s = 0;
-      for (int w2 = 0; w2 < NWV; w2++) s += wcnt[w2][jj][b];
-      run[jj][b] += s;
+    for (int i = tid; i < NC * TPW; i += kHingeBuildThreads) {
+      const int b = i / TPW, jj = i % TPW;
+      int sm = 0;
+      for (int w2 = 0; w2 < NWV; w2++) sm += wcnt[w2][jj][b];
+      run[jj][b] += sm;
     }
     __syncthreads();
   }
@@ -301,17 +374,16 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   for (int i = tid; i < TPW * 32; i += kHingeBuildThreads) {
     const int jj = i >> 5, tl = blockIdx.x * TPW + jj;
     if (tl >= ntiles) continue;
-    const int listed = start[jj][6], nch = start[jj][7], slot = listed + (i & 31);
+    const int listed = start[jj][NC], nch = start[jj][NC + 1], slot = listed + (i & 31);
     if (slot < 32 * nch) {
       LinEntry e;
-      e.m = kLinNull | 0x55u << kLinRowShift;  // (object 0's inputs against the all-zero gain row, four times)
+      e.m = kLinNull;  // (object 0's inputs against the all-zero rows)
       e.row = ps.zero_row;
       e.p0 = e.scale = 0.0f;
       hl.lin[(size_t)tl * hl.cap + slot] = e;
       HingeEntry h;
-      h.fac_f = h.fac_b = 0u;
-      h.s_before = h.s_after = 0.0f;
-      if (chunk_flags(jj, slot >> 5) & 3u) hl.hinge[(size_t)tl * hl.cap + slot] = h;
+      h.fac[0] = h.fac[1] = h.fac[2] = h.fac[3] = 0u;
+      if (chunk_flags(jj, slot >> 5)) hl.hinge[(size_t)tl * hl.cap + slot] = h;
     }
     if ((i & 31) == 0) {
       hl.count[tl * 4 + 0] = nch;
@@ -320,7 +392,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   }
   for (int i = tid; i < TPW * (hl.cap / 32); i += kHingeBuildThreads) {
     const int jj = i / (hl.cap / 32), c = i % (hl.cap / 32), tl = blockIdx.x * TPW + jj;
-    if (tl < ntiles && c < start[jj][7]) hl.cflags[(size_t)tl * (hl.cap / 32) + c] = chunk_flags(jj, c);
+    if (tl < ntiles && c < start[jj][NC + 1]) hl.cflags[(size_t)tl * (hl.cap / 32) + c] = chunk_flags(jj, c);
   }
 }
 
@@ -328,31 +400,34 @@ typedef _Float16 hg_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ hg_h2 as_h2(uint32_t u) { return __builtin_bit_cast(hg_h2, u); }
 __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast(uint32_t, h); }
 
-// K1.  grid = (tiles, grid-level splits of the chunk schedule, column super-groups), block = 256 threads:
-// wave w = samples [64 w, 64 w + 64) of the workgroup's 256-sample tile.
+// K1.  grid = (tiles, grid-level splits of the chunk schedule, column super-groups), block = 64 NW threads (NW = 8 or 4):
+// wave w = samples [64 w, 64 w + 64) of the workgroup's tile of 64 NW samples.
 //
 // A chunk of 32 list slots is ONE step between two workgroup barriers: the line (inputs split, 72 MFMAs per 48 columns),
-// then — where the chunk has them — its forward and its backward kinks (36 each; a wave skips those that cannot reach
-// its samples).  The vector-memory counter is in order, so everything is requested in one place, at the start of a
-// step: first the gain rows of the chunk after next (four rows per slot: the points kc - 2 .. kc + 1 cover its line and
-// both its kinks), then the inputs of the next chunk into the registers the split has just freed (one chunk ahead:
+// then — where the chunk has them — its kink sets (first forward, first backward, second forward, second backward: 36
+// MFMAs each; a wave skips those that cannot reach its samples).  The vector-memory counter is in order, so everything
+// is requested in one place, at the start of a step: first the rows of the chunk after next (per slot the two gain rows
+// of its line and the kink rows of its kinks; a kink it does not have: the all-zero row, which stays in L1), then the
+// inputs of the next chunk into the registers the split has just freed (one chunk ahead:
 // two sets of inputs do not fit the register file beside the 96 accumulators, the operand pieces the kinks need, and
 // the rows on their way).  The rows go through a wave-private piece of LDS, a chunk's worth at a time: a step first
 // turns the rows staged a step ago into the operand fragments of the NEXT chunk (all three sets; fragments alternate
 // between two buffers), then stages the rows that have arrived meanwhile.  The scaled high piece (h 2^-11, gain_h2.h)
 // is made from h where it is used.
-template <int NCT>
-__global__ void __launch_bounds__(256, 2)
+template <int NCT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, unsigned *wide_next, const unsigned *gate) {
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate); they clear the words of the next
-  constexpr int NW = 4, NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = kHingeTile;
+  constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = 64 * NW;
   constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
+  constexpr int KS = NW / 2;         // kink sets: one (4 waves: 256-sample tiles) or two (8 waves: 512) on either side of the centre
+  constexpr int NR = 2 + KS;         // rows a slot asks for: its kink rows and the two gain rows of its line
   constexpr int RING = 4;
   constexpr int OP = TS + 4;
   // fragments (1 KB each: 64 lanes x 8 f16), two sets (even / odd chunks) of: the line {B0, B1} x column tiles x {h, l}, the
-  // forward kinks and the backward kinks (column tiles x {h, l})
-  constexpr int FL = 4 * NCT, FH = 2 * NCT, FSET = FL + 2 * FH, NFRAGS = 2 * FSET;
+  // kink sets (column tiles x {h, l} each)
+  constexpr int FL = 4 * NCT, FH = 2 * NCT, FSET = FL + KS * FH, NFRAGS = 2 * FSET;
   constexpr size_t kFragBytes = sizeof(u32x4) * NFRAGS * 64, kTileBytes = sizeof(float) * NW * 16 * OP;
   __shared__ __attribute__((aligned(16))) unsigned char fmem[kFragBytes > kTileBytes ? kFragBytes : kTileBytes];  // (the waves' output
                                                                                             // tiles, once the last step is through)
@@ -361,9 +436,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
   __shared__ __attribute__((aligned(16))) u32x4 fdummy[1];
   __shared__ __attribute__((aligned(16))) uint32_t ring[RING][CH];   // byte offsets of the slots' input rows (below 4 GB: api_core.hip checks)
   __shared__ __attribute__((aligned(16))) u32x4 ringe[RING][2 * CH];  // the LinEntries [0, 32) and the HingeEntries [32, 64)
-  __shared__ __attribute__((aligned(16))) uint32_t ringf[RING][2][CH];  // ... their factor words, packed for the lanes
+  __shared__ __attribute__((aligned(16))) uint32_t ringf[RING][KS][CH];  // ... their factor words, packed for the lanes
   __shared__ uint32_t ringc[RING];                                    // chunk flags
-  __shared__ __attribute__((aligned(16))) float stage[NW][NQ * 4 * 16 * NCT];  // a wave's gain rows: [slot][4 rows][16 NCT columns]
+  __shared__ __attribute__((aligned(16))) float stage[NW][NQ * NR * 16 * NCT];  // a wave's rows: [slot][NR rows][16 NCT columns]
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
@@ -372,7 +447,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
   // what this kernel is short of: 2 % of its time, measured; any mapping is correct)
   const int wgtile = [&] {
     const int b = blockIdx.x, n = gridDim.x, per = n >> 3;
-    if (b >= per * 8 || (per & 63)) return xcd_tile(b, n);
+    if (NW != 4 || b >= per * 8 || (per & 63)) return xcd_tile(b, n);
     const int k = b >> 3;
     return (b & 7) * per + (((k >> 6) << 6) | ((k & 31) << 1) | ((k >> 5) & 1));
   }();
@@ -470,6 +545,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       const int nvec = (P.nsamples + 3) & ~3;
       const uint32_t rstride = (uint32_t)(P.in_stride * sizeof(float));
       const float g_scale = 0.5f * gcol[col0 + min(lane, 16 * NCT - 1)];  // the scale of the lane's gain column
+      const uint32_t kink_off = (uint32_t)P.ps.kink_row0 * (rowlen * 4u);     // kink rows: bytes behind the gain rows' start
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       typedef float f32x3 __attribute__((ext_vector_type(3)));
       typedef const uint32_t __attribute__((address_space(4))) *ConstWords;  // (K0 wrote them, this kernel only reads: scalar loads)
@@ -481,10 +557,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         int lane, li, kg;
         unsigned xlane;      // byte offset of the lane's float4 inside an input row
         unsigned glane;      // byte offset of the lane's 12 bytes inside a gain row
-        int rsh;             // where the place of the lane's row (R_kg) is in a LinEntry's first word
-        float *sw;           // where the lane's 12 bytes of slot 0 go in the wave's staged rows
+        float *sw;           // where the lane's 12 bytes of request 0 go in the wave's staged rows
         const float *sf;     // the lane's column in them
-        int fe;              // the lane's entry in a fragment its wave fills
         int fpair;           // the lane's fragment pair (h, l) inside a set of column tiles, or -1: no column
       };
       auto lane_ctx = [&](bool opaque) {
@@ -496,10 +570,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         L.kg = L.lane >> 4;
         L.xlane = (unsigned)min(tile_s0 + L.li * NRT, nvec - 4) * 4u;
         L.glane = (unsigned)(col0 + NCT * L.li) * 4u;
-        L.rsh = kLinRowShift + 2 * L.kg;
         L.sw = reinterpret_cast<float *>(&stage[w][0]) + L.kg * (16 * NCT) + NCT * L.li;
         L.sf = reinterpret_cast<const float *>(&stage[w][0]) + min(L.lane, 16 * NCT - 1);
-        L.fe = w * 16 + L.li;
         L.fpair = L.lane < 16 * NCT ? 2 * L.kg : -1;
         return L;
       };
@@ -513,7 +585,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         const int cc = min(c, total - 1);
         const int s = 32 * cc + (L.lane & 31);
         ring_next_cf = c < c_hi ? ((ConstWords)cfbase)[cc] : 0u;
-        const bool want = L.lane < 32 || (ring_next_cf & 3u);
+        const bool want = L.lane < 32 || ring_next_cf != 0u;
         const u32x4 *pa = L.lane < 32 ? reinterpret_cast<const u32x4 *>(lbase + s) : reinterpret_cast<const u32x4 *>(hbase + s);
         ring_next = want ? *pa : u32x4{0u, 0u, 0u, 0u};
       };
@@ -524,8 +596,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           ring[sl][L.lane] = (ring_next[0] & kLinObjMask) * rstride;
           if (L.lane == 0) ringc[sl] = ring_next_cf;
         } else {
-          ringf[sl][0][L.lane - 32] = ring_next[0];
-          ringf[sl][1][L.lane - 32] = ring_next[1];
+#pragma unroll
+          for (int g = 0; g < KS; g++) ringf[sl][g][L.lane - 32] = ring_next[g];
         }
       };
       // ---- inputs of chunk c: 8 requests of 16 bytes per lane (slots 8 kg .. 8 kg + 7, the lane's 4 samples)
@@ -538,75 +610,91 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           for (int i = 0; i < 4; i++) x[q + i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (mw[i] + L.xlane)));
         }
       };
-      // ---- gain rows of the slots NQ w .. NQ w + NQ - 1 of chunk c, four rows each (R0 .. R3 of its LinEntry): request q
-      // is slot q's — lane (kg, li) takes 12 bytes (columns 3 li .. 3 li + 2 of the workgroup's 48) of row R_kg — so that
-      // nothing about a request depends on the lane but its row
-      auto load_gains = [&](const LaneCtx &L, int c, f32x3 (&G)[NQ]) {
+      // ---- the rows of the slots NQ w .. NQ w + NQ - 1 of chunk c, NR each (the kink rows of the backward kinks, second
+      // one first; gain rows R1, R2 of the line; the kink rows of the forward kinks): request i is rows 4 i .. 4 i + 3 of the
+      // wave's NQ NR — lane (kg, li) takes 12 bytes (columns 3 li .. 3 li + 2 of the workgroup's 48) of row 4 i + kg
+      constexpr int NREQ = NQ * NR / 4;
+      auto load_gains = [&](const LaneCtx &L, int c, f32x3 (&G)[NREQ]) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringe[c & (RING - 1)][w * NQ + q]);  // (m | rows' places, row R1)
-          const unsigned row = mr[1] + ((mr[0] >> L.rsh) & 3u) - 1u;
+        for (int i = 0; i < NREQ; i++) {
+          const int ridx = 4 * i + L.kg, q = ridx / NR, jj = ridx - q * NR - KS / 2;  // jj = 0, 1: the gain rows
+          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringe[c & (RING - 1)][w * NQ + q]);  // (object | kinks, row R1)
+          const unsigned d2 = (mr[0] >> 16) & 1u;
+          const bool is_kink = jj < 0 || jj > 1;
+          // backward kink nb = -jj (1, 2): kink 2 nb - 1, the point nb - 1 in front of R1; forward nf = jj - 1: kink 2 nf - 2,
+          // the point nf - 1 behind R2
+          const int kbit = jj < 0 ? kLinKinkShift - 2 * jj - 1 : kLinKinkShift + 2 * jj - 4;
+          const unsigned rel = jj < 0 ? (unsigned)(jj + 1) : (jj == 0 ? 0u : d2 + (unsigned)(jj > 1 ? jj - 2 : 0));
+          const bool present = !is_kink || ((mr[0] >> kbit) & 1u);
+          const unsigned row = present ? mr[1] + rel : 0u;  // (absent: the all-zero row of its image)
           // (uniform base + 32-bit lane offset: the image of the curves is below 4 GB, api_core.hip checks)
-          const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(gain) + (row * (rowlen * 4u) + L.glane));
-          if constexpr (NCT == 3) G[q] = *reinterpret_cast<const f32x3 *>(gp);
-          else if constexpr (NCT == 2) G[q] = f32x3{gp[0], gp[1], 0.0f};
-          else G[q] = f32x3{gp[0], 0.0f, 0.0f};
+          const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(gain) +
+                                                            (row * (rowlen * 4u) + L.glane + (is_kink ? kink_off : 0u)));
+          if constexpr (NCT == 3) G[i] = *reinterpret_cast<const f32x3 *>(gp);
+          else if constexpr (NCT == 2) G[i] = f32x3{gp[0], gp[1], 0.0f};
+          else G[i] = f32x3{gp[0], 0.0f, 0.0f};
         }
       };
-      auto stage_gains = [&](const LaneCtx &L, const f32x3 (&G)[NQ]) {
+      auto stage_gains = [&](const LaneCtx &L, const f32x3 (&G)[NREQ]) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          float *d = L.sw + q * (4 * 16 * NCT);
-          if constexpr (NCT == 3) *reinterpret_cast<f32x3 *>(d) = G[q];
-          else if constexpr (NCT == 2) d[0] = G[q][0], d[1] = G[q][1];
-          else d[0] = G[q][0];
+        for (int i = 0; i < NREQ; i++) {
+          float *d = L.sw + i * (4 * 16 * NCT);
+          if constexpr (NCT == 3) *reinterpret_cast<f32x3 *>(d) = G[i];
+          else if constexpr (NCT == 2) d[0] = G[i][0], d[1] = G[i][1];
+          else d[0] = G[i][0];
         }
       };
-      // scaled and split -> LDS: v[q] of the wave's NQ slots into the fragment pair (h, l) at f (k = NQ w + q: entry 16 w + column)
-      auto store_frag = [&](const LaneCtx &L, const float (&v)[NQ], int f) {
-        uint32_t h[NQ / 2], l[NQ / 2];
-#pragma unroll
-        for (int i = 0; i < NQ / 2; i++) {
-          const uint32_t H = pack_f16(v[2 * i], v[2 * i + 1]);
-          h[i] = H;
-          l[i] = pack_f16(v[2 * i] - f16_lo(H), v[2 * i + 1] - f16_hi(H));  // residuals: exact in fp32
-        }
-        if (L.fpair >= 0) {  // (lanes 48 .. 63 have no column)
-          frag[f + L.fpair][L.fe] = u32x4{h[0], h[1], h[2], h[3]};
-          frag[f + L.fpair + 1][L.fe] = u32x4{l[0], l[1], l[2], l[3]};
-        }
+      // The conversions in slices of four of the wave's slots (4 sl .. 4 sl + 3: half a fragment entry, k = 8 of its 32), so
+      // that they can be woven between the MFMAs.  (Lanes 48 .. 63 have no column: they all write the same 8 bytes nobody
+      // reads — no branch, the slices stay inside the MFMA blocks' basic block.)
+      constexpr int NSL = NQ / 4;
+      auto store_slice = [&](const LaneCtx &L, uint32_t H0, uint32_t H1, uint32_t L0, uint32_t L1, int f, int sl) {
+        const int gs = NQ * w + 4 * sl, fe = (gs >> 3) * 16 + L.li, hf = (gs >> 2) & 1;
+        u32x2 *ph = L.fpair >= 0 ? reinterpret_cast<u32x2 *>(&frag[f + L.fpair][fe]) + hf : reinterpret_cast<u32x2 *>(&fdummy[0]);
+        u32x2 *pl = L.fpair >= 0 ? reinterpret_cast<u32x2 *>(&frag[f + L.fpair + 1][fe]) + hf : reinterpret_cast<u32x2 *>(&fdummy[0]) + 1;
+        *ph = u32x2{H0, H1};
+        *pl = u32x2{L0, L1};
+      };
+      auto store_split = [&](const LaneCtx &L, const float (&v)[4], int f, int sl) {  // scaled values: split here
+        const uint32_t H0 = pack_f16(v[0], v[1]), H1 = pack_f16(v[2], v[3]);
+        const uint32_t L0 = pack_f16(v[0] - f16_lo(H0), v[1] - f16_hi(H0)), L1 = pack_f16(v[2] - f16_lo(H1), v[3] - f16_hi(H1));
+        store_slice(L, H0, H1, L0, L1, f, sl);
       };
       // the line of chunk c from the staged rows -> its fragment set
-      auto convert_lin = [&](const LaneCtx &L, int c) {
-        float b0[NQ], b1[NQ];
+      auto convert_lin_slice = [&](const LaneCtx &L, int c, int sl) {
+        float b0[4], b1[4];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const float R1 = L.sf[(4 * q + 1) * (16 * NCT)], dC = L.sf[(4 * q + 2) * (16 * NCT)] - R1;
+        for (int i = 0; i < 4; i++) {
+          const int q = 4 * sl + i;
+          const float R1 = L.sf[(NR * q + KS / 2) * (16 * NCT)], dC = L.sf[(NR * q + KS / 2 + 1) * (16 * NCT)] - R1;
           const u32x2 ps2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][w * NQ + q]) + 8);
           const float p0 = __uint_as_float(ps2[0]), sc = __uint_as_float(ps2[1]);
-          b0[q] = __builtin_fmaf(p0, dC, R1) * g_scale;  // the line at the tile start: S + p (E - S) (gain_interpolator.hpp:272-274)
-          b1[q] = (sc * dC) * g_scale;                   // its slope per sample
+          b0[i] = __builtin_fmaf(p0, dC, R1) * g_scale;  // the line at the tile start: S + p (E - S) (gain_interpolator.hpp:272-274)
+          b1[i] = (sc * dC) * g_scale;                   // its slope per sample
         }
         const int f0 = (c & 1) * FSET;
-        store_frag(L, b0, f0);
-        store_frag(L, b1, f0 + 2 * NCT);
+        store_split(L, b0, f0, sl);
+        store_split(L, b1, f0 + 2 * NCT, sl);
       };
-      // the kinks of chunk c: T x (slope behind the kink - slope in front of it)
-      auto convert_hinges = [&](const LaneCtx &L, int c, uint32_t cf) {
-        float dF[NQ], dB[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const float R0 = L.sf[(4 * q) * (16 * NCT)], R1 = L.sf[(4 * q + 1) * (16 * NCT)], R2 = L.sf[(4 * q + 2) * (16 * NCT)],
-                      R3 = L.sf[(4 * q + 3) * (16 * NCT)];
-          const float sc = __uint_as_float(ringe[c & (RING - 1)][w * NQ + q][3]);
-          const u32x2 s2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][32 + w * NQ + q]) + 8);
-          const float mc = sc * (R2 - R1), ma = __uint_as_float(s2[0]) * (R1 - R0), mb = __uint_as_float(s2[1]) * (R3 - R2);
-          dF[q] = (mb - mc) * (g_scale * ((float)T / kHingeFactorScale));
-          dB[q] = (mc - ma) * (g_scale * ((float)T / kHingeFactorScale));
-        }
+      // the kink sets g0 .. g1 - 1 of chunk c: their rows hold the operands' pieces already (k_kink_rows); regrouped into
+      // fragments (an f16 pair = two SLOTS of one column)
+      auto convert_kinks_slice = [&](const LaneCtx &L, int c, int sl, int g0, int g1) {
+        const uint32_t *su = reinterpret_cast<const uint32_t *>(L.sf);
         const int f0 = (c & 1) * FSET + FL;
-        if (cf & 1u) store_frag(L, dF, f0);
-        if (cf & 2u) store_frag(L, dB, f0 + FH);
+#pragma unroll
+        for (int g = 0; g < KS; g++) {
+          if (g < g0 || g >= g1) continue;
+          const int j = (g & 1) ? KS / 2 - 1 - (g >> 1) : KS / 2 + 2 + (g >> 1);  // the staged row of kink g
+          uint32_t hw[2], lw[2];
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const int q = 4 * sl + 2 * i;
+            const uint32_t w0 = su[(NR * q + j) * (16 * NCT)], w1 = su[(NR * (q + 1) + j) * (16 * NCT)];
+            hw[i] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+            lw[i] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+          }
+          store_slice(L, hw[0], hw[1], lw[0], lw[1], f0 + g * FH, sl);
+        }
       };
 
       // ---- prologue: ring slots of the first chunks; fragments of the first chunk; rows of the second one staged
@@ -622,60 +710,19 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           }
         }
         __syncthreads();
-        f32x3 G[NQ];
+        f32x3 G[NREQ];
         load_gains(L, c_lo, G);
         stage_gains(L, G);
         load_gains(L, c_lo + 1, G);
         load_x(L, c_lo, X0);
-        convert_lin(L, c_lo);
-        const uint32_t cf0 = ringc[c_lo & (RING - 1)];
-        if (cf0 & 3u) convert_hinges(L, c_lo, cf0);
+#pragma unroll
+        for (int sl = 0; sl < NSL; sl++) {
+          convert_lin_slice(L, c_lo, sl);
+          convert_kinks_slice(L, c_lo, sl, 0, KS);
+        }
         stage_gains(L, G);
       }
 
-      // the conversions in half-slices (slots 4 hf .. 4 hf + 3 of the wave's eight), so that they can be woven between the MFMAs
-      auto store_half = [&](const LaneCtx &L, const float (&v)[4], int f, int hf) {
-        const uint32_t H0 = pack_f16(v[0], v[1]), H1 = pack_f16(v[2], v[3]);
-        const uint32_t L0 = pack_f16(v[0] - f16_lo(H0), v[1] - f16_hi(H0)), L1 = pack_f16(v[2] - f16_lo(H1), v[3] - f16_hi(H1));
-        // (lanes 48 .. 63 have no column: they all write the same 8 bytes nobody reads — no branch, the slices stay inside
-        // the MFMA blocks' basic block, where the scheduler can weave them between the MFMAs)
-        u32x2 *ph = L.fpair >= 0 ? reinterpret_cast<u32x2 *>(&frag[f + L.fpair][L.fe]) + hf : reinterpret_cast<u32x2 *>(&fdummy[0]);
-        u32x2 *pl = L.fpair >= 0 ? reinterpret_cast<u32x2 *>(&frag[f + L.fpair + 1][L.fe]) + hf : reinterpret_cast<u32x2 *>(&fdummy[0]) + 1;
-        *ph = u32x2{H0, H1};
-        *pl = u32x2{L0, L1};
-      };
-      auto convert_lin_half = [&](const LaneCtx &L, int c, int hf) {
-        float b0[4], b1[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int q = 4 * hf + i;
-          const float R1 = L.sf[(4 * q + 1) * (16 * NCT)], dC = L.sf[(4 * q + 2) * (16 * NCT)] - R1;
-          const u32x2 ps2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][w * NQ + q]) + 8);
-          const float p0 = __uint_as_float(ps2[0]), sc = __uint_as_float(ps2[1]);
-          b0[i] = __builtin_fmaf(p0, dC, R1) * g_scale;
-          b1[i] = (sc * dC) * g_scale;
-        }
-        const int f0 = (c & 1) * FSET;
-        store_half(L, b0, f0, hf);
-        store_half(L, b1, f0 + 2 * NCT, hf);
-      };
-      auto convert_hinges_half = [&](const LaneCtx &L, int c, int hf) {
-        float dF[4], dB[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int q = 4 * hf + i;
-          const float R0 = L.sf[(4 * q) * (16 * NCT)], R1 = L.sf[(4 * q + 1) * (16 * NCT)], R2 = L.sf[(4 * q + 2) * (16 * NCT)],
-                      R3 = L.sf[(4 * q + 3) * (16 * NCT)];
-          const float sc = __uint_as_float(ringe[c & (RING - 1)][w * NQ + q][3]);
-          const u32x2 s2 = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringe[c & (RING - 1)][32 + w * NQ + q]) + 8);
-          const float mc = sc * (R2 - R1), ma = __uint_as_float(s2[0]) * (R1 - R0), mb = __uint_as_float(s2[1]) * (R3 - R2);
-          dF[i] = (mb - mc) * (g_scale * ((float)T / kHingeFactorScale));
-          dB[i] = (mc - ma) * (g_scale * ((float)T / kHingeFactorScale));
-        }
-        const int f0 = (c & 1) * FSET + FL;
-        store_half(L, dF, f0, hf);
-        store_half(L, dB, f0 + FH, hf);
-      };
       auto load_x_part = [&](const LaneCtx &L, int c, f32x4 (&x)[8], int q0) {  // requests q0, q0 + 1
         const char *bp = reinterpret_cast<const char *>(P.in);
         const u32x2 mw = *reinterpret_cast<const u32x2 *>(&ring[c & (RING - 1)][L.kg * 8 + q0]);
@@ -687,7 +734,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         __syncthreads();  // the fragments of chunk c are in place; ring slots up to c + RD - 1 are visible
         const LaneCtx L = lane_ctx(true);
         const uint32_t cf = ringc[c & (RING - 1)];
-        f32x3 G[NQ];
+        f32x3 G[NREQ];
         load_gains(L, c + 2, G);  // (past the schedule: the clamped last chunk's, never used)
         if (w == 0) ring_load(L, c + RD);  // (stored behind the line's MFMAs)
         __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
@@ -745,9 +792,11 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             if (it < 4) {
               load_x_part(L, cx, X, 2 * it);
             } else if (it < 6) {
-              convert_lin_half(L, c + 1, it - 4);
+              if (it - 4 < NSL) convert_lin_slice(L, c + 1, it - 4);
+            } else if (NSL == 2) {  // (whether the next chunk has kinks or not: no branch inside the blocks)
+              convert_kinks_slice(L, c + 1, it - 6, 0, KS);
             } else {
-              convert_hinges_half(L, c + 1, it - 6);  // (whether the next chunk has kinks or not: no branch inside the blocks)
+              convert_kinks_slice(L, c + 1, 0, (KS / 2) * (it - 6), (KS / 2) * (it - 5));
             }
           }
           // issue order: the LDS reads of the next block first, then the MFMAs with the other work between them
@@ -785,8 +834,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         if (w == 0) ring_store(L, c + RD);
         // ======== its kinks: forward, then backward
 #pragma unroll 1
-        for (int g = 0; g < 2; g++) {
-          if (!((cf >> (8 + 4 * g + w)) & 1u)) continue;  // (wave-uniform) no such kinks, or none that reach this wave's samples
+        for (int g = 0; g < KS; g++) {
+          if (!((cf >> (8 * g + w)) & 1u)) continue;  // (wave-uniform) no such kinks, or none that reach this wave's samples
           // the lane's 8 factor words -> (slope, slope) and (offset, offset) pairs of its slot pairs
           const u32x4 fa = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][L.kg * 8]);
           const u32x4 fb = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][L.kg * 8 + 4]);

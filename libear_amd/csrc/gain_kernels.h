@@ -54,6 +54,7 @@ struct PointStore {
   int zero_row;          // index of an all-zero gain row (the row behind it is all zero as well)
   int npoints;           // points of all objects together
   int rows;              // rows of the gain image (the arena: all regions, live or not)
+  int kink_row0;         // hinge kernel: the kink rows (gain_hg.h, k_kink_rows) start this many rows behind `gain`; 0: none
   int force_ramp;        // policy mode: every object is ONE ramp through its 2 points,
                          // extrapolated outside (LinearInterp*::apply_interp as called directly)
 };

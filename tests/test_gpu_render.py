@@ -957,8 +957,10 @@ def test_render_block_size_with_a_large_prime_factor():
                           ("ragged", 100, "9+10+3", 256, 9, [9]), ("dense", 96, "9+10+3", 512, 5, [5]),
                           ("constant", 130, "0+5+0", 1024, 3, [3]), ("short", 64, "9+10+3", 512, 4, [4]),
                           ("mixed", 160, "4+5+0", 512, 7, [7]), ("moving", 40, "9+10+3", 100, 13, [13])])
-def test_hinge_kernel_vs_oracle(kind, m, layout, block, nblocks, calls):
-    """k_gain_mix_hg forced for every curve family (EARHIP_MFMA=6): curves that ramp all the time with their points
+@pytest.mark.parametrize("hg_tile", [512, 256])
+def test_hinge_kernel_vs_oracle(kind, m, layout, block, nblocks, calls, hg_tile):
+    """k_gain_mix_hg forced for every curve family (EARHIP_MFMA=6), in both its forms (8 waves on 512-sample tiles with
+    up to two kinks on either side of a tile's centre, 4 waves on 256 with one): curves that ramp all the time with their points
     off the tile grid (what it is for: a line per object and tile plus a hinge per curve point), long ramps with holds,
     block-aligned ramps and static gains (no hinges at all), and curves it can only send through its exact path (short
     ramps, steps, dense points), per channel.  `mixed`: every fourth object of a moving scene on ADM-like short ramps."""
@@ -1006,8 +1008,8 @@ def test_hinge_kernel_vs_oracle(kind, m, layout, block, nblocks, calls):
             c.close()
         return out, plan
 
-    got, plan = _with_env({"EARHIP_MFMA": "6"}, render)
-    assert plan["kernel"] == 5 and plan["tile"] == 256, plan
+    got, plan = _with_env({"EARHIP_MFMA": "6", "EARHIP_HG_TILE": str(hg_tile)}, render)
+    assert plan["kernel"] == 5 and plan["tile"] == hg_tile, plan
     assert np.isfinite(got).all()
     assert scenes.rel_rms(got, want) <= 1e-6, (scenes.rel_rms(got, want), plan)
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6, (scenes.rel_rms_per_channel(got, want), plan)
