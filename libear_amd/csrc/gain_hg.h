@@ -549,10 +549,10 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       typedef float f32x3 __attribute__((ext_vector_type(3)));
       typedef const uint32_t __attribute__((address_space(4))) *ConstWords;  // (K0 wrote them, this kernel only reads: scalar loads)
-      // What a step needs to know about its lane.  Made anew from the lane number in every chunk (through an opaque
-      // copy of it): carried through the chunk loop as so many loop invariants these addresses and offsets were what the
-      // register allocator spilled, and a reload behind the input requests waits for the inputs (the vector-memory
-      // counter is in order).
+      // What a step needs to know about its lane.  (An earlier form of this kernel made these anew in every chunk from
+      // an opaque copy of the lane number: carried through the chunk loop they were what the register allocator spilled,
+      // and a reload behind the input requests waits for the inputs.  With the kink rows precomputed the registers are
+      // there: 4 % faster on 256-sample tiles, the same on 512.)
       struct LaneCtx {
         int lane, li, kg;
         unsigned xlane;      // byte offset of the lane's float4 inside an input row
@@ -570,7 +570,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         L.kg = L.lane >> 4;
         L.xlane = (unsigned)min(tile_s0 + L.li * NRT, nvec - 4) * 4u;
         L.glane = (unsigned)(col0 + NCT * L.li) * 4u;
-        L.sw = reinterpret_cast<float *>(&stage[w][0]) + L.kg * (16 * NCT) + NCT * L.li;
+        L.sw = reinterpret_cast<float *>(&stage[w][0]) + L.kg * (NR * 16 * NCT) + NCT * L.li;
         L.sf = reinterpret_cast<const float *>(&stage[w][0]) + min(L.lane, 16 * NCT - 1);
         L.fpair = L.lane < 16 * NCT ? 2 * L.kg : -1;
         return L;
@@ -610,35 +610,44 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           for (int i = 0; i < 4; i++) x[q + i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + (mw[i] + L.xlane)));
         }
       };
-      // ---- the rows of the slots NQ w .. NQ w + NQ - 1 of chunk c, NR each (the kink rows of the backward kinks, second
-      // one first; gain rows R1, R2 of the line; the kink rows of the forward kinks): request i is rows 4 i .. 4 i + 3 of the
-      // wave's NQ NR — lane (kg, li) takes 12 bytes (columns 3 li .. 3 li + 2 of the workgroup's 48) of row 4 i + kg
+      // ---- the rows of the slots NQ w .. NQ w + NQ - 1 of chunk c, NR each (j = 0 ..: the kink rows of the backward kinks,
+      // second one first; gain rows R1, R2 of the line; the kink rows of the forward kinks).  Request i is row j = i % NR of
+      // four slots — lane (kg, li) takes 12 bytes (columns 3 li .. 3 li + 2 of the workgroup's 48) of slot 4 (i / NR) + kg's —
+      // so that which row a request is for is known at compile time and a lane reads its slot's entry once per group
       constexpr int NREQ = NQ * NR / 4;
       auto load_gains = [&](const LaneCtx &L, int c, f32x3 (&G)[NREQ]) {
 #pragma unroll
-        for (int i = 0; i < NREQ; i++) {
-          const int ridx = 4 * i + L.kg, q = ridx / NR, jj = ridx - q * NR - KS / 2;  // jj = 0, 1: the gain rows
-          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringe[c & (RING - 1)][w * NQ + q]);  // (object | kinks, row R1)
-          const unsigned d2 = (mr[0] >> 16) & 1u;
-          const bool is_kink = jj < 0 || jj > 1;
-          // backward kink nb = -jj (1, 2): kink 2 nb - 1, the point nb - 1 in front of R1; forward nf = jj - 1: kink 2 nf - 2,
-          // the point nf - 1 behind R2
-          const int kbit = jj < 0 ? kLinKinkShift - 2 * jj - 1 : kLinKinkShift + 2 * jj - 4;
-          const unsigned rel = jj < 0 ? (unsigned)(jj + 1) : (jj == 0 ? 0u : d2 + (unsigned)(jj > 1 ? jj - 2 : 0));
-          const bool present = !is_kink || ((mr[0] >> kbit) & 1u);
-          const unsigned row = present ? mr[1] + rel : 0u;  // (absent: the all-zero row of its image)
-          // (uniform base + 32-bit lane offset: the image of the curves is below 4 GB, api_core.hip checks)
-          const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(gain) +
-                                                            (row * (rowlen * 4u) + L.glane + (is_kink ? kink_off : 0u)));
-          if constexpr (NCT == 3) G[i] = *reinterpret_cast<const f32x3 *>(gp);
-          else if constexpr (NCT == 2) G[i] = f32x3{gp[0], gp[1], 0.0f};
-          else G[i] = f32x3{gp[0], 0.0f, 0.0f};
+        for (int grp = 0; grp < NQ / 4; grp++) {
+          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringe[c & (RING - 1)][w * NQ + 4 * grp + L.kg]);  // (object | kinks, row R1)
+          const unsigned r1 = mr[1] * (rowlen * 4u) + L.glane, r2 = r1 + ((mr[0] >> 16) & 1u) * (rowlen * 4u);
+#pragma unroll
+          for (int j = 0; j < NR; j++) {
+            const int jj = j - KS / 2;  // jj = 0, 1: the gain rows
+            unsigned off;
+            if (jj == 0) {
+              off = r1;
+            } else if (jj == 1) {
+              off = r2;
+            } else {
+              // backward kink nb = -jj (1, 2): kink 2 nb - 1, the point nb - 1 in front of R1; forward nf = jj - 1: kink
+              // 2 nf - 2, the point nf - 1 behind R2; a kink the pair does not have: the all-zero row of the kink image
+              const int kbit = jj < 0 ? kLinKinkShift - 2 * jj - 1 : kLinKinkShift + 2 * jj - 4;
+              const unsigned at = jj < 0 ? r1 - (unsigned)(-jj - 1) * (rowlen * 4u) : r2 + (unsigned)(jj - 2) * (rowlen * 4u);
+              off = kink_off + (((mr[0] >> kbit) & 1u) ? at : L.glane);
+            }
+            // (uniform base + 32-bit lane offset: the image of the curves is below 4 GB, api_core.hip checks)
+            const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(gain) + off);
+            f32x3 &g = G[grp * NR + j];
+            if constexpr (NCT == 3) g = *reinterpret_cast<const f32x3 *>(gp);
+            else if constexpr (NCT == 2) g = f32x3{gp[0], gp[1], 0.0f};
+            else g = f32x3{gp[0], 0.0f, 0.0f};
+          }
         }
       };
       auto stage_gains = [&](const LaneCtx &L, const f32x3 (&G)[NREQ]) {
 #pragma unroll
         for (int i = 0; i < NREQ; i++) {
-          float *d = L.sw + i * (4 * 16 * NCT);
+          float *d = L.sw + ((i / NR) * 4 * NR + i % NR) * (16 * NCT);  // staged row NR slot + j
           if constexpr (NCT == 3) *reinterpret_cast<f32x3 *>(d) = G[i];
           else if constexpr (NCT == 2) d[0] = G[i][0], d[1] = G[i][1];
           else d[0] = G[i][0];
@@ -732,7 +741,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
 
       auto chunk_body = [&](int c, f32x4 (&X)[8]) __attribute__((always_inline)) {
         __syncthreads();  // the fragments of chunk c are in place; ring slots up to c + RD - 1 are visible
-        const LaneCtx L = lane_ctx(true);
+        const LaneCtx L = lane_ctx(false);
         const uint32_t cf = ringc[c & (RING - 1)];
         f32x3 G[NREQ];
         load_gains(L, c + 2, G);  // (past the schedule: the clamped last chunk's, never used)
