@@ -646,7 +646,9 @@ struct MixLaunch {
   int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
   bool paired = false;         // with pieces: the lists' paired layout (gain_p2.h)
   bool hinge = false;          // matrix-core kernel on f16x2 split operands with the curve points inside a tile as hinges (gain_hg.h)
-  int hinge_tile = 512;        // with hinge: 512 (8 waves, up to two kinks on either side of a tile's centre) or 256 (4 waves, one)
+  int hinge_tile = 256;        // with hinge: 256 (4 waves, one kink on either side of a tile's centre) or 512 (8 waves, up to two:
+                               // EARHIP_HG_TILE=512; 4 % faster per step, but its line runs twice as far from its segment and
+                               // the kinks cancel twice as much: 9.7e-7 from the CPU path on the always-ramping scene, not 8.3e-7)
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
@@ -707,7 +709,7 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
     if (L.hinge) {
-      if (const char *e = getenv("EARHIP_HG_TILE")) L.hinge_tile = atoi(e) == 256 ? 256 : 512;  // tuning knob
+      if (const char *e = getenv("EARHIP_HG_TILE")) L.hinge_tile = atoi(e) == 512 ? 512 : 256;  // tuning knob
       // (the piece lists stand by on the same tiles, packed: k_hinge_gate)
       L.pieces = false, L.paired = false, L.pw = L.hinge_tile / 64;
     }

@@ -115,7 +115,11 @@ __device__ __forceinline__ uint32_t f16_bits(float v) { return (uint32_t)__built
 // ---------------------------------------------------------------------------
 // K0.  What one (object, tile) pair is for the hinge kernel.  NW = waves of the kernel's workgroup: tiles of 64 NW samples;
 // a pair may have NW / 4 kinks on either side of the centre (one on 256-sample tiles, two on 512).
-constexpr int kHgClasses = 32, kHgSecond = 30, kHgExact = 31;
+// (sort classes of a pair: 9 (4 waves) or 25 (8 waves) by the waves its first kinks reach, then "has second kinks", then "exact")
+template <int NW>
+struct HgClasses {
+  static constexpr int N = NW == 4 ? 16 : 32, kSecond = N - 2, kExact = N - 1;
+};
 // the six records around the centre: points kc - 3 .. kc + 2 (missing ones: never looked at)
 struct HingeRecs {
   PointRec r[6];
@@ -133,7 +137,7 @@ __device__ __forceinline__ HingeRecs hinge_load(const PointStore &ps, int base, 
 }
 struct HingePair {
   int cls;          // sort class of the pair: (first wave its forward kink reaches, last wave its backward kink reaches),
-                    // kHgSecond: it has second kinks, kHgExact: not a pair for this kernel
+                    // HgClasses::kSecond: it has second kinks, kExact: not a pair for this kernel
   uint32_t kinks;   // bit g: kink g (HingeEntry::fac's order)
   int pos[4];       // their places, samples from the tile start
 };
@@ -142,7 +146,7 @@ template <int NW>
 __host__ __device__ inline uint32_t hinge_class_masks(int cls) {
   constexpr int H = NW / 2;
   const uint32_t all = (1u << NW) - 1, upper = all & ~((1u << H) - 1), lower = (1u << H) - 1;
-  if (cls == kHgSecond) return upper | lower << 8 | upper << 16 | lower << 24;
+  if (cls == HgClasses<NW>::kSecond) return upper | lower << 8 | upper << 16 | lower << 24;
   const int wf = cls / (H + 1) + H, wb = cls % (H + 1) - 1;  // wf = NW: no forward kink, wb = -1: no backward kink
   const uint32_t mf = wf < NW ? all & ~((1u << wf) - 1) : 0u, mb = wb >= 0 ? (1u << (wb + 1)) - 1 : 0u;
   return mf | mb << 8;
@@ -194,9 +198,9 @@ __device__ __forceinline__ HingePair hinge_classify(const PointStore &ps, const 
     if (kink_at(i) && pos + 1 < T) hp.kinks |= 1u << (2 * j), hp.pos[2 * j] = pos;
   }
   if (!simple) {
-    hp.cls = kHgExact;
+    hp.cls = HgClasses<NW>::kExact;
   } else if (hp.kinks & 0xcu) {
-    hp.cls = kHgSecond;
+    hp.cls = HgClasses<NW>::kSecond;
   } else {
     const int wf = (hp.kinks & 1u) ? (hp.pos[0] + 1) / 64 : NW, wb = (hp.kinks & 2u) ? (hp.pos[1] - 1) / 64 : -1;
     hp.cls = (max(wf, H) - H) * (H + 1) + (min(wb, H - 1) + 1);
@@ -275,7 +279,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate)
   constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
   constexpr int NWV = kHingeBuildThreads / 64;
-  constexpr int T = 64 * NW, NC = kHgClasses;
+  constexpr int T = 64 * NW, NC = HgClasses<NW>::N, kHgExact = HgClasses<NW>::kExact;
   extern __shared__ int hg_cache[];         // [M][TPW]: kc << 5 | class
   __shared__ int cnt[TPW][NC];              // objects per class
   __shared__ int start[TPW][NC + 2];        // first slot of a class (the listed ones: all but kHgExact), [NC]: listed objects, [NC + 1]: chunks
@@ -299,7 +303,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       int cls = hinge_classify<NW>(ps, R, t0, t1).cls;
       if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - kHingeQuietBinades)
         cls = kHgExact;
-      hg_cache[(size_t)m * TPW + j] = kc << 5 | cls;
+      hg_cache[(size_t)m * TPW + j] = kc << 5 | cls;  // (classes below 32)
       atomicAdd(&cnt[j][cls], 1);
     }
   }
