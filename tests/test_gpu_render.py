@@ -638,6 +638,62 @@ def test_f16x2_kernel_non_finite_input_stays_local():
     assert (~np.isfinite(got[:, 3 * block:])).any()
 
 
+@pytest.mark.parametrize("layout,tile,wgs", [("4+5+0", "512", "8"), ("4+5+0", "512", "16"), ("0+5+0", "256", "8"), ("9+10+3", "512", "8"),
+                                             ("4+5+0", "256", "8")])
+def test_grid_kernel_several_tiles_per_workgroup(layout, tile, wgs):
+    """The grid kernel works through a workgroup's tiles in one software pipeline (gain_h2.h; the forms with a tile per
+    workgroup: gain_h2_t1.h): a call of 41 blocks on 8 or 16 workgroups (EARHIP_H2_WGS), with everything that happens at
+    the END of a tile happening in tiles that are not a workgroup's first or last — objects off the grid (exact path
+    inside the tile), bursts 10^4 above the probed level (the tile is noted and redone exactly behind the loop) — and a
+    ragged last tile."""
+    from libear_amd import capi
+    if os.environ.get("EARHIP_MFMA") not in (None, "3", "4"):
+        pytest.skip("kernel forced by EARHIP_MFMA")
+    block, nblocks, m = 512, 41, 96
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks - 0  # (whole blocks; the ragged tile comes from the 256-/512-sample tiles of a 41-block call)
+    curves = scenes.dense_curves(m, n, block, nblocks, seed=5)
+    odd = scenes.adm_curves(2, n, total, period=700, ramp=150, seed=3)
+    curves[17], curves[90] = odd[0], odd[1]
+    x = (scenes.audio(m, total, seed=23) * np.float32(1e-3)).astype(np.float32)
+
+    def probed(obj):  # the samples k_level_probe reads of this object's row (gain_kernels.h: 16 runs of 4 float4s)
+        nvec, per, nrun = total >> 2, 4, 16
+        stretch = nvec // nrun
+        out = set()
+        for g in range(nrun):
+            h = ((obj * 2654435761) & 0xffffffff) ^ (g * 40503)
+            room = stretch - per + 1 if stretch > per else 1
+            for sub in range(per):
+                at = min(g * stretch + ((h * room) >> 32) + sub, nvec - 1)
+                out.update(range(4 * at, 4 * at + 4))
+        return out
+
+    for b0 in (3, 17, 18, 33, 40):  # bursts in samples the level probe does not read: their tiles overflow the f16 range
+        obj, s0 = (b0 * 7) % m, b0 * block + 201
+        while probed(obj) & set(range(s0, s0 + 3)):
+            s0 += 8
+        x[obj, s0:s0 + 3] *= np.float32(1e4)
+    want = run_oracle(curves, x, n, block, dec, 255)
+
+    def render():
+        r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+        set_renderer_curves(r, curves, True)
+        out = r.process(x)
+        plan = r.last_plan()
+        r.close()
+        return out, plan
+
+    got, plan = _with_env({"EARHIP_H2_TILE": tile, "EARHIP_H2_WGS": wgs}, render)
+    assert plan["kernel"] == 3 and plan["tile"] == int(tile), plan
+    assert np.isfinite(got).all()
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6, (scenes.rel_rms_per_channel(got, want), plan)
+    # and with the whole call on its usual number of workgroups: the same values
+    got2, _ = _with_env({"EARHIP_H2_TILE": tile}, render)
+    assert np.array_equal(got, got2)
+
+
 @pytest.mark.parametrize("tile", [None, "256", "512"])
 def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
     """A few objects whose metadata ignores the block grid (2 of 128 here; up to M / 32) do not move the
