@@ -1017,7 +1017,7 @@ def main():
                         and not args.stream_only and not args.no_secondary and args.row_pad == 0
                         and all(getattr(args, k) is None for k in ("objects", "hoa", "blocks", "block_size", "layout", "buses")))
         if default_call:
-            result["secondary"] = secondary_runs(max(5, min(args.steps, 48)))
+            result["secondary"] = secondary_runs(max(5, min(args.steps, 80)))
         print(json.dumps(result), flush=True)
         if result.get("parity") and not result["parity"]["pass"]:
             print("bench.py: PARITY FAILED - the timed output differs from the CPU path by "
@@ -1048,7 +1048,7 @@ def secondary_runs(steps):
     scene and buffers; this process keeps the GPU but is idle meanwhile), reduced to the figures that matter"""
     out = []
     for name, extra in SECONDARY:
-        cmd = [sys.executable, os.path.abspath(__file__), "--brief", "--no-secondary", "--steps", str(steps), "--warmup", "6",
+        cmd = [sys.executable, os.path.abspath(__file__), "--brief", "--no-secondary", "--steps", str(steps), "--warmup", "20",
                "--kernel-timing-every", "4"] + extra
         t0 = time.perf_counter()
         entry = {"workload": name, "args": " ".join(extra)}
