@@ -1094,8 +1094,10 @@ def test_hinge_kernel_is_chosen_for_always_ramping_curves_off_the_grid():
         assert scenes.rel_rms_per_channel(got, run_oracle(curves, x, n, block, dec, 255)) <= 1e-6
 
 
-def test_curves_updated_object_by_object_between_block_mode_calls():
-    """interp_points is a per-object vector the caller changes freely (gain_interpolator.hpp:42-43): between block-mode
+@pytest.mark.parametrize("force", [None, "6"])
+def test_curves_updated_object_by_object_between_block_mode_calls(force):
+    """(force = 6: on the hinge kernel, whose kink rows — a row per curve point derived on the device behind every upload —
+    have to follow the same updates.)  interp_points is a per-object vector the caller changes freely (gain_interpolator.hpp:42-43): between block-mode
     calls a few objects get a new window of curve points (longer ones too: their region of the curve image moves), most
     keep theirs — the device image follows object by object (CurveSet::commit uploads what changed), the stream equals
     the oracle's with the same updates, and a renderer whose objects are ALL set again gives the same output bit for bit."""
@@ -1112,8 +1114,12 @@ def test_curves_updated_object_by_object_between_block_mode_calls():
         return t, rng.uniform(0, 1, (length, n)).astype(np.float32), rng.uniform(0, 1, (length, n)).astype(np.float32)
 
     cur = [window(0, 6, 13 * (i % 3)) for i in range(m)]  # a third of the objects on the block grid, the others off it
-    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=1)
-    full = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=1)
+    if force is not None and os.environ.get("EARHIP_MFMA") is not None:
+        pytest.skip("kernel forced by EARHIP_MFMA")
+    c_own = _with_env({"EARHIP_MFMA": force}, lambda: capi.Context(0)) if force else None  # (the choice is read at context creation)
+    c_use = c_own if c_own is not None else ctx()
+    r = capi.Renderer(c_use, m, n, block, dec, 255, max_blocks=1)
+    full = capi.Renderer(c_use, m, n, block, dec, 255, max_blocks=1)
     o = _oracle.ObjectsRenderer(m, n, block, dec, 255)
     for i, (t, d, f) in enumerate(cur):
         r.set_object_points(i, t, d, f)
@@ -1137,7 +1143,11 @@ def test_curves_updated_object_by_object_between_block_mode_calls():
         got[:, sl] = r.process(x[:, sl])
         got_full[:, sl] = full.process(x[:, sl])
         want[:, sl] = o.process(x[:, sl])
+    kernel = r.last_plan()["kernel"]
     r.close()
     full.close()
+    if c_own is not None:
+        c_own.close()
+        assert kernel == 5, kernel
     assert np.array_equal(got, got_full)
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6
