@@ -97,9 +97,12 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   pl.pieces = reinterpret_cast<Piece *>(desc);  // (the list builders need no descriptors)
   pl.M = M;
   pl.paired = ml.paired ? 1 : 0;
-  pl.slots = cs.piece_cap(ml.tile(), ml.paired);
-  pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * ml.ntiles);
-  pl.ovf = pl.count + (size_t)8 * ml.ntiles;
+  // (the piece lists that stand by behind the hinge kernel have their own tiles: 64 pw samples, whatever the hinge kernel's)
+  const int ptile = ml.hinge ? 64 * ml.pw : ml.tile();
+  const int pnt = ml.hinge ? (nsamples + ptile - 1) / ptile : ml.ntiles;
+  pl.slots = cs.piece_cap(ptile, ml.paired);
+  pl.count = reinterpret_cast<int *>(pl.pieces + (size_t)pl.cap() * pnt);
+  pl.ovf = pl.count + (size_t)8 * pnt;
   // f16x2 gain kernel: a word per tile, "some object needs the exact path here" (see gain_h2.h)
   unsigned *slow_cur = nullptr, *slow_next = nullptr;
   if (ml.split) {
@@ -146,20 +149,20 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch
   const bool one_pass = ml.pieces || ml.hinge;
   if (ml.pieces || (ml.hinge && gate)) {  // (behind the hinge kernel's builder: the lists of the call it may not take)
-    if (M > kMaxPieceObjects || ml.tile() > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
+    if (M > kMaxPieceObjects || ptile > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     unsigned *obj_lv = probe.obj_level;
     // tiles per workgroup: as many as leave one workgroup per CU (eight tiles = eight lanes per object reading
     // neighbouring points beat four tiles and two workgroups per CU: 0.084 vs 0.096 ms on the ADM scene)
     int tpw = 1;
-    while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus) tpw *= 2;
+    while (tpw < 8 && pnt / (2 * tpw) >= ctx->num_cus) tpw *= 2;
     if (const char *e = getenv("EARHIP_BUILD_TPW")) {  // tuning knob
       const int v = atoi(e);
       if (v == 1 || v == 2 || v == 4 || v == 8) tpw = v;
     }
-    const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
+    const dim3 bgrid((pnt + tpw - 1) / tpw);
 #define EARHIP_BUILD_CASE(T_)                                                                                          \
   if (tpw == T_)                                                                                                       \
-    hipLaunchKernelGGL(k_piece_build<T_>, bgrid, dim3(kBuildThreads), 0, ctx->stream, ps, M, ml.ntiles, ml.tile(), t_call, \
+    hipLaunchKernelGGL(k_piece_build<T_>, bgrid, dim3(kBuildThreads), 0, ctx->stream, ps, M, pnt, ptile, t_call, \
                        t_call + nsamples, pl, obj_lv, level_cur, ml.hinge ? gate : nullptr);
     EARHIP_BUILD_CASE(1) EARHIP_BUILD_CASE(2) EARHIP_BUILD_CASE(4) EARHIP_BUILD_CASE(8)
 #undef EARHIP_BUILD_CASE
@@ -228,7 +231,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     launched = true;
   }
   if (ml.pieces || (ml.hinge && gate)) {
-    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+    const dim3 bgrid(pnt, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
 #define EARHIP_P2_CASE(NCT_, PR_)                                                                                   \

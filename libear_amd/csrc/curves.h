@@ -646,9 +646,9 @@ struct MixLaunch {
   int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
   bool paired = false;         // with pieces: the lists' paired layout (gain_p2.h)
   bool hinge = false;          // matrix-core kernel on f16x2 split operands with the curve points inside a tile as hinges (gain_hg.h)
-  int hinge_tile = 256;        // with hinge: 256 (4 waves, one kink on either side of a tile's centre) or 512 (8 waves, up to two:
-                               // EARHIP_HG_TILE=512; 4 % faster per step, but its line runs twice as far from its segment and
-                               // the kinks cancel twice as much: 9.7e-7 from the CPU path on the always-ramping scene, not 8.3e-7)
+  int hinge_tile = 512;        // with hinge: 512 (8 waves, up to two kinks on either side of a tile's centre) or 256 (4 waves, one:
+                               // EARHIP_HG_TILE=256; 4 % slower per step, 8.1e-7 instead of 8.6e-7 from the CPU path on the
+                               // always-ramping scene at 1024 objects)
   int spl;                     // VALU: samples per lane (2 or 4); tile = 64 * spl samples
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
@@ -709,9 +709,9 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
     if (L.hinge) {
-      if (const char *e = getenv("EARHIP_HG_TILE")) L.hinge_tile = atoi(e) == 512 ? 512 : 256;  // tuning knob
-      // (the piece lists stand by on the same tiles, packed: k_hinge_gate)
-      L.pieces = false, L.paired = false, L.pw = L.hinge_tile / 64;
+      if (const char *e = getenv("EARHIP_HG_TILE")) L.hinge_tile = atoi(e) == 256 ? 256 : 512;  // tuning knob
+      // (the piece lists stand by on 256-sample tiles of their own, packed: k_hinge_gate)
+      L.pieces = false, L.paired = false, L.pw = 4;
     }
   }
   // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
@@ -776,7 +776,11 @@ size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml);
 // (f32 kernel), piece lists sized from the curves, hinge lists (+ the piece lists standing by for them)
 inline size_t scratch_units(const CurveSet &cs, const MixLaunch &ml, int M) {
   const size_t nt = (size_t)ml.ntiles;
-  if (ml.hinge) return std::max(hinge_units((size_t)M, nt), piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired)));
+  // (the piece lists that stand by behind the hinge kernel: tiles of 64 pw samples, at most tile / (64 pw) times as many)
+  if (ml.hinge) {
+    const size_t pnt = nt * (size_t)std::max(1, ml.tile() / (64 * ml.pw));
+    return std::max(hinge_units((size_t)M, nt), piece_units((size_t)M, pnt, (size_t)cs.piece_cap(64 * ml.pw, ml.paired)));
+  }
   if (ml.pieces) return piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired));
   if (ml.split || !ml.mfma) return (size_t)M * nt + 1;
   return desc_units((size_t)M, nt);

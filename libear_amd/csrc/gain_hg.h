@@ -65,8 +65,7 @@ struct LinEntry {
   uint32_t m;   // object | kLinD2 | which kinks the pair has (kLinF1 ..) | kLinNull
   int32_t row;  // gain row R1 of the point the centre segment starts at (kc - 1, clipped into the object's points); its end
                 // (point kc) is row R1 + 1 when kLinD2 is set, else R1 again (no such point: constant)
-  float p0;     // libear's p at the tile start, (float)(s0 - start) * scale (gain_interpolator.hpp:272); negative when the
-                // segment starts inside the tile; 0: constant
+  float p0;     // libear's p at the tile's centre sample c, (float)(c - start) * scale (gain_interpolator.hpp:272); 0: constant
   float scale;  // 1.0f / (float)(end - start) of the centre segment; 0: constant
 };
 // the factors of a pair's kinks: f16 pairs (slope of F: +-1 / kHingeFactorScale, offset of F: -+(r - s0) / kHingeFactorScale),
@@ -209,7 +208,7 @@ __device__ __forceinline__ HingePair hinge_classify(const PointStore &ps, const 
 }
 // the two list entries of a pair
 __device__ __forceinline__ void hinge_entries(const PointStore &ps, const HingeRecs &R, int base, int n, int kc, int m, int64_t t0,
-                                              const HingePair &hp, LinEntry &e, HingeEntry &h) {
+                                              const HingePair &hp, int half, LinEntry &e, HingeEntry &h) {
   const uint32_t allflat = (1u << ps.nbus) - 1;
   const int k1 = min(max(kc - 1, 0), n - 1);  // the point R1 stands for
   const bool d2 = kc < n && kc > k1;
@@ -219,7 +218,9 @@ __device__ __forceinline__ void hinge_entries(const PointStore &ps, const HingeR
   e.scale = 0.0f;
   if (R.has[3] && R.has[2] && (R.r[3].flat & allflat) != allflat) {  // (constant on every bus: E == S bit for bit, nothing to interpolate)
     e.scale = R.r[3].scale;
-    e.p0 = (float)(int32_t)(t0 - R.r[2].time) * R.r[3].scale;
+    // (the line is anchored at the tile's CENTRE — a sample of its own segment: libear's p there, no extrapolation in the
+    // operand; anchored at the tile start its value there ran up to half a tile's slope beyond the gains' range)
+    e.p0 = (float)(int32_t)(t0 + half - R.r[2].time) * R.r[3].scale;
   }
   const float slope = 1.0f / kHingeFactorScale;
 #pragma unroll
@@ -360,7 +361,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
         const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
         LinEntry e;
         HingeEntry h;
-        hinge_entries(ps, R, base, n, kc, m, t0, hp, e, h);
+        hinge_entries(ps, R, base, n, kc, m, t0, hp, T / 2, e, h);
         hl.lin[(size_t)tile * hl.cap + slot] = e;
         if (chunk_flags(j, slot >> 5)) hl.hinge[(size_t)tile * hl.cap + slot] = h;
       }
@@ -940,8 +941,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
   }
 
   if (tile_len <= 0) return;
-  // D fragment of row tile r: rows 4 kg + e = samples 16 kg + 4 e + r; (s - s0) counts from the WORKGROUP tile's start
-  const float wf0 = (float)(wave_s0 + kg * 16);
+  // D fragment of row tile r: rows 4 kg + e = samples 16 kg + 4 e + r; (s - c) counts from the WORKGROUP tile's centre
+  // (where the line is anchored: LinEntry::p0)
+  const float wf0 = (float)(wave_s0 + kg * 16 - T / 2);
   float inv_gc[NCT];
 #pragma unroll
   for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;

@@ -57,11 +57,11 @@ def test_every_baseline_config_gives_a_complete_parity_checked_line(config):
     assert line["step_ms"]["median"] > 0 and line["block_mode"]["ms_per_block"] > 0
 
 
-@pytest.mark.parametrize("scene,kernel,tile", [("adm", "k_gain_mix_p2", 512), ("moving", "k_gain_mix_hg", 256),
+@pytest.mark.parametrize("scene,kernel,tile", [("adm", "k_gain_mix_p2", 512), ("moving", "k_gain_mix_hg", 512),
                                                ("mixed", "k_gain_mix_h2", 512), ("panned-adm", "k_gain_mix_p2", 512)])
 def test_scenes_at_the_headline_size_pass_the_parity_gate_of_their_own_launch_plan(scene, kernel, tile):
     """1024 objects x 512 blocks: the calls long enough for the launch plans only long calls get (the piece-list
-    kernel's paired lists on 8-wave, 512-sample tiles for ADM-like metadata, the hinge kernel on 256 for curves that
+    kernel's paired lists on 8-wave, 512-sample tiles for ADM-like metadata, the hinge kernel on 512 for curves that
     ramp all the time; a ramp that starts on a tile's last sample was lost there once) — the parity gate compares the
     timed call's own output with the CPU path, per channel"""
     forced = any(os.environ.get(k) is not None for k in ("EARHIP_P2_PAIRS", "EARHIP_P2_TILE", "EARHIP_H2_TILE", "EARHIP_MFMA", "EARHIP_HINGE", "EARHIP_HG_TILE"))
