@@ -247,7 +247,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
       const int ol = opaque_lane(), li = ol & 15, kg = ol >> 4;
       // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
       // four row tiles are 4 consecutive samples.  (s - s0) of the rows: sample 64w + 16kg + 4e + r.
-      const float wf0 = (float)(w * TS + kg * 16);
+      const float wf0 = (float)(w * TS + kg * 16 - (TS * NW) / 2);  // (s - c): the line is anchored at the tile's centre
       float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
 #pragma unroll
       for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
@@ -392,7 +392,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
         // (a select between two uniform values: "rs + (ramp ? 1 : 0)" turns the uniform condition into a lane value and
         // the row products into eight quarter-rate vector multiplies per chunk)
         const unsigned re = (valid && (d.info & kSegRamp)) ? (unsigned)d.row + 1u : rs;
-        D.p0[q] = (float)d.d0 * d.scale;  // gain_interpolator.hpp:272 at the tile start
+        // gain_interpolator.hpp:272 at the workgroup tile's CENTRE sample (constant segments: scale = 0): the line is anchored
+        // there — (s - c) runs over +-half a tile, not over a whole one: half the weight on the slope totals' rounding
+        D.p0[q] = d.scale != 0.0f ? (float)(d.d0 + (TS * NW) / 2) * d.scale : 0.0f;
         D.scale[q] = d.scale;             // constant segments: scale = 0, d0 = 0
         const float *rps = gain + (size_t)rs * rowlen, *rpe = gain + (size_t)re * rowlen;
         S[q] = rps[bcol_e];
