@@ -3,7 +3,9 @@
 // the launcher of K0/K1 over them.
 #pragma once
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include <algorithm>
@@ -175,8 +177,22 @@ class CurveSet {
   // mirror while its last upload is still in flight, synchronises.
   void commit(earhip_ctx *ctx) {
     if (dirty_list_.empty()) return;
+#ifdef EARHIP_COMMIT_TIMING  // (-DEARHIP_COMMIT_TIMING: where a commit's time goes, printed at exit; tools/commit_cost.py)
+    static double acc[6] = {0, 0, 0, 0, 0, 0};
+    static long ncalls = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq = now();
+    auto lap = [&](int i) { const double t = now(); acc[i] += t - tq; tq = t; };
+    struct Print { ~Print() { if (ncalls) fprintf(stderr, "commit timing (us/call over %ld): sync %.2f regions %.2f mirror+stats %.2f finish %.2f upload %.2f tail %.2f\n", ncalls, acc[0]/ncalls, acc[1]/ncalls, acc[2]/ncalls, acc[3]/ncalls, acc[4]/ncalls, acc[5]/ncalls); } };
+    static Print printer;
+    ncalls++;
+#define EARHIP_LAP(i) lap(i)
+#else
+#define EARHIP_LAP(i)
+#endif
     const size_t row = (size_t)plan_.row;
     if (staged_) EARHIP_HIP(hipEventSynchronize(staged_));  // the mirror is free again
+    EARHIP_LAP(0);
     // ---- regions: an object that outgrew its region moves to the end of the arena
     bool full_upload = !uploaded_once_;
     for (int m : dirty_list_) {
@@ -233,6 +249,7 @@ class CurveSet {
       h_off_.reserve(M_), h_cnt_.reserve(M_), h_changed_.reserve(M_), h_gcol_.reserve(row);
       d_off_.alloc(M_), d_cnt_.alloc(M_), d_gcol_.alloc(row);
     }
+    EARHIP_LAP(1);
     // ---- the changed objects: mirror, statistics
     const float old_scale = gain_scale();
     bool cmax_shrunk = false;
@@ -270,6 +287,7 @@ class CurveSet {
           cmax_[c] = v <= cmax_[c] ? cmax_[c] : v;
         }
     }
+    EARHIP_LAP(2);
     finish_stats();
     // per-column gain scales (the split-operand kernels scale every output column's gains by its own power of two: a
     // loudspeaker that only ever gets small gains — an object 120 dB down alone on it — keeps both f16 pieces of its
@@ -284,6 +302,7 @@ class CurveSet {
       gcol_changed = gcol_changed || v != h_gcol_.p[c];
       h_gcol_.p[c] = v;
     }
+    EARHIP_LAP(3);
     // ---- upload
     if (gcol_changed) EARHIP_HIP(hipMemcpyAsync(d_gcol_.p, h_gcol_.p, row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (full_upload || dirty_list_.size() > (size_t)M_ / 4) {
@@ -301,6 +320,7 @@ class CurveSet {
                          (int)row);
       EARHIP_HIP(hipGetLastError());
     }
+    EARHIP_LAP(4);
     // kink rows (hinge kernel; once it has been planned for this set): of the changed objects, or of everybody when
     // everything went up again or a column's scale changed
     if (kinks_) {
@@ -314,7 +334,9 @@ class CurveSet {
     for (int m : dirty_list_) obj_[m].dirty = false;
     dirty_list_.clear();
     uploaded_once_ = true;
+    EARHIP_LAP(5);
   }
+#undef EARHIP_LAP
 
   // The hinge kernel has been planned for this set: from now on it keeps a kink row per point (gain_hg.h) behind the
   // gain rows, in the same buffer (twice its size; sets that never meet that kernel never pay for it).  Called with
