@@ -169,12 +169,17 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   }
   if (!fused_prep && !one_pass) {
     const dim3 ogrid((M + 15) / 16);
+    QuietMark qm;  // (what the probe found goes into the descriptors as they are made)
+    if (probe.obj_level) {
+      qm.obj_level = probe.obj_level, qm.cap = ctx->obj_level_cap, qm.level = level_cur;
+      qm.wide = ml.split ? wide_cur : nullptr;
+    }
     if (ml.ntiles >= 2048)
       hipLaunchKernelGGL(k_seg_prep<4>, dim3((ml.ntiles + 63) / 64, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, slow_cur);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, qm, slow_cur);
     else
       hipLaunchKernelGGL(k_seg_prep<2>, dim3((ml.ntiles + 31) / 32, ogrid.x), dim3(256), 0, ctx->stream, ps, M,
-                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, probe, slow_cur);
+                         ml.ntiles, ml.tile(), t_call, t_call + nsamples, desc, qm, slow_cur);
   }
   SlotLists sl;
   sl.slots = reinterpret_cast<Slot *>(desc + (size_t)M * ml.ntiles);
@@ -184,9 +189,6 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (slots)
     hipLaunchKernelGGL(k_slot_list, dim3(ml.ntiles), dim3(256), 0, ctx->stream, ps, M, ml.tile(),
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
-  if (probe.obj_level && !one_pass)
-    hipLaunchKernelGGL(k_mark_quiet, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, desc, M, ml.ntiles, probe.obj_level,
-                       ctx->obj_level_cap, level_cur, slow_cur, ml.split ? wide_cur : nullptr);
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
   P.sl = sl;

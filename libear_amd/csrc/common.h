@@ -132,7 +132,7 @@ struct earhip_ctx {
   int level_idx = 0;
   int last_gate_idx = -1;  // the mode word ([2 + idx]) of the last call planned for the hinge kernel; -1: the last call was not
   // [2][tile_slow_cap] words used alternately by successive calls of the f16x2 gain kernel: non-zero = some object
-  // of the tile needs the kernel's exact path (set by K0 / k_mark_quiet, cleared for the call after next by K1)
+  // of the tile needs the kernel's exact path (set by K0: k_seg_prep, cleared for the call after next by K1)
   earhip::DevBuf<unsigned> tile_slow;
   size_t tile_slow_cap = 0;
   int tile_slow_idx = 0;

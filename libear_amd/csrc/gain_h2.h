@@ -98,7 +98,7 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // chunk: 4 % of this kernel on the headline scene (measured by bisection; neither reading the third piece a block
 // ahead, nor making it from h in registers, nor v_fma_mix forms of the split bring that down).  So both forms
 // exist, as two instantiations launched back to back: the level probe decides on the device which one works
-// (k_mark_quiet sets *wide_cur when some object lies more than kPlainBinades below the loudest) and the other
+// (k_seg_prep sets *wide_cur when some object lies more than kPlainBinades below the loudest) and the other
 // returns at once (an empty grid: ~3 us).  Without a probe (wide_cur == NULL) only the wide form is launched.  The
 // mode words alternate between calls like the level words.
 // NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
@@ -176,7 +176,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   };
   clear_totals();
 
-  // (objects the level probe found far below the call's level — kSegQuiet, set by k_mark_quiet
+  // (objects the level probe found far below the call's level — kSegQuiet, set by k_seg_prep
   // — are treated like objects with a curve point inside the tile: zero row in the main loop,
   // this path afterwards)
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA
@@ -563,8 +563,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     // the pipeline moves on
     auto tile_end = [&](int t) __attribute__((always_inline)) {
       {
-        // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0 and
-        // k_mark_quiet leave a word per tile; this call clears the words of the call after next (they alternate).
+        // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0:
+        // k_seg_prep leaves a word per tile; this call clears the words of the call after next (they alternate).
         // (a scalar load: a vector load here would have to wait for every input request in flight)
         typedef const unsigned __attribute__((address_space(4))) *ConstWord;
         const bool any_slow = !slow_cur || ((ConstWord)slow_cur)[t] != 0u;

@@ -18,7 +18,7 @@ namespace earhip {
 // chunk: 4 % of this kernel on the headline scene (measured by bisection; neither reading the third piece a block
 // ahead, nor making it from h in registers, nor v_fma_mix forms of the split bring that down).  So both forms
 // exist, as two instantiations launched back to back: the level probe decides on the device which one works
-// (k_mark_quiet sets *wide_cur when some object lies more than kPlainBinades below the loudest) and the other
+// (k_seg_prep sets *wide_cur when some object lies more than kPlainBinades below the loudest) and the other
 // returns at once (an empty grid: ~3 us).  Without a probe (wide_cur == NULL) only the wide form is launched.  The
 // mode words alternate between calls like the level words.
 // NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
@@ -59,8 +59,8 @@ k_gain_mix_h2_t1(GainMixParams P, int zero_row, float x_scale, const float *__re
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *level_next = 0;
   }
-  // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0 and
-  // k_mark_quiet leave a word per tile; this call clears the words of the call after next (they alternate).
+  // does any object of this tile need the exact path (a curve point inside the tile, a quiet object)?  K0:
+  // k_seg_prep leaves a word per tile; this call clears the words of the call after next (they alternate).
   const bool any_slow = !slow_cur || slow_cur[wgtile] != 0u;
   if (slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[wgtile] = 0u;
   const int nparts = gridDim.y;
@@ -86,7 +86,7 @@ k_gain_mix_h2_t1(GainMixParams P, int zero_row, float x_scale, const float *__re
   };
   clear_totals();
 
-  // (objects the level probe found far below the call's level — kSegQuiet, set by k_mark_quiet
+  // (objects the level probe found far below the call's level — kSegQuiet, set by k_seg_prep
   // — are treated like objects with a curve point inside the tile: zero row in the main loop,
   // this path afterwards)
   // ---- slow path: one object, all its pieces inside this wave's tile, exact f32 MFMA

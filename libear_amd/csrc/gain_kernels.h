@@ -255,26 +255,33 @@ k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cu
 
 // kPrepRun consecutive tiles per thread: 2 for up to 2047 tiles (headline: K0 0.020 -> 0.018 ms), 4 beyond
 // (ADM scene, 4096 tiles of 128 samples: K0 + K0s 0.112 -> 0.092 ms)
+// What the level probe (a kernel of its own, ahead of this one: complete and visible here) means for the descriptors:
+// objects it found "quiet" (level_is_quiet) get kSegQuiet in every tile, which sends them through the split-operand
+// kernels' exact path (and their tiles' words in tile_slow raised); *wide is raised when some object FALLS more than
+// kPlainBinades below the call's level at some probed instant (zero before the launch; every writer writes 1) — an
+// object that is loud at some instants and 60 dB down at others needs the scaled low pieces there.  (Round 3 did this in
+// a launch of its own behind this kernel, k_mark_quiet: the probe ran inside this kernel then.)
+struct QuietMark {
+  const unsigned *obj_level = nullptr;  // [2][cap]: largest / smallest non-zero magnitude probed per object; nullptr: no probe
+  int cap = 0;
+  const unsigned *level = nullptr;      // the call's level
+  unsigned *wide = nullptr;
+};
 template <int kPrepRun>
 static __global__ void __launch_bounds__(256)
 k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end,
-           SegDesc *desc, LevelProbe probe, unsigned *tile_slow = nullptr) {
+           SegDesc *desc, QuietMark qm, unsigned *tile_slow = nullptr) {
   // a thread searches the segment of its object at its FIRST tile and walks on from there for the
   // next kPrepRun - 1 (the index only grows): a workgroup covers 16 objects x 16 runs of tiles
   __shared__ SegDesc sh[16 * kPrepRun][17];
   const int ti = threadIdx.x & 15, oi = threadIdx.x >> 4;
   const int tile0 = (blockIdx.x * 16 + ti) * kPrepRun, m = blockIdx.y * 16 + oi;
-  // the probe is requested first and looked at last: its latency (a TLB miss, typically) hides behind
-  // the segment search
-  float4 px = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (probe.in) {  // (wave-uniform branch)
-#pragma unroll
-    for (int j = 0; j < kPrepRun; j++) {
-      const int tile = tile0 + j;
-      const int s = tile * tile_samples + 4 * ((m + 5 * tile) & 15);
-      if (tile < ntiles && m < M && tile % probe.every == 0 && s + 3 < probe.nsamples)
-        px = *reinterpret_cast<const float4 *>(probe.in + (size_t)m * probe.in_stride + s);
-    }
+  bool quiet = false;
+  if (qm.obj_level && m < M) {
+    const unsigned call = *qm.level, lv = qm.obj_level[m], lo = qm.obj_level[qm.cap + m];
+    quiet = level_is_quiet(lv, call);
+    if (qm.wide && blockIdx.x == 0 && ti == 0 && lo != 0u && call != 0u && (int)(lo >> 23) < (int)(call >> 23) - kPlainBinades)
+      atomicOr(qm.wide, 1u);
   }
   if (tile0 < ntiles && m < M) {
     const int base = ps.off[m], n = ps.cnt[m];
@@ -291,11 +298,12 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       } else {
         while (k < n && ps.time[base + k] <= t0) k++;  // = upper_bound_time(.., t0), from the previous tile's
       }
-      const SegDesc d = describe_segment_rec(ps, base, n, k, t0, t_end);
+      SegDesc d = describe_segment_rec(ps, base, n, k, t0, t_end);
+      if (quiet) d.info |= kSegQuiet;
       sh[ti * kPrepRun + j][oi] = d;
-      // (f16x2 gain kernel: a curve point inside the tile sends the object through its exact path there; tiles
-      // without any such object — all of them on block-aligned metadata — skip the scan for them)
-      if (tile_slow && (d.info & kSegMulti)) atomicOr(&tile_slow[tile], 1u);
+      // (f16x2 gain kernel: a curve point inside the tile — or a quiet object — sends the object through its exact path
+      // there; tiles without any such object — all of them on block-aligned metadata — skip the scan for them)
+      if (tile_slow && (quiet || (d.info & kSegMulti))) atomicOr(&tile_slow[tile], 1u);
     }
   }
   __syncthreads();
@@ -305,42 +313,6 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
     const int to = (threadIdx.x >> 4) + 16 * j, oo = threadIdx.x & 15;
     const int tile_o = blockIdx.x * 16 * kPrepRun + to, m_o = blockIdx.y * 16 + oo;
     if (tile_o < ntiles && m_o < M) desc[(size_t)tile_o * M + m_o] = sh[to][oo];
-  }
-  if (probe.in) {
-    unsigned v = max(max(__float_as_uint(px.x) & 0x7fffffffu, __float_as_uint(px.y) & 0x7fffffffu),
-                     max(__float_as_uint(px.z) & 0x7fffffffu, __float_as_uint(px.w) & 0x7fffffffu));
-    // the 16 lanes of one object (its 16 runs of tiles) first: the object's own level
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
-    if (probe.obj_level && ti == 0 && m < M && v != 0) atomicMax(probe.obj_level + m, v);
-#pragma unroll
-    for (int d = 32; d >= 16; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d));
-    // one atomic per wave would serialise thousands of them on one address: look first — new maxima
-    // get rare quickly (a stale read only costs an unnecessary atomic)
-    if ((threadIdx.x & 63) == 0 && v != 0)  // (only the waves that probed something touch the word)
-      if (v > __atomic_load_n(probe.level, __ATOMIC_RELAXED)) atomicMax(probe.level, v);
-  }
-}
-
-// Behind k_seg_prep (a kernel boundary: its descriptors and levels are complete and visible), ahead of the
-// split-operand gain kernels: the descriptors of "quiet" objects (level_is_quiet) get kSegQuiet in every
-// tile, which sends them through those kernels' exact path; the per-object levels are cleared for the
-// next call.  A thread per object: nothing to do unless the object is quiet.  (Doing this in
-// k_seg_prep's last workgroup instead needs a device-scope fence per workgroup — an L2 write-back on this
-// chip — and made K0 ten times slower.)
-static __global__ void __launch_bounds__(256)
-k_mark_quiet(SegDesc *desc, int M, int ntiles, const unsigned *obj_level, int cap, const unsigned *level_cur, unsigned *tile_slow,
-             unsigned *wide) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  const unsigned lv = obj_level[m], lo = obj_level[cap + m];
-  // (wide: zero before the launch; every writer writes 1.  The decision looks at how far any object FALLS, not only at
-  // how loud it gets: an object that is loud at some instants and 60 dB down at others needs the scaled low pieces there)
-  if (wide && lo != 0u && *level_cur != 0u && (int)(lo >> 23) < (int)(*level_cur >> 23) - kPlainBinades) atomicOr(wide, 1u);
-  if (!level_is_quiet(lv, *level_cur)) return;
-  for (int t = 0; t < ntiles; t++) {
-    desc[(size_t)t * M + m].info |= kSegQuiet;
-    if (tile_slow) tile_slow[t] = 1u;  // (every writer writes 1)
   }
 }
 
