@@ -316,8 +316,12 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE config 4): --objects in total, split over the GPUs; "
                          "weak: --objects per GPU")
-    ap.add_argument("--row-pad", type=int, default=0,
-                    help="floats of padding between the input rows (row stride = samples + pad; multiple of 4)")
+    ap.add_argument("--row-pad", type=int, default=256,
+                    help="floats of padding between the input rows (row stride = samples + pad; multiple of 4).  Default 256: "
+                         "rows a power of two apart (2 MB at the headline's size, 8 MB at config 3's) put the 32 rows a chunk "
+                         "reads on the same memory channels — config 3's gain kernel 0.48 (0.456-0.543 from run to run) -> "
+                         "0.45 ms, config 5's 0.225 -> 0.220, headline and config 2 unchanged; the caller owns this layout "
+                         "(libear takes channel POINTERS: ptr_adapter.hpp:17-24)")
     ap.add_argument("--brief", action="store_true",
                     help="the timed stream-mode steps, their per-kernel times and the parity gate on the timed buffer only "
                          "(no block-mode, exact-f32, strict or CPU-baseline legs): what the `secondary` entries of the default line run")
@@ -472,8 +476,10 @@ def main():
             gen.manual_seed(1234 + seed)
             self.in_stride = total + args.row_pad
             rows = max(self.M, 1)
-            self.x_full = torch.rand((rows, self.in_stride), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+            # (the samples do not depend on the padding: the rows are drawn as a [rows][total] block)
+            self.x_full = torch.zeros((rows, self.in_stride), device=dev, dtype=torch.float32)
             self.x = self.x_full[:, :total]  # planar rows, in_stride floats apart
+            self.x.copy_(torch.rand((rows, total), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0)
             if args.scene.startswith("bursty"):
                 blv = scenes.bursty_levels(rows, T, self.solo, seed=91 + seed)
                 self.x_full[:, :total].unflatten(1, (T, B)).mul_(torch.as_tensor(blv, device=dev)[:, :, None])
@@ -765,6 +771,7 @@ def main():
                 "workload": workload, "baseline_config": args.config,
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
                 "blocks_per_step": T, "buses": K, "scene": args.scene, "gains": gains_desc,
+                "input_row_stride_samples": wl.in_stride,
                 "parallelism": (f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels"
                                 + (f" + gather of the owned slices on rank {gather_root}" if world > 1 and backend == "nccl" else "")
                                 + (": libearhip's own RCCL communicator (earhip_comm, api_comm.hip)" if native_comm is not None
@@ -1014,7 +1021,7 @@ def main():
         # configurations and of the scenes whose curves take the other gain kernels, each a child process of its own
         # (`--brief`: timed steps between barriers exactly as above, per-kernel events, parity gate on its own timed buffer)
         default_call = (world == 1 and args.config == "C4" and args.scene == "dense" and not args.strict and not args.brief
-                        and not args.stream_only and not args.no_secondary and args.row_pad == 0
+                        and not args.stream_only and not args.no_secondary and args.row_pad == 256
                         and all(getattr(args, k) is None for k in ("objects", "hoa", "blocks", "block_size", "layout", "buses")))
         if default_call:
             result["secondary"] = secondary_runs(max(5, min(args.steps, 80)))

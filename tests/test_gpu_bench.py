@@ -23,6 +23,31 @@ def _free_port():
     return port
 
 
+def _run_with_one_retry(cmd, env, timeout):
+    """Several ranks sharing ONE GPU over gloo (the functional check of the multi-rank control flow on a one-GPU box) hung
+    once in some dozens of runs — both ranks alive, no progress, nothing in their output — and ran through when started
+    again; a rendezvous over TCP between processes that time-slice one device is not what is under test here.  So:
+    a bounded wait and one second try; a second hang fails the test."""
+    import signal
+    for attempt in (0, 1):
+        # (its own process group: on a timeout the launcher AND the ranks it started are ended, by that group's id)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            proc.communicate()
+            if attempt == 1:
+                raise
+            if "--master-port" in cmd:  # a fresh port for the second try
+                cmd = list(cmd)
+                cmd[cmd.index("--master-port") + 1] = str(_free_port())
+
+
 def run_bench(args, nproc=1, env=None):
     cmd = [sys.executable]
     if nproc > 1:
@@ -31,7 +56,7 @@ def run_bench(args, nproc=1, env=None):
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
     e = dict(os.environ)
     e.update(env or {})
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=e, cwd=ROOT)
+    res = _run_with_one_retry(cmd, e, 900 if nproc == 1 else 300)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -99,7 +124,7 @@ def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
     e["EARHIP_BENCH_CHECK"] = "force"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--objects", "128", "--blocks", "32", "--steps", "3",
            "--warmup", "1", "--cpu-blocks", "0"]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=e, cwd=ROOT)
+    res = _run_with_one_retry(cmd, e, 300)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
