@@ -132,19 +132,27 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)M * v <= (size_t)kMaxHingeCached) tpw = v;
     }
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
-    const size_t lds = sizeof(int) * (size_t)M * tpw;
-#define EARHIP_HBUILD_CASE(T_)                                                                                        \
-  if (tpw == T_)                                                                                                      \
+    const size_t lds = sizeof(HingeCached) * (size_t)M * tpw;
+    // (more than 64 KB of dynamic LDS has to be asked for, once per instantiation)
+#define EARHIP_HBUILD_ONE(T_, NW_)                                                                                    \
   {                                                                                                                   \
-    if (ml.tile() == 256)                                                                                             \
-      hipLaunchKernelGGL((k_hinge_build<T_, 4>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                         t_call + nsamples, hl, obj_lv, level_cur, gate);                                             \
-    else                                                                                                              \
-      hipLaunchKernelGGL((k_hinge_build<T_, 8>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                         t_call + nsamples, hl, obj_lv, level_cur, gate);                                             \
+    static size_t allowed = 64 * 1024;                                                                                \
+    if (lds > allowed) {                                                                                              \
+      EARHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hinge_build<T_, NW_>),                         \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));                 \
+      allowed = 128 * 1024;                                                                                           \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_hinge_build<T_, NW_>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
+                       t_call + nsamples, hl, obj_lv, level_cur, gate);                                               \
+  }
+#define EARHIP_HBUILD_CASE(T_)                                                                                        \
+  if (tpw == T_) {                                                                                                    \
+    if (ml.tile() == 256) EARHIP_HBUILD_ONE(T_, 4)                                                                    \
+    else EARHIP_HBUILD_ONE(T_, 8)                                                                                     \
   }
     EARHIP_HBUILD_CASE(1) EARHIP_HBUILD_CASE(2) EARHIP_HBUILD_CASE(4) EARHIP_HBUILD_CASE(8)
 #undef EARHIP_HBUILD_CASE
+#undef EARHIP_HBUILD_ONE
   }
   // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch
   const bool one_pass = ml.pieces || ml.hinge;

@@ -52,7 +52,7 @@ namespace earhip {
 
 constexpr int kHingeTile = 256;     // samples of the smaller form's tile (what the curve statistics count in)
 constexpr int kHingeMinLen = 128;   // ramps that meet a kink are at least this long
-constexpr int kMaxHingeCached = 12288;
+constexpr int kMaxHingeCached = 8192;  // (object, tile) pairs a list-building workgroup keeps between its two passes (16 B each, LDS); also the most objects
 // The factor of a kink is kept as 16 (s - r) / T, its gain operand as T D / 16: with F in [1 / 256, 1] the product F x of a quiet
 // object's input would be a subnormal f16 (x sits 2^-10 below the call's level at -100 dB; the packed-f16 products have no
 // wider intermediate), 16 F x stays normal — and its residual exactly representable — down to 17 binades below the level.
@@ -271,8 +271,15 @@ constexpr int kHingeBuildThreads = 1024;
 // objects, the tile index fastest (the lanes of an object read neighbouring points: gain_p2.h, k_piece_build).  Two
 // passes over the objects: the first finds every pair's centre segment (one search) and class and counts the classes of
 // each tile, the second — the classes' places in the list known — ranks the pairs of a class in object order (ballots:
-// the lists are deterministic) and writes the entries.  What the first pass found is kept in LDS (dynamic: 4 M TPW
-// bytes).  NW: the waves of the kernel the lists are for (tiles of 64 NW samples).
+// the lists are deterministic) and writes the entries.  What the first pass found is kept in LDS (dynamic: 16 M TPW
+// bytes: segment index and class, the pair's kinks and their places, the line's position and 1 / length — the second pass
+// looks at no curve point again).  NW: the waves of the kernel the lists are for (tiles of 64 NW samples).
+struct HingeCached {
+  uint32_t code;   // kc << 5 | class, bits 23 .. 31: the place of kink 3
+  uint32_t kinks;  // bits 0 .. 3: which kinks, then 9 bits each: the places of kinks 0 .. 2
+  float p0, scale; // of the LinEntry
+};
+static_assert(sizeof(HingeCached) == 16, "");
 template <int TPW, int NW>
 __global__ void __launch_bounds__(kHingeBuildThreads)
 k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
@@ -281,7 +288,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
   constexpr int NWV = kHingeBuildThreads / 64;
   constexpr int T = 64 * NW, NC = HgClasses<NW>::N, kHgExact = HgClasses<NW>::kExact;
-  extern __shared__ int hg_cache[];         // [M][TPW]: kc << 5 | class
+  extern __shared__ HingeCached hg_cache[];  // [M][TPW]
   __shared__ int cnt[TPW][NC];              // objects per class
   __shared__ int start[TPW][NC + 2];        // first slot of a class (the listed ones: all but kHgExact), [NC]: listed objects, [NC + 1]: chunks
   __shared__ int run[TPW][NC];              // objects of a class placed by the batches so far
@@ -301,10 +308,19 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       const int base = ps.off[m], n = ps.cnt[m];
       const int kc = upper_bound_time_window(ps.time + base, n, t0 + T / 2);
       const HingeRecs R = hinge_load(ps, base, n, kc);
-      int cls = hinge_classify<NW>(ps, R, t0, t1).cls;
+      const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
+      int cls = hp.cls;
       if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - kHingeQuietBinades)
         cls = kHgExact;
-      hg_cache[(size_t)m * TPW + j] = kc << 5 | cls;  // (classes below 32)
+      LinEntry e;
+      HingeEntry h;
+      hinge_entries(ps, R, base, n, kc, m, t0, hp, T / 2, e, h);
+      HingeCached hc;
+      auto place = [&](int g) { return (hp.kinks >> g) & 1u ? (uint32_t)hp.pos[g] & 511u : 0u; };
+      hc.code = (uint32_t)(kc << 5 | cls) | place(3) << 23;  // (classes below 32, kc below 2^18)
+      hc.kinks = hp.kinks | place(0) << 4 | place(1) << 13 | place(2) << 22;
+      hc.p0 = e.p0, hc.scale = e.scale;
+      hg_cache[(size_t)m * TPW + j] = hc;
       atomicAdd(&cnt[j][cls], 1);
     }
   }
@@ -339,8 +355,9 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   for (int mb = 0; mb < M; mb += OB) {
     const int m = mb + oi;
     const bool in = m < M && tile < ntiles;
-    const int code = in ? hg_cache[(size_t)m * TPW + j] : -1;
-    const int cls = in ? code & 31 : -1, kc = code >> 5;
+    HingeCached hc = {0u, 0u, 0.0f, 0.0f};
+    if (in) hc = hg_cache[(size_t)m * TPW + j];
+    const int cls = in ? (int)(hc.code & 31u) : -1, kc = (int)((hc.code >> 5) & 0x3ffffu);
     unsigned long long mine = 0;
     for (int b = 0; b < NC; b++) {
       const unsigned long long bal = __ballot(cls == b);
@@ -357,11 +374,23 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       } else {
         const int slot = start[j][cls] + at;
         const int base = ps.off[m], n = ps.cnt[m];
-        const HingeRecs R = hinge_load(ps, base, n, kc);
-        const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
+        // (the entries from what the first pass kept: hinge_entries' own expressions)
+        const int k1 = min(max(kc - 1, 0), n - 1);
+        const uint32_t kinks = hc.kinks & 15u;
         LinEntry e;
+        e.m = (uint32_t)m | ((kc < n && kc > k1) ? kLinD2 : 0u) | kinks << kLinKinkShift;
+        e.row = base + k1;
+        e.p0 = hc.p0, e.scale = hc.scale;
         HingeEntry h;
-        hinge_entries(ps, R, base, n, kc, m, t0, hp, T / 2, e, h);
+        const float slope = 1.0f / kHingeFactorScale;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const uint32_t pos = g < 3 ? (hc.kinks >> (4 + 9 * g)) & 511u : hc.code >> 23;
+          h.fac[g] = 0u;
+          if (!((kinks >> g) & 1u)) continue;
+          if (g & 1) h.fac[g] = f16_bits(-slope) | f16_bits((float)pos * slope) << 16;
+          else h.fac[g] = f16_bits(slope) | f16_bits(-(float)pos * slope) << 16;
+        }
         hl.lin[(size_t)tile * hl.cap + slot] = e;
         if (chunk_flags(j, slot >> 5)) hl.hinge[(size_t)tile * hl.cap + slot] = h;
       }
