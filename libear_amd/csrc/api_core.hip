@@ -136,7 +136,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // (more than 64 KB of dynamic LDS has to be asked for, once per instantiation)
 #define EARHIP_HBUILD_ONE(T_, NW_)                                                                                    \
   {                                                                                                                   \
-    static size_t allowed = 64 * 1024;                                                                                \
+    static size_t allowed = 32 * 1024;                                                                                \
     if (lds > allowed) {                                                                                              \
       EARHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hinge_build<T_, NW_>),                         \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));                 \
