@@ -59,3 +59,17 @@ def test_bench_lines_of_the_round_are_tracked_and_parse():
         assert d["value"] > 0 and d["unit"] == "Msamples/s"
         if "parity" in d and d["parity"] and "pass" in d["parity"]:
             assert d["parity"]["pass"], f
+
+
+def test_default_line_of_the_round_carries_the_other_workloads():
+    """profiles/r04_bench_default.json: the default `python bench.py` line as the driver runs it — headline + the
+    `secondary` array (configs 2, 3, 5, the scenes that take the other gain kernels, a rank's share at 8 GPUs), every entry
+    parity-gated on its own timed buffer"""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    assert d["config"]["baseline_config"] == "C4" and d["parity"]["pass"]
+    assert d["parity"]["gpu_rel_rms_vs_float64"] <= d["parity"]["cpu_rel_rms_vs_float64"]
+    sec = {s["workload"]: s for s in d["secondary"]}
+    assert len(sec) >= 8, sorted(sec)
+    for name, s in sec.items():
+        assert "error" not in s, (name, s.get("error"))
+        assert s["value"] > 0 and s["parity"]["pass"] and s["parity"]["max_channel_rel_rms_vs_cpu"] <= 1e-6, name
