@@ -107,7 +107,7 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // (the 4-wave forms with two or three column tiles: gain_h2_t1.h, a tile per workgroup)
 constexpr bool h2_persistent(int nct, int nw) { return nw == 8 || nct == 1; }
 template <int NCT, int NW, bool WIDE>
-__global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 4 : (NW == 4 ? 2 : 1))
+__global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 2 : (NW == 4 ? 2 : 1))
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next, const unsigned *wide_cur, unsigned *wide_next) {
   if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
