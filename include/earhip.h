@@ -15,7 +15,9 @@
  *   - `*_device` entry points take device pointers in the same planar layout
  *     (channel c at base + c * stride) and enqueue on the context's stream
  *     without synchronising;
- *   - no entry point allocates host or device memory in a `process` call.
+ *   - no entry point allocates host or device memory in a `process` call: buffers
+ *     are made at create and where curves are committed (earhip_render_commit; a
+ *     process call that finds uncommitted curves commits them first).
  *
  * Errors: every function returns an int status.  Nothing throws across this
  * boundary.  earhip_last_error() returns the message of the calling thread's
@@ -64,6 +66,20 @@ int earhip_ctx_synchronize(earhip_ctx *ctx);
  * so M->N results are bit-identical to the CPU path.  Default 0: fused
  * multiply-adds and tree accumulation (faster, within 1e-6 relative RMS). */
 int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
+/* Run-time configuration (libear has none: its only knob is the FFT plugin; SURVEY 5 asks for "a small runtime config").
+ * Every tuning knob is an option of the context: key = one of the names below (case-insensitive, an "EARHIP_" prefix is
+ * accepted), value = a decimal integer as text, or NULL / "" to return the option to its default ("the library decides").
+ * At earhip_ctx_create every option is taken ONCE from the environment variable EARHIP_<KEY>; after that only this call
+ * changes it — no process call reads the environment.  An option takes effect for calls / objects made after it is
+ * set.  Unknown key: EARHIP_INVALID_ARGUMENT.
+ *   gain stage:   MFMA (0 VALU | 1 exact-f32 MFMA | 3 default | 4 grid kernel | 5 piece lists | 6 hinge kernel),
+ *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, BUILD_TPW, HBUILD_TPW (1 2 4 8),
+ *                 SPL (2 | 4), WAVES (1..8), TPW (1..8), NRT (4 | 8), XSCALE (log2 of a fixed input prescale), PROBE_RUNS
+ *   renderer:     K2_WG, K2_OWN_BLOCK (0 | 1), RUN (odd blocks per decorrelator run), GSPLIT (1..32) — read by
+ *                 earhip_render_create; GRAPH (0 | 1: block-mode calls replay a captured HIP graph, default 1)
+ *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING */
+int earhip_ctx_set_option(earhip_ctx *ctx, const char *key, const char *value);
+int earhip_ctx_get_option(const earhip_ctx *ctx, const char *key, int *is_set, int *value);
 /* Host memory the device reaches directly (pinned and mapped).  libear's interfaces take `float **` channel
  * pointers into the caller's own memory (include/ear/dsp/ptr_adapter.hpp:17-24: the columns of a matrix);
  * when those buffers come from earhip_host_alloc, or were registered once with earhip_host_register
@@ -361,8 +377,14 @@ int earhip_render_destroy(earhip_render *r);
 int earhip_render_set_object_points(earhip_render *r, int object, int npoints,
                                     const int64_t *times, const float *direct,
                                     const float *diffuse);
-/* Upload pending curve changes now (otherwise done at the next process). */
+/* Upload pending curve changes now (otherwise done at the next process), and make everything a call on the new curves
+ * can need: the scratch of the list kernels (sized from the curves) and, for curves the hinge kernel is planned for, its
+ * kink rows — for calls of max_blocks, max_blocks / 2 and one block.  This is where the library allocates and
+ * synchronises when curves outgrow what is there; a process call on committed curves does neither.  (One exception: a
+ * process call whose launch plan no commit foresaw — an option changed in between — grows the scratch itself;
+ * earhip_render_scratch_regrows counts such calls: 0 in the library's own tests and benchmarks.) */
 int earhip_render_commit(earhip_render *r);
+int earhip_render_scratch_regrows(const earhip_render *r, long *count);
 /* Zero the DSP state (convolver tails, delay line) and set the sample clock. */
 int earhip_render_reset(earhip_render *r, int64_t sample_time);
 /* Process nblocks blocks from device memory: in_dev [n_objects][in_stride],
@@ -393,8 +415,9 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind);
 /* Kernel 5 keeps 1e-6 for inputs down to 16 binades below the call's level (kernel 4: 21), so a
  * call it is planned for is decided ON THE DEVICE, from the level probe of the call's inputs: the
  * hinge kernel or the piece lists launched behind it.  *standby = 1 when the last call of this
- * context was planned for kernel 5 and the piece lists did it, else 0.  Synchronises the stream
- * (for benchmarks and tests that must name the kernel they measured). */
+ * renderer was planned for kernel 5 and the piece lists did it, else 0.  Synchronises the stream
+ * (for benchmarks and tests that must name the kernel they measured).  Valid until the next process
+ * call of ANY renderer or gain stage on the same context: the decision word belongs to the context. */
 int earhip_render_hinge_standby(earhip_render *r, int *standby);
 /* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.

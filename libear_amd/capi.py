@@ -124,6 +124,16 @@ class Context:
     def synchronize(self):
         check(load().earhip_ctx_synchronize(self.h))
 
+    def set_option(self, key, value=None):
+        """a tuning knob of this context (include/earhip.h: earhip_ctx_set_option); value None: back to the default"""
+        check(load().earhip_ctx_set_option(self.h, key.encode(), None if value is None else str(value).encode()))
+
+    def get_option(self, key):
+        """None when the option is at its default, else its integer value"""
+        is_set, v = C.c_int(0), C.c_int(0)
+        check(load().earhip_ctx_get_option(self.h, key.encode(), C.byref(is_set), C.byref(v)))
+        return v.value if is_set.value else None
+
     def read_bandwidth(self, dev_ptr, rows, stride, nsamples, reps=5):
         """(ms linear stream over rows*stride floats, ms gain-stage row pattern over rows*nsamples floats)"""
         ms = (C.c_double * 2)()
@@ -622,6 +632,12 @@ class Renderer:
         """device scratch (descriptors, lists) the last call needed"""
         v = C.c_size_t(0)
         check(load().earhip_render_scratch_bytes(self.h, C.byref(v)))
+        return v.value
+
+    def scratch_regrows(self):
+        """process calls that had to grow the list scratch themselves (0 on committed curves)"""
+        v = C.c_long(0)
+        check(load().earhip_render_scratch_regrows(self.h, C.byref(v)))
         return v.value
 
     def last_plan(self):

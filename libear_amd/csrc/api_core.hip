@@ -1,7 +1,9 @@
 // api_core.hip — context, error reporting, the interpolation-policy entry
 // points (A) and the whole-curve GainInterpolator (A') of include/earhip.h.
+#include <cctype>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 #include <memory>
 #include <mutex>
 
@@ -84,9 +86,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     }
     probe.obj_level = ctx->obj_level.p;
     probe.level = level_cur;
-    static const int probe_runs = [] {  // tuning knob: runs of consecutive samples per object (1 .. 64)
-      const char *e = getenv("EARHIP_PROBE_RUNS");
-      const int v = e ? atoi(e) : 0;
+    const int probe_runs = [&] {  // tuning knob: runs of consecutive samples per object (1 .. 64)
+      const int v = ctx->get(OPT_PROBE_RUNS);
       return v >= 1 && v <= 64 && (v & (v - 1)) == 0 ? v : 16;
     }();
     hipLaunchKernelGGL(k_level_probe, dim3((M + kProbeObjects - 1) / kProbeObjects), dim3(64 * kProbeObjects), 0, ctx->stream, in_dev,
@@ -127,24 +128,16 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate);
     int tpw = 1;
     while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
-    if (const char *e = getenv("EARHIP_HBUILD_TPW")) {  // tuning knob
-      const int v = atoi(e);
+    if (ctx->has(OPT_HBUILD_TPW)) {  // tuning knob
+      const int v = ctx->get(OPT_HBUILD_TPW);
       if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)M * v <= (size_t)kMaxHingeCached) tpw = v;
     }
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
     const size_t lds = sizeof(HingeCached) * (size_t)M * tpw;
-    // (more than 64 KB of dynamic LDS has to be asked for, once per instantiation)
+    // (more than 64 KB of dynamic LDS has to be asked for, per device and instantiation: earhip_ctx_create does, hinge_build_allow_lds)
 #define EARHIP_HBUILD_ONE(T_, NW_)                                                                                    \
-  {                                                                                                                   \
-    static size_t allowed = 32 * 1024;                                                                                \
-    if (lds > allowed) {                                                                                              \
-      EARHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hinge_build<T_, NW_>),                         \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));                 \
-      allowed = 128 * 1024;                                                                                           \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((k_hinge_build<T_, NW_>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                       t_call + nsamples, hl, obj_lv, level_cur, gate);                                               \
-  }
+  hipLaunchKernelGGL((k_hinge_build<T_, NW_>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
+                     t_call + nsamples, hl, obj_lv, level_cur, gate);
 #define EARHIP_HBUILD_CASE(T_)                                                                                        \
   if (tpw == T_) {                                                                                                    \
     if (ml.tile() == 256) EARHIP_HBUILD_ONE(T_, 4)                                                                    \
@@ -163,8 +156,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // neighbouring points beat four tiles and two workgroups per CU: 0.084 vs 0.096 ms on the ADM scene)
     int tpw = 1;
     while (tpw < 8 && pnt / (2 * tpw) >= ctx->num_cus) tpw *= 2;
-    if (const char *e = getenv("EARHIP_BUILD_TPW")) {  // tuning knob
-      const int v = atoi(e);
+    if (ctx->has(OPT_BUILD_TPW)) {  // tuning knob
+      const int v = ctx->get(OPT_BUILD_TPW);
       if (v == 1 || v == 2 || v == 4 || v == 8) tpw = v;
     }
     const dim3 bgrid((pnt + tpw - 1) / tpw);
@@ -263,7 +256,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // through its share of the tiles in one software pipeline (gain_h2.h)
     const int per_cu = ml.tile() == 512 ? (cp.nct == 1 ? 2 : 1) : (cp.nct == 1 ? 3 : 2);
     int wgs = std::max(8, (ctx->num_cus * per_cu / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
-    if (const char *e = getenv("EARHIP_H2_WGS")) wgs = std::max(1, atoi(e));  // tuning knob
+    if (ctx->has(OPT_H2_WGS)) wgs = std::max(1, ctx->get(OPT_H2_WGS));  // tuning knob
     wgs = std::max(wgs, ((ml.ntiles + 63) / 64 + 7) & ~7);  // (at most 64 tiles per workgroup: its redo mask)
     if (!h2_persistent(cp.nct, ml.tile() == 512 ? 8 : 4)) wgs = ml.ntiles;  // (a tile per workgroup)
     const dim3 bgrid(std::min(ml.ntiles, wgs), ml.gsplit, cp.mnz * cp.mgroups);
@@ -321,6 +314,18 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (!launched) fail_internal("no gain_mix instantiation for this column plan");
   if (ev) EARHIP_HIP(hipEventRecord(ev[3], ctx->stream));
   EARHIP_HIP(hipGetLastError());
+}
+
+// k_hinge_build keeps up to 128 KB of dynamic LDS per workgroup: the limit is an attribute of the function ON A DEVICE, so
+// every context raises it for its own device when it is created (a process-wide "done" flag left the other GPUs of a
+// multi-GPU process at the default 64 KB: launches with more failed there).
+void hinge_build_allow_lds() {
+#define EARHIP_HBUILD_ATTR(T_, NW_)                                                                       \
+  EARHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hinge_build<T_, NW_>),                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
+  EARHIP_HBUILD_ATTR(1, 4) EARHIP_HBUILD_ATTR(2, 4) EARHIP_HBUILD_ATTR(4, 4) EARHIP_HBUILD_ATTR(8, 4)
+  EARHIP_HBUILD_ATTR(1, 8) EARHIP_HBUILD_ATTR(2, 8) EARHIP_HBUILD_ATTR(4, 8) EARHIP_HBUILD_ATTR(8, 8)
+#undef EARHIP_HBUILD_ATTR
 }
 
 // Device-resident M -> N gain stage with host staging; shared by the policy
@@ -389,6 +394,22 @@ struct GainStage {
 }  // namespace earhip
 
 using namespace earhip;
+
+// keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
+static const char *const kOptNames[OPT_COUNT] = {
+    "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "P2_TILE", "P2_PAIRS", "HINGE", "HG_TILE", "HBUILD_TPW",
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "GRAPH"};
+
+void earhip_ctx::apply_options() {
+  spl = 4, use_mfma = 3, x_scale_log2 = 14, x_scale_auto = true, max_waves = 4, tiles_per_wg = 4, tiles_per_wg_forced = false, nrt = 8;
+  if (has(OPT_SPL) && (get(OPT_SPL) == 2 || get(OPT_SPL) == 4)) spl = get(OPT_SPL);  // samples per lane in gain_mix
+  if (has(OPT_MFMA)) use_mfma = get(OPT_MFMA);
+  if (has(OPT_XSCALE) && get(OPT_XSCALE) >= -64 && get(OPT_XSCALE) <= 64)  // f16x2 kernel: log2 of the input prescale
+    x_scale_log2 = get(OPT_XSCALE), x_scale_auto = false;
+  if (has(OPT_WAVES) && get(OPT_WAVES) >= 1 && get(OPT_WAVES) <= 8) max_waves = get(OPT_WAVES);
+  if (has(OPT_TPW) && get(OPT_TPW) >= 1 && get(OPT_TPW) <= 8) tiles_per_wg = get(OPT_TPW), tiles_per_wg_forced = true;
+  if (has(OPT_NRT) && (get(OPT_NRT) == 4 || get(OPT_NRT) == 8)) nrt = get(OPT_NRT);
+}
 
 struct earhip_gain_interp {
   std::unique_ptr<GainStage> stage;
@@ -556,28 +577,47 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
     hipDeviceProp_t prop;
     EARHIP_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("EARHIP_SPL")) {  // tuning knob: samples per lane in gain_mix
-      const int v = atoi(e);
-      if (v == 2 || v == 4) c->spl = v;
+    hinge_build_allow_lds();  // (this device's limit)
+    // the options: once, from the environment (EARHIP_<KEY>); afterwards only earhip_ctx_set_option changes them
+    for (int o = 0; o < OPT_COUNT; o++) {
+      const std::string name = std::string("EARHIP_") + kOptNames[o];
+      if (const char *e = getenv(name.c_str())) c->opt[o].set = true, c->opt[o].v = atoi(e);
     }
-    if (const char *e = getenv("EARHIP_MFMA")) c->use_mfma = atoi(e);
-    if (const char *e = getenv("EARHIP_XSCALE")) {  // f16x2 kernel: log2 of the input prescale
-      const int v = atoi(e);
-      if (v >= -64 && v <= 64) c->x_scale_log2 = v, c->x_scale_auto = false;
-    }
-    if (const char *e = getenv("EARHIP_WAVES")) {
-      const int v = atoi(e);
-      if (v >= 1 && v <= 8) c->max_waves = v;
-    }
-    if (const char *e = getenv("EARHIP_TPW")) {
-      const int v = atoi(e);
-      if (v >= 1 && v <= 8) c->tiles_per_wg = v, c->tiles_per_wg_forced = true;
-    }
-    if (const char *e = getenv("EARHIP_NRT")) {
-      const int v = atoi(e);
-      if (v == 4 || v == 8) c->nrt = v;
-    }
+    c->apply_options();
     *out = c.release();
+  });
+}
+
+int earhip_ctx_set_option(earhip_ctx *ctx, const char *key, const char *value) {
+  return guarded([&] {
+    require(ctx != nullptr && key != nullptr, "NULL argument");
+    std::string k(key);
+    for (auto &ch : k) ch = (char)std::toupper((unsigned char)ch);
+    if (k.compare(0, 7, "EARHIP_") == 0) k = k.substr(7);
+    for (int o = 0; o < OPT_COUNT; o++)
+      if (k == kOptNames[o]) {
+        ctx->opt[o].set = value != nullptr && value[0] != 0;
+        ctx->opt[o].v = ctx->opt[o].set ? atoi(value) : 0;
+        ctx->apply_options();
+        return;
+      }
+    fail_invalid("unknown option '" + std::string(key) + "'");
+  });
+}
+
+int earhip_ctx_get_option(const earhip_ctx *ctx, const char *key, int *is_set, int *value) {
+  return guarded([&] {
+    require(ctx != nullptr && key != nullptr && is_set != nullptr && value != nullptr, "NULL argument");
+    std::string k(key);
+    for (auto &ch : k) ch = (char)std::toupper((unsigned char)ch);
+    if (k.compare(0, 7, "EARHIP_") == 0) k = k.substr(7);
+    for (int o = 0; o < OPT_COUNT; o++)
+      if (k == kOptNames[o]) {
+        *is_set = ctx->opt[o].set ? 1 : 0;
+        *value = ctx->opt[o].v;
+        return;
+      }
+    fail_invalid("unknown option '" + std::string(key) + "'");
   });
 }
 

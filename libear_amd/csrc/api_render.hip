@@ -62,13 +62,13 @@ template <int L>
 static void launch_decor_t(const DecorParams &P, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((k_decorrelate_delay_mix<L>), grid, dim3(256), 0, s, P);
 }
-static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s, bool force_wg = false) {
+static void launch_decor(int L, const DecorParams &P, dim3 grid, hipStream_t s, bool force_wg) {
   switch (L) {
     case 128: launch_decor_t<128>(P, grid, s); break;
     case 256: launch_decor_t<256>(P, grid, s); break;
     case 512: launch_decor_t<512>(P, grid, s); break;
     case 1024:
-      if (force_wg || getenv("EARHIP_K2_WG")) {  // the workgroup-per-run kernel (FIRs of several partitions; tuning)
+      if (force_wg) {  // the workgroup-per-run kernel (FIRs of several partitions; option K2_WG)
         launch_decor_t<1024>(P, grid, s);
       } else {  // one wave per run, kDecorWaves runs per workgroup
         hipLaunchKernelGGL(k_decorrelate_wave, dim3((grid.x + kDecorWaves - 1) / kDecorWaves, grid.y),
@@ -186,6 +186,8 @@ struct earhip_render {
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
   size_t last_scratch_bytes = 0;  // K0 / K1 scratch the last call needed
+  long scratch_regrows = 0;       // process calls that had to grow the scratch themselves (none on committed curves)
+  int last_gate_idx = -1;  // the context's mode word of THIS renderer's last call when it was planned for the hinge kernel, else -1
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
                        // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
@@ -261,22 +263,51 @@ struct earhip_render {
     return ml;
   }
 
+  // Everything a call on the CURRENT curves can need beyond what earhip_render_create allocated — K0 / K1 scratch for
+  // the plan of the call (piece or hinge lists are sized from the curves), the kink rows of the hinge kernel — is made
+  // HERE, where curves change (earhip_render_commit, or the implicit commit of the first process call after
+  // set_object_points), for the longest call (max_blocks), a call half as long and a single block, with a quarter of
+  // headroom: process calls on committed curves neither allocate nor synchronise (include/earhip.h, conventions).
+  size_t last_in_stride = 0;
+  void reserve_for_curves() {
+    size_t need = 0;
+    bool hinge = false;
+    const size_t lens[3] = {(size_t)T, (size_t)std::max(1, T / 2), (size_t)1};
+    for (size_t nb : lens) {
+      const MixLaunch ml = plan_call(nb, last_in_stride ? last_in_stride : nb * (size_t)B);
+      need = std::max(need, scratch_units(*curves, ml, M));
+      hinge = hinge || ml.hinge;
+    }
+    if (hinge) curves->ensure_kinks(ctx);
+    if (need > desc.n) {
+      EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // (the old scratch may still be in use)
+      desc.reserve(need + need / 4);
+    }
+  }
+
   void process_device(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev,
                       size_t out_stride) {
     const int nsamples = (int)(nblocks * (size_t)B);
-    curves->commit(ctx);
+    last_in_stride = in_stride;
+    if (curves->dirty()) {
+      curves->commit(ctx);
+      reserve_for_curves();
+    }
     const bool strict = ctx->strict;
     MixLaunch ml = plan_call(nblocks, in_stride);
-    if (ml.hinge) curves->ensure_kinks(ctx);
+    if (ml.hinge) curves->ensure_kinks(ctx);  // (already there unless an option changed the plan since the commit)
 
     last_kind = ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     {
-      // K0 / K1 scratch for THIS plan and THESE curves (round 3: 537 MB at the headline's size for any curves).  Grows
-      // when a call needs more than any before it (a synchronising hipMalloc: curves or call lengths that change the plan)
+      // K0 / K1 scratch for THIS plan and THESE curves (round 3: 537 MB at the headline's size for any curves): reserved
+      // when the curves were committed (reserve_for_curves).  The one exception, documented in earhip.h: a plan that no
+      // commit foresaw (an option changed between commit and call, a call on a time grid the curves' phase statistics
+      // did not predict) grows it here, geometrically, behind a synchronisation.
       const size_t need = scratch_units(*curves, ml, M);
       if (need > desc.n) {
         EARHIP_HIP(hipStreamSynchronize(ctx->stream));
-        desc.reserve(need + need / 8);
+        desc.reserve(need + need / 2);
+        scratch_regrows++;
       }
       last_scratch_bytes = need * 16;
     }
@@ -317,7 +348,7 @@ struct earhip_render {
       P.bus_stride = bus_stride;
       P.part_stride = part_stride;
       P.nparts = ml.gsplit;
-      const bool wave_k2 = Lk == 1024 && NP == 1 && !getenv("EARHIP_K2_WG");
+      const bool wave_k2 = Lk == 1024 && NP == 1 && !ctx->get(OPT_K2_WG);
       const int kblocks = (int)(nblocks * (size_t)(B / Bk));  // the call in decorrelator partitions
       if (wave_k2 && ml.gsplit > 1) {
         // The wave kernel has one wave per run: summing the object splits there is a chain of
@@ -357,7 +388,7 @@ struct earhip_render {
                              0, ctx->stream, P);
           EARHIP_HIP(hipGetLastError());
         } else {
-          launch_decor(Lk, P, grid, ctx->stream, NP > 1);
+          launch_decor(Lk, P, grid, ctx->stream, true);
         }
       }
       if (evp) EARHIP_HIP(hipEventRecord(evp[5], ctx->stream));
@@ -365,6 +396,7 @@ struct earhip_render {
       fresh = false;
     }
     if (timed) pending.push_back(pd);
+    last_gate_idx = ctx->last_gate_idx;  // (set by launch_gain_mix for this call)
     t += nsamples;
   }
 };
@@ -404,14 +436,14 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     r->D = cfg->delay;
     r->T = cfg->max_blocks;
     r->Bk = r->B;
-    if (r->K == 2 && r->B > 512 && r->B % 512 == 0 && cfg->n_taps <= 512 && !getenv("EARHIP_K2_OWN_BLOCK")) r->Bk = 512;
+    if (r->K == 2 && r->B > 512 && r->B % 512 == 0 && cfg->n_taps <= 512 && !ctx->get(OPT_K2_OWN_BLOCK)) r->Bk = 512;
     r->Lk = 2 * r->Bk;
     // workgroup decorrelator kernel: blocks per run.  Block 1024 (BASELINE config 5, 512 blocks x 24
     // loudspeakers): 7 -> K2 0.113 ms, 5 -> 0.117, 11 -> 0.128, 15 -> 0.140 (two rounds of workgroups that fill
     // the chip evenly beat one ragged round)
     if (r->Lk == 2048) r->run_len = 7;
-    if (const char *e = getenv("EARHIP_RUN")) {  // tuning knob: blocks per decorrelator run (odd)
-      const int v = atoi(e);
+    if (ctx->has(OPT_RUN)) {  // tuning knob: blocks per decorrelator run (odd)
+      const int v = ctx->get(OPT_RUN);
       if (v >= 1 && v <= 255) r->run_len = v | 1, r->run_len_set = true;
     }
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
@@ -428,8 +460,8 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     // 2 * num_cus, so gsplit * ntiles < (4 * num_cus + gsplit) * tpw with tiles of at most 256 samples
     // (tpw = 1) or 16 * nrt samples (f32 MFMA kernel, tpw adjacent tiles per workgroup).
     r->max_gsplit = 16;  // block mode: more splits make K2 sum more partial slabs than K1 gains
-    if (const char *e = getenv("EARHIP_GSPLIT")) {  // tuning knob: grid-level splits of short calls
-      const int v = atoi(e);
+    if (ctx->has(OPT_GSPLIT)) {  // tuning knob: grid-level splits of short calls
+      const int v = ctx->get(OPT_GSPLIT);
       if (v >= 1 && v <= 32) r->max_gsplit = v;
     }
     r->bus.alloc_zero((size_t)r->K * r->N * bus_samples_bound(ctx, max_samples, r->max_gsplit), ctx->stream);
@@ -511,6 +543,7 @@ int earhip_render_commit(earhip_render *r) {
     require(r != nullptr, "render must not be NULL");
     r->ctx->use();
     r->curves->commit(r->ctx);
+    r->reserve_for_curves();
   });
 }
 
@@ -552,7 +585,7 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     r->d_in.reserve(cap * r->M);
     r->d_out.reserve(cap * r->N);
     const size_t in_bytes = sizeof(float) * n * r->M;
-    const bool dbg = getenv("EARHIP_DEBUG_TIMING") != nullptr;
+    const bool dbg = ctx->get(OPT_DEBUG_TIMING) != 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = dbg ? now() : 0.0;
     const bool short_call = in_bytes < ((size_t)16 << 20) || r->M < 16;
@@ -584,7 +617,7 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       // segment descriptors — the part of K0 that does not look at the inputs — ahead of the gather was measured
       // too and loses: 0.146 / 0.125 / 0.138: the launch is host time in front of the gather, and the probe it
       // leaves behind the transfer is one more kernel in the chain)
-      static const int groups_env = getenv("EARHIP_BLOCK_GROUPS") ? atoi(getenv("EARHIP_BLOCK_GROUPS")) : 0;
+      const int groups_env = ctx->get(OPT_BLOCK_GROUPS);
       const int groups = groups_env >= 1 && groups_env <= 8 ? groups_env : (in_bytes >= ((size_t)1 << 20) ? 2 : 1);
       for (int g = 0; g < groups; g++) {
         const int m0 = (int)((int64_t)r->M * g / groups), m1 = (int)((int64_t)r->M * (g + 1) / groups);
@@ -672,10 +705,12 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby) {
     require(r != nullptr && standby != nullptr, "NULL argument");
     *standby = 0;
     earhip_ctx *ctx = r->ctx;
-    if (r->last_kind != 5 || ctx->last_gate_idx < 0 || !ctx->level.p) return;
+    // (this renderer's own word index; the word itself belongs to the context and is cleared by the next probed call of
+    // ANY stage on it: the query is valid until then — include/earhip.h)
+    if (r->last_kind != 5 || r->last_gate_idx < 0 || !ctx->level.p) return;
     ctx->use();
     unsigned word = 0;
-    EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + ctx->last_gate_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + r->last_gate_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     *standby = (word & kGateHingeUnsafe) ? 1 : 0;
   });
@@ -685,6 +720,13 @@ int earhip_render_scratch_bytes(const earhip_render *r, size_t *bytes) {
   return guarded([&] {
     require(r != nullptr && bytes != nullptr, "NULL argument");
     *bytes = r->last_scratch_bytes;
+  });
+}
+
+int earhip_render_scratch_regrows(const earhip_render *r, long *count) {
+  return guarded([&] {
+    require(r != nullptr && count != nullptr, "NULL argument");
+    *count = r->scratch_regrows;
   });
 }
 

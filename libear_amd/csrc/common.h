@@ -118,7 +118,28 @@ namespace earhip {
 void vbs_orphan(earhip_vbs *v);
 }  // namespace earhip
 
+namespace earhip {
+// Run-time configuration of a context ("a small runtime config"): every tuning knob is an OPTION of the context,
+// set with earhip_ctx_set_option(ctx, key, value) or taken ONCE, at earhip_ctx_create, from the environment variable
+// EARHIP_<KEY>.  Nothing on a process call's path reads the environment.  (include/earhip.h, group A, lists the keys.)
+enum Opt {
+  OPT_SPL, OPT_MFMA, OPT_XSCALE, OPT_WAVES, OPT_TPW, OPT_NRT,            // gain kernels' shapes (context-wide)
+  OPT_H2_TILE, OPT_H2_WGS, OPT_P2_TILE, OPT_P2_PAIRS, OPT_HINGE, OPT_HG_TILE, OPT_HBUILD_TPW, OPT_BUILD_TPW,  // launch plan of a call
+  OPT_K2_WG, OPT_K2_OWN_BLOCK, OPT_RUN, OPT_GSPLIT,                      // decorrelator kernel / renderer creation
+  OPT_PROBE_RUNS, OPT_BLOCK_GROUPS, OPT_DEBUG_TIMING, OPT_GRAPH,
+  OPT_COUNT
+};
+struct OptVal {
+  bool set = false;
+  int v = 0;
+};
+}  // namespace earhip
+
 struct earhip_ctx {
+  earhip::OptVal opt[earhip::OPT_COUNT];
+  bool has(earhip::Opt o) const { return opt[o].set; }
+  int get(earhip::Opt o, int dflt = 0) const { return opt[o].set ? opt[o].v : dflt; }
+  void apply_options();  // the derived fields below from opt[] (api_core.hip)
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;

@@ -102,6 +102,7 @@ class CurveSet {
     cmax_.assign(plan_.row, 0.0f);
     obj_cmax_.assign((size_t)M * plan_.row, 0.0f);
     cm_scratch_.assign(plan_.row, 0.0f);
+    shrunk_cols_.assign(plan_.row, 0);
     dirty_list_.reserve(M);
     for (auto &p : phases_) p.items.reserve(M);
   }
@@ -274,18 +275,20 @@ class CurveSet {
       admit(o.st, cm);
       o.has_stats = true;
     }
-    // A column's largest gain went away with an old curve: the set's maxima may be smaller now.  They only set the
-    // columns' scales (powers of two): a maximum that stays too large for a while costs the small gains of that column
-    // a bit of precision each binade, nothing else — so everybody's maxima are looked at again (O(M x columns)) when
-    // everything is uploaded anyway, and otherwise every 256th commit that could have shrunk one.
-    if (cmax_shrunk && (full_upload || ++shrink_pending_ >= 256)) {
-      shrink_pending_ = 0;
-      cmax_.assign(row, 0.0f);
-      for (int m = 0; m < M_; m++)
-        for (size_t c = 0; c < row; c++) {
-          const float v = obj_cmax_[(size_t)m * row + c];
-          cmax_[c] = v <= cmax_[c] ? cmax_[c] : v;
+    // A column's largest gain went away with an old curve: that column's maximum is looked up again among all objects, now
+    // (O(M) for that column; round 4 put it off for up to 256 commits, during which a column left with gains around
+    // -120 dB kept the scale of the loud one and lost the low f16 piece of its gains to subnormals).
+    if (cmax_shrunk) {
+      for (size_t c = 0; c < row; c++) {
+        if (!shrunk_cols_[c]) continue;
+        shrunk_cols_[c] = 0;
+        float v = 0.0f;
+        for (int m = 0; m < M_; m++) {
+          const float a = obj_cmax_[(size_t)m * row + c];
+          v = a <= v ? v : a;  // (a NaN replaces the maximum)
         }
+        cmax_[c] = v;
+      }
     }
     EARHIP_LAP(2);
     finish_stats();
@@ -353,6 +356,7 @@ class CurveSet {
     EARHIP_HIP(hipEventRecord(staged_, ctx->stream));
   }
   bool has_kinks() const { return kinks_; }
+  bool dirty() const { return !dirty_list_.empty(); }  // set_object since the last commit
 
   // true when no curve point can fall strictly inside a tile of `tile` samples of a
   // call that starts at t_call (all point times lie on tile boundaries)
@@ -556,7 +560,11 @@ class CurveSet {
     }
     grid_stale_ = true;  // (a gcd cannot be un-done: recomputed over the objects' own, finish_stats)
     bool shrunk = false;
-    for (size_t c = 0; c < cmax_.size(); c++) shrunk = shrunk || (cm[c] > 0.0f && !(cm[c] < cmax_[c]));
+    for (size_t c = 0; c < cmax_.size(); c++) {
+      // (a NaN maximum — cm != cm — goes away with its object as well)
+      const bool was_max = cm[c] != cm[c] || (cm[c] > 0.0f && !(cm[c] < cmax_[c]));
+      if (was_max) shrunk_cols_[c] = 1, shrunk = true;
+    }
     return shrunk;
   }
   void admit(const ObjStats &s, const float *cm) {
@@ -615,7 +623,6 @@ class CurveSet {
   std::vector<int> dirty_list_;
   bool uploaded_once_ = false;
   size_t arena_used_ = 2, arena_cap_ = 0, abandoned_ = 0;  // in points (rows 0, 1: the all-zero rows)
-  int shrink_pending_ = 0;
   // statistics of the set
   struct Totals {
     double span = 0, ramp = 0, npts = 0, bad = 0, points = 0;
@@ -638,6 +645,7 @@ class CurveSet {
   } phases_[2];
   std::vector<float> obj_cmax_;  // [M][row] the objects' column maxima
   std::vector<float> cm_scratch_;  // [row]
+  std::vector<uint8_t> shrunk_cols_;  // [row] columns whose maximum went away with a retired curve (commit)
   bool grid_stale_ = true;
   int64_t t_ref_ = 0;
   uint64_t grid_ = 0;
@@ -694,16 +702,14 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // long calls on a 512 grid: 8-wave workgroups on 512-sample tiles (two rounds of workgroups or more:
   // 512 blocks of 512: K1 0.215 vs 0.236 ms; one round, 256 blocks: 0.127 vs 0.120)
   // (EARHIP_H2_TILE=256|512 forces one of them where the curves allow it: tests, tuning)
-  const char *force_tile = getenv("EARHIP_H2_TILE");
-  const int forced = force_tile ? atoi(force_tile) : 0;
+  const int forced = ctx->get(OPT_H2_TILE);
   // Piece-list kernel: everything else the f16x2 operands can represent — metadata that ignores the tile
   // grid costs its curve points, not a different kernel (5 forces it for aligned curves as well).
   L.pieces = L.mfma && !L.split && M >= 32 && M <= kMaxPieceObjects && gain_scale > 0.0f &&
              (ctx->use_mfma == 3 || ctx->use_mfma == 5 || ctx->use_mfma == 6);
   if ((ctx->use_mfma == 5 || ctx->use_mfma == 6) && L.pieces) L.split = false;
   if (L.pieces) {
-    const char *pt = getenv("EARHIP_P2_TILE");
-    const int ptile = pt ? atoi(pt) : 0;
+    const int ptile = ctx->get(OPT_P2_TILE);
     // Layout of the lists: paired (an object's base and delta piece share one input request, and the objects without a
     // ramp in a tile skip the position factors) unless objects often have several ramps inside one tile — every ramp
     // beyond the first costs a slot more than in the packed layout (always-ramping curves: a third more chunks).
@@ -714,7 +720,7 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // EARHIP_P2_PAIRS=0|1 and EARHIP_P2_TILE=256|512 force one of them (tests, tuning).
     const double kPairWaste = 0.06;
     L.paired = pair_waste256 < kPairWaste;
-    if (const char *e = getenv("EARHIP_P2_PAIRS")) L.paired = atoi(e) != 0;
+    if (ctx->has(OPT_P2_PAIRS)) L.paired = ctx->get(OPT_P2_PAIRS) != 0;
     // (short calls — block mode — keep the 256-sample tiles: twice the workgroups)
     const bool long_call = nsamples / 512 >= 2 * ctx->num_cus;
     L.pw = ptile == 512 ? 8 : ptile == 256 ? 4 : (L.paired && long_call && pair_waste512 < kPairWaste) ? 8 : 4;
@@ -727,11 +733,11 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // factors of the objects at rest.  6 forces it, EARHIP_HINGE=0 / 1 overrides the choice.
     const double kHingeExact = 0.005, kHingeRamps = 0.5;
     L.hinge = M <= kMaxHingeCached && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps;
-    if (const char *e = getenv("EARHIP_HINGE")) L.hinge = atoi(e) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
+    if (ctx->has(OPT_HINGE)) L.hinge = ctx->get(OPT_HINGE) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
     if (L.hinge) {
-      if (const char *e = getenv("EARHIP_HG_TILE")) L.hinge_tile = atoi(e) == 256 ? 256 : 512;  // tuning knob
+      if (ctx->has(OPT_HG_TILE)) L.hinge_tile = ctx->get(OPT_HG_TILE) == 256 ? 256 : 512;  // tuning knob
       // (the piece lists stand by on 256-sample tiles of their own, packed: k_hinge_gate)
       L.pieces = false, L.paired = false, L.pw = 4;
     }

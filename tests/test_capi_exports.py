@@ -115,3 +115,19 @@ def test_launch_plans_fit_the_bus_buffer_on_cpu(tmp_path):
                     os.path.join(ROOT, "libear_amd", "csrc"), src, "-o", str(exe)], check=True)
     res = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
     assert res.returncode == 0, res.stdout
+
+
+def test_the_environment_is_read_once_at_context_creation():
+    """SURVEY 5 / include/earhip.h (earhip_ctx_set_option): tuning knobs are options of the context; the only getenv of
+    the library is the loop in earhip_ctx_create — nothing on a process call's path reads the environment."""
+    sites = []
+    base = os.path.join(ROOT, "libear_amd", "csrc")
+    for f in sorted(os.listdir(base)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            for i, ln in enumerate(open(os.path.join(base, f), errors="ignore"), 1):
+                if re.search(r"\bgetenv\s*\(", ln):
+                    sites.append(f"{f}:{i}")
+    assert len(sites) == 1 and sites[0].startswith("api_core.hip:"), sites
+    text = open(os.path.join(base, "api_core.hip")).read()
+    create = text[text.index("int earhip_ctx_create("):text.index("int earhip_ctx_set_option(")]
+    assert "getenv" in create

@@ -16,7 +16,7 @@ import pytest
 
 import _oracle
 import scenes
-from _hip import ctx, set_oracle_curves, set_renderer_curves
+from _hip import ctx, set_oracle_curves, set_renderer_curves, with_options
 from layouts import LAYOUTS
 
 pytestmark = pytest.mark.gpu
@@ -59,18 +59,7 @@ def run_oracle(curves, x, n_out, block, dec, delay):
 
 
 def _with_env(env, fn):
-    keep = {k: os.environ.get(k) for k in env}
-    try:
-        for k, v in env.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
-        return fn()
-    finally:
-        for k, v in keep.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+    return with_options(env, fn)
 
 
 @pytest.mark.parametrize("m,n,block,nblocks", [(1, 6, 512, 3), (64, 10, 512, 4), (5, 3, 64, 9), (33, 24, 256, 5)])
@@ -534,7 +523,7 @@ def test_decorrelator_partition_size_is_the_renderers_choice(block, nblocks, cal
                                                  (200, 9, [9], "5"), (24, 40, [40], "1")])
 def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
     """block 512 has two K2 kernels: one wave per run of blocks (default) and the workgroup
-    kernel (EARHIP_K2_WG, read per launch).  Both against the oracle, over run boundaries (several
+    kernel (option K2_WG, looked at per launch).  Both against the oracle, over run boundaries (several
     runs per call, odd run lengths through EARHIP_RUN) and over object splits of short calls."""
     layout, block = "4+5+0", 512
     n = len(LAYOUTS[layout])
@@ -543,22 +532,10 @@ def test_block_512_decorrelator_kernels_agree(m, nblocks, calls, run):
     curves = scenes.adm_curves(m, n, total, period=1500, ramp=300, seed=nblocks)
     x = scenes.audio(m, total, seed=m)
     want = run_oracle(curves, x, n, block, dec, 255)
-    keep = {k: os.environ.get(k) for k in ("EARHIP_K2_WG", "EARHIP_RUN")}
-    try:
-        outs = []
-        for wg in (False, True):
-            os.environ.pop("EARHIP_K2_WG", None)
-            os.environ.pop("EARHIP_RUN", None)
-            if wg:
-                os.environ["EARHIP_K2_WG"] = "1"
-            if run:
-                os.environ["EARHIP_RUN"] = run
-            outs.append(run_hip(curves, x, n, block, dec, 255, calls))
-    finally:
-        for k, v in keep.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+    outs = []
+    for wg in (False, True):
+        outs.append(with_options({"EARHIP_K2_WG": "1" if wg else None, "EARHIP_RUN": run},
+                                 lambda: run_hip(curves, x, n, block, dec, 255, calls)))
     assert scenes.rel_rms(outs[0], want) <= 1e-6
     assert scenes.rel_rms(outs[1], want) <= 1e-6
     assert scenes.rel_rms(outs[0], outs[1]) <= 1e-6

@@ -21,7 +21,7 @@ import pytest
 
 import _oracle
 import scenes
-from _hip import ctx
+from _hip import ctx, with_options
 from layouts import LAYOUTS
 
 pytestmark = pytest.mark.gpu
@@ -71,17 +71,10 @@ def render_device(curves, x_dev, n_out, block, dec, delay, calls, t0=0):
 
 
 def _with_hinge(value, fn):
-    """run fn with EARHIP_HINGE set to value (None: as the environment has it): the launch plan reads it at every call"""
+    """run fn with the option HINGE set to value (None: as the context has it): the launch plan looks at it at every call"""
     if value is None:
         return fn()
-    keep = os.environ.get("EARHIP_HINGE")
-    os.environ["EARHIP_HINGE"] = value
-    try:
-        return fn()
-    finally:
-        os.environ.pop("EARHIP_HINGE", None)
-        if keep is not None:
-            os.environ["EARHIP_HINGE"] = keep
+    return with_options({"EARHIP_HINGE": value}, fn)
 
 
 def check_windows(curves, x_dev, out_dev, n_out, block, dec, delay, windows, two_bus=True, tol=TOL):
@@ -235,16 +228,10 @@ def test_seed_sweep_at_1024_objects(scene):
         else:
             curves = scenes.adm_curves(m, n, total, period=240, ramp=240, seed=300 + seed)
         x = device_audio(m, total, 400 + seed)
-        keep = os.environ.get("EARHIP_P2_TILE")
         if scene == "adm-512":
-            os.environ["EARHIP_P2_TILE"] = "512"
-        try:
+            out, plan = with_options({"EARHIP_P2_TILE": "512"}, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
+        else:
             out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
-        finally:
-            if scene == "adm-512":
-                os.environ.pop("EARHIP_P2_TILE", None)
-                if keep is not None:
-                    os.environ["EARHIP_P2_TILE"] = keep
         if scene == "adm-512" and os.environ.get("EARHIP_MFMA") in (None, "3", "5"):
             assert plan["kernel"] == 4 and plan["tile"] == 512, plan
         worst.append(check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks - 3, 3)]))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the bench lines of every configuration / scene for profiles/ (on the GPU box):
 #   bash tools/collect_round.sh <tag>     -> gpurun_out/<tag>_bench_<name>.json
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT && mkdir -p gpurun_out
 run() { # name, bench args...
@@ -9,6 +9,8 @@ run() { # name, bench args...
   timeout 400 python bench.py "$@" 2> gpurun_out/${TAG}_bench_${name}.err | tail -1 > gpurun_out/${TAG}_bench_${name}.json
   python tools/benchline.py < gpurun_out/${TAG}_bench_${name}.json | sed "s/^/$name: /"
 }
+# the driver's entry point first: a round must not end with smoke() red
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.txt 2>&1 && echo "smoke: ok" || { echo "smoke: FAILED"; tail -5 gpurun_out/${TAG}_smoke.txt; }
 run C4
 run C2 --config C2
 run C3 --config C3
