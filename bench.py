@@ -316,6 +316,13 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE config 4): --objects in total, split over the GPUs; "
                          "weak: --objects per GPU")
+    ap.add_argument("--shard", choices=("objects", "objects-nogather", "time"), default="objects",
+                    help="decomposition over the GPUs (DESIGN 6).  objects (north_star): every rank renders its objects, RCCL "
+                         "reduce-scatter of the partial outputs over the channels + gather of the shared bus on rank 0; "
+                         "objects-nogather: the same without the gather (a consumer that takes the bus channel-sharded: half "
+                         "the exchange); time: every rank renders ALL objects for its T / G blocks of the stream after one lead "
+                         "block that recomputes the overlap-add tail and the delay line — no exchange at all, the outputs of "
+                         "different time ranges live on different ranks")
     ap.add_argument("--row-pad", type=int, default=256,
                     help="floats of padding between the input rows (row stride = samples + pad; multiple of 4).  Default 256: "
                          "rows a power of two apart (2 MB at the headline's size, 8 MB at config 3's) put the 32 rows a chunk "
@@ -380,7 +387,7 @@ def main():
     import scenes
     from layouts import LAYOUTS
     from libear_amd import capi
-    from libear_amd.distributed import channel_range, exchange, padded_channels, shard_range
+    from libear_amd.distributed import channel_range, exchange, exchange_model, padded_channels, shard_range, time_range
 
     names = LAYOUTS[cfg["layout"]]
     N, B, T, K = len(names), cfg["block_size"], cfg["blocks"], cfg["buses"]
@@ -426,14 +433,18 @@ def main():
         in HBM, with its renderer and double-buffered output / exchange buffers"""
 
         def __init__(self, objects, hoa, scaling, seed_base=0, context=None):
-            if scaling == "strong":  # the scene has `objects` in total; this rank renders its shard
+            self.time_sharded = args.shard == "time" and world > 1 and scaling == "strong"
+            if self.time_sharded:  # every rank has the whole scene (the same seeds) and renders its blocks of the stream
+                assert T % world == 0, "--shard time needs the blocks of a step to divide by the GPUs"
+                self.M_obj, self.M_total = objects, objects + hoa
+            elif scaling == "strong":  # the scene has `objects` in total; this rank renders its shard
                 lo, hi = shard_range(objects, rank, world)
                 self.M_obj, self.M_total = hi - lo, objects + hoa
             else:
                 self.M_obj, self.M_total = objects, (objects + hoa) * world
-            self.M_hoa = hoa if (rank == 0 or scaling == "weak") else 0  # the bed goes to one rank (SURVEY 8e)
+            self.M_hoa = hoa if (rank == 0 or scaling == "weak" or self.time_sharded) else 0  # the bed goes to one rank (SURVEY 8e)
             self.M = self.M_obj + self.M_hoa
-            m, seed = max(self.M_obj, 1), seed_base + rank
+            m, seed = max(self.M_obj, 1), seed_base + (0 if self.time_sharded else rank)
             if args.scene in ("adm", "levels-adm", "bursty-adm"):
                 curves = scenes.adm_curves(m, N, total, seed=11 + seed)
             elif args.scene in ("moving", "bursty-moving"):  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
@@ -475,6 +486,8 @@ def main():
             self.curves = curves
             gen = torch.Generator(device=dev)
             gen.manual_seed(1234 + seed)
+            # (time-sharded: a rank's blocks [b0, b1) of the stream and `lead` blocks in front of them)
+            self.b0, self.b1, self.lead = time_range(T, rank, world, partitions=(-(-512 // B) if K == 2 else 1)) if self.time_sharded else (0, T, 0)
             self.in_stride = total + args.row_pad
             rows = max(self.M, 1)
             # (the samples do not depend on the padding: the rows are drawn as a [rows][total] block)
@@ -493,17 +506,21 @@ def main():
             # collectives of a chunk run beside the render of the NEXT chunk of the same step (not only beside the next
             # step); the shared bus lands on the root chunk by chunk, [nch][n_pad][clen] (double buffered over the steps).
             self.nch = 1
-            if world > 1:
+            self.gather = args.shard == "objects"
+            if world > 1 and not self.time_sharded:
                 want = int(os.environ.get("EARHIP_BENCH_CHUNKS", "4"))
                 while want > 1 and (T % want or T // want < 8):
                     want //= 2
                 self.nch = max(want, 1)
             self.Tc, self.clen = T // self.nch, total // self.nch
+            if self.time_sharded:  # one call per step: the lead block + this rank's blocks
+                self.Tc = self.b1 - self.b0 + self.lead
+                self.clen = self.Tc * B
             self.outs = [torch.zeros((n_pad, self.clen), device=dev, dtype=torch.float32) for _ in range(2)]
             self.owned = [torch.zeros((n_pad // world, self.clen), device=dev, dtype=torch.float32) for _ in range(2)] \
-                if world > 1 else None
+                if world > 1 and not self.time_sharded else None
             self.full = [[torch.zeros((n_pad, self.clen), device=dev, dtype=torch.float32) for _ in range(self.nch)] for _ in range(2)] \
-                if world > 1 and rank == gather_root else None
+                if world > 1 and rank == gather_root and self.gather and not self.time_sharded else None
             self.head = torch.zeros((n_pad, self.clen), device=dev, dtype=torch.float32) if world > 1 else None
             self.r = self.renderer(context or ctx)
             self.pending = [None, None]
@@ -511,7 +528,7 @@ def main():
             self.last_slot = 0
 
         def renderer(self, context, max_blocks=None, npoints=None):
-            r = capi.Renderer(context, max(self.M, 1), N, B, dec, delay, max_blocks=max_blocks or T)
+            r = capi.Renderer(context, max(self.M, 1), N, B, dec, delay, max_blocks=max_blocks or max(T, self.Tc))
             for m, (t, d, f) in enumerate(self.curves):
                 r.set_object_points(m, t[:npoints], d[:npoints], f[:npoints] if K == 2 else None)
             r.commit()
@@ -519,6 +536,17 @@ def main():
 
         def step(self, i, exchange_outputs=True, r=None, keep_head=False):
             r = r or self.r
+            if self.time_sharded:
+                # this rank's time range: the DSP state at its first block comes from ONE lead block rendered from the zero
+                # state (tail: the previous block's; delay line: 255 samples), whose outputs are not used
+                slot = self.k % 2
+                self.k += 1
+                t_lo = (self.b0 - self.lead) * B
+                r.reset(t_lo)
+                dst = self.head if keep_head else self.outs[slot]
+                r.process_device(self.Tc, self.x.data_ptr() + 4 * t_lo, self.in_stride, dst.data_ptr(), self.clen)
+                self.last_slot = slot
+                return
             r.reset(0)
             for c in range(self.nch):
                 slot = self.k % 2
@@ -531,16 +559,17 @@ def main():
                 dst = self.head if (keep_head and c == 0) else self.outs[slot]  # (keep_head: the step's first blocks for the parity gate)
                 r.process_device(self.Tc, self.x.data_ptr() + 4 * c * self.clen, self.in_stride, dst.data_ptr(), self.clen)
                 self.last_slot = slot
-                if world > 1 and exchange_outputs:
+                if world > 1 and exchange_outputs and args.shard != "time":  # (weak scaling under --shard time: independent streams)
                     per = n_pad // world
                     full_c = self.full[i % 2][c] if self.full is not None else None
                     if native_comm is not None:
                         native_comm.exchange_device(slot, self.outs[slot].data_ptr(), self.owned[slot].data_ptr(), per, self.clen)
-                        native_comm.gather_device(slot, self.owned[slot].data_ptr(), full_c.data_ptr() if full_c is not None else None,
-                                                  per, self.clen, gather_root)
+                        if self.gather:
+                            native_comm.gather_device(slot, self.owned[slot].data_ptr(), full_c.data_ptr() if full_c is not None else None,
+                                                      per, self.clen, gather_root)
                     else:
                         _, work = exchange(self.outs[slot], self.owned[slot], async_op=True)
-                        if backend == "nccl":  # (gloo: the all-reduce leaves the whole bus on every rank already)
+                        if backend == "nccl" and self.gather:  # (gloo: the all-reduce leaves the whole bus on every rank already)
                             work.wait()  # stream-orders the gather behind the reduce-scatter; does not block the host
                             work = dist.gather(self.owned[slot], list(full_c.split(per)) if rank == gather_root else None,
                                                dst=gather_root, async_op=True)
@@ -614,8 +643,25 @@ def main():
 
     # multi-rank self-check (outside the timed region, all ranks take part): the slice this rank
     # owns after the reduce-scatter equals the sum of all ranks' partial outputs
-    exchange_err = None
-    if world > 1 and (backend == "nccl" or os.environ.get("EARHIP_BENCH_CHECK") == "force"):
+    exchange_err, exchange_repeat_identical, lead_check = None, None, None
+    if world > 1 and wl.time_sharded:
+        # time sharding's own check: the rank's blocks after ONE lead block equal the same blocks after THREE (the state a
+        # lead block leaves is the stream's: nothing older than one block reaches a block's output)
+        if wl.b0 >= 3:
+            wl.step(0, exchange_outputs=False)
+            torch.cuda.synchronize()
+            one = wl.outs[wl.last_slot][:N, wl.lead * B:(wl.lead + 4) * B].clone()
+            t_lo = (wl.b0 - 3) * B
+            wl.r.reset(t_lo)
+            wl.r.process_device(min(7, wl.Tc), wl.x.data_ptr() + 4 * t_lo, wl.in_stride, wl.outs[wl.last_slot].data_ptr(), wl.clen)
+            torch.cuda.synchronize()
+            three = wl.outs[wl.last_slot][:N, 3 * B:7 * B]
+            err = ((one - three).abs().max() / three.abs().max().clamp_min(1e-30)).to(torch.float64).reshape(1)
+        else:
+            err = torch.zeros(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+        lead_check = float(err.item())
+    if world > 1 and not wl.time_sharded and (backend == "nccl" or os.environ.get("EARHIP_BENCH_CHECK") == "force"):
         # (on the LAST chunk of the last step: the buffers of its exchange slot still hold it)
         w = min(wl.clen, 4096)
         last = (args.steps - 1) % 2
@@ -635,22 +681,50 @@ def main():
         ref = part.clone()
         dist.all_reduce(ref, op=dist.ReduceOp.SUM)
         err = ((got - ref[rank * per:(rank + 1) * per]).abs().max() / ref.abs().max().clamp_min(1e-30))
-        if backend == "nccl" and rank == gather_root:  # ... and the bus gathered on the root equals all of it
+        if backend == "nccl" and rank == gather_root and wl.gather:  # ... and the bus gathered on the root equals all of it
             err = torch.maximum(err, (wl.full[last][wl.nch - 1][:, :w] - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
         err = err.to(torch.float64).reshape(1)
         dist.all_reduce(err, op=dist.ReduceOp.MAX)
         exchange_err = float(err.item())
+        # run-to-run reproducibility ("reduction order across ranks should be deterministic"): the same partial
+        # outputs exchanged a second time give bit-identical owned slices
+        first = got.clone()
+        again_in = torch.zeros_like(wl.outs[slot])
+        again_in[:, :w] = part
+        if backend == "nccl":
+            again_out = torch.zeros_like(wl.owned[slot])
+            if native_comm is not None:
+                native_comm.wait(slot)
+                native_comm.exchange_device(slot, again_in.data_ptr(), again_out.data_ptr(), per, wl.clen)
+                native_comm.wait(slot)
+                torch.cuda.synchronize()
+            else:
+                exchange(again_in, again_out)
+            second = again_out[:, :w]
+        else:
+            _, work = exchange(again_in, None, async_op=True)
+            work.wait()
+            second = again_in[rank * per:(rank + 1) * per, :w]
+        same = torch.tensor([1 if torch.equal(first, second) else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        exchange_repeat_identical = bool(int(same.item()))
     # what the exchange moved and how fast (native communicator: HIP events around the collectives of the last
     # two steps on its own stream — with the renders of the following step running beside them)
     exchange_info = None
-    if world > 1:
+    if world > 1 and wl.time_sharded:
+        exchange_info = {"mode": "time", "reduce_scatter_bytes_per_rank": 0, "gather_bytes_into_root": 0,
+                         "blocks_of_this_rank": [wl.b0, wl.b1], "lead_blocks": wl.lead,
+                         "note": "no exchange: every rank renders all objects for its blocks of the stream; the outputs of "
+                                 "different time ranges live on different ranks"}
+    elif world > 1:
         per = n_pad // world
         rs_bytes = (world - 1) * per * total * 4       # reduce-scatter: sent (and received) by every rank
-        ga_bytes = (world - 1) * per * total * 4       # gather: received by the root, one slice from every other rank
-        exchange_info = {"reduce_scatter_bytes_per_rank": rs_bytes, "gather_bytes_into_root": ga_bytes, "root": gather_root,
+        ga_bytes = (world - 1) * per * total * 4 if wl.gather else 0  # gather: received by the root, one slice from every other rank
+        exchange_info = {"mode": args.shard, "reduce_scatter_bytes_per_rank": rs_bytes, "gather_bytes_into_root": ga_bytes,
+                         "root": gather_root if wl.gather else None,
                          "rows_per_rank": per, "row_floats": total, "chunks_per_step": wl.nch,
                          "overlap": "a chunk's collectives run beside the render of the step's next chunk (and the last one's beside the next step)"}
-        if native_comm is not None:
+        if native_comm is not None and not wl.time_sharded:
             # (the slots hold the collectives of the last two CHUNKS: a step's are wl.nch of them)
             ms = 0.5 * (native_comm.last_exchange_ms(0) + native_comm.last_exchange_ms(1)) * wl.nch
             tms = torch.tensor([ms], device=dev, dtype=torch.float64)
@@ -687,25 +761,20 @@ def main():
         k1_ms = timing["gain_mix_ms"] / timed_calls * wl.nch
         k2_ms = timing["decor_ms"] / timed_calls * wl.nch
         k0_ms = timing["prep_ms"] / timed_calls * wl.nch
-        achieved = gain_b * T / (k1_ms * 1e-3) / 1e9
+        T_rank = wl.Tc * wl.nch  # blocks this rank renders per step (time-sharded: its share of the stream + the lead block)
+        achieved = gain_b * T_rank / (k1_ms * 1e-3) / 1e9
         whole = (gain_b + dec_b + dm_b) * T / t_step / 1e9
         if exchange_info is not None:
-            # What the step should take: every rank renders its shard completely (K0 + K1 on M / G objects, K2 on all
-            # loudspeakers), the exchange moves N_pad / G rows of the step to every peer and the owned rows on to the root,
-            # each transfer over its own xGMI link (point to point, all links at once), chunk by chunk beside the render:
-            # predicted = max(compute, exchange) + what the first chunk's render and the last chunk's exchange leave
-            # uncovered.  The link rate is an ASSUMPTION (EARHIP_XGMI_GBPS, per direction and link; 50 of the nominal 64).
+            # What the step should take under the decomposition that ran, from this rank's measured kernels and an ASSUMED
+            # link rate (EARHIP_XGMI_GBPS, per direction and link; 50 of the nominal 64): libear_amd/distributed.py
+            # exchange_model.  Objects modes: every rank renders its shard completely (K0 + K1 on M / G objects, K2 on all
+            # loudspeakers), the exchange runs chunk by chunk beside the render: predicted = max(compute, exchange) + what the
+            # first chunk's render and the last chunk's exchange leave uncovered.  Time mode: compute only.
             link = float(os.environ.get("EARHIP_XGMI_GBPS", "50"))
-            slice_ms = (n_pad // world) * total * 4 / (link * 1e9) * 1e3
             t_comp = k0_ms + k1_ms + k2_ms
-            t_ex = 2 * slice_ms  # reduce-scatter (one slice to every peer) + gather (the owned slice to the root)
-            exchange_info["model"] = {
-                "link_GBps_per_direction_assumed": link, "compute_ms_per_step": round(t_comp, 4),
-                "exchange_ms_per_step": round(t_ex, 4),
-                "predicted_ms_per_step": round(max(t_comp, t_ex) + min(t_comp, t_ex) / wl.nch, 4),
-                "measured_ms_per_step": round(t_step * 1e3, 4),
-                "exchange_equals_compute_at_link_GBps": round(2 * (n_pad // world) * total * 4 / (t_comp * 1e-3) / 1e9, 1),
-                "note": "compute = this rank's kernels (HIP events); exchange = 2 slices of N_pad / G rows over one link each"}
+            exchange_info["model"] = exchange_model(args.shard, world, n_pad, total, t_comp, link, wl.nch)
+            exchange_info["model"]["measured_ms_per_step"] = round(t_step * 1e3, 4)
+            exchange_info["model"]["note"] = "compute = this rank's kernels (HIP events); the exchange figures are a model"
         # what the fused chain itself moves: K1's bytes, plus (two buses) K2 reading the buses back and writing the outputs
         fused_b = gain_b + (4 * (K * N * B) + 4 * N * B + 2 * 4 * N * 255 / max(T, 1) if K == 2 else 0)
         whole_fused = fused_b * T / t_step / 1e9
@@ -773,8 +842,11 @@ def main():
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
                 "blocks_per_step": T, "buses": K, "scene": args.scene, "gains": gains_desc,
                 "input_row_stride_samples": wl.in_stride,
-                "parallelism": (f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels"
-                                + (f" + gather of the owned slices on rank {gather_root}" if world > 1 and backend == "nccl" else "")
+                "shard": args.shard if world > 1 else None,
+                "parallelism": ((f"time-sharded over {world} GPUs: every rank renders all objects for T / G blocks of the stream "
+                                 "behind one lead block; no exchange") if wl.time_sharded else
+                                f"objects sharded over {world} GPU(s), reduce-scatter of the bus over channels"
+                                + (f" + gather of the owned slices on rank {gather_root}" if world > 1 and backend == "nccl" and wl.gather else "")
                                 + (": libearhip's own RCCL communicator (earhip_comm, api_comm.hip)" if native_comm is not None
                                    else f": torch.distributed ({backend})" if world > 1 else "")
                                 + (f" [{native_note}]" if native_note else "")
@@ -795,11 +867,14 @@ def main():
                          "peak_measured": peak_measured,
                          "frac_of_measured_read": round(achieved / best_read, 4) if best_read else None,
                          "launches_per_step": round(k1_launches, 2),
-                         "algorithmic_bytes_per_launch": int(gain_b * T / k1_launches),
+                         "algorithmic_bytes_per_launch": int(gain_b * T_rank / k1_launches),
                          "avg_launch_ms": round(k1_ms / k1_launches, 4)},
-            "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T, k1_ms),
-            "exchange_check": None if exchange_err is None else
-                              {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}")},
+            "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T_rank, k1_ms),
+            "exchange_check": ({"max_rel_diff_one_lead_block_vs_three": float(f"{lead_check:.3e}"),
+                                "bit_identical": bool(lead_check == 0.0)} if lead_check is not None else
+                               None if exchange_err is None else
+                               {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}"),
+                                "same_partials_exchanged_twice_bit_identical": exchange_repeat_identical}),
             "exchange": exchange_info,
             "weak_scaling": weak,
             "kernel_timing": {"timed_steps": timed_steps, "every": time_every},
@@ -915,6 +990,7 @@ def main():
             parity_plan = wl.r.last_plan()
             buf = wl.head if world > 1 else wl.outs[wl.last_slot]  # (several ranks: the step's first call)
             nblk = wl.Tc
+            base = wl.b0 - wl.lead  # absolute block of the buffer's first block (time-sharded ranks: not 0)
 
             def make_oracle():
                 if K == 2:
@@ -924,27 +1000,28 @@ def main():
             def window(b0, count):
                 """blocks [b0, b0 + count) of the timed buffer and the CPU path's render of them (one lead block in front of
                 a window inside the stream: tail and delay line of the oracle are the stream's by then — FIRs of one partition)"""
-                lead = 1 if b0 > 0 else 0
-                lo, hi = (b0 - lead) * B, (b0 + count) * B
+                a0 = base + b0
+                lead = 1 if a0 > 0 else 0
+                lo, hi = (a0 - lead) * B, (a0 + count) * B
                 xs_ = wl.x[:, lo:hi].cpu().numpy()
                 win_ = scenes.window_curves(wl.curves, lo, hi)
                 o = make_oracle()
                 for m, (t, d, f) in enumerate(win_):
                     o.set_points(m, 0, t, d)
                     o.set_points(m, 1, t, f if K == 2 else np.zeros_like(d))
-                return buf[:N, b0 * B:hi].cpu().numpy(), o.process(xs_)[:, lead * B:], xs_, win_
+                return buf[:N, b0 * B:(b0 + count) * B].cpu().numpy(), o.process(xs_)[:, lead * B:], xs_, win_
 
             # three windows of the timed buffer: its first, middle and last blocks (tests/test_gpu_render_full.py::check_windows)
-            starts = [0]
+            starts = [wl.lead]  # (a time-sharded rank's lead block is not output)
             if nblk >= 3 * nb + 2:
                 starts += [nblk // 2 - nb // 2, nblk - nb]
-            got, want, xs, win = window(0, nb)
+            got, want, xs, win = window(starts[0], nb)
             truth = scenes.render_f64([(t, d, f if K == 2 else None) for t, d, f in win], xs, N, dec, delay)
-            windows = [{"first_block": 0, "blocks": nb, "rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
+            windows = [{"first_block": base + starts[0], "blocks": nb, "rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
                         "max_channel_rel_rms_vs_cpu": float(f"{scenes.rel_rms_per_channel(got, want):.3e}")}]
             for b0 in starts[1:]:
                 g_, w_, _, _ = window(b0, nb)
-                windows.append({"first_block": b0, "blocks": nb, "rel_rms_vs_cpu": float(f"{scenes.rel_rms(g_, w_):.3e}"),
+                windows.append({"first_block": base + b0, "blocks": nb, "rel_rms_vs_cpu": float(f"{scenes.rel_rms(g_, w_):.3e}"),
                                 "max_channel_rel_rms_vs_cpu": float(f"{scenes.rel_rms_per_channel(g_, w_):.3e}"),
                                 "finite": bool(np.isfinite(g_).all())})
             worst_ch = max(w["max_channel_rel_rms_vs_cpu"] for w in windows)

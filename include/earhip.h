@@ -165,6 +165,17 @@ int earhip_fft_reverse(earhip_fft_plan *plan, const float *in_complex, float *ou
  * src/dsp/block_convolver_impl.cpp:10-243).  block_size in [1, 4096], any
  * factorisation (480, 960, 1920, 441, primes ... as well as the powers of two;
  * large prime factors at the cost stated under (B)).
+ *
+ * libear's Context takes an FFTImpl<float> plugin by reference (block_convolver.hpp:34,
+ * include/ear/fft.hpp:54-62) and runs ITS transforms.  Here the transform is part of
+ * the device convolver (earhip_conv_ctx_create takes no plugin); the C++ mirror's
+ * Context(size_t, FFTImpl<float>&) accepts the plugin that is this transform —
+ * ear::get_fft_hip(), which ear::get_fft_kiss<float>() also returns — and REFUSES any
+ * other plugin with ear::invalid_argument at construction: a caller's host FFT cannot
+ * run inside a device kernel, and routing the convolver through host transforms would
+ * be the CPU path this library does not have (tests/cpp/test_dropin.cpp,
+ * "foreign FFTImpl is refused").  Callers with their own FFTImpl keep libear's
+ * BlockConvolver for that object; results agree to the convolver tests' 1e-6.
  * ---------------------------------------------------------------------- */
 typedef struct earhip_conv_ctx earhip_conv_ctx;
 typedef struct earhip_conv_filter earhip_conv_filter;

@@ -57,3 +57,37 @@ def exchange(partial, owned=None, group=None, async_op=False):
         return owned, work
     work = dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return partial[rank * per:(rank + 1) * per], work
+
+
+# ---- the three decompositions of a render over G ranks -----------------------------------------
+SHARD_MODES = ("objects", "objects-nogather", "time")
+
+
+def time_range(n_blocks, rank, world, partitions=1):
+    """`time` sharding: rank r renders blocks [b0, b1) of the stream for ALL objects, after `lead` blocks rendered only to
+    bring the DSP state to where the stream has it (the overlap-add tail of a one-partition decorrelator depends on
+    the previous block only, the 255-sample delay line on less than one: one lead block reproduces both exactly — the
+    decorrelator kernel recomputes a run's first tail the same way).  No exchange at all; the outputs of different time
+    ranges live on different ranks.  A decorrelator FIR of P partitions (blocks shorter than its 512 taps) reaches P blocks
+    back: `partitions` lead blocks.  Returns (b0, b1, lead)."""
+    b0 = (n_blocks * rank) // world
+    b1 = (n_blocks * (rank + 1)) // world
+    return b0, b1, min(b0, max(1, partitions))
+
+
+def exchange_model(mode, world, n_pad, samples, compute_ms, link_gbps, chunks=1):
+    """What a step should take under a decomposition, from this rank's measured compute time and an ASSUMED xGMI link
+    rate per direction (no multi-GPU box was available to measure one: every figure here is a model, not a measurement).
+
+    objects:          reduce-scatter (a slice of n_pad / G rows to every peer, each over its own link) + gather of the
+                      owned slices on one rank: two slices over one link each;
+    objects-nogather: the consumer takes the bus channel-sharded: one slice;
+    time:             no exchange (a lead block per rank is part of compute_ms)."""
+    slice_ms = (n_pad // world) * samples * 4 / (link_gbps * 1e9) * 1e3
+    t_ex = {"objects": 2.0 * slice_ms, "objects-nogather": slice_ms, "time": 0.0}[mode]
+    pred = max(compute_ms, t_ex) + (min(compute_ms, t_ex) / max(chunks, 1) if t_ex > 0 else 0.0)
+    return {"mode": mode, "link_GBps_per_direction_assumed": link_gbps, "compute_ms_per_step": round(compute_ms, 4),
+            "exchange_ms_per_step": round(t_ex, 4), "predicted_ms_per_step": round(pred, 4),
+            "exchange_equals_compute_at_link_GBps": (round(t_ex / slice_ms * (n_pad // world) * samples * 4 / (compute_ms * 1e-3) / 1e9, 1)
+                                                     if t_ex > 0 and compute_ms > 0 else None),
+            "status": "model, unmeasured (no N > 1 hardware run exists)"}

@@ -115,6 +115,35 @@ def test_multi_rank_control_flow_on_one_gpu_over_gloo(nproc, layout):
     assert line["weak_scaling"]["objects_total"] == 96 * nproc and line["weak_scaling"]["value"] > 0
 
 
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_time_sharding_on_one_gpu_over_gloo(nproc):
+    """--shard time: every rank renders ALL objects for its T / G blocks behind one lead block; no exchange.  The line's
+    own check: a rank's blocks after one lead block are bit-identical to the same blocks after three."""
+    line = run_bench(["--objects", "96", "--blocks", "48", "--steps", "3", "--warmup", "1", "--cpu-blocks", "0", "--shard", "time"],
+                     nproc=nproc, env={"EARHIP_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == nproc and line["config"]["shard"] == "time"
+    assert line["config"]["objects_total"] == 96 and line["config"]["objects_per_gpu"] == 96
+    assert line["exchange"]["mode"] == "time" and line["exchange"]["reduce_scatter_bytes_per_rank"] == 0
+    assert line["exchange"]["blocks_of_this_rank"] == [0, 48 // nproc]
+    assert line["exchange"]["model"]["exchange_ms_per_step"] == 0
+    assert line["exchange_check"]["max_rel_diff_one_lead_block_vs_three"] <= 1e-6
+    assert "time-sharded" in line["config"]["parallelism"]
+
+
+def test_objects_without_gather_on_one_gpu_over_gloo():
+    """--shard objects-nogather: the reduce-scatter alone (the consumer takes the bus channel-sharded); the exchange
+    model counts one slice instead of two; the same partials exchanged twice give bit-identical slices"""
+    line = run_bench(["--objects", "96", "--blocks", "32", "--steps", "3", "--warmup", "1", "--cpu-blocks", "0",
+                      "--shard", "objects-nogather"], nproc=2, env={"EARHIP_BENCH_BACKEND": "gloo", "EARHIP_BENCH_CHECK": "force"})
+    assert line["config"]["shard"] == "objects-nogather"
+    assert line["exchange"]["gather_bytes_into_root"] == 0 and line["exchange"]["root"] is None
+    assert line["exchange"]["reduce_scatter_bytes_per_rank"] == 12 * 32 * 512 * 4
+    assert line["exchange_check"]["max_rel_err_owned_slice_vs_all_reduce"] <= 1e-6
+    assert line["exchange_check"]["same_partials_exchanged_twice_bit_identical"] is True
+    m = line["exchange"]["model"]
+    assert m["mode"] == "objects-nogather" and "unmeasured" in m["status"]
+
+
 def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
     """`python3 bench.py --gpus 2 ...` exactly as the driver runs the N = 1 command, no launcher around it: bench.py
     starts its ranks itself (a fresh torchrun child) and relays rank 0's line.  On a one-GPU box the two ranks share

@@ -144,6 +144,22 @@ def test_hoa_decode_matrix_equals_oracle(layout, order, norm):
     assert not got[lfe].any()
 
 
+def test_hoa_decode_matrix_equals_the_float64_fixture():
+    """the device's AllRAD design against tests/golden/hoa_allrad_f64.npz (independent float64 evaluation, see
+    tests/test_oracle_hoa.py): float32 values within 1e-6 of the matrix's largest entry"""
+    import os
+    from libear_amd import capi
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hoa_allrad_f64.npz"))
+    cases = sorted({k.rsplit("|", 1)[0] for k in z.files if "|" in k})
+    assert len(cases) >= 6
+    for key in cases:
+        layout, order, kind = key.split("|")
+        want = z[key + "|D"]
+        got = capi.hoa_decode_matrix(ctx(), layout, z[key + "|orders"].tolist(), z[key + "|degrees"].tolist(), kind)
+        assert got.shape == want.shape, key
+        assert np.max(np.abs(got - want)) <= 1e-6 * max(1.0, np.max(np.abs(want))), (key, np.max(np.abs(got - want)))
+
+
 def test_hoa_exceptions():
     """tests/gain_calculator_hoa_tests.cpp:39-80"""
     from libear_amd import capi

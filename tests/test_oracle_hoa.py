@@ -100,3 +100,25 @@ def test_exceptions():
     with pytest.raises(_oracle.OracleError) as e:
         _oracle.hoa_decode_matrix("0+5+0", [0], [0], "foo")
     assert e.value.code == 1 and "unknown normalization" in str(e.value)
+
+
+def _hoa_golden():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hoa_allrad_f64.npz")
+    z = np.load(path)
+    cases = sorted({k.rsplit("|", 1)[0] for k in z.files if "|" in k})
+    return z, cases
+
+
+def test_decode_matrix_against_the_independent_float64_fixture():
+    """tests/golden/hoa_allrad_f64.npz (made by tests/golden/make_hoa_golden.py: scipy harmonics + numpy algebra over the
+    panner's gains at the reference's own 5200 design directions): the oracle's restatement of hoa.hpp agrees to 1e-12.
+    The reference's tests hold no values for this matrix, so this is "cannot drift", not "pinned by the reference"."""
+    z, cases = _hoa_golden()
+    assert len(cases) >= 6
+    for key in cases:
+        layout, order, kind = key.split("|")
+        want = z[key + "|D"]
+        got = _oracle.hoa_decode_matrix(layout, z[key + "|orders"].tolist(), z[key + "|degrees"].tolist(), kind)
+        assert got.shape == want.shape, key
+        assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want))), (key, np.max(np.abs(got - want)))
