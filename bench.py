@@ -432,8 +432,9 @@ def main():
         """this rank's shard of a scene of `objects` objects (+ `hoa` bed channels on rank 0), resident
         in HBM, with its renderer and double-buffered output / exchange buffers"""
 
-        def __init__(self, objects, hoa, scaling, seed_base=0, context=None):
-            self.time_sharded = args.shard == "time" and world > 1 and scaling == "strong"
+        def __init__(self, objects, hoa, scaling, seed_base=0, context=None, shard=None):
+            self.shard = shard or args.shard
+            self.time_sharded = self.shard == "time" and world > 1 and scaling == "strong"
             if self.time_sharded:  # every rank has the whole scene (the same seeds) and renders its blocks of the stream
                 assert T % world == 0, "--shard time needs the blocks of a step to divide by the GPUs"
                 self.M_obj, self.M_total = objects, objects + hoa
@@ -506,7 +507,7 @@ def main():
             # collectives of a chunk run beside the render of the NEXT chunk of the same step (not only beside the next
             # step); the shared bus lands on the root chunk by chunk, [nch][n_pad][clen] (double buffered over the steps).
             self.nch = 1
-            self.gather = args.shard == "objects"
+            self.gather = self.shard == "objects"
             if world > 1 and not self.time_sharded:
                 want = int(os.environ.get("EARHIP_BENCH_CHUNKS", "4"))
                 while want > 1 and (T % want or T // want < 8):
@@ -559,7 +560,7 @@ def main():
                 dst = self.head if (keep_head and c == 0) else self.outs[slot]  # (keep_head: the step's first blocks for the parity gate)
                 r.process_device(self.Tc, self.x.data_ptr() + 4 * c * self.clen, self.in_stride, dst.data_ptr(), self.clen)
                 self.last_slot = slot
-                if world > 1 and exchange_outputs and args.shard != "time":  # (weak scaling under --shard time: independent streams)
+                if world > 1 and exchange_outputs and self.shard != "time":  # (weak scaling under --shard time: independent streams)
                     per = n_pad // world
                     full_c = self.full[i % 2][c] if self.full is not None else None
                     if native_comm is not None:
@@ -750,6 +751,26 @@ def main():
         ww.close()
         del ww
 
+    # the other decompositions of the same scene, short runs in the same line (N > 1: the first contact with a multi-GPU
+    # node then measures all three)
+    other_modes = None
+    if world > 1 and args.scaling == "strong" and not args.stream_only and T % world == 0:
+        other_modes = {}
+        for mode in ("objects", "objects-nogather", "time"):
+            if mode == args.shard:
+                continue
+            wo = Workload(cfg["objects"], cfg["hoa"], "strong", shard=mode)
+            osteps = max(3, min(args.steps, 10))
+            odt, _ = wo.timed(osteps, 2)
+            other_modes[mode] = {"value": round(wo.M_total * total / (odt / osteps) / 1e6, 1), "unit": "Msamples/s",
+                                 "ms_per_step": round(odt / osteps * 1e3, 4), "steps": osteps,
+                                 "objects_per_gpu": wo.M, "blocks_per_gpu": wo.Tc * wo.nch,
+                                 "note": {"objects": "reduce-scatter + gather of the shared bus on rank 0 (north_star)",
+                                          "objects-nogather": "reduce-scatter only: the bus stays channel-sharded",
+                                          "time": "no exchange: T / G blocks per rank behind one lead block"}[mode]}
+            wo.close()
+            del wo
+
     result = None
     if rank == 0:
         gain_b, dec_b, dm_b = algorithmic_bytes(wl.M_obj, N, B, K, wl.M_hoa)
@@ -842,6 +863,7 @@ def main():
                 "objects_per_gpu": M, "objects_total": M_total, "channels": N, "block": B,
                 "blocks_per_step": T, "buses": K, "scene": args.scene, "gains": gains_desc,
                 "input_row_stride_samples": wl.in_stride,
+                "buffers": {"input": hex(wl.x_full.data_ptr()), "outputs": [hex(o.data_ptr()) for o in wl.outs]},
                 "shard": args.shard if world > 1 else None,
                 "parallelism": ((f"time-sharded over {world} GPUs: every rank renders all objects for T / G blocks of the stream "
                                  "behind one lead block; no exchange") if wl.time_sharded else
@@ -877,6 +899,7 @@ def main():
                                 "same_partials_exchanged_twice_bit_identical": exchange_repeat_identical}),
             "exchange": exchange_info,
             "weak_scaling": weak,
+            "other_shard_modes": other_modes,
             "kernel_timing": {"timed_steps": timed_steps, "every": time_every},
             "kernels_ms": {"seg_prep": round(k0_ms, 4), "gain_mix": round(k1_ms, 4),
                            "decorrelate_delay_mix": round(k2_ms, 4)},

@@ -113,6 +113,10 @@ def test_multi_rank_control_flow_on_one_gpu_over_gloo(nproc, layout):
     assert line["config"]["objects_total"] == 96 and line["config"]["objects_per_gpu"] == 96 // nproc
     assert line["exchange_check"]["max_rel_err_owned_slice_vs_all_reduce"] <= 1e-6
     assert line["weak_scaling"]["objects_total"] == 96 * nproc and line["weak_scaling"]["value"] > 0
+    if 32 % nproc == 0:  # the same line measures the other two decompositions (short runs)
+        assert set(line["other_shard_modes"]) == {"objects-nogather", "time"}
+        assert all(m["value"] > 0 for m in line["other_shard_modes"].values())
+        assert line["other_shard_modes"]["time"]["objects_per_gpu"] == 96
 
 
 @pytest.mark.parametrize("nproc", [2, 3])

@@ -19,5 +19,5 @@ ip, op = capi._chan_ptrs(x), capi._chan_ptrs(ob)
 lib = capi.load()
 for i in range(30):
     if i == 24:
-        os.environ["EARHIP_DEBUG_TIMING"] = "1"
+        c.set_option("DEBUG_TIMING", 1)
     capi.check(lib.earhip_render_process(r.h, ctypes.c_size_t(1), ip, op))

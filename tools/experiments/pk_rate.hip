@@ -1,0 +1,92 @@
+// pk_rate.hip — issue rate of the packed-f32 VALU instructions K2 (render_kernels.h, k_decorrelate_wave) is made of,
+// against plain f32 instructions doing the same arithmetic: cycles per wave-instruction at 1 / 2 / 3 / 4 waves per SIMD.
+// hipcc --offload-arch=gfx950 -O3 pk_rate.hip -o pk_rate && ./pk_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate(float *out, int iters, float seed) {
+  // 8 independent chains per lane (dependent latency hidden), 32 instructions per loop iteration
+  v2f a[8];
+  float s[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = v2f{seed + i, seed - i};
+#pragma unroll
+  for (int i = 0; i < 16; i++) s[i] = seed + 0.5f * i;
+  const v2f w = {0.999f, 0.001f};
+  const float ws = 0.999f, wt = 0.001f;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+      if (KIND == 0) {  // 8 v_pk_fma_f32 (plain operands)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(w));
+      } else if (KIND == 1) {  // 16 v_fma_f32: the same flops
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[i]) : "v"(s[(i + 1) & 15]), "v"(ws));
+      } else if (KIND == 2) {  // 8 v_pk_mul_f32 with op_sel (the complex multiply's first half)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(w));
+      } else if (KIND == 3) {  // 8 v_pk_add_f32 with neg / op_sel (a + i t)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(w));
+      } else if (KIND == 4) {  // 8 v_pk_fma_f32 with an SGPR-pair operand and modifiers (wave_cmul_k)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(w));
+      } else if (KIND == 5) {  // 16 v_mul_f32
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s[i]) : "v"(s[(i + 1) & 15]), "v"(ws));
+      } else if (KIND == 6) {  // 16 v_add_f32
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("v_add_f32 %0, %1, %2" : "=v"(s[i]) : "v"(s[(i + 1) & 15]), "v"(wt));
+      } else {  // 8 v_pk_add_f32 plain
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(w));
+      }
+    }
+  }
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r += a[i].x + a[i].y;
+#pragma unroll
+  for (int i = 0; i < 16; i++) r += s[i];
+  if (r == 123.456f) out[0] = r;
+}
+
+template <int KIND>
+static void run(const char *name, int per_iter, float *out) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int iters = 20000;
+  for (int wps = 1; wps <= 4; wps++) {  // waves per SIMD: blocks of 256 threads = one wave per SIMD each
+    const int blocks = 256 * wps;
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    // instructions per SIMD = wps * iters * 4 reps * per_iter; cycles at an assumed 2.4 GHz and 2.05 GHz
+    const double n = (double)wps * iters * 4 * per_iter;
+    printf("%-44s %d waves/SIMD: %.3f ms, %.2f ns per wave-instruction per SIMD (%.2f cyc at 2.4 GHz)\n", name, wps, ms,
+           ms * 1e6 / n, ms * 1e6 / n * 2.4);
+  }
+}
+
+int main() {
+  float *out;
+  hipMalloc(&out, 64);
+  run<1>("v_fma_f32 x16", 16, out);
+  run<0>("v_pk_fma_f32 x8 (same flops)", 8, out);
+  run<4>("v_pk_fma_f32 x8, SGPR operand + op_sel/neg", 8, out);
+  run<2>("v_pk_mul_f32 x8, op_sel", 8, out);
+  run<5>("v_mul_f32 x16", 16, out);
+  run<3>("v_pk_add_f32 x8, op_sel/neg", 8, out);
+  run<7>("v_pk_add_f32 x8 plain", 8, out);
+  run<6>("v_add_f32 x16", 16, out);
+  return 0;
+}

@@ -6,8 +6,9 @@ import sys
 
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
+extra = sys.argv[3].split() if len(sys.argv) > 3 else []  # e.g. "-DEARHIP_BUILD_OCC=8"
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", src, "-o",
-       "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"]
+       "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"] + extra
 out = subprocess.run(cmd, capture_output=True, text=True, cwd="/root/repo/libear_amd/csrc").stderr
 cur, rows = None, {}
 for ln in out.splitlines():
