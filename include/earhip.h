@@ -76,7 +76,8 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, BUILD_TPW, HBUILD_TPW (1 2 4 8),
  *                 SPL (2 | 4), WAVES (1..8), TPW (1..8), NRT (4 | 8), XSCALE (log2 of a fixed input prescale), PROBE_RUNS
  *   renderer:     K2_WG, K2_OWN_BLOCK (0 | 1), RUN (odd blocks per decorrelator run), GSPLIT (1..32) — read by
- *                 earhip_render_create; GRAPH (0 | 1: block-mode calls replay a captured HIP graph, default 1)
+ *                 earhip_render_create; TAILCUT (0 | 1, default 1: a stream call of k rounds of tiles plus at most a
+ *                 quarter round runs as two consecutive calls, earhip_render_last_tail_blocks)
  *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING */
 int earhip_ctx_set_option(earhip_ctx *ctx, const char *key, const char *value);
 int earhip_ctx_get_option(const earhip_ctx *ctx, const char *key, int *is_set, int *value);
@@ -434,6 +435,11 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby);
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
  * For tests and benchmarks that must know which kernel instantiation they measured. */
 int earhip_render_last_plan(const earhip_render *r, int out[4]);
+/* A stream call whose tiles are whole rounds of the chip's workgroups plus a few (1025 blocks of 512 samples on 256 CUs)
+ * is run as two consecutive calls — the whole rounds, then the few blocks behind them spread over the chip by object
+ * splits — instead of paying a whole round for the few.  *blocks = the blocks of the last call that ran as such a tail
+ * (0: the call was not cut).  Results are those of the two calls made by the caller. */
+int earhip_render_last_tail_blocks(const earhip_render *r, int *blocks);
 /* Bytes of device scratch (segment descriptors, slot / piece / hinge lists) the last process call needed: sized per call
  * from its launch plan and the curves (the piece lists from the most ramps any window of a tile's length overlaps, per
  * object), not for the worst case. */

@@ -640,6 +640,12 @@ class Renderer:
         check(load().earhip_render_scratch_regrows(self.h, C.byref(v)))
         return v.value
 
+    def last_tail_blocks(self):
+        """blocks of the last call that ran as a tail of their own behind the whole rounds of tiles (0: the call was not cut)"""
+        v = C.c_int(0)
+        check(load().earhip_render_last_tail_blocks(self.h, C.byref(v)))
+        return v.value
+
     def last_plan(self):
         """launch plan of the last call: gain kernel, samples per workgroup tile, tiles, object splits"""
         out = (C.c_int * 4)()

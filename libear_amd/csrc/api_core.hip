@@ -398,7 +398,7 @@ using namespace earhip;
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
     "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "P2_TILE", "P2_PAIRS", "HINGE", "HG_TILE", "HBUILD_TPW",
-    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "GRAPH"};
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT"};
 
 void earhip_ctx::apply_options() {
   spl = 4, use_mfma = 3, x_scale_log2 = 14, x_scale_auto = true, max_waves = 4, tiles_per_wg = 4, tiles_per_wg_forced = false, nrt = 8;

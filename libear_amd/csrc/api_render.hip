@@ -207,10 +207,12 @@ struct earhip_render {
   std::unique_ptr<GatherPool> gather;  // staging threads of long host-pointer calls
   // timing
   bool timing = false;
+  bool last_timed = false;
   int timing_every = 1;      // time every n-th process call (the event records cost ~3 us of idle GPU each)
   long timing_calls = 0;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  struct Pending { hipEvent_t e[6]; bool has_k2; };
+  // (a call cut into a main part and a tail — process_device — is ONE call of the timing: its two sets of events add up)
+  struct Pending { hipEvent_t e[6]; bool has_k2; bool continues; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
   double acc_ms[3] = {0, 0, 0};
@@ -238,13 +240,14 @@ struct earhip_render {
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     for (auto &p : pending) {
       float ms = 0;
+      const double one = p.continues ? 0.0 : 1.0;  // (the second part of a call cut in two adds time, not a call)
       EARHIP_HIP(hipEventElapsedTime(&ms, p.e[0], p.e[1]));
-      acc_ms[2] += ms; acc_n[2] += 1;
+      acc_ms[2] += ms; acc_n[2] += one;
       EARHIP_HIP(hipEventElapsedTime(&ms, p.e[2], p.e[3]));
-      acc_ms[0] += ms; acc_n[0] += 1;
+      acc_ms[0] += ms; acc_n[0] += one;
       if (p.has_k2) {
         EARHIP_HIP(hipEventElapsedTime(&ms, p.e[4], p.e[5]));
-        acc_ms[1] += ms; acc_n[1] += 1;
+        acc_ms[1] += ms; acc_n[1] += one;
       }
       for (auto e : p.e)
         if (e) pool.push_back(e);
@@ -285,8 +288,52 @@ struct earhip_render {
     }
   }
 
-  void process_device(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev,
-                      size_t out_stride) {
+  // Workgroups of the gain kernel the chip holds at once for a plan: the tiles of a call are worked off in rounds of so many
+  // (8-wave forms: one workgroup per CU; 4-wave forms: two)
+  int resident_workgroups(const MixLaunch &ml) const {
+    if (!(ml.split || ml.pieces || ml.hinge)) return 0;
+    return ctx->num_cus * (ml.tile() >= 512 ? 1 : 2);
+  }
+
+  // A tile of the headline scene is 100 us of one CU: a call of k rounds of tiles PLUS A FEW (1025 blocks; the 513 of a
+  // time-sharded rank: its share and a lead block) used to cost k + 1 rounds — 0.306 ms for 513 blocks where 512 take 0.235.
+  // Such a call is cut in two: the whole rounds as they were, and the few tiles behind them as a short call of their own,
+  // which the planner spreads over the chip by splitting the objects (as in block mode).  The cut costs a second K0, a
+  // second K2 launch and the boundaries (~30 us): taken when the tail is at most a quarter of a round.  Results are those
+  // of two consecutive calls (every call length is a valid call: the state carries over).
+  void process_device(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev, size_t out_stride) {
+    if (!ctx->strict && ctx->get(OPT_TAILCUT, 1) != 0 && nblocks >= 2) {
+      if (curves->dirty()) {
+        curves->commit(ctx);
+        reserve_for_curves();
+      }
+      const MixLaunch ml = plan_call(nblocks, in_stride);
+      const int W = resident_workgroups(ml);
+      if (W > 0 && ml.gsplit == 1 && ml.ntiles > W) {
+        const size_t tile = (size_t)ml.tile();
+        const size_t full = (size_t)ml.ntiles / (size_t)W, rest = (size_t)ml.ntiles % (size_t)W;
+        const size_t main_samples = full * (size_t)W * tile;
+        if (rest > 0 && rest <= (size_t)W / 4 && main_samples % (size_t)B == 0) {
+          const size_t main_blocks = main_samples / (size_t)B;
+          process_span(main_blocks, in_dev, in_stride, out_dev, out_stride, false);
+          const int kind = last_kind, plan3[3] = {last_plan[0], last_plan[1], last_plan[2]};
+          const size_t scratch = last_scratch_bytes;
+          process_span(nblocks - main_blocks, in_dev + main_samples, in_stride, out_dev + main_samples, out_stride, true);
+          last_kind = kind;  // (what the call is reported as: its main part)
+          for (int i = 0; i < 3; i++) last_plan[i] = plan3[i];
+          last_scratch_bytes = scratch;
+          last_tail_blocks = (int)(nblocks - main_blocks);
+          return;
+        }
+      }
+    }
+    last_tail_blocks = 0;
+    process_span(nblocks, in_dev, in_stride, out_dev, out_stride, false);
+  }
+  int last_tail_blocks = 0;  // blocks of the last call that ran as its tail part (0: the call was not cut)
+
+  void process_span(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev,
+                    size_t out_stride, bool continues) {
     const int nsamples = (int)(nblocks * (size_t)B);
     last_in_stride = in_stride;
     if (curves->dirty()) {
@@ -321,10 +368,13 @@ struct earhip_render {
     last_plan[2] = ml.gsplit;
     Pending pd;
     hipEvent_t *evp = nullptr;
-    const bool timed = timing && (timing_calls++ % timing_every) == 0;
+    // (the second part of a call cut in two is timed when its first part was)
+    const bool timed = timing && (continues ? last_timed : (timing_calls++ % timing_every) == 0);
+    last_timed = timed;
     if (timed) {
       for (int i = 0; i < 6; i++) pd.e[i] = get_event();
       pd.has_k2 = K == 2;
+      pd.continues = continues;
       evp = pd.e;
     }
     if (K == 1) {
@@ -727,6 +777,13 @@ int earhip_render_scratch_regrows(const earhip_render *r, long *count) {
   return guarded([&] {
     require(r != nullptr && count != nullptr, "NULL argument");
     *count = r->scratch_regrows;
+  });
+}
+
+int earhip_render_last_tail_blocks(const earhip_render *r, int *blocks) {
+  return guarded([&] {
+    require(r != nullptr && blocks != nullptr, "NULL argument");
+    *blocks = r->last_tail_blocks;
   });
 }
 

@@ -399,3 +399,44 @@ def test_bursty_audio_at_the_headline_size(kind):
     # start (loud), deep inside the -80 dB stretch, the silence behind the +40 dB block, the fade's tail at -90 dB
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (20, 3), (mid - 6, 3), (mid + 4, 3), (mid + 60, 3), (nblocks - 3, 3)])
     print(f"bursty audio ({kind}): worst per-channel rel RMS over the windows {worst:.3e}, plan {plan}")
+
+
+@pytest.mark.parametrize("kind,nblocks", [("dense", 257), ("dense", 300), ("adm", 259), ("moving", 258)])
+def test_a_call_of_whole_rounds_plus_a_few_blocks_is_cut_in_two(kind, nblocks):
+    """A stream call whose tiles are whole rounds of the chip's workgroups plus a few (257 blocks of 512 samples on 256
+    CUs) runs as the whole rounds and a short call behind them (earhip_render_last_tail_blocks): same results as the
+    uncut call within the kernels' tolerance, every sample against the oracle, the DSP state carried over the cut."""
+    layout, m, block = "4+5+0", 96, 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = (scenes.dense_curves(m, n, block, nblocks) if kind == "dense" else scenes.adm_curves(m, n, total, seed=5) if kind == "adm"
+              else scenes.adm_curves(m, n, total, period=240, ramp=240, seed=6))
+    x = device_audio(m, total, 99)
+    from libear_amd import capi
+    import torch
+
+    def render(cut):
+        def go():
+            r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+            for i, (t, d, f) in enumerate(curves):
+                r.set_object_points(i, t, d, f)
+            out = torch.zeros((n, total), device=x.device, dtype=torch.float32)
+            r.process_device(nblocks, x.data_ptr(), total, out.data_ptr(), total)
+            ctx().synchronize()
+            tail, plan = r.last_tail_blocks(), r.last_plan()
+            r.close()
+            return out, tail, plan
+        return with_options({"EARHIP_TAILCUT": cut}, go)
+
+    out1, tail1, plan1 = render(None)
+    out0, tail0, plan0 = render("0")
+    assert tail0 == 0
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    per_round = cus * (1 if plan0["tile"] >= 512 else 2) * plan0["tile"] // block
+    if plan0["gsplit"] == 1 and plan0["kernel"] in (3, 4, 5) and 0 < nblocks % per_round <= per_round // 4 and nblocks > per_round:
+        assert tail1 == nblocks % per_round, (tail1, plan1, plan0)
+    a, b = out1.cpu().numpy(), out0.cpu().numpy()
+    assert scenes.rel_rms_per_channel(a, b) <= 5e-7
+    worst = check_windows(curves, x, out1, n, block, dec, 255, [(0, 3), (nblocks - 6, 6)])
+    print(f"cut call ({kind}, {nblocks} blocks): tail {tail1} blocks, plan {plan1}, worst channel {worst:.3e}")
