@@ -76,8 +76,8 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, BUILD_TPW, HBUILD_TPW (1 2 4 8),
  *                 SPL (2 | 4), WAVES (1..8), TPW (1..8), NRT (4 | 8), XSCALE (log2 of a fixed input prescale), PROBE_RUNS
  *   renderer:     K2_WG, K2_OWN_BLOCK (0 | 1), RUN (odd blocks per decorrelator run), GSPLIT (1..32) — read by
- *                 earhip_render_create; TAILCUT (0 | 1, default 1: a stream call of k rounds of tiles plus at most a
- *                 quarter round runs as two consecutive calls, earhip_render_last_tail_blocks)
+ *                 earhip_render_create; TAILCUT (v = 0..7, default 2: a stream call of k rounds of tiles plus at most v / 8
+ *                 of a round runs as two consecutive calls, earhip_render_last_tail_blocks; longer tails measured slower cut)
  *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING */
 int earhip_ctx_set_option(earhip_ctx *ctx, const char *key, const char *value);
 int earhip_ctx_get_option(const earhip_ctx *ctx, const char *key, int *is_set, int *value);

@@ -313,7 +313,9 @@ struct earhip_render {
         const size_t tile = (size_t)ml.tile();
         const size_t full = (size_t)ml.ntiles / (size_t)W, rest = (size_t)ml.ntiles % (size_t)W;
         const size_t main_samples = full * (size_t)W * tile;
-        if (rest > 0 && rest <= (size_t)W / 4 && main_samples % (size_t)B == 0) {
+        // (option TAILCUT = v: tails of up to v / 8 of a round are cut off; default 2, 0: never)
+        const size_t eighths = (size_t)std::min(std::max(ctx->get(OPT_TAILCUT, 2), 0), 7);
+        if (rest > 0 && rest <= (size_t)W * eighths / 8 && main_samples % (size_t)B == 0) {
           const size_t main_blocks = main_samples / (size_t)B;
           process_span(main_blocks, in_dev, in_stride, out_dev, out_stride, false);
           const int kind = last_kind, plan3[3] = {last_plan[0], last_plan[1], last_plan[2]};
