@@ -440,3 +440,31 @@ def test_a_call_of_whole_rounds_plus_a_few_blocks_is_cut_in_two(kind, nblocks):
     assert scenes.rel_rms_per_channel(a, b) <= 5e-7
     worst = check_windows(curves, x, out1, n, block, dec, 255, [(0, 3), (nblocks - 6, 6)])
     print(f"cut call ({kind}, {nblocks} blocks): tail {tail1} blocks, plan {plan1}, worst channel {worst:.3e}")
+
+
+@pytest.mark.parametrize("kind,block", [("dense", 512), ("adm", 512), ("dense", 256)])
+def test_time_sharding_on_the_device_equals_one_call(kind, block):
+    """--shard time on the HIP path: blocks [b0, b1) rendered behind `lead` blocks from the zero state (as many as
+    the decorrelator FIRs have partitions: libear_amd.distributed.time_range) equal the same blocks of ONE call over the whole
+    stream — to the kernels' own rounding (the decorrelators pair blocks differently when a run starts elsewhere), every
+    shard also against the oracle."""
+    from libear_amd.distributed import time_range
+    layout, m, nblocks, world = "4+5+0", 96, 48, 3
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.dense_curves(m, n, block, nblocks) if kind == "dense" else scenes.adm_curves(m, n, total, seed=15)
+    x = device_audio(m, total, 123)
+    full, _ = render_device(curves, x, n, block, dec, 255, [nblocks])
+    full = full.cpu().numpy()
+    worst = 0.0
+    for rank in range(world):
+        b0, b1, lead = time_range(nblocks, rank, world, partitions=-(-512 // block))
+        lo = (b0 - lead) * block
+        part, _ = render_device(curves, x[:, lo:b1 * block].contiguous(), n, block, dec, 255, [b1 - b0 + lead], t0=lo)
+        got = part.cpu().numpy()[:, lead * block:]
+        want = full[:, b0 * block:b1 * block]
+        e = scenes.rel_rms_per_channel(got, want)
+        worst = max(worst, e)
+        assert e <= 2e-7, (rank, e)
+    print(f"time sharding on the device ({kind}, block {block}): worst channel vs one call {worst:.3e}")
