@@ -39,6 +39,16 @@ namespace ear {
       /// bit-exact libear arithmetic in the gain kernels (slower)
       void set_strict(bool strict) { check(earhip_ctx_set_strict(ctx_, strict ? 1 : 0)); }
       void synchronize() { check(earhip_ctx_synchronize(ctx_)); }
+      /// A tuning knob of this context (include/earhip.h, earhip_ctx_set_option: "MFMA", "H2_TILE", "TAILCUT" ...); the
+      /// environment variable EARHIP_<KEY> is only read when a context is created.  reset_option: back to the library's choice.
+      void set_option(const char *key, int value) { check(earhip_ctx_set_option(ctx_, key, std::to_string(value).c_str())); }
+      void reset_option(const char *key) { check(earhip_ctx_set_option(ctx_, key, nullptr)); }
+      /// false: the option is at its default
+      bool get_option(const char *key, int &value) const {
+        int is_set = 0;
+        check(earhip_ctx_get_option(ctx_, key, &is_set, &value));
+        return is_set != 0;
+      }
       /// Host memory the device reaches directly.  Channel buffers taken from here (or registered once with
       /// register_host: e.g. the storage of an Eigen matrix whose columns PtrAdapter points at,
       /// include/ear/dsp/ptr_adapter.hpp:17-24) let ObjectsRenderer::process skip its staging copies for

@@ -1048,8 +1048,64 @@ static void test_communicator_single_rank() {
   hc.release_host(partial);
 }
 
+// Run-time configuration: knobs are options of a context — set, read back, reset; unknown keys are refused with
+// libear's invalid_argument; a gain kernel forced by option is the one that runs.
+static void test_context_options() {
+  hip::Context hc(0);
+  int v = -1;
+  CHECK(!hc.get_option("H2_TILE", v) || v >= 0);  // (set only when the environment had it at creation)
+  hc.set_option("h2_tile", 256);
+  CHECK(hc.get_option("EARHIP_H2_TILE", v) && v == 256);
+  hc.reset_option("H2_TILE");
+  CHECK(!hc.get_option("H2_TILE", v));
+  bool refused = false;
+  try {
+    hc.set_option("NO_SUCH_KNOB", 1);
+  } catch (const ear::invalid_argument &) {
+    refused = true;
+  }
+  CHECK(refused);
+  // the exact-f32 gain kernel by option: same scene, within 1e-6 of the default kernels' result
+  const std::vector<std::string> names{"M+030", "M-030", "M+000", "LFE1", "M+110", "M-110"};
+  const size_t M = 40, N = names.size(), B = 512, T = 2;
+  const auto dec = designDecorrelators(names);
+  std::vector<Vec> in(M);
+  for (size_t m = 0; m < M; m++) in[m] = random_vec(B * T, 700 + (unsigned)m);
+  std::vector<const float *> ip(M);
+  for (size_t m = 0; m < M; m++) ip[m] = in[m].data();
+  std::mt19937 g(5);
+  std::vector<Vec> outs[2];
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) hc.set_option("MFMA", 1);
+    ObjectsRenderer r(M, N, B, dec, decorrelatorCompensationDelay(), T, hc);
+    std::mt19937 gg(5);
+    for (size_t m = 0; m < M; m++) {
+      std::vector<std::vector<float>> d(T + 1, Vec(N)), f(T + 1, Vec(N));
+      std::vector<int64_t> times;
+      for (size_t t = 0; t <= T; t++) {
+        times.push_back((int64_t)(t * B));
+        for (size_t c = 0; c < N; c++) d[t][c] = (float)((double)gg() / 4294967296.0), f[t][c] = (float)((double)gg() / 4294967296.0);
+      }
+      r.set_object_points(m, times, d, f);
+    }
+    outs[pass].assign(N, Vec(B * T));
+    std::vector<float *> op(N);
+    for (size_t c = 0; c < N; c++) op[c] = outs[pass][c].data();
+    r.process(T, ip.data(), op.data());
+  }
+  double num = 0, den = 0;
+  for (size_t c = 0; c < N; c++)
+    for (size_t i = 0; i < B * T; i++) {
+      const double e = (double)outs[0][c][i] - outs[1][c][i];
+      num += e * e, den += (double)outs[1][c][i] * outs[1][c][i];
+    }
+  CHECK(den > 0 && std::sqrt(num / den) <= 1e-6);
+  (void)g;
+}
+
 int main() {
   try {
+    test_context_options();
     test_no_allocation_in_process();
     test_fft_plugin_point();
     test_communicator_single_rank();

@@ -468,3 +468,18 @@ def test_time_sharding_on_the_device_equals_one_call(kind, block):
         worst = max(worst, e)
         assert e <= 2e-7, (rank, e)
     print(f"time sharding on the device ({kind}, block {block}): worst channel vs one call {worst:.3e}")
+
+
+def test_a_cut_call_on_the_direct_bus_only():
+    """the same cut with one bus (BASELINE config 2's shape: no decorrelators, the gain kernel writes the outputs): 1026
+    blocks on 256-sample tiles = four rounds of workgroups and four tiles"""
+    layout, m, block, nblocks = "4+5+0", 40, 512, 1026
+    n = len(LAYOUTS[layout])
+    total = block * nblocks
+    curves = [(t, d, None) for t, d, _ in scenes.dense_curves(m, n, block, nblocks)]
+    x = device_audio(m, total, 7)
+    out1, plan1 = render_device(curves, x, n, block, None, 0, [nblocks])
+    out0, plan0 = with_options({"EARHIP_TAILCUT": "0"}, lambda: render_device(curves, x, n, block, None, 0, [nblocks]))
+    assert scenes.rel_rms_per_channel(out1.cpu().numpy(), out0.cpu().numpy()) <= 5e-7
+    worst = check_windows(curves, x, out1, n, block, None, 0, [(0, 2), (nblocks - 8, 8)], two_bus=False)
+    print(f"cut call, one bus: plan {plan1}, worst channel {worst:.3e}")
