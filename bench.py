@@ -59,9 +59,10 @@ def algorithmic_bytes(m, n, b, k, m_static=0):
     return gain, dec, dm
 
 
-GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 3: "k_gain_mix_h2 (f16x2 MFMA)",
+GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)", 2: "k_gain_mix_f32g (f32 MFMA on the tile grid)",
+                3: "k_gain_mix_h2 (f16x2 MFMA)",
                 4: "k_gain_mix_p2 (f16x2 MFMA over piece lists)", 5: "k_gain_mix_hg (f16x2 MFMA, hinges)"}
-GAIN_DTYPES = {0: "f32 (VALU, libear's exact arithmetic)", 1: "f32 (f32 MFMA, f32 accumulate)",
+GAIN_DTYPES = {0: "f32 (VALU, libear's exact arithmetic)", 1: "f32 (f32 MFMA, f32 accumulate)", 2: "f32 (f32 MFMA, f32 accumulate)",
                3: "f32 io / f16x2-split MFMA, f32 accumulate", 4: "f32 io / f16x2-split MFMA, f32 accumulate"}
 
 

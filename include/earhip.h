@@ -418,11 +418,12 @@ int earhip_render_enable_timing(earhip_render *r, int enable);
  * launches.  Synchronises the stream. */
 int earhip_render_get_timing(earhip_render *r, double out[6]);
 /* Which gain kernel the last process call used: 0 = VALU with libear's exact
- * arithmetic (strict mode), 1 = f32 MFMA over slot lists, 3 = f16x2-split MFMA (all
+ * arithmetic (strict mode), 1 = f32 MFMA over slot lists, 2 = f32 MFMA on the tile grid (option
+ * MFMA = 1 with every curve point on the 512-sample grid of a call of whole tiles), 3 = f16x2-split MFMA (all
  * curve points on the kernel's tile boundaries), 4 = f16x2-split MFMA over piece lists
  * (metadata that ignores the tile grid), 5 = f16x2-split MFMA with hinges (curves that ramp
  * all the time off the tile grid; the piece lists stand by: see below); -1 before the first
- * call.  (2 was the bf16x3 kernel of the first round: removed.) */
+ * call. */
 int earhip_render_gain_kernel(const earhip_render *r, int *kind);
 /* Kernel 5 keeps 1e-6 for inputs down to 16 binades below the call's level (kernel 4: 21), so a
  * call it is planned for is decided ON THE DEVICE, from the level probe of the call's inputs: the

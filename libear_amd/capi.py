@@ -615,7 +615,8 @@ class Renderer:
                 "decor_launches": out[3], "prep_ms": out[4], "prep_launches": out[5]}
 
     def gain_kernel(self):
-        """0 strict VALU, 1 f32 MFMA (slot lists), 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists, 5 f16x2 MFMA with hinges: the gain kernel of
+        """0 strict VALU, 1 f32 MFMA (slot lists), 2 f32 MFMA on the tile grid, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists, 5 f16x2 MFMA
+        with hinges: the gain kernel of
         the last call"""
         kind = C.c_int(-1)
         check(load().earhip_render_gain_kernel(self.h, C.byref(kind)))

@@ -15,6 +15,7 @@
 #include "gain_h2_t1.h"
 #include "gain_p2.h"
 #include "gain_hg.h"
+#include "gain_f32g.h"
 
 namespace earhip {
 
@@ -48,7 +49,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   const ColumnPlan &cp = cs.plan();
   const PointStore ps = cs.device();
   const int M = cs.M();
-  const bool slots = ml.mfma && !ml.split && !ml.pieces && !ml.hinge;
+  const bool slots = ml.mfma && !ml.split && !ml.pieces && !ml.hinge && !ml.f32grid;
   if (slots && M > kMaxSlotObjects) fail_internal("slot lists address objects with 16 bits");
   if (ev) EARHIP_HIP(hipEventRecord(ev[0], ctx->stream));
   // K0: segment descriptors; for the f32 MFMA kernel K0s then turns them into the
@@ -249,6 +250,15 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
     EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)
 #undef EARHIP_P2_CASE
+    launched = true;
+  }
+  if (ml.f32grid) {  // exact f32 on the tile grid (gain_f32g.h): a workgroup per 512-sample tile, descriptors from k_seg_prep
+    if (nsamples % kF32GridTile != 0) fail_internal("f32 grid kernel: the call is not whole tiles");
+    const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
+#define EARHIP_F32G_CASE(NCT_)                                                                       \
+  if (cp.nct == NCT_) hipLaunchKernelGGL((k_gain_mix_f32g<NCT_>), bgrid, dim3(512), 0, ctx->stream, P, ps.zero_row);
+    EARHIP_F32G_CASE(1) EARHIP_F32G_CASE(2) EARHIP_F32G_CASE(3)
+#undef EARHIP_F32G_CASE
     launched = true;
   }
   if (ml.split) {

@@ -188,7 +188,7 @@ struct earhip_render {
   size_t last_scratch_bytes = 0;  // K0 / K1 scratch the last call needed
   long scratch_regrows = 0;       // process calls that had to grow the scratch themselves (none on committed curves)
   int last_gate_idx = -1;  // the context's mode word of THIS renderer's last call when it was planned for the hinge kernel, else -1
-  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
+  int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 f32 MFMA on the tile grid, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
                        // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
   bool run_len_set = false;  // EARHIP_RUN given: also fixes the run length of the wave kernel
@@ -260,7 +260,7 @@ struct earhip_render {
     const int nsamples = (int)(nblocks * (size_t)B);
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, ctx->strict, max_gsplit, curves->aligned_tile(t),
                             curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste(256), curves->pair_waste(512),
-                            curves->hinge_exact_share(in_stride, (size_t)nsamples));
+                            curves->hinge_exact_share(in_stride, (size_t)nsamples), curves->tiles_aligned(kF32GridTile, t));
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;
     while (ml.gsplit > 1 && bus_stride * K * N * ml.gsplit > bus.n) ml.gsplit /= 2;
     return ml;
@@ -346,7 +346,7 @@ struct earhip_render {
     MixLaunch ml = plan_call(nblocks, in_stride);
     if (ml.hinge) curves->ensure_kinks(ctx);  // (already there unless an option changed the plan since the commit)
 
-    last_kind = ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
+    last_kind = ml.f32grid ? 2 : ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
     {
       // K0 / K1 scratch for THIS plan and THESE curves (round 3: 537 MB at the headline's size for any curves): reserved
       // when the curves were committed (reserve_for_curves).  The one exception, documented in earhip.h: a plan that no

@@ -16,6 +16,7 @@
 #include "gain_kernels.h"
 #include "gain_p2.h"
 #include "gain_hg.h"
+#include "gain_f32g.h"
 
 namespace earhip {
 
@@ -675,6 +676,7 @@ struct MixLaunch {
   bool pieces = false;         // matrix-core kernel on f16x2 split operands over per-tile piece lists (gain_p2.h)
   int pw = 2;                  // with pieces: waves per workgroup (2 or 4); tile = 64 pw samples
   bool paired = false;         // with pieces: the lists' paired layout (gain_p2.h)
+  bool f32grid = false;        // exact-f32 matrix-core kernel for curves on the 512-sample tile grid (gain_f32g.h)
   bool hinge = false;          // matrix-core kernel on f16x2 split operands with the curve points inside a tile as hinges (gain_hg.h)
   int hinge_tile = 512;        // with hinge: 512 (8 waves, up to two kinks on either side of a tile's centre) or 256 (4 waves, one:
                                // EARHIP_HG_TILE=256; 4 % slower per step, 8.1e-7 instead of 8.6e-7 from the CPU path on the
@@ -683,13 +685,13 @@ struct MixLaunch {
   int nrt;                     // MFMA: 16-sample row tiles per wave; tile = 16 * nrt samples
   int ntiles, wsplit, gsplit;  // tiles, in-workgroup object splits, grid-level splits
   int tpw = 1;                 // MFMA: adjacent tiles per workgroup
-  int tile() const { return hinge ? hinge_tile : pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
+  int tile() const { return f32grid ? kF32GridTile : hinge ? hinge_tile : pieces ? 64 * pw : split ? (wide ? 512 : 256) : mfma ? 16 * nrt : 64 * spl; }
 };
 
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
                           float gain_scale = 0.0f, double point_density = 0.0, double pair_waste256 = 1.0,
-                          double pair_waste512 = 1.0, double hinge_exact_share = 2.0) {
+                          double pair_waste512 = 1.0, double hinge_exact_share = 2.0, bool grid512_strict = false) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
@@ -746,12 +748,17 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
   // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments
   // grew a third piece: 0.296 ms against 0.261 for the 4-wave form at three workgroups per CU, same box)
   L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || (nsamples / 512 >= 2 * ctx->num_cus && cp.nct > 1));
+  // Exact f32 asked for (MFMA = 1) and EVERY curve point on the 512-sample tile grid of a call of whole tiles: the line form
+  // of the ramp on the f32 matrix pipe, no per-sample arithmetic in front of it (gain_f32g.h).  Finite gains only (a
+  // constant segment's row is used as it is, but a ramp through a non-finite gain is libear's own arithmetic's business).
+  L.f32grid = L.mfma && !L.split && !L.pieces && !L.hinge && ctx->use_mfma == 1 && grid512_strict && gain_scale > 0.0f &&
+              nsamples % kF32GridTile == 0 && M >= 16;
   // the slot lists of the f32 MFMA kernel address objects with 16 bits
-  if (L.mfma && !L.split && !L.pieces && !L.hinge && M > kMaxSlotObjects) L.mfma = false;
+  if (L.mfma && !L.split && !L.pieces && !L.hinge && !L.f32grid && M > kMaxSlotObjects) L.mfma = false;
   L.spl = ctx->spl;
   L.nrt = ctx->nrt;
   L.ntiles = (nsamples + L.tile() - 1) / L.tile();
-  if (L.split || L.pieces || L.hinge) {
+  if (L.split || L.pieces || L.hinge || L.f32grid) {
     // one workgroup = 4 adjacent 64-sample tiles x all objects of its grid-level
     // split; few tiles (block mode): split the objects across workgroups
     L.wsplit = 1;
@@ -810,7 +817,7 @@ inline size_t scratch_units(const CurveSet &cs, const MixLaunch &ml, int M) {
     return std::max(hinge_units((size_t)M, nt), piece_units((size_t)M, pnt, (size_t)cs.piece_cap(64 * ml.pw, ml.paired)));
   }
   if (ml.pieces) return piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired));
-  if (ml.split || !ml.mfma) return (size_t)M * nt + 1;
+  if (ml.split || ml.f32grid || !ml.mfma) return (size_t)M * nt + 1;
   return desc_units((size_t)M, nt);
 }
 

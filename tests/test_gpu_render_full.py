@@ -483,3 +483,60 @@ def test_a_cut_call_on_the_direct_bus_only():
     assert scenes.rel_rms_per_channel(out1.cpu().numpy(), out0.cpu().numpy()) <= 5e-7
     worst = check_windows(curves, x, out1, n, block, None, 0, [(0, 2), (nblocks - 8, 8)], two_bus=False)
     print(f"cut call, one bus: plan {plan1}, worst channel {worst:.3e}")
+
+
+@pytest.mark.parametrize("layout,m,nblocks,kind", [("9+10+3", 1024, 64, "dense"), ("4+5+0", 100, 40, "dense"), ("0+5+0", 33, 16, "static"),
+                                                   ("9+10+3", 256, 24, "holds")])
+def test_exact_f32_on_the_tile_grid(layout, m, nblocks, kind):
+    """Option MFMA = 1 with every curve point on the 512-sample grid: k_gain_mix_f32g (kernel 2) — libear's ramp as a line per
+    tile on the f32 matrix pipe, no operand split, no prescale.  Against the oracle per channel (1e-6), no further from a
+    float64 render than the CPU path, equal to the slot kernel (option H2_TILE irrelevant; curves off the grid keep kernel 1)
+    to rounding; object counts that are no multiple of the chunk, one to three column tiles, ramps / constants / holds."""
+    from libear_amd import capi
+    import torch
+    block = 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    if kind == "dense":
+        curves = scenes.dense_curves(m, n, block, nblocks, seed=3)
+    elif kind == "static":
+        curves = scenes.constant_curves(m, n, seed=4)
+    else:  # ramps over one block, then held for two (constant segments between equal points), on the grid
+        base = scenes.dense_curves(m, n, block, nblocks, seed=5)
+        curves = []
+        for t, d, f in base:
+            keep = [i for i in range(len(t)) if i % 3 != 2]
+            tt, dd, ff = t[keep], d[keep].copy(), f[keep].copy()
+            for i in range(1, len(tt), 2):  # every second point repeats its predecessor's gains: a hold
+                dd[i] = dd[i - 1]
+                ff[i] = ff[i - 1]
+            curves.append((tt, dd, ff))
+    x = device_audio(m, total, 31)
+    c1 = with_options({"EARHIP_MFMA": "1"}, lambda: capi.Context(0))
+    try:
+        def render(off_grid):
+            r = capi.Renderer(c1, m, n, block, dec, 255, max_blocks=nblocks)
+            for i, (t, d, f) in enumerate(curves):
+                r.set_object_points(i, t + (37 if off_grid and i == 0 else 0), d, f)
+            out = torch.zeros((n, total), device=x.device, dtype=torch.float32)
+            r.process_device(nblocks, x.data_ptr(), total, out.data_ptr(), total)
+            c1.synchronize()
+            k = r.gain_kernel()
+            r.close()
+            return out, k
+        out, k = render(False)
+        assert k == 2, k
+        worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks - 3, 3)])
+        _, k_off = render(True)
+        assert k_off == 1, k_off  # one object off the grid: the slot kernel
+    finally:
+        c1.close()
+    nb = 2
+    xs = x[:, :nb * block].cpu().numpy()
+    got = out[:, :nb * block].cpu().numpy()
+    want = oracle_window(curves, xs, n, block, dec, 255, 0)
+    truth = scenes.render_f64(scenes.window_curves(curves, 0, nb * block), xs, n, dec, 255)
+    e_gpu, e_cpu = scenes.rel_rms(got, truth), scenes.rel_rms(want, truth)
+    print(f"f32 grid kernel ({layout}, {m} objects, {kind}): worst channel vs oracle {worst:.3e}; vs float64: GPU {e_gpu:.3e}, CPU path {e_cpu:.3e}")
+    assert e_gpu <= 1.25 * e_cpu + 1e-8, (e_gpu, e_cpu)
