@@ -540,3 +540,23 @@ def test_exact_f32_on_the_tile_grid(layout, m, nblocks, kind):
     e_gpu, e_cpu = scenes.rel_rms(got, truth), scenes.rel_rms(want, truth)
     print(f"f32 grid kernel ({layout}, {m} objects, {kind}): worst channel vs oracle {worst:.3e}; vs float64: GPU {e_gpu:.3e}, CPU path {e_cpu:.3e}")
     assert e_gpu <= 1.25 * e_cpu + 1e-8, (e_gpu, e_cpu)
+
+
+def test_a_cut_call_through_the_host_pointer_entry_point():
+    """earhip_render_process (host channel pointers, staged) with a call that is cut in two on the device: every sample
+    against the oracle"""
+    from libear_amd import capi
+    layout, m, block, nblocks = "4+5+0", 40, 512, 258
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks, seed=12)
+    x = scenes.audio(m, block * nblocks, seed=5)
+    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+    for i, (t, d, f) in enumerate(curves):
+        r.set_object_points(i, t, d, f)
+    got = r.process(x)
+    tail = r.last_tail_blocks()
+    r.close()
+    want = oracle_window(curves, x, n, block, dec, 255, 0)
+    assert tail == 2, tail
+    assert scenes.rel_rms_per_channel(got, want) <= 1e-6
