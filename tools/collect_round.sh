@@ -30,3 +30,7 @@ run obj512 --objects 512 --brief
 run obj256 --objects 256 --brief
 run obj128 --objects 128 --brief
 run refbench --config refbench --steps 50 --warmup 5
+EARHIP_MFMA=1 run f32_exact --brief
+run blocks513 --blocks 513 --brief
+run blocks257 --blocks 257 --brief
+run blocks129 --blocks 129 --brief
