@@ -430,6 +430,9 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   }
 }
 
+#ifndef EARHIP_HG_RINGU
+#define EARHIP_HG_RINGU 1
+#endif
 typedef _Float16 hg_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ hg_h2 as_h2(uint32_t u) { return __builtin_bit_cast(hg_h2, u); }
 __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast(uint32_t, h); }
@@ -619,9 +622,17 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         const int cc = min(c, total - 1);
         const int s = 32 * cc + (L.lane & 31);
         ring_next_cf = c < c_hi ? ((ConstWords)cfbase)[cc] : 0u;
-        const bool want = L.lane < 32 || ring_next_cf != 0u;
         const u32x4 *pa = L.lane < 32 ? reinterpret_cast<const u32x4 *>(lbase + s) : reinterpret_cast<const u32x4 *>(hbase + s);
+#if EARHIP_HG_RINGU
+        // The HingeEntries are requested whether the chunk has kinks or not (round 5).  Asking only when the chunk's flag word
+        // said so made the request depend on a load: wave 0 sat in `s_waitcnt vmcnt(0)` — everything in flight, inputs and
+        // gain rows included — behind every chunk's barrier, and seven waves waited for it at the next one.  A chunk without
+        // kinks reads 512 bytes nobody looks at (its factor words are only used behind the flag word's test).
+        ring_next = *pa;
+#else
+        const bool want = L.lane < 32 || ring_next_cf != 0u;
         ring_next = want ? *pa : u32x4{0u, 0u, 0u, 0u};
+#endif
       };
       auto ring_store = [&](const LaneCtx &L, int c) {
         const int sl = c & (RING - 1);
@@ -751,6 +762,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             ring_load(L, c_lo + jn);
             ring_store(L, c_lo + jn);
           }
+#if EARHIP_HG_RINGU
+          ring_load(L, c_lo + RD);  // (stored by the first chunk: every chunk requests the slot the NEXT one stores)
+#endif
         }
         __syncthreads();
         f32x3 G[NREQ];
@@ -779,7 +793,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         const uint32_t cf = ringc[c & (RING - 1)];
         f32x3 G[NREQ];
         load_gains(L, c + 2, G);  // (past the schedule: the clamped last chunk's, never used)
+#if !EARHIP_HG_RINGU
         if (w == 0) ring_load(L, c + RD);  // (stored behind the line's MFMAs)
+#endif
         __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
         // operand split of the inputs (gain_h2.h, wide form): 2 x 2 blocks, an f16 pair packs two SLOTS of one row tile
 #pragma unroll
@@ -875,6 +891,12 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         __builtin_amdgcn_sched_barrier(0);
         stage_gains(L, G);  // the rows of the chunk after next replace the next chunk's (same wave: in order)
         if (w == 0) ring_store(L, c + RD);
+#if EARHIP_HG_RINGU
+        // wave 0's list requests for the slot the NEXT chunk stores, here, behind its own store and a whole chunk ahead of their
+        // use: requests inside a branch are invisible to the compiler's wait counts — in front of the split they made wave 0
+        // wait for gain rows it had only just asked for before it could touch its inputs
+        if (w == 0) ring_load(L, c + 1 + RD);
+#endif
         // ======== its kinks: forward, then backward
 #pragma unroll 1
         for (int g = 0; g < KS; g++) {
