@@ -73,7 +73,8 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  * changes it — no process call reads the environment.  An option takes effect for calls / objects made after it is
  * set.  Unknown key: EARHIP_INVALID_ARGUMENT.
  *   gain stage:   MFMA (0 VALU | 1 exact-f32 MFMA | 3 default | 4 grid kernel | 5 piece lists | 6 hinge kernel),
- *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, BUILD_TPW, HBUILD_TPW (1 2 4 8),
+ *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, P2_WGS (workgroups of the launch;
+ *                 P2_WGS 0: one per tile), BUILD_TPW, HBUILD_TPW (1 2 4 8),
  *                 SPL (2 | 4), WAVES (1..8), TPW (1..8), NRT (4 | 8), XSCALE (log2 of a fixed input prescale), PROBE_RUNS
  *   renderer:     K2_WG, K2_OWN_BLOCK (0 | 1), RUN (odd blocks per decorrelator run), GSPLIT (1..32) — read by
  *                 earhip_render_create; TAILCUT (v = 0..7, default 2: a stream call of k rounds of tiles plus at most v / 8

@@ -235,17 +235,21 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     launched = true;
   }
   if (ml.pieces || (ml.hinge && gate)) {
-    const dim3 bgrid(pnt, ml.gsplit, cp.mnz * cp.mgroups);
+    // as many workgroups as are resident at once (a multiple of 8: a workgroup's tiles stay on its XCD), each carrying its
+    // pipeline from one tile's list into the next (gain_p2.h); option P2_WGS: that number (0: a workgroup per tile)
+    int wgs = std::max(8, (ctx->num_cus * (ml.pw == 4 ? 2 : 1) / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
+    if (ctx->has(OPT_P2_WGS)) wgs = ctx->get(OPT_P2_WGS) > 0 ? ctx->get(OPT_P2_WGS) : pnt;
+    const dim3 bgrid(std::min(pnt, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
 #define EARHIP_P2_CASE(NCT_, PR_)                                                                                   \
   if (cp.nct == NCT_ && ml.paired == PR_) {                                                                         \
     if (ml.pw == 4)                                                                                                 \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4, PR_>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next, wide_next, ml.hinge ? gate : nullptr);                                          \
+                         level_next, wide_next, ml.hinge ? gate : nullptr, pnt);                                     \
     else                                                                                                            \
       hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8, PR_>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next, wide_next, ml.hinge ? gate : nullptr);                                          \
+                         level_next, wide_next, ml.hinge ? gate : nullptr, pnt);                                     \
   }
     EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
     EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)
@@ -407,7 +411,7 @@ using namespace earhip;
 
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
-    "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "P2_TILE", "P2_PAIRS", "HINGE", "HG_TILE", "HBUILD_TPW",
+    "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
     "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT"};
 
 void earhip_ctx::apply_options() {

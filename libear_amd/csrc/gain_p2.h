@@ -359,13 +359,19 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
   }
 }
 
-// K1p.  grid = (workgroup tiles, grid-level splits of the chunk schedule, column super-groups),
-// block = 64 NW threads; P.ntiles / P.desc refer to WORKGROUP tiles of 64 NW samples.
+// K1p.  grid = (workgroups, grid-level splits of the chunk schedule, column super-groups), block = 64 NW threads;
+// ntl = WORKGROUP tiles (64 NW samples) of the call.  Workgroup b does tiles b, b + gridDim.x, ... (the host launches as many
+// workgroups as are resident at once, a multiple of 8: a workgroup's tiles stay on its XCD) and carries its pipeline of piece
+// words and gain rows from one tile's list straight into the next one's: by the time a tile's last chunk is done, the ring
+// holds the first chunks of the next list, their gain rows are on their way and the first chunk's B fragments are being
+// written — only the inputs of the next tile's first two chunks are requested anew, in front of the stores of the tile
+// just finished.  (A workgroup per tile spent ~9 us of a tile's 117 outside its chunk loop on the ADM scene: the dependent
+// trips list -> gain rows / inputs -> first MFMA with nothing else on the CU, the stores, the next workgroup's launch.)
 // x_scale, g_scale: exact powers of two (gain_h2.h).
 template <int NCT, int NW, bool PAIRED>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next, unsigned *wide_next, const unsigned *gate = nullptr) {
+              unsigned *level_next, unsigned *wide_next, const unsigned *gate, int ntl) {
   if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel, which did this call (k_hinge_gate)
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
@@ -377,17 +383,17 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
   __shared__ float inv_gcol[16 * NCT];  // 1 / the gain scale of the workgroup's columns: read at the END of a tile, where a
                                         // round trip to memory would stand in the open (3 us of a 130-us tile)
-  __shared__ __attribute__((aligned(16))) uint64_t ring[RING][CH];     // ... byte offsets of the objects' input rows (object x row
-                                                                       // stride: one 64-bit multiply per piece by wave 0 instead
-                                                                       // of one per request by every wave — quarter-rate each)
+  // ... byte offsets of the objects' input rows (object x row stride: one 64-bit multiply per piece by wave 0 instead of one
+  // per request by every wave — quarter-rate each); slot RING: zeros — what requests past the end of a list read
+  __shared__ __attribute__((aligned(16))) uint64_t ring[RING + 1][CH];
   __shared__ __attribute__((aligned(16))) u32x4 ringp[RING][CH];       // ... the whole pieces (rows, p0, scale)
   constexpr int NGI = (2 * NQ * 4 * NCT + 63) / 64;                    // float4 gain-row requests per wave and chunk
   __shared__ __attribute__((aligned(16))) f32x4 stage[NW][NGI * 64];   // the wave's gain rows of a chunk: [2 NQ][16 NCT] floats
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
-  const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
   if (threadIdx.x < 16 * NCT) inv_gcol[threadIdx.x] = 1.0f / gcol[blockIdx.z * 16 * NCT + threadIdx.x];
+  if (threadIdx.x < CH) ring[RING][threadIdx.x] = 0ull;
   __syncthreads();
   if (level_cur) {  // input scale of THIS call from the level K0 probed (gain_h2.h)
     const unsigned lv = *level_cur;
@@ -405,13 +411,26 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   const int nparts = gridDim.y;
   const int part = blockIdx.y;
   const int col0 = blockIdx.z * 16 * NCT;
-  const int wave_s0 = w * TS;                          // first sample of this wave inside the workgroup tile
-  const int tile_s0 = wgtile * (TS * NW) + wave_s0;    // ... inside the call
-  const int tile_len = max(0, min(TS, P.nsamples - tile_s0));
-  const int64_t tile_t0 = P.t_call + tile_s0;
-  const int64_t tile_t1 = tile_t0 + tile_len;
+  const int wave_s0 = w * TS;  // first sample of this wave inside a workgroup tile
+  // the tile the workgroup is on (wave-uniform; set_tile)
+  int wgtile = 0, tile_s0 = 0, tile_len = 0;  // ... the wave's first sample inside the call, its samples
+  int64_t tile_t0 = 0, tile_t1 = 0;
+  auto set_tile = [&](int t) {
+    wgtile = t;
+    tile_s0 = t * (TS * NW) + wave_s0;
+    tile_len = max(0, min(TS, P.nsamples - tile_s0));
+    tile_t0 = P.t_call + tile_s0;
+    tile_t1 = tile_t0 + tile_len;
+  };
   const float *__restrict__ gain = P.ps.gain;
   const unsigned rowlen = (unsigned)P.ps.row;
+  // what runs between two tiles (the exact paths, the stores) makes its lane numbers anew, from a value the compiler cannot
+  // see through, so that nothing of it is computed ahead of the tile loop and held in registers through the chunk loop
+  auto opaque_lane = [&]() __attribute__((always_inline)) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
 
   // running totals in scaled units: bus = tot / (x_scale g_scale)
   f32x4 tot[NRT][NCT];
@@ -421,13 +440,13 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
 #pragma unroll
       for (int c = 0; c < NCT; c++) tot[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   };
-  clear_totals();
 
   // ---- exact path: one object, all its pieces inside this wave's 64 samples, f32 MFMA with k = {a, b}
   // of ONE object (k slots 2, 3 idle), accumulated into tot in units of 1 / (sx sg)
   // (sg: the gains are scaled by their column's scale, like the split operands — or not at all)
   auto single_object = [&](int m, float sx, bool sg) {
     if (tile_len <= 0) return;
+    const int ol = opaque_lane(), li = ol & 15, kg = ol >> 4;
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
@@ -474,6 +493,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   // inside the tolerance of this (non-strict) kernel.
   auto single_piece = [&](const Piece pc) {
     if (tile_len <= 0) return;
+    const int ol = opaque_lane(), li = ol & 15, kg = ol >> 4;
     const bool delta = pc.m & kPieceDelta;
     const float *row = P.in + (size_t)(pc.m & ~kPieceDelta) * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
@@ -498,352 +518,468 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
         tot[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], gv[c], tot[r][c], 0, 0, 0);
   };
 
-  float inv_x = 1.0f / x_scale;  // exact: a power of two
-  bool col_scaled = true;        // the totals are in units of 1 / (x_scale x the column's gain scale)
-  const int *cnt = pl.count + wgtile * 8;
-
-  if (P.vec_ok) {
-    // ---- the chunk schedule of this workgroup: the tile's list, 32 pieces per chunk
-    // Three KINDS of chunk (k_piece_build's two layouts):
-    //   single  32 base pieces of 32 objects: every p is 1, the position factor is skipped (the first cnt[2] chunks of
-    //           a list: all of them when the tile has no delta piece at all, the singles of the paired layout);
-    //   pair    16 pairs (base or null-gain piece, delta piece) of 16 objects: 4 input requests per lane instead of 8,
-    //           position factors for the odd slots only;
-    //   packed  any 32 pieces in a row: a position factor for all of them, 8 requests of which the repeats hit in the
-    //           first-level cache.
-    const Piece *lbase = pl.pieces + (size_t)wgtile * pl.cap();
-    const int total = cnt[0];
-    const int n_single = cnt[2];
-    const bool has_delta = cnt[1] > 0;
-    const int pair_adj = PAIRED ? pl.pair_off() - 32 * n_single : 0;  // the pairs' region starts at pl.pair_off()
-    const int zero_row = P.ps.zero_row;
-    // (paired layout: parts start at even chunks — the single chunks come in twos, k_piece_build pads them so)
-    const int tunits = PAIRED ? (total + 1) / 2 : total, tu = PAIRED ? 2 : 1;
-    const int c_lo = tu * (int)(((int64_t)tunits * part) / nparts), c_hi = min(total, tu * (int)(((int64_t)tunits * (part + 1)) / nparts));
-    // first piece of chunk c (clamped: requests past the schedule re-read its last chunk)
-    auto chunk_ptr = [&](int c) -> const Piece * {
-      c = min(c, total - 1);
-      return lbase + 32 * c + (c >= n_single ? pair_adj : 0);
-    };
-    constexpr int KS = 0, KP = 1, KK = 2;
-
-    if (c_hi > c_lo) {
-      const int nvec = (P.nsamples + 3) & ~3;
-      // byte offset of this lane's float4 inside an input row (lanes past the end of the call re-read the
-      // last vector: never stored)
-      const unsigned xlane = (unsigned)min(tile_s0 + li * NRT, nvec - 4) * 4u;
-      const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;          // fragment triple (h, l, h 2^-11) this lane fills
-      const uint64_t rstride = P.in_stride * sizeof(float);
-      const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
-
-      // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested RD + 1
-      // chunks ahead, stored RD ahead (visible after the next barrier), read two — pair chunks four — ahead (input
-      // addresses, gain rows)
-      // (one 16-byte request per chunk: every other per-piece datum the waves need comes out of this ring)
-      auto ring_load = [&](int c) -> u32x4 { return *reinterpret_cast<const u32x4 *>(chunk_ptr(c) + (lane & 31)); };
-      auto ring_store = [&](int c, u32x4 v) {
-        if (lane < 32) {
-          ring[c & (RING - 1)][lane] = (uint64_t)(v[0] & ~kPieceDelta) * rstride;
-          ringp[c & (RING - 1)][lane] = v;
+  // the tile is done: scale and store.  inv_x: the inverse of the input scale the totals carry (exact: a power of two);
+  // col_scaled: they are in units of 1 / (the column's gain scale) as well
+  auto store_tile = [&](float inv_x, bool col_scaled) {
+    if (tile_len <= 0) return;
+    const int ol = opaque_lane(), li = ol & 15, kg = ol >> 4;
+    // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
+    // four row tiles are 4 consecutive samples.
+    float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
+    const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
+    float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
+#pragma unroll
+    for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < NCT; c++) {
+      if (whole) {  // transposed through wave-private LDS: whole 256-byte rows per store instruction (gain_h2.h)
+        float *ot = otile[w];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_gc[c];
+          *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
         }
-      };
-      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-      auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u64x2 *>(&ring[c & (RING - 1)][kg * 8 + q0]); };
-      // inputs q0 .. q0 + n - 1 (n even) of chunk c, requested as a chunk of kind K.  Single and pair chunks ask for
-      // every input once: streaming requests.  Packed chunks: ordinary ones — the pieces of one object are neighbours
-      // in the list, so a lane asks for the same 16 bytes again in its next request; found in the first-level cache,
-      // the repeat costs no second trip to L2 (ADM scene K1 0.545 -> 0.503 ms, always-ramping 0.91 -> 0.84).
-      // Pair chunks need the even slots' inputs only — four registers: a chunk's go to the even (PAR = 0) or the odd
-      // (PAR = 1) half of x, so that FOUR pair chunks are in flight in the registers that hold two others (half the
-      // bytes per chunk: with two in flight the requests outstanding no longer cover the memory latency).
-      // tr ("transition", single kind): the odd half takes the even slots of chunk c + 2 instead of the odd slots of
-      // chunk c — what the last two single chunks request for the first four pair chunks behind them.
-      auto lane_word = [&](int c, int slot) { return ring[c & (RING - 1)][kg * 8 + slot]; };
-      auto load_x_part = [&](auto kind_tag, auto par_tag, int c, f32x4 (&x)[8], int q0, int n, bool tr) __attribute__((always_inline)) {
-        constexpr int K = decltype(kind_tag)::value, PAR = decltype(par_tag)::value;
-        const char *bp = reinterpret_cast<const char *>(P.in) + xlane;
 #pragma unroll
-        for (int q = 0; q < 8; q += 2)
-          if (q >= q0 && q < q0 + n) {
-            if constexpr (K == KK) {
-              const u64x2 mw = lane_word2(c, q);
-              x[q] = *reinterpret_cast<const f32x4 *>(bp + mw[0]);
-              x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + mw[1]);
-            } else if constexpr (K == KS) {
-              const uint64_t m0 = lane_word(c, q), m1 = lane_word(tr ? c + 2 : c, tr ? q : q + 1);
-              x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m0));
-              x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m1));
-            } else {
-              const uint64_t m0 = lane_word(c, q);
-              x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m0));
-            }
-          }
-      };
-      // (prologue.  Paired kernel: as single chunks do — a part without single chunks starts in the transition form)
-      auto load_x_all = [&](int c, f32x4 (&x)[8]) __attribute__((always_inline)) {
-        load_x_part(std::integral_constant<int, PAIRED ? KS : KK>{}, std::integral_constant<int, 0>{}, c, x, 0, 8,
-                    PAIRED && c_lo >= n_single);
-      };
-      // (p0, scale) of the lane's piece q of chunk c, out of the ring (read where it is used)
-      auto piece_ps = [&](int c, int q) {
-        const u32x2 v = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringp[c & (RING - 1)][kg * 8 + q]) + 8);
-        return f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
-      };
-      // The gain operand of a piece is row X minus row Y: delta (E, S), base (S, the all-zero row).  What this
-      // WAVE converts for chunk c are pieces NQ w + q: their 2 NQ rows (16 NCT floats each) come in as NGI
-      // requests of 16 bytes per lane — slot s = lane + 64 i covers floats 4 (s mod 4 NCT) .. + 3 of row
-      // s div 4 NCT — instead of one 4-byte gather per row: the vector-memory address unit is the busiest unit
-      // of this kernel (two thirds of all cycles) and pays per instruction, not per byte.  The rows go through a
-      // wave-private piece of LDS to the lanes that convert them (lane = column).
-      constexpr int RS = 4 * NCT;  // 16-byte slots per row
-      auto load_gains = [&](int c, f32x4 (&G)[NGI]) {
-#pragma unroll
-        for (int i = 0; i < NGI; i++) {
-          const int sl = min(lane + 64 * i, 2 * NQ * RS - 1);
-          const int r = sl / RS, cg = sl - r * RS;
-          const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringp[c & (RING - 1)][w * NQ + (r >> 1)]);  // (m, row)
-          const bool d = mr[0] & kPieceDelta;
-          const unsigned row = (r & 1) ? (d ? mr[1] : (unsigned)zero_row) : mr[1] + (d ? 1u : 0u);
-          G[i] = *reinterpret_cast<const f32x4 *>(gain + (size_t)row * rowlen + col0 + 4 * cg);
+        for (int j = 0; j < 4; j++) {  // lane: column 4 j + (lane >> 4), samples 4 (lane & 15) .. + 3
+          const int cl = 4 * j + kg, col = col0 + c * 16 + cl;
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + cl * OP + li * 4);
+          if (col < P.ncols) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(op + (size_t)col * P.out_stride + li * 4));
         }
-      };
-      const int col_e = min(lane, 16 * NCT - 1);  // the lane's gain column inside the wave's rows
-      const float g_scale = gcol[col0 + col_e];   // ... and that column's scale (a power of two)
-      auto stage_gains = [&](const f32x4 (&G)[NGI], float (&X)[NQ], float (&Y)[NQ]) {
-#pragma unroll
-        for (int i = 0; i < NGI; i++) stage[w][lane + 64 * i] = G[i];
-        const float *sf = reinterpret_cast<const float *>(&stage[w][0]);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          X[q] = sf[(2 * q) * (16 * NCT) + col_e];
-          Y[q] = sf[(2 * q + 1) * (16 * NCT) + col_e];
-        }
-      };
-      // the B operand of the wave's NQ pieces, scaled and split -> LDS
-      // (k = NQ w + q of the fragment entry of lane 16 (k / 8) + column)
-      auto store_b = [&](const float (&X)[NQ], const float (&Y)[NQ], int buf) {
-        uint32_t h[NQ / 2], l[NQ / 2], hs[NQ / 2];
-#pragma unroll
-        for (int i = 0; i < NQ / 2; i++) {
-          float v[2];
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const int q = 2 * i + j;
-            v[j] = (X[q] - Y[q]) * g_scale;
-          }
-          const uint32_t H = pack_f16(v[0], v[1]);
-          h[i] = H;
-          l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
-          hs[i] = scale_f16x2_down(H);                            // h 2^-11: partner of the inputs' scaled low piece (gain_h2.h)
-        }
-        u32x4 *f = &bfrag[buf][bfr][0];
-        const int col = lane & 15;
-        if constexpr (NQ == 8) {
-          f[w * 16 + col] = u32x4{h[0], h[1], h[2], h[3]};
-          f[64 + w * 16 + col] = u32x4{l[0], l[1], l[2], l[3]};
-          f[128 + w * 16 + col] = u32x4{hs[0], hs[1], hs[2], hs[3]};
-        } else {  // half an entry: words 2 (w & 1), + 1 of k group w / 2
-          u32x2 *g = reinterpret_cast<u32x2 *>(f + (w >> 1) * 16 + col) + (w & 1);
-          g[0] = u32x2{h[0], h[1]};
-          g[128] = u32x2{l[0], l[1]};
-          g[256] = u32x2{hs[0], hs[1]};
-        }
-      };
-
-      // ---- prologue: piece words of the first chunks into the ring, gains of the first chunk, inputs of
-      // the first two
-      constexpr int RD = PAIRED ? 5 : 4;  // ring slots up to chunk c + RD - 1 are visible during chunk c
-      u32x4 ring_next = {0u, 0u, 0u, 0u};
-      if (w == 0) {
-#pragma unroll
-        for (int j = 0; j < RD; j++) ring_store(c_lo + j, ring_load(c_lo + j));
-        ring_next = ring_load(c_lo + RD);  // (stored by the first chunk)
+        continue;
       }
-      __syncthreads();
-      f32x4 X0[8], X1[8];
-      // gain rows on their way: requested TWO chunks ahead of their use, converted one chunk ahead (a chunk of 36 MFMAs
-      // is shorter than a loaded trip to L2): the chunks that use X0 request into GA and convert GB, the others the
-      // other way round
-      f32x4 GA[NGI], GB[NGI];
-      {
-        f32x4 G[NGI];
-        float S[NQ], E[NQ];
-        load_gains(c_lo, G);
-        load_gains(c_lo + 1, GB);  // (converted by the first chunk)
-        load_x_all(c_lo, X0);
-        load_x_all(c_lo + 1, X1);
-        stage_gains(G, S, E);
-        store_b(S, E, c_lo & 1);
-      }
-
-      // chunk c: inputs in xc, B fragments in bfrag[c & 1].  KC: its kind — the inputs it requests (chunk c + 2; a pair
-      // chunk: c + 4) are requested as that kind's; PAR: the half of xc a pair chunk's inputs are in; tr: see
-      // load_x_part; Gld / Gcv: the gain rows it requests (chunk c + 2) and converts (chunk c + 1)
-      auto chunk = [&](auto kc_tag, auto par_tag, int c, f32x4 (&xc)[8], f32x4 (&Gld)[NGI], f32x4 (&Gcv)[NGI], bool tr) __attribute__((always_inline)) {
-        constexpr int KC = decltype(kc_tag)::value, K2 = KC, PAR = decltype(par_tag)::value;
-        const int buf = c & 1;
-        __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free; ring slots <= c + 3 are visible
-        if (w == 0) {
-          ring_store(c + RD, ring_next);
-          ring_next = ring_load(c + RD + 1);
-        }
-        load_gains(c + 2, Gld);  // the rows of chunk c + 2 (its pieces have been in the ring for two chunks or more)
-        __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
-
-        // A fragments: row tile r = sample 4*li + r of the 8 pieces of this lane.  2 x 2 blocks: an f16
-        // pair packs two PIECES (q, q+1) of one row tile, the scaling and the exact residual
-        // subtractions pair two SAMPLES (r, r+1) of one piece.  A piece's ramp position is part of its
-        // input scale: x_scale clamp(p0 + s scale, 0, 1) (base pieces: p = 1).
-        u32x4 ah[NRT], al[NRT];
-        auto split = [&](auto ks_tag) __attribute__((always_inline)) {
-          constexpr int KSP = decltype(ks_tag)::value;  // how the pieces' inputs become operands: as a single, pair or packed chunk's
+      const int col = col0 + c * 16 + li;
+      if (col >= P.ncols) continue;
+      float *o = op + (size_t)col * P.out_stride;
 #pragma unroll
-          for (int qp = 0; qp < 4; qp++) {
+      for (int e = 0; e < 4; e++) {
+        const int s = kg * 16 + e * 4;
+        f32x4 v;
 #pragma unroll
-            for (int rp = 0; rp < NRT; rp += 2) {
-              const int XE = KSP == KP ? 2 * qp + PAR : 2 * qp;  // (a pair chunk's inputs: one half of xc)
-              f32x2 s0 = f32x2{xc[XE][rp], xc[XE][rp + 1]} * x_scale;  // piece 2qp
-              f32x2 s1;                                                        // piece 2qp+1
-              if constexpr (KSP == KP) s1 = s0;  // (the same input)
-              else s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;
-              if constexpr (KSP != KS) {
-                const float f0 = lane_sf + (float)rp, f1 = lane_sf + (float)(rp + 1);
-                // (the compiler folds the median-of-three into the FMA's output clamp: one instruction per value)
-                if constexpr (KSP == KK) {
-                  const f32x2 a = piece_ps(c, 2 * qp);
-                  s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
-                              __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
-                }
-                const f32x2 b = piece_ps(c, 2 * qp + 1);
-                s1 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, b[1], b[0]), 0.0f, 1.0f),
-                            __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, b[1], b[0]), 0.0f, 1.0f)};
-              }
-              const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
-              ah[rp][qp] = H0;
-              ah[rp + 1][qp] = H1;
-              const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * kLowPieceScale;  // exact residuals, scaled (gain_h2.h)
-              const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * kLowPieceScale;
-              al[rp][qp] = pack_f16(r0[0], r1[0]);
-              al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
-            }
-          }
-        };
-        if constexpr (KC == KK) {  // (a packed list without any delta piece: every p is 1 — uniform over the workgroup)
-          if (has_delta) split(std::integral_constant<int, KK>{});
-          else split(std::integral_constant<int, KS>{});
+        for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_gc[c];
+        if (P.vec_ok && s + 3 < tile_len) {
+          *reinterpret_cast<f32x4 *>(o + s) = v;
         } else {
-          split(kc_tag);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (s + i < tile_len) o[s + i] = v[i];
         }
-        __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
-        // NCT blocks of 12 MFMAs (three partial products of one column tile, smallest first).  The inputs
-        // of chunk c + 2 go into the registers just freed, a few requests per block; the conversion of the
-        // next chunk's B operand is woven between the MFMAs of the last block.
-        constexpr int XB = NCT >= 3 ? 2 : 1;  // blocks that carry input requests (4 or 8 each)
-        auto load_b = [&](int fr, u32x4 (&bb)[2]) {
+      }
+    }
+  };
+
+  const int gx = gridDim.x;
+  if (!P.vec_ok) {  // unaligned rows: every object on the exact path
+    const int m_lo = (int)(((int64_t)P.M * part) / nparts), m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
+    for (int vb = blockIdx.x; vb < ntl; vb += gx) {
+      set_tile(xcd_tile(vb, ntl));
+      clear_totals();
+      for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);
+      store_tile(1.0f, false);
+    }
+    return;
+  }
+
+  // ---- the chunk schedule of a tile: its list, 32 pieces per chunk
+  // Three KINDS of chunk (k_piece_build's two layouts):
+  //   single  32 base pieces of 32 objects: every p is 1, the position factor is skipped (the first cnt[2] chunks of
+  //           a list: all of them when the tile has no delta piece at all, the singles of the paired layout);
+  //   pair    16 pairs (base or null-gain piece, delta piece) of 16 objects: 4 input requests per lane instead of 8,
+  //           position factors for the odd slots only;
+  //   packed  any 32 pieces in a row: a position factor for all of them, 8 requests of which the repeats hit in the
+  //           first-level cache.
+  struct Sched {
+    const Piece *lbase;
+    int total, n_single, pair_adj;  // chunks of the list, the single chunks among them, where the pairs' region starts
+    int c_lo, c_hi;                 // this part's chunks
+    bool has_delta;
+  };
+  auto tile_sched = [&](int t) {
+    // (through the constant address space: scalar loads — K0 wrote the counts, this kernel only reads them)
+    typedef const int __attribute__((address_space(4))) *ConstInt;
+    ConstInt cn = (ConstInt)(pl.count + (size_t)t * 8);
+    Sched s;
+    s.lbase = pl.pieces + (size_t)t * pl.cap();
+    s.total = cn[0];
+    s.n_single = cn[2];
+    s.has_delta = cn[1] > 0;
+    s.pair_adj = PAIRED ? pl.pair_off() - 32 * s.n_single : 0;  // the pairs' region starts at pl.pair_off()
+    // (paired layout: parts start at even chunks — the single chunks come in twos, k_piece_build pads them so)
+    const int tunits = PAIRED ? (s.total + 1) / 2 : s.total, tu = PAIRED ? 2 : 1;
+    s.c_lo = tu * (int)(((int64_t)tunits * part) / nparts);
+    s.c_hi = min(s.total, tu * (int)(((int64_t)tunits * (part + 1)) / nparts));
+    return s;
+  };
+  constexpr int KS = 0, KP = 1, KK = 2;
+  constexpr int RD = PAIRED ? 5 : 4;  // ring slots up to chunk c + RD - 1 are visible during chunk c
+  const int zero_row = P.ps.zero_row;
+  const int nvec = (P.nsamples + 3) & ~3;
+  Sched cur, nxt;           // the tile the workgroup is on and its next one
+  bool prime_next = false;  // chunks past the end of cur's list are the first ones of nxt's
+  int goff = 0;             // chunk c of cur's list is the workgroup's (c + goff)-th: ring slots and fragment buffers go by that
+  int live_end = 0;         // input requests for chunks from here on read the zero slot
+  // byte offset of this lane's float4 inside an input row (lanes past the end of the call re-read the
+  // last vector: never stored)
+  auto lane_offset = [&](int t) { return (unsigned)min(t * (TS * NW) + wave_s0 + li * NRT, nvec - 4) * 4u; };
+  unsigned xlane = 0;
+  const int bfr = lane < 16 * NCT ? (lane >> 4) * 3 : NFRAG;          // fragment triple (h, l, h 2^-11) this lane fills
+  const uint64_t rstride = P.in_stride * sizeof(float);
+  const float lane_sf = (float)(wave_s0 + li * NRT);  // the lane's first sample inside the workgroup tile
+
+  // first piece of chunk c of cur's list; past its end: of nxt's first chunks (prime_next), else clamped (requests
+  // past the schedule re-read its last chunk)
+  auto chunk_ptr = [&](int c) -> const Piece * {
+    const bool over = prime_next && c >= cur.c_hi;
+    const Piece *lb = over ? nxt.lbase : cur.lbase;
+    const int tt = over ? nxt.total : cur.total, ns = over ? nxt.n_single : cur.n_single, pa = over ? nxt.pair_adj : cur.pair_adj;
+    c = min(over ? nxt.c_lo + (c - cur.c_hi) : c, tt - 1);
+    return lb + 32 * c + (c >= ns ? pa : 0);
+  };
+
+  // piece words (the object) of chunk c for the lanes: wave 0 brings them into the ring, requested RD + 1
+  // chunks ahead, stored RD ahead (visible after the next barrier), read two — pair chunks four — ahead (input
+  // addresses, gain rows)
+  // (one 16-byte request per chunk: every other per-piece datum the waves need comes out of this ring)
+  auto ring_load = [&](int c) -> u32x4 { return *reinterpret_cast<const u32x4 *>(chunk_ptr(c) + (lane & 31)); };
+  auto ring_store = [&](int c, u32x4 v) {
+    if (lane < 32) {
+      ring[(c + goff) & (RING - 1)][lane] = (uint64_t)(v[0] & ~kPieceDelta) * rstride;
+      ringp[(c + goff) & (RING - 1)][lane] = v;
+    }
+  };
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  auto xslot = [&](int c) { return c < live_end ? (c + goff) & (RING - 1) : RING; };
+  auto lane_word2 = [&](int c, int q0) { return *reinterpret_cast<const u64x2 *>(&ring[xslot(c)][kg * 8 + q0]); };
+  // inputs q0 .. q0 + n - 1 (n even) of chunk c, requested as a chunk of kind K.  Single and pair chunks ask for
+  // every input once: streaming requests.  Packed chunks: ordinary ones — the pieces of one object are neighbours
+  // in the list, so a lane asks for the same 16 bytes again in its next request; found in the first-level cache,
+  // the repeat costs no second trip to L2 (ADM scene K1 0.545 -> 0.503 ms, always-ramping 0.91 -> 0.84).
+  // Pair chunks need the even slots' inputs only — four registers: a chunk's go to the even (PAR = 0) or the odd
+  // (PAR = 1) half of x, so that FOUR pair chunks are in flight in the registers that hold two others (half the
+  // bytes per chunk: with two in flight the requests outstanding no longer cover the memory latency).
+  // tr ("transition", single kind): the odd half takes the even slots of chunk c + 2 instead of the odd slots of
+  // chunk c — what the last two single chunks request for the first four pair chunks behind them.
+  auto lane_word = [&](int c, int slot) { return ring[xslot(c)][kg * 8 + slot]; };
+  auto load_x_part = [&](auto kind_tag, auto par_tag, int c, f32x4 (&x)[8], int q0, int n, bool tr) __attribute__((always_inline)) {
+    constexpr int K = decltype(kind_tag)::value, PAR = decltype(par_tag)::value;
+    const char *bp = reinterpret_cast<const char *>(P.in) + xlane;
 #pragma unroll
-          for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][fr + q][lane];
-        };
-        u32x4 b[2][2], b2;  // (the scaled high piece is read as its block starts: gain_h2.h)
-        f32x4 tsum[2][NRT];  // (packed chunks: the sums of a block's products, see below)
-        load_b(0, b[0]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    for (int q = 0; q < 8; q += 2)
+      if (q >= q0 && q < q0 + n) {
+        if constexpr (K == KK) {
+          const u64x2 mw = lane_word2(c, q);
+          x[q] = *reinterpret_cast<const f32x4 *>(bp + mw[0]);
+          x[q + 1] = *reinterpret_cast<const f32x4 *>(bp + mw[1]);
+        } else if constexpr (K == KS) {
+          const uint64_t m0 = lane_word(c, q), m1 = lane_word(tr ? c + 2 : c, tr ? q : q + 1);
+          x[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m0));
+          x[q + 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m1));
+        } else {
+          const uint64_t m0 = lane_word(c, q);
+          x[q + PAR] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(bp + m0));
+        }
+      }
+  };
+  // (the first two chunks of a list.  Paired kernel: as single chunks do — tr: a part without single chunks starts in the
+  // transition form)
+  auto load_x_all = [&](int c, f32x4 (&x)[8], bool tr) __attribute__((always_inline)) {
+    load_x_part(std::integral_constant<int, PAIRED ? KS : KK>{}, std::integral_constant<int, 0>{}, c, x, 0, 8, tr);
+  };
+  // (p0, scale) of the lane's piece q of chunk c, out of the ring (read where it is used)
+  auto piece_ps = [&](int c, int q) {
+    const u32x2 v = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const char *>(&ringp[(c + goff) & (RING - 1)][kg * 8 + q]) + 8);
+    return f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+  };
+  // The gain operand of a piece is row X minus row Y: delta (E, S), base (S, the all-zero row).  What this
+  // WAVE converts for chunk c are pieces NQ w + q: their 2 NQ rows (16 NCT floats each) come in as NGI
+  // requests of 16 bytes per lane — slot s = lane + 64 i covers floats 4 (s mod 4 NCT) .. + 3 of row
+  // s div 4 NCT — instead of one 4-byte gather per row: the vector-memory address unit is the busiest unit
+  // of this kernel (two thirds of all cycles) and pays per instruction, not per byte.  The rows go through a
+  // wave-private piece of LDS to the lanes that convert them (lane = column).
+  constexpr int RS = 4 * NCT;  // 16-byte slots per row
+  auto load_gains = [&](int c, f32x4 (&G)[NGI]) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-          u32x4(&bc)[2] = b[ct & 1];
-          b2 = bfrag[buf][ct * 3 + 2][lane];
-          if (ct + 1 < NCT) load_b((ct + 1) * 3, b[(ct + 1) & 1]);
-          if constexpr (KC == KK && kChunkSums) {
-            // Packed lists have the longest chains (three pieces per object when every object ramps all the time: ~300
-            // MFMAs on one accumulator, each of which rounds the running total): the chunk's three products are summed
-            // among themselves first, the total takes ONE addition per chunk (rounding error of the total ~ 1 / sqrt 3)
-            // (a block's sums are added behind the first MFMAs of the NEXT block — the last block's behind the conversion
-            // of the next chunk's gains —, where they do not wait for the chain they close)
-            f32x4(&t)[NRT] = tsum[ct & 1];
+    for (int i = 0; i < NGI; i++) {
+      const int sl = min(lane + 64 * i, 2 * NQ * RS - 1);
+      const int r = sl / RS, cg = sl - r * RS;
+      const u32x2 mr = *reinterpret_cast<const u32x2 *>(&ringp[(c + goff) & (RING - 1)][w * NQ + (r >> 1)]);  // (m, row)
+      const bool d = mr[0] & kPieceDelta;
+      const unsigned row = (r & 1) ? (d ? mr[1] : (unsigned)zero_row) : mr[1] + (d ? 1u : 0u);
+      G[i] = *reinterpret_cast<const f32x4 *>(gain + (size_t)row * rowlen + col0 + 4 * cg);
+    }
+  };
+  const int col_e = min(lane, 16 * NCT - 1);  // the lane's gain column inside the wave's rows
+  const float g_scale = gcol[col0 + col_e];   // ... and that column's scale (a power of two)
+  auto stage_gains = [&](const f32x4 (&G)[NGI], float (&X)[NQ], float (&Y)[NQ]) {
 #pragma unroll
-            for (int r = 0; r < NRT; r++) t[r] = mfma_f16(ah[r], bc[1], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
-            if (ct > 0) {
+    for (int i = 0; i < NGI; i++) stage[w][lane + 64 * i] = G[i];
+    const float *sf = reinterpret_cast<const float *>(&stage[w][0]);
 #pragma unroll
-              for (int r = 0; r < NRT; r++) tot[r][ct - 1] += tsum[(ct - 1) & 1][r];
+    for (int q = 0; q < NQ; q++) {
+      X[q] = sf[(2 * q) * (16 * NCT) + col_e];
+      Y[q] = sf[(2 * q + 1) * (16 * NCT) + col_e];
+    }
+  };
+  // the B operand of the wave's NQ pieces, scaled and split -> LDS
+  // (k = NQ w + q of the fragment entry of lane 16 (k / 8) + column)
+  auto store_b = [&](const float (&X)[NQ], const float (&Y)[NQ], int buf) {
+    uint32_t h[NQ / 2], l[NQ / 2], hs[NQ / 2];
+#pragma unroll
+    for (int i = 0; i < NQ / 2; i++) {
+      float v[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int q = 2 * i + j;
+        v[j] = (X[q] - Y[q]) * g_scale;
+      }
+      const uint32_t H = pack_f16(v[0], v[1]);
+      h[i] = H;
+      l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+      hs[i] = scale_f16x2_down(H);                            // h 2^-11: partner of the inputs' scaled low piece (gain_h2.h)
+    }
+    u32x4 *f = &bfrag[buf][bfr][0];
+    const int col = lane & 15;
+    if constexpr (NQ == 8) {
+      f[w * 16 + col] = u32x4{h[0], h[1], h[2], h[3]};
+      f[64 + w * 16 + col] = u32x4{l[0], l[1], l[2], l[3]};
+      f[128 + w * 16 + col] = u32x4{hs[0], hs[1], hs[2], hs[3]};
+    } else {  // half an entry: words 2 (w & 1), + 1 of k group w / 2
+      u32x2 *g = reinterpret_cast<u32x2 *>(f + (w >> 1) * 16 + col) + (w & 1);
+      g[0] = u32x2{h[0], h[1]};
+      g[128] = u32x2{l[0], l[1]};
+      g[256] = u32x2{hs[0], hs[1]};
+    }
+  };
+
+  u32x4 ring_next = {0u, 0u, 0u, 0u};
+  f32x4 X0[8], X1[8];
+  // gain rows on their way: requested TWO chunks ahead of their use, converted one chunk ahead (a chunk of 36 MFMAs
+  // is shorter than a loaded trip to L2): the chunks that use X0 request into GA and convert GB, the others the
+  // other way round
+  f32x4 GA[NGI], GB[NGI];
+
+  // ---- prologue of a list nothing was carried into: piece words of the first chunks into the ring, gains of the first
+  // chunk, inputs of the first two
+  auto prologue = [&](bool first) __attribute__((always_inline)) {
+    if (!first) __syncthreads();  // (the list before is done with the ring and the fragments)
+    if (w == 0) {
+#pragma unroll
+      for (int j = 0; j < RD; j++) ring_store(cur.c_lo + j, ring_load(cur.c_lo + j));
+      ring_next = ring_load(cur.c_lo + RD);  // (stored by the first chunk)
+    }
+    __syncthreads();
+    f32x4 G[NGI];
+    float S[NQ], E[NQ];
+    load_gains(cur.c_lo, G);
+    load_gains(cur.c_lo + 1, GB);  // (converted by the first chunk)
+    load_x_all(cur.c_lo, X0, PAIRED && cur.c_lo >= cur.n_single);
+    load_x_all(cur.c_lo + 1, X1, PAIRED && cur.c_lo >= cur.n_single);
+    stage_gains(G, S, E);
+    store_b(S, E, (cur.c_lo + goff) & 1);
+  };
+
+  // chunk c: inputs in xc, B fragments in bfrag[(c + goff) & 1].  KC: its kind — the inputs it requests (chunk c + 2; a pair
+  // chunk: c + 4) are requested as that kind's; PAR: the half of xc a pair chunk's inputs are in; tr: see
+  // load_x_part; Gld / Gcv: the gain rows it requests (chunk c + 2) and converts (chunk c + 1)
+  auto chunk = [&](auto kc_tag, auto par_tag, int c, f32x4 (&xc)[8], f32x4 (&Gld)[NGI], f32x4 (&Gcv)[NGI], bool tr) __attribute__((always_inline)) {
+    constexpr int KC = decltype(kc_tag)::value, K2 = KC, PAR = decltype(par_tag)::value;
+    const int buf = (c + goff) & 1;
+    __syncthreads();  // B fragments of chunk c are in bfrag[buf]; bfrag[buf^1] is free; ring slots <= c + 3 are visible
+    if (w == 0) {
+      ring_store(c + RD, ring_next);
+      ring_next = ring_load(c + RD + 1);
+    }
+    load_gains(c + 2, Gld);  // the rows of chunk c + 2 (its pieces have been in the ring for two chunks or more)
+    __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
+
+    // A fragments: row tile r = sample 4*li + r of the 8 pieces of this lane.  2 x 2 blocks: an f16
+    // pair packs two PIECES (q, q+1) of one row tile, the scaling and the exact residual
+    // subtractions pair two SAMPLES (r, r+1) of one piece.  A piece's ramp position is part of its
+    // input scale: x_scale clamp(p0 + s scale, 0, 1) (base pieces: p = 1).
+    u32x4 ah[NRT], al[NRT];
+    auto split = [&](auto ks_tag) __attribute__((always_inline)) {
+      constexpr int KSP = decltype(ks_tag)::value;  // how the pieces' inputs become operands: as a single, pair or packed chunk's
+#pragma unroll
+      for (int qp = 0; qp < 4; qp++) {
+#pragma unroll
+        for (int rp = 0; rp < NRT; rp += 2) {
+          const int XE = KSP == KP ? 2 * qp + PAR : 2 * qp;  // (a pair chunk's inputs: one half of xc)
+          f32x2 s0 = f32x2{xc[XE][rp], xc[XE][rp + 1]} * x_scale;  // piece 2qp
+          f32x2 s1;                                                        // piece 2qp+1
+          if constexpr (KSP == KP) s1 = s0;  // (the same input)
+          else s1 = f32x2{xc[2 * qp + 1][rp], xc[2 * qp + 1][rp + 1]} * x_scale;
+          if constexpr (KSP != KS) {
+            const float f0 = lane_sf + (float)rp, f1 = lane_sf + (float)(rp + 1);
+            // (the compiler folds the median-of-three into the FMA's output clamp: one instruction per value)
+            if constexpr (KSP == KK) {
+              const f32x2 a = piece_ps(c, 2 * qp);
+              s0 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, a[1], a[0]), 0.0f, 1.0f),
+                          __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, a[1], a[0]), 0.0f, 1.0f)};
             }
-#pragma unroll
-            for (int r = 0; r < NRT; r++) t[r] = mfma_f16(al[r], b2, t[r]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) t[r] = mfma_f16(ah[r], bc[0], t[r]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[1], tot[r][ct]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(al[r], b2, tot[r][ct]);
-#pragma unroll
-            for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
+            const f32x2 b = piece_ps(c, 2 * qp + 1);
+            s1 *= f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(f0, b[1], b[0]), 0.0f, 1.0f),
+                        __builtin_amdgcn_fmed3f(__builtin_fmaf(f1, b[1], b[0]), 0.0f, 1.0f)};
           }
-          if (ct < XB) load_x_part(kc_tag, par_tag, KC == KP ? c + 4 : c + 2, xc, ct * (8 / XB), 8 / XB, tr);
-          const bool conv = ct == NCT - 1;
-          if (conv) {
-            float S[NQ], E[NQ];
-            stage_gains(Gcv, S, E);  // (the rows of chunk c + 1)
-            store_b(S, E, buf ^ 1);
-          }
-          if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (ct < XB && !conv) {
-            constexpr int NL = (K2 == KP ? 4 : 8) / XB;  // requests of this block
+          const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
+          ah[rp][qp] = H0;
+          ah[rp + 1][qp] = H1;
+          const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * kLowPieceScale;  // exact residuals, scaled (gain_h2.h)
+          const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * kLowPieceScale;
+          al[rp][qp] = pack_f16(r0[0], r1[0]);
+          al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
+        }
+      }
+    };
+    if constexpr (KC == KK) {  // (a packed list without any delta piece: every p is 1 — uniform over the workgroup)
+      if (cur.has_delta) split(std::integral_constant<int, KK>{});
+      else split(std::integral_constant<int, KS>{});
+    } else {
+      split(kc_tag);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
+    // NCT blocks of 12 MFMAs (three partial products of one column tile, smallest first).  The inputs
+    // of chunk c + 2 go into the registers just freed, a few requests per block; the conversion of the
+    // next chunk's B operand is woven between the MFMAs of the last block.
+    constexpr int XB = NCT >= 3 ? 2 : 1;  // blocks that carry input requests (4 or 8 each)
+    auto load_b = [&](int fr, u32x4 (&bb)[2]) {
 #pragma unroll
-            for (int k = 0; k < NL; k++) {  // MFMAs, then one request (address arithmetic + load)
-              __builtin_amdgcn_sched_group_barrier(0x008, 12 / NL, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-          }
-        }
-        if constexpr (KC == KK && kChunkSums) {
+      for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][fr + q][lane];
+    };
+    u32x4 b[2][2], b2;  // (the scaled high piece is read as its block starts: gain_h2.h)
+    f32x4 tsum[2][NRT];  // (packed chunks: the sums of a block's products, see below)
+    load_b(0, b[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-          for (int r = 0; r < NRT; r++) tot[r][NCT - 1] += tsum[(NCT - 1) & 1][r];
+    for (int ct = 0; ct < NCT; ct++) {
+      u32x4(&bc)[2] = b[ct & 1];
+      b2 = bfrag[buf][ct * 3 + 2][lane];
+      if (ct + 1 < NCT) load_b((ct + 1) * 3, b[(ct + 1) & 1]);
+      if constexpr (KC == KK && kChunkSums) {
+        // Packed lists have the longest chains (three pieces per object when every object ramps all the time: ~300
+        // MFMAs on one accumulator, each of which rounds the running total): the chunk's three products are summed
+        // among themselves first, the total takes ONE addition per chunk (rounding error of the total ~ 1 / sqrt 3)
+        // (a block's sums are added behind the first MFMAs of the NEXT block — the last block's behind the conversion
+        // of the next chunk's gains —, where they do not wait for the chain they close)
+        f32x4(&t)[NRT] = tsum[ct & 1];
+#pragma unroll
+        for (int r = 0; r < NRT; r++) t[r] = mfma_f16(ah[r], bc[1], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+        if (ct > 0) {
+#pragma unroll
+          for (int r = 0; r < NRT; r++) tot[r][ct - 1] += tsum[(ct - 1) & 1][r];
         }
-      };
-      constexpr std::integral_constant<int, 0> p0{};
-      constexpr std::integral_constant<int, 1> p1{};
-      if constexpr (PAIRED) {
-        // the single chunks of this part (an even number), the last two of them in the transition form, then its
-        // pair chunks, four in flight
-        const int c_mid = min(max(n_single, c_lo), c_hi);
-        constexpr std::integral_constant<int, KS> ks{};
-        constexpr std::integral_constant<int, KP> kp{};
-        int c = c_lo;
-#pragma unroll 1
-        for (; c + 3 < c_mid; c += 2) {
-          chunk(ks, p0, c, X0, GA, GB, false);
-          chunk(ks, p0, c + 1, X1, GB, GA, false);
-        }
-        if (c < c_mid) {
-          chunk(ks, p0, c, X0, GA, GB, true);
-          chunk(ks, p0, c + 1, X1, GB, GA, true);
-          c += 2;
-        }
-#pragma unroll 1
-        for (; c < c_hi; c += 4) {
-          chunk(kp, p0, c, X0, GA, GB, false);
-          if (c + 1 < c_hi) chunk(kp, p0, c + 1, X1, GB, GA, false);
-          if (c + 2 < c_hi) chunk(kp, p1, c + 2, X0, GA, GB, false);
-          if (c + 3 < c_hi) chunk(kp, p1, c + 3, X1, GB, GA, false);
-        }
+#pragma unroll
+        for (int r = 0; r < NRT; r++) t[r] = mfma_f16(al[r], b2, t[r]);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) t[r] = mfma_f16(ah[r], bc[0], t[r]);
       } else {
-        constexpr std::integral_constant<int, KK> kk{};
-#pragma unroll 1
-        for (int c = c_lo; c < c_hi; c += 2) {
-          chunk(kk, p0, c, X0, GA, GB, false);
-          if (c + 1 < c_hi) chunk(kk, p0, c + 1, X1, GB, GA, false);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[1], tot[r][ct]);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(al[r], b2, tot[r][ct]);
+#pragma unroll
+        for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
+      }
+      if (ct < XB) load_x_part(kc_tag, par_tag, KC == KP ? c + 4 : c + 2, xc, ct * (8 / XB), 8 / XB, tr);
+      const bool conv = ct == NCT - 1;
+      if (conv) {
+        float S[NQ], E[NQ];
+        stage_gains(Gcv, S, E);  // (the rows of chunk c + 1)
+        store_b(S, E, buf ^ 1);
+      }
+      if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (ct < XB && !conv) {
+        constexpr int NL = (K2 == KP ? 4 : 8) / XB;  // requests of this block
+#pragma unroll
+        for (int k = 0; k < NL; k++) {  // MFMAs, then one request (address arithmetic + load)
+          __builtin_amdgcn_sched_group_barrier(0x008, 12 / NL, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+      }
+    }
+    if constexpr (KC == KK && kChunkSums) {
+#pragma unroll
+      for (int r = 0; r < NRT; r++) tot[r][NCT - 1] += tsum[(NCT - 1) & 1][r];
+    }
+  };
+  // cur's chunks of this part
+  auto run_chunks = [&]() __attribute__((always_inline)) {
+    const int c_lo = cur.c_lo, c_hi = cur.c_hi;
+    constexpr std::integral_constant<int, 0> p0{};
+    constexpr std::integral_constant<int, 1> p1{};
+    if constexpr (PAIRED) {
+      // the single chunks of this part (an even number), the last two of them in the transition form, then its
+      // pair chunks, four in flight
+      const int c_mid = min(max(cur.n_single, c_lo), c_hi);
+      constexpr std::integral_constant<int, KS> ks{};
+      constexpr std::integral_constant<int, KP> kp{};
+      int c = c_lo;
+#pragma unroll 1
+      for (; c + 3 < c_mid; c += 2) {
+        chunk(ks, p0, c, X0, GA, GB, false);
+        chunk(ks, p0, c + 1, X1, GB, GA, false);
+      }
+      if (c < c_mid) {
+        chunk(ks, p0, c, X0, GA, GB, true);
+        chunk(ks, p0, c + 1, X1, GB, GA, true);
+        c += 2;
+      }
+#pragma unroll 1
+      for (; c < c_hi; c += 4) {
+        chunk(kp, p0, c, X0, GA, GB, false);
+        if (c + 1 < c_hi) chunk(kp, p0, c + 1, X1, GB, GA, false);
+        if (c + 2 < c_hi) chunk(kp, p1, c + 2, X0, GA, GB, false);
+        if (c + 3 < c_hi) chunk(kp, p1, c + 3, X1, GB, GA, false);
+      }
+    } else {
+      constexpr std::integral_constant<int, KK> kk{};
+#pragma unroll 1
+      for (int c = c_lo; c < c_hi; c += 2) {
+        chunk(kk, p0, c, X0, GA, GB, false);
+        if (c + 1 < c_hi) chunk(kk, p0, c + 1, X1, GB, GA, false);
+      }
+    }
+  };
+
+  bool primed = false, first = true;
+  for (int vb = blockIdx.x; vb < ntl; vb += gx) {
+    const int t = xcd_tile(vb, ntl);
+    set_tile(t);
+    if (!primed) {
+      cur = tile_sched(t);
+      goff = 0;
+    }
+    const bool has_next = vb + gx < ntl;
+    const int tn = xcd_tile(has_next ? vb + gx : vb, ntl);
+    nxt = tile_sched(tn);
+    // (the next list takes over ring entries up to its chunk RD: it has to have them)
+    prime_next = has_next && cur.c_hi > cur.c_lo && nxt.c_hi - nxt.c_lo >= RD + 2;
+    live_end = cur.c_hi;
+    xlane = lane_offset(t);
+    clear_totals();
+    if (cur.c_hi > cur.c_lo) {
+      if (!primed) prologue(first);
+      first = false;
+      run_chunks();
+      // (carried into the next list: the gain rows of ITS second chunk, requested by this list's last chunk — into GA when
+      // that was an odd one of the loop's pairs)
+      if (prime_next && ((cur.c_hi - cur.c_lo) & 1)) {
+#pragma unroll
+        for (int i = 0; i < NGI; i++) GB[i] = GA[i];
       }
     }
 
     // objects that take the exact path (too many ramps for the lists, quiet ones): part 0 only
-    if (part == 0) {
-      const int *ovf = pl.ovf + (size_t)wgtile * P.M;
-      const int novf = cnt[4];
+    float inv_x = 1.0f / x_scale;  // exact: a power of two
+    bool col_scaled = true;        // the totals are in units of 1 / (x_scale x the column's gain scale)
+    typedef const int __attribute__((address_space(4))) *ConstInt;
+    const int novf = ((ConstInt)(pl.count + (size_t)wgtile * 8))[4];
+    const int *ovf = pl.ovf + (size_t)wgtile * P.M;
+    if (part == 0)
       for (int i = 0; i < novf; i++) single_object(ovf[i], x_scale, true);
-    }
     // an input beyond the f16 range (or not finite) shows as non-finite totals: redo the wave's tile
     // exactly, unscaled (every part redoes its share of the pieces)
     bool bad = false;
@@ -857,63 +993,26 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       clear_totals();
       inv_x = 1.0f;
       col_scaled = false;
-      for (int c = c_lo; c < c_hi; c++)
+      for (int c = cur.c_lo; c < cur.c_hi; c++)
         for (int j = 0; j < CH; j++) single_piece(chunk_ptr(c)[j]);
-      if (part == 0) {
-        const int *ovf = pl.ovf + (size_t)wgtile * P.M;
-        for (int i = 0; i < cnt[4]; i++) single_object(ovf[i], 1.0f, false);
-      }
+      if (part == 0)
+        for (int i = 0; i < novf; i++) single_object(ovf[i], 1.0f, false);
     }
-  } else {
-    inv_x = 1.0f;
-    col_scaled = false;
-    const int m_lo = (int)(((int64_t)P.M * part) / nparts), m_hi = (int)(((int64_t)P.M * (part + 1)) / nparts);
-    for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);  // unaligned rows
-  }
-
-  if (tile_len <= 0) return;
-  // D fragment of row tile r: rows 4kg + e = samples 16kg + 4e + r: for fixed e the
-  // four row tiles are 4 consecutive samples.
-  float *op = P.out + (size_t)blockIdx.y * P.part_stride + tile_s0;
-  const bool whole = P.vec_ok && tile_len == TS;  // (wave-uniform)
-  float inv_gc[NCT];  // inverse gain scale of the lane's column in each column tile (the D fragments' layout)
-#pragma unroll
-  for (int c = 0; c < NCT; c++) inv_gc[c] = col_scaled ? inv_gcol[c * 16 + li] : 1.0f;
-#pragma unroll
-  for (int c = 0; c < NCT; c++) {
-    if (whole) {  // transposed through wave-private LDS: whole 256-byte rows per store instruction (gain_h2.h)
-      float *ot = otile[w];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_gc[c];
-        *reinterpret_cast<f32x4 *>(ot + li * OP + kg * 16 + e * 4) = v;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {  // lane: column 4 j + (lane >> 4), samples 4 (lane & 15) .. + 3
-        const int cl = 4 * j + kg, col = col0 + c * 16 + cl;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + cl * OP + li * 4);
-        if (col < P.ncols) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(op + (size_t)col * P.out_stride + li * 4));
-      }
-      continue;
+    if (prime_next) {
+      // the ring holds nxt's first chunks, the B fragments of its first one are written, the gain rows of its second
+      // are on their way.  Its first inputs are requested here, in front of this tile's stores (behind the rare paths
+      // above, which want the registers)
+      live_end = 0x7fffffff;
+      xlane = lane_offset(tn);
+      const bool trn = PAIRED && nxt.c_lo >= nxt.n_single;
+      load_x_all(cur.c_hi, X0, trn);
+      load_x_all(cur.c_hi + 1, X1, trn);
     }
-    const int col = col0 + c * 16 + li;
-    if (col >= P.ncols) continue;
-    float *o = op + (size_t)col * P.out_stride;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int s = kg * 16 + e * 4;
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < NRT; r++) v[r] = (tot[r][c][e] * inv_x) * inv_gc[c];
-      if (P.vec_ok && s + 3 < tile_len) {
-        *reinterpret_cast<f32x4 *>(o + s) = v;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (s + i < tile_len) o[s + i] = v[i];
-      }
+    store_tile(inv_x, col_scaled);
+    primed = prime_next;
+    if (primed) {
+      goff += cur.c_hi - nxt.c_lo;
+      cur = nxt;
     }
   }
 }

@@ -804,6 +804,69 @@ def test_piece_list_kernel_vs_oracle(pairs, tile, kind, m, layout, block, nblock
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6, (scenes.rel_rms_per_channel(got, want), plan)
 
 
+@pytest.mark.parametrize("gsplit", ["1", None])
+@pytest.mark.parametrize("pairs", ["0", "1"])
+@pytest.mark.parametrize("tile", ["256", "512"])
+@pytest.mark.parametrize("kind,m,block,nblocks,calls",
+                         [("adm", 200, 512, 24, [24]), ("adm", 40, 512, 21, [10, 11]), ("ragged", 100, 256, 37, [37]),
+                          ("short", 330, 512, 16, [16]), ("constant", 130, 512, 9, [9]), ("mixed", 400, 512, 20, [13, 7])])
+def test_piece_list_pipeline_runs_through_a_workgroups_tiles(gsplit, pairs, tile, kind, m, block, nblocks, calls):
+    """k_gain_mix_p2 carries its pipeline (piece words, gain rows, B fragments) from one tile's list into the next tile of the
+    same workgroup (option P2_WGS: workgroups of the launch; 0: one per tile, nothing carried).  With 1, 3 and 8 workgroups
+    for 9-74 tiles every workgroup crosses several list boundaries — odd and even chunk counts, lists too short to be
+    carried into (40 objects: two chunks), calls that end inside a tile, lists whose length changes from tile to tile
+    ("mixed": a quarter of the objects ramps only in the first third of the call), whole lists per workgroup (GSPLIT 1) and
+    the planner's split of a short call's lists into parts: the same bits as a workgroup per tile, and the oracle within 1e-6."""
+    from libear_amd import capi
+    layout = "9+10+3"
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    if kind == "adm":
+        curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
+    elif kind == "ragged":
+        curves = scenes.ragged_curves(m, n, total, seed=m)
+    elif kind == "constant":
+        curves = scenes.constant_curves(m, n, seed=m)
+    elif kind == "mixed":
+        curves = scenes.adm_curves(m, n, total, period=700, ramp=150, seed=m)
+        const = scenes.constant_curves(m, n, seed=m + 1)
+        for i in range(0, m, 4):  # these stop moving after the first third
+            t, d, f = curves[i]
+            keep = t < total // 3
+            curves[i] = (t[keep], d[keep], f[keep]) if keep.sum() >= 2 else const[i]
+    else:
+        curves = scenes.adm_curves(m, n, total, period=333, ramp=9, seed=m)
+    x = scenes.audio(m, total, seed=m)
+    want = run_oracle(curves, x, n, block, dec, 255)
+
+    def render():
+        c = capi.Context(0)
+        try:
+            r = capi.Renderer(c, m, n, block, dec, 255, max_blocks=max(calls))
+            set_renderer_curves(r, curves, True)
+            out = np.zeros((n, total), np.float32)
+            ofs = 0
+            for nb in calls:
+                out[:, ofs:ofs + nb * block] = r.process(x[:, ofs:ofs + nb * block])
+                ofs += nb * block
+            plan = r.last_plan()
+            r.close()
+        finally:
+            c.close()
+        return out, plan
+
+    outs = {}
+    for wgs in ("0", "1", "3", "8"):
+        got, plan = _with_env({"EARHIP_MFMA": "5", "EARHIP_P2_TILE": tile, "EARHIP_P2_PAIRS": pairs, "EARHIP_P2_WGS": wgs,
+                               "EARHIP_TAILCUT": "0", "EARHIP_GSPLIT": gsplit}, render)
+        assert plan["kernel"] == 4, plan
+        outs[wgs] = got
+    assert scenes.rel_rms_per_channel(outs["0"], want) <= 1e-6, (scenes.rel_rms_per_channel(outs["0"], want), plan)
+    for wgs in ("1", "3", "8"):
+        assert np.array_equal(outs[wgs], outs["0"]), (wgs, float(np.abs(outs[wgs] - outs["0"]).max()))
+
+
 @pytest.mark.parametrize("block,n_taps,nblocks,calls", [(64, 512, 24, [24]), (128, 512, 10, [1, 2, 7]), (256, 512, 8, [3, 5]),
                                                         (512, 1300, 6, [2, 4]), (1024, 1025, 4, [1, 3]), (256, 700, 9, [9])])
 def test_decorrelator_firs_longer_than_a_block(block, n_taps, nblocks, calls):

@@ -41,6 +41,27 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, float seed)
       } else if (KIND == 6) {  // 16 v_add_f32
 #pragma unroll
         for (int i = 0; i < 16; i++) asm volatile("v_add_f32 %0, %1, %2" : "=v"(s[i]) : "v"(s[(i + 1) & 15]), "v"(wt));
+      } else if (KIND >= 8) {  // 16 of one plain-encoded instruction the operand split is made of (round 5: what a split costs)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          float &d = s[i];
+          const float &b = s[(i + 1) & 15];
+          if (KIND == 8) asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(d) : "v"(b));
+          if (KIND == 9) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(d) : "v"(b));
+          if (KIND == 10) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 11) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 12) asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 13) asm volatile("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 14) asm volatile("v_and_b32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 15) asm volatile("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 16) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 17) asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 18) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 19) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 20) asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 21) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(d) : "v"(b));
+          if (KIND == 22) asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(d) : "v"(b), "v"(ws));
+        }
       } else {  // 8 v_pk_add_f32 plain
 #pragma unroll
         for (int i = 0; i < 8; i++) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(w));
@@ -88,5 +109,20 @@ int main() {
   run<3>("v_pk_add_f32 x8, op_sel/neg", 8, out);
   run<7>("v_pk_add_f32 x8 plain", 8, out);
   run<6>("v_add_f32 x16", 16, out);
+  run<8>("v_cvt_f32_f16 x16", 16, out);
+  run<9>("v_cvt_f32_f16_sdwa WORD_1 x16", 16, out);
+  run<10>("v_cvt_pk_f16_f32 x16", 16, out);
+  run<19>("v_cvt_pkrtz_f16_f32 x16", 16, out);
+  run<11>("v_fma_mix_f32 (f16 lo, f32, f32) x16", 16, out);
+  run<12>("v_fma_mixlo_f16 x16", 16, out);
+  run<13>("v_fma_mixhi_f16 (c: f16) x16", 16, out);
+  run<14>("v_and_b32 x16", 16, out);
+  run<15>("v_fma_f32 clamp x16", 16, out);
+  run<16>("v_pk_mul_f16 x16", 16, out);
+  run<17>("v_pk_fma_f16 x16", 16, out);
+  run<18>("v_perm_b32 x16", 16, out);
+  run<20>("v_med3_f32 x16", 16, out);
+  run<21>("v_cvt_f32_i32 x16", 16, out);
+  run<22>("v_lshl_add_u32 x16", 16, out);
   return 0;
 }
