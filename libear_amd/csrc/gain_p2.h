@@ -57,6 +57,10 @@
 
 #include "gain_h2.h"
 
+#ifndef EARHIP_P2_ABL
+#define EARHIP_P2_ABL 0  // (timing-only ablations, NOTES round 5: 1 no input requests, 2 no gain-row requests inside the chunk loop)
+#endif
+
 namespace earhip {
 
 struct Piece {
@@ -791,7 +795,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       ring_store(c + RD, ring_next);
       ring_next = ring_load(c + RD + 1);
     }
+#if !(EARHIP_P2_ABL & 2)
     load_gains(c + 2, Gld);  // the rows of chunk c + 2 (its pieces have been in the ring for two chunks or more)
+#endif
     __builtin_amdgcn_sched_barrier(0);  // every gain row is requested before any input
 
     // A fragments: row tile r = sample 4*li + r of the 8 pieces of this lane.  2 x 2 blocks: an f16
@@ -881,7 +887,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
 #pragma unroll
         for (int r = 0; r < NRT; r++) tot[r][ct] = mfma_f16(ah[r], bc[0], tot[r][ct]);
       }
+#if !(EARHIP_P2_ABL & 1)
       if (ct < XB) load_x_part(kc_tag, par_tag, KC == KP ? c + 4 : c + 2, xc, ct * (8 / XB), 8 / XB, tr);
+#endif
       const bool conv = ct == NCT - 1;
       if (conv) {
         float S[NQ], E[NQ];
