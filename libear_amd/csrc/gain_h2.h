@@ -73,6 +73,20 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
 }
 __device__ __forceinline__ float f16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
 __device__ __forceinline__ float f16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
+// v - (the low / high half of u as a float): the exact residual of a split in ONE instruction (v_fma_mix_f32 converts its
+// f16 operand on the way in; the conversion alone, v_cvt_f32_f16, issues at the same 4.3 cycles, and the subtraction came on
+// top — profiles/r05_valu_issue_rates.txt)
+// (written out: the compiler turns fma(half, -1, v) back into a conversion and a subtraction)
+__device__ __forceinline__ float sub_f16_lo(float v, uint32_t u) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(u), "v"(v));
+  return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float v, uint32_t u) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(u), "v"(v));
+  return r;
+}
 
 // Wide mode: the low piece of an input is kept as (residual x 2^11) and multiplied with (h x 2^-11) of the gain —
 // both exact scalings, the same product — so that it is a normal f16 over 21 binades below the level the prescale
@@ -416,7 +430,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
         }
         const uint32_t H = pack_f16(v[0], v[1]);
         h[i] = H;
-        l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+        l[i] = pack_f16(sub_f16_lo(v[0], H), sub_f16_hi(v[1], H));  // residuals: exact in fp32
         hs[i] = WIDE ? scale_f16x2_down(H) : 0u;                // h 2^-11: the partner of the inputs' scaled low piece
       }
       u32x4 *f = &bfrag[buf][bfr][blane] + (part ? bfr1 * 64 : 0);
@@ -481,8 +495,8 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
           const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
           // residuals (exact); wide mode scales them by 2^11 before they are rounded to f16
           constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
-          const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * LOW;
-          const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * LOW;
+          const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * LOW;
+          const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * LOW;
           ah[rp][qp] = H0;
           ah[rp + 1][qp] = H1;
           al[rp][qp] = pack_f16(r0[0], r1[0]);

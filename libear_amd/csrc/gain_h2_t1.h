@@ -241,7 +241,7 @@ k_gain_mix_h2_t1(GainMixParams P, int zero_row, float x_scale, const float *__re
         }
         const uint32_t H = pack_f16(v[0], v[1]);
         h[i] = H;
-        l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+        l[i] = pack_f16(sub_f16_lo(v[0], H), sub_f16_hi(v[1], H));  // residuals: exact in fp32
         hs[i] = WIDE ? scale_f16x2_down(H) : 0u;                // h 2^-11: the partner of the inputs' scaled low piece
       }
       u32x4 *f = &bfrag[buf][bfr][blane] + (part ? bfr1 * 64 : 0);
@@ -300,8 +300,8 @@ k_gain_mix_h2_t1(GainMixParams P, int zero_row, float x_scale, const float *__re
           const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
           // residuals (exact); wide mode scales them by 2^11 before they are rounded to f16
           constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
-          const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * LOW;
-          const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * LOW;
+          const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * LOW;
+          const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * LOW;
           ah[rp][qp] = H0;
           ah[rp + 1][qp] = H1;
           al[rp][qp] = pack_f16(r0[0], r1[0]);

@@ -711,7 +711,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       };
       auto store_split = [&](const LaneCtx &L, const float (&v)[4], int f, int sl) {  // scaled values: split here
         const uint32_t H0 = pack_f16(v[0], v[1]), H1 = pack_f16(v[2], v[3]);
-        const uint32_t L0 = pack_f16(v[0] - f16_lo(H0), v[1] - f16_hi(H0)), L1 = pack_f16(v[2] - f16_lo(H1), v[3] - f16_hi(H1));
+        const uint32_t L0 = pack_f16(sub_f16_lo(v[0], H0), sub_f16_hi(v[1], H0)), L1 = pack_f16(sub_f16_lo(v[2], H1), sub_f16_hi(v[3], H1));
         store_slice(L, H0, H1, L0, L1, f, sl);
       };
       // the line of chunk c from the staged rows -> its fragment set
@@ -805,8 +805,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             const f32x2 s0 = f32x2{X[2 * qp][rp], X[2 * qp][rp + 1]} * x_scale;
             const f32x2 s1 = f32x2{X[2 * qp + 1][rp], X[2 * qp + 1][rp + 1]} * x_scale;
             const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
-            const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * kLowPieceScale;
-            const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * kLowPieceScale;
+            const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * kLowPieceScale;
+            const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * kLowPieceScale;
             ah[rp][qp] = H0;
             ah[rp + 1][qp] = H1;
             al[rp][qp] = pack_f16(r0[0], r1[0]);

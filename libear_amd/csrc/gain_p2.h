@@ -740,7 +740,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       }
       const uint32_t H = pack_f16(v[0], v[1]);
       h[i] = H;
-      l[i] = pack_f16(v[0] - f16_lo(H), v[1] - f16_hi(H));  // residuals: exact in fp32
+      l[i] = pack_f16(sub_f16_lo(v[0], H), sub_f16_hi(v[1], H));  // residuals: exact in fp32
       hs[i] = scale_f16x2_down(H);                            // h 2^-11: partner of the inputs' scaled low piece (gain_h2.h)
     }
     u32x4 *f = &bfrag[buf][bfr][0];
@@ -831,8 +831,8 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
           const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
           ah[rp][qp] = H0;
           ah[rp + 1][qp] = H1;
-          const f32x2 r0 = (s0 - f32x2{f16_lo(H0), f16_lo(H1)}) * kLowPieceScale;  // exact residuals, scaled (gain_h2.h)
-          const f32x2 r1 = (s1 - f32x2{f16_hi(H0), f16_hi(H1)}) * kLowPieceScale;
+          const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * kLowPieceScale;  // exact residuals, scaled (gain_h2.h)
+          const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * kLowPieceScale;
           al[rp][qp] = pack_f16(r0[0], r1[0]);
           al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
         }
