@@ -165,7 +165,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #define EARHIP_BUILD_CASE(T_)                                                                                          \
   if (tpw == T_)                                                                                                       \
     hipLaunchKernelGGL(k_piece_build<T_>, bgrid, dim3(kBuildThreads), 0, ctx->stream, ps, M, pnt, ptile, t_call, \
-                       t_call + nsamples, pl, obj_lv, level_cur, ml.hinge ? gate : nullptr);
+                       t_call + nsamples, pl, obj_lv, level_cur, ml.hinge ? gate : nullptr, ctx->obj_level_cap, wide_cur);
     EARHIP_BUILD_CASE(1) EARHIP_BUILD_CASE(2) EARHIP_BUILD_CASE(4) EARHIP_BUILD_CASE(8)
 #undef EARHIP_BUILD_CASE
   }
@@ -242,18 +242,25 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 bgrid(std::min(pnt, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
+    // two forms of the kernel, back to back: the one the device-side mode word names runs, the other returns at once
+    // (gain_p2.h); without a probe only the wide form
+#define EARHIP_P2_LAUNCH(NCT_, NW_, PR_, WIDE_)                                                                      \
+  hipLaunchKernelGGL((k_gain_mix_p2<NCT_, NW_, PR_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, pl, xs, gs,  \
+                     level_cur, level_next, wide_cur, wide_next, ml.hinge ? gate : nullptr, pnt);
 #define EARHIP_P2_CASE(NCT_, PR_)                                                                                   \
   if (cp.nct == NCT_ && ml.paired == PR_) {                                                                         \
-    if (ml.pw == 4)                                                                                                 \
-      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 4, PR_>), bgrid, dim3(256), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next, wide_next, ml.hinge ? gate : nullptr, pnt);                                     \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_gain_mix_p2<NCT_, 8, PR_>), bgrid, dim3(512), 0, ctx->stream, P, pl, xs, gs, level_cur, \
-                         level_next, wide_next, ml.hinge ? gate : nullptr, pnt);                                     \
+    if (ml.pw == 4) {                                                                                               \
+      if (wide_cur) EARHIP_P2_LAUNCH(NCT_, 4, PR_, false)                                                           \
+      EARHIP_P2_LAUNCH(NCT_, 4, PR_, true)                                                                          \
+    } else {                                                                                                        \
+      if (wide_cur) EARHIP_P2_LAUNCH(NCT_, 8, PR_, false)                                                           \
+      EARHIP_P2_LAUNCH(NCT_, 8, PR_, true)                                                                          \
+    }                                                                                                               \
   }
     EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
     EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)
 #undef EARHIP_P2_CASE
+#undef EARHIP_P2_LAUNCH
     launched = true;
   }
   if (ml.f32grid) {  // exact f32 on the tile grid (gain_f32g.h): a workgroup per 512-sample tile, descriptors from k_seg_prep

@@ -222,8 +222,20 @@ constexpr int kBuildThreads = 1024;
 template <int TPW>
 __global__ void __launch_bounds__(kBuildThreads)
 k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end, PieceLists pl,
-              const unsigned *obj_level, const unsigned *level_cur, const unsigned *gate = nullptr) {
+              const unsigned *obj_level, const unsigned *level_cur, const unsigned *gate = nullptr, int level_cap = 0,
+              unsigned *wide = nullptr) {
   if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel's builder, which does this call (k_hinge_gate)
+  // the form of k_gain_mix_p2 this call needs (gain_h2.h, k_seg_prep): wide when some object falls more than kPlainBinades
+  // below the call's level at some probed instant
+  if (wide && obj_level && blockIdx.x == 0) {
+    const unsigned call = level_cur ? *level_cur : 0u;
+    bool w = false;
+    for (int m = threadIdx.x; m < M; m += kBuildThreads) {
+      const unsigned lo = obj_level[level_cap + m];
+      w |= lo != 0u && call != 0u && (int)(lo >> 23) < (int)(call >> 23) - kPlainBinades;
+    }
+    if (w) atomicOr(wide, 1u);
+  }
   constexpr int OB = kBuildThreads / TPW;  // objects per batch
   constexpr int WPT = OB / 64;             // waves that scan one tile's objects
   static_assert(OB % 64 == 0, "a tile's objects of a batch are whole waves of the scan");
@@ -372,11 +384,15 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 // just finished.  (A workgroup per tile spent ~9 us of a tile's 117 outside its chunk loop on the ADM scene: the dependent
 // trips list -> gain rows / inputs -> first MFMA with nothing else on the CU, the stores, the next workgroup's launch.)
 // x_scale, g_scale: exact powers of two (gain_h2.h).
-template <int NCT, int NW, bool PAIRED>
+// WIDE: the low pieces of the inputs are kept scaled (kLowPieceScale, gain_h2.h) — 16 more multiplies, a third fragment of
+// every column tile to write and to read.  Both forms are launched back to back when the call was probed (wide_cur): the one
+// the probe's word names works, the other returns at once; without a probe only the wide form is launched.
+template <int NCT, int NW, bool PAIRED, bool WIDE>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next, unsigned *wide_next, const unsigned *gate, int ntl) {
+              unsigned *level_next, const unsigned *wide_cur, unsigned *wide_next, const unsigned *gate, int ntl) {
   if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel, which did this call (k_hinge_gate)
+  if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
   constexpr int NFRAG = NCT * 3;  // column tiles x {h, l, h 2^-11}
@@ -741,19 +757,19 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       const uint32_t H = pack_f16(v[0], v[1]);
       h[i] = H;
       l[i] = pack_f16(sub_f16_lo(v[0], H), sub_f16_hi(v[1], H));  // residuals: exact in fp32
-      hs[i] = scale_f16x2_down(H);                            // h 2^-11: partner of the inputs' scaled low piece (gain_h2.h)
+      hs[i] = WIDE ? scale_f16x2_down(H) : 0u;                // h 2^-11: partner of the inputs' scaled low piece (gain_h2.h)
     }
     u32x4 *f = &bfrag[buf][bfr][0];
     const int col = lane & 15;
     if constexpr (NQ == 8) {
       f[w * 16 + col] = u32x4{h[0], h[1], h[2], h[3]};
       f[64 + w * 16 + col] = u32x4{l[0], l[1], l[2], l[3]};
-      f[128 + w * 16 + col] = u32x4{hs[0], hs[1], hs[2], hs[3]};
+      if constexpr (WIDE) f[128 + w * 16 + col] = u32x4{hs[0], hs[1], hs[2], hs[3]};
     } else {  // half an entry: words 2 (w & 1), + 1 of k group w / 2
       u32x2 *g = reinterpret_cast<u32x2 *>(f + (w >> 1) * 16 + col) + (w & 1);
       g[0] = u32x2{h[0], h[1]};
       g[128] = u32x2{l[0], l[1]};
-      g[256] = u32x2{hs[0], hs[1]};
+      if constexpr (WIDE) g[256] = u32x2{hs[0], hs[1]};
     }
   };
 
@@ -831,8 +847,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
           const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
           ah[rp][qp] = H0;
           ah[rp + 1][qp] = H1;
-          const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * kLowPieceScale;  // exact residuals, scaled (gain_h2.h)
-          const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * kLowPieceScale;
+          constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
+          const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * LOW;  // exact residuals (wide: scaled, gain_h2.h)
+          const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * LOW;
           al[rp][qp] = pack_f16(r0[0], r1[0]);
           al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
         }
@@ -853,14 +870,15 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
 #pragma unroll
       for (int q = 0; q < 2; q++) bb[q] = bfrag[buf][fr + q][lane];
     };
-    u32x4 b[2][2], b2;  // (the scaled high piece is read as its block starts: gain_h2.h)
+    u32x4 b[2][2], b2;  // (wide: the scaled high piece is read as its block starts: gain_h2.h)
     f32x4 tsum[2][NRT];  // (packed chunks: the sums of a block's products, see below)
     load_b(0, b[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) {
       u32x4(&bc)[2] = b[ct & 1];
-      b2 = bfrag[buf][ct * 3 + 2][lane];
+      if constexpr (WIDE) b2 = bfrag[buf][ct * 3 + 2][lane];
+      else b2 = bc[0];  // (plain: the low pieces meet the high pieces of the gains as they are)
       if (ct + 1 < NCT) load_b((ct + 1) * 3, b[(ct + 1) & 1]);
       if constexpr (KC == KK && kChunkSums) {
         // Packed lists have the longest chains (three pieces per object when every object ramps all the time: ~300
@@ -896,8 +914,12 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
         stage_gains(Gcv, S, E);  // (the rows of chunk c + 1)
         store_b(S, E, buf ^ 1);
       }
-      if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if constexpr (WIDE) {
+        if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      } else {
+        if (ct + 1 < NCT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
       if (ct < XB && !conv) {
         constexpr int NL = (K2 == KP ? 4 : 8) / XB;  // requests of this block
 #pragma unroll
