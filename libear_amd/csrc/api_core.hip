@@ -126,7 +126,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (!hinge_addressable(M, in_stride, nsamples, (size_t)ps.kink_row0 + ps.rows, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
     unsigned *obj_lv = probe.obj_level;
     // with a probe: does the hinge kernel's span of levels cover this call?  (decided on the device: k_hinge_gate)
-    if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate);
+    if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate, wide_cur != nullptr);
     int tpw = 1;
     while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
     if (ctx->has(OPT_HBUILD_TPW)) {  // tuning knob
@@ -223,15 +223,22 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
+#define EARHIP_HG_LAUNCH(NCT_, NW_, WIDE_)                                                                           \
+  hipLaunchKernelGGL((k_gain_mix_hg<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, hl, xs, gs, level_cur, \
+                     level_next, wide_cur, wide_next, gate);
 #define EARHIP_HG_CASE(NCT_)                                                                                          \
   if (cp.nct == NCT_) {                                                                                               \
-    if (ml.tile() == 256)                                                                                             \
-      hipLaunchKernelGGL((k_gain_mix_hg<NCT_, 4>), bgrid, dim3(256), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next, gate); \
-    else                                                                                                              \
-      hipLaunchKernelGGL((k_gain_mix_hg<NCT_, 8>), bgrid, dim3(512), 0, ctx->stream, P, hl, xs, gs, level_cur, level_next, wide_next, gate); \
+    if (ml.tile() == 256) {                                                                                           \
+      if (wide_cur) EARHIP_HG_LAUNCH(NCT_, 4, false)                                                                  \
+      EARHIP_HG_LAUNCH(NCT_, 4, true)                                                                                 \
+    } else {                                                                                                          \
+      if (wide_cur) EARHIP_HG_LAUNCH(NCT_, 8, false)                                                                  \
+      EARHIP_HG_LAUNCH(NCT_, 8, true)                                                                                 \
+    }                                                                                                                 \
   }
     EARHIP_HG_CASE(1) EARHIP_HG_CASE(2) EARHIP_HG_CASE(3)
 #undef EARHIP_HG_CASE
+#undef EARHIP_HG_LAUNCH
     launched = true;
   }
   if (ml.pieces || (ml.hinge && gate)) {

@@ -451,11 +451,16 @@ __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast
 // turns the rows staged a step ago into the operand fragments of the NEXT chunk (all three sets; fragments alternate
 // between two buffers), then stages the rows that have arrived meanwhile.  The scaled high piece (h 2^-11, gain_h2.h)
 // is made from h where it is used.
-template <int NCT, int NW>
+// WIDE: the low pieces of the inputs scaled by 2^11 (gain_h2.h), their partner made from the gains' high pieces as they are
+// read; the plain form saves those multiplies (16 + 4 per block of 12 MFMAs).  Both forms are launched when the call was
+// probed (wide_cur: bit 0 of the gate word, k_hinge_gate); the one the word names works.
+template <int NCT, int NW, bool WIDE>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next, unsigned *wide_next, const unsigned *gate) {
+              unsigned *level_next, const unsigned *wide_cur, unsigned *wide_next, const unsigned *gate) {
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate); they clear the words of the next
+  if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
+  constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = 64 * NW;
   constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
   constexpr int KS = NW / 2;         // kink sets: one (4 waves: 256-sample tiles) or two (8 waves: 512) on either side of the centre
@@ -805,8 +810,8 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             const f32x2 s0 = f32x2{X[2 * qp][rp], X[2 * qp][rp + 1]} * x_scale;
             const f32x2 s1 = f32x2{X[2 * qp + 1][rp], X[2 * qp + 1][rp + 1]} * x_scale;
             const uint32_t H0 = pack_f16(s0[0], s1[0]), H1 = pack_f16(s0[1], s1[1]);
-            const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * kLowPieceScale;
-            const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * kLowPieceScale;
+            const f32x2 r0 = f32x2{sub_f16_lo(s0[0], H0), sub_f16_lo(s0[1], H1)} * LOW;
+            const f32x2 r1 = f32x2{sub_f16_hi(s1[0], H0), sub_f16_hi(s1[1], H1)} * LOW;
             ah[rp][qp] = H0;
             ah[rp + 1][qp] = H1;
             al[rp][qp] = pack_f16(r0[0], r1[0]);
@@ -839,7 +844,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           if constexpr (blk + 1 < NBLK) bh[(blk + 1) & 1] = frag[frag_of(blk + 1)][L.lane];
           u32x4 bs;
 #pragma unroll
-          for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(ch[i]);  // h 2^-11: partner of the inputs' scaled low piece
+          for (int i = 0; i < 4; i++) bs[i] = WIDE ? scale_f16x2_down(ch[i]) : ch[i];  // h 2^-11: partner of the inputs' scaled low piece
 #pragma unroll
           for (int r = 0; r < NRT; r++) tt[r][ct] = mfma_f16(al[r], bs, tt[r][ct]);
 #pragma unroll
@@ -926,7 +931,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
               for (int qp = 0; qp < 4; qp++) {
                 const int r = rh + r2;
                 const hg_h2 zero = {(_Float16)0.0f, (_Float16)0.0f};
-                const hg_h2 k2048 = {(_Float16)kLowPieceScale, (_Float16)kLowPieceScale};
+                const hg_h2 k2048 = {(_Float16)LOW, (_Float16)LOW};
                 const hg_h2 F = __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero);
                 const hg_h2 xh = as_h2(ah[r][qp]), xl = as_h2(al[r][qp]);
                 const hg_h2 Ah = F * xh;                                         // rn(F xh)
@@ -940,7 +945,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
               const u32x4 bh = frag[fh + 2 * ct][L.lane];
               u32x4 bs;
 #pragma unroll
-              for (int i = 0; i < 4; i++) bs[i] = scale_f16x2_down(bh[i]);
+              for (int i = 0; i < 4; i++) bs[i] = WIDE ? scale_f16x2_down(bh[i]) : bh[i];
 #pragma unroll
               for (int r2 = 0; r2 < 2; r2++) tot0[rh + r2][ct] = mfma_f16(Fl[r2], bs, tot0[rh + r2][ct]);
               const u32x4 bl = frag[fh + 2 * ct + 1][L.lane];

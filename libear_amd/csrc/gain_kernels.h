@@ -242,7 +242,7 @@ k_level_probe(const float *in, size_t in_stride, int nsamples, int M, unsigned *
 constexpr int kHingeSpreadBinades = 16;
 constexpr unsigned kGateHingeUnsafe = 2u;
 static __global__ void __launch_bounds__(256)
-k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cur, unsigned *gate) {
+k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cur, unsigned *gate, bool wide) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   bool unsafe = false;
   if (m < M) {
@@ -251,6 +251,16 @@ k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cu
     unsafe = !exact_anyway && lo != 0u && call != 0u && (int)(lo >> 23) < (int)(call >> 23) - kHingeSpreadBinades;
   }
   if (__syncthreads_or(unsafe ? 1 : 0) && threadIdx.x == 0) atomicOr(gate, kGateHingeUnsafe);
+  // bit 0 of the same word, when `wide` (else the split-operand kernels behind this launch run their wide form only): the form
+  // they need — wide when some object falls more than kPlainBinades below the call's level at some probed instant (k_seg_prep)
+  if (wide) {
+    bool wd = false;
+    if (m < M) {
+      const unsigned lo = obj_level[cap + m], call = *level_cur;
+      wd = lo != 0u && call != 0u && (int)(lo >> 23) < (int)(call >> 23) - kPlainBinades;
+    }
+    if (__syncthreads_or(wd ? 1 : 0) && threadIdx.x == 0) atomicOr(gate, 1u);
+  }
 }
 
 // kPrepRun consecutive tiles per thread: 2 for up to 2047 tiles (headline: K0 0.020 -> 0.018 ms), 4 beyond
