@@ -246,6 +246,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // pipeline from one tile's list into the next (gain_p2.h); option P2_WGS: that number (0: a workgroup per tile)
     int wgs = std::max(8, (ctx->num_cus * (ml.pw == 4 ? 2 : 1) / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
     if (ctx->has(OPT_P2_WGS)) wgs = ctx->get(OPT_P2_WGS) > 0 ? ctx->get(OPT_P2_WGS) : pnt;
+    if (!p2_persistent(cp.nct, ml.pw, ml.paired)) wgs = pnt;  // (a tile per workgroup)
     const dim3 bgrid(std::min(pnt, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();

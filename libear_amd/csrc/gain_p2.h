@@ -387,6 +387,8 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 // WIDE: the low pieces of the inputs are kept scaled (kLowPieceScale, gain_h2.h) — 16 more multiplies, a third fragment of
 // every column tile to write and to read.  Both forms are launched back to back when the call was probed (wide_cur): the one
 // the probe's word names works, the other returns at once; without a probe only the wide form is launched.
+// (the 4-wave form on paired lists with three column tiles sits at the register limit: a workgroup per tile, nothing carried)
+constexpr bool p2_persistent(int nct, int nw, bool paired) { return !(nw == 4 && nct == 3 && paired); }
 template <int NCT, int NW, bool PAIRED, bool WIDE>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
@@ -986,7 +988,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
     const int tn = xcd_tile(has_next ? vb + gx : vb, ntl);
     nxt = tile_sched(tn);
     // (the next list takes over ring entries up to its chunk RD: it has to have them)
-    prime_next = has_next && cur.c_hi > cur.c_lo && nxt.c_hi - nxt.c_lo >= RD + 2;
+    prime_next = p2_persistent(NCT, NW, PAIRED) && has_next && cur.c_hi > cur.c_lo && nxt.c_hi - nxt.c_lo >= RD + 2;
     live_end = cur.c_hi;
     xlane = lane_offset(t);
     clear_totals();
