@@ -223,18 +223,13 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 bgrid(ml.ntiles, ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
-#define EARHIP_HG_LAUNCH(NCT_, NW_, WIDE_)                                                                           \
-  hipLaunchKernelGGL((k_gain_mix_hg<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, hl, xs, gs, level_cur, \
+#define EARHIP_HG_LAUNCH(NCT_, NW_)                                                                                  \
+  hipLaunchKernelGGL((k_gain_mix_hg<NCT_, NW_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, hl, xs, gs, level_cur,     \
                      level_next, wide_cur, wide_next, gate);
 #define EARHIP_HG_CASE(NCT_)                                                                                          \
   if (cp.nct == NCT_) {                                                                                               \
-    if (ml.tile() == 256) {                                                                                           \
-      if (wide_cur) EARHIP_HG_LAUNCH(NCT_, 4, false)                                                                  \
-      EARHIP_HG_LAUNCH(NCT_, 4, true)                                                                                 \
-    } else {                                                                                                          \
-      if (wide_cur) EARHIP_HG_LAUNCH(NCT_, 8, false)                                                                  \
-      EARHIP_HG_LAUNCH(NCT_, 8, true)                                                                                 \
-    }                                                                                                                 \
+    if (ml.tile() == 256) EARHIP_HG_LAUNCH(NCT_, 4)                                                                   \
+    else EARHIP_HG_LAUNCH(NCT_, 8)                                                                                    \
   }
     EARHIP_HG_CASE(1) EARHIP_HG_CASE(2) EARHIP_HG_CASE(3)
 #undef EARHIP_HG_CASE
@@ -250,20 +245,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 bgrid(std::min(pnt, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
-    // two forms of the kernel, back to back: the one the device-side mode word names runs, the other returns at once
-    // (gain_p2.h); without a probe only the wide form
-#define EARHIP_P2_LAUNCH(NCT_, NW_, PR_, WIDE_)                                                                      \
-  hipLaunchKernelGGL((k_gain_mix_p2<NCT_, NW_, PR_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, pl, xs, gs,  \
+    // (both forms of the kernel body in one kernel: the device-side mode word picks; without a probe the wide form)
+#define EARHIP_P2_LAUNCH(NCT_, NW_, PR_)                                                                             \
+  hipLaunchKernelGGL((k_gain_mix_p2<NCT_, NW_, PR_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, pl, xs, gs,         \
                      level_cur, level_next, wide_cur, wide_next, ml.hinge ? gate : nullptr, pnt);
 #define EARHIP_P2_CASE(NCT_, PR_)                                                                                   \
   if (cp.nct == NCT_ && ml.paired == PR_) {                                                                         \
-    if (ml.pw == 4) {                                                                                               \
-      if (wide_cur) EARHIP_P2_LAUNCH(NCT_, 4, PR_, false)                                                           \
-      EARHIP_P2_LAUNCH(NCT_, 4, PR_, true)                                                                          \
-    } else {                                                                                                        \
-      if (wide_cur) EARHIP_P2_LAUNCH(NCT_, 8, PR_, false)                                                           \
-      EARHIP_P2_LAUNCH(NCT_, 8, PR_, true)                                                                          \
-    }                                                                                                               \
+    if (ml.pw == 4) EARHIP_P2_LAUNCH(NCT_, 4, PR_)                                                                  \
+    else EARHIP_P2_LAUNCH(NCT_, 8, PR_)                                                                             \
   }
     EARHIP_P2_CASE(1, false) EARHIP_P2_CASE(2, false) EARHIP_P2_CASE(3, false)
     EARHIP_P2_CASE(1, true) EARHIP_P2_CASE(2, true) EARHIP_P2_CASE(3, true)
@@ -292,7 +281,9 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
     // two forms of the kernel, back to back: the one the device-side mode word names runs, the other returns at once
-    // (gain_h2.h); without a probe only the wide form
+    // (gain_h2.h; the piece-list and hinge kernels carry both forms in one kernel — for this one the merged kernel measured
+    // slower: config 2 0.224 -> 0.259 ms, its 4-wave form loses a wave per SIMD to the larger of the two register counts);
+    // without a probe only the wide form
 #define EARHIP_H2_LAUNCH(NCT_, NW_, WIDE_)                                                                          \
   hipLaunchKernelGGL((k_gain_mix_h2<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, ps.zero_row, xs,  \
                      gs, level_cur, level_next, slow_cur, slow_next, wide_cur, wide_next);

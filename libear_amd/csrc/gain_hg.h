@@ -452,15 +452,14 @@ __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast
 // between two buffers), then stages the rows that have arrived meanwhile.  The scaled high piece (h 2^-11, gain_h2.h)
 // is made from h where it is used.
 // WIDE: the low pieces of the inputs scaled by 2^11 (gain_h2.h), their partner made from the gains' high pieces as they are
-// read; the plain form saves those multiplies (16 + 4 per block of 12 MFMAs).  Both forms are launched when the call was
-// probed (wide_cur: bit 0 of the gate word, k_hinge_gate); the one the word names works.
-template <int NCT, int NW, bool WIDE>
+// read; the plain form saves those multiplies (16 + 4 per block of 12 MFMAs).  Both forms are in the kernel; the probe's word
+// (wide_cur: bit 0 of the gate word, k_hinge_gate) picks at run time.
+template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, const unsigned *wide_cur, unsigned *wide_next, const unsigned *gate) {
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate); they clear the words of the next
-  if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
-  constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
+
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = 64 * NW;
   constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
   constexpr int KS = NW / 2;         // kink sets: one (4 waves: 256-sample tiles) or two (8 waves: 512) on either side of the centre
@@ -481,6 +480,11 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
   __shared__ __attribute__((aligned(16))) uint32_t ringf[RING][KS][CH];  // ... their factor words, packed for the lanes
   __shared__ uint32_t ringc[RING];                                    // chunk flags
   __shared__ __attribute__((aligned(16))) float stage[NW][NQ * NR * 16 * NCT];  // a wave's rows: [slot][NR rows][16 NCT columns]
+  // Both forms of the body (WIDE or not) in ONE kernel, the probe's word picking at run time: two kernels launched back to
+  // back, one of which looks at the word and returns, cost 5 us per call for the one that returns
+  auto body = [&](auto wide_tag) __attribute__((always_inline)) {
+  constexpr bool WIDE = decltype(wide_tag)::value;
+  constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
@@ -1044,6 +1048,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       }
     }
   }
+  };  // body
+  if (!wide_cur || (*wide_cur & 1u) != 0u) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 }  // namespace earhip

@@ -385,16 +385,15 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
 // trips list -> gain rows / inputs -> first MFMA with nothing else on the CU, the stores, the next workgroup's launch.)
 // x_scale, g_scale: exact powers of two (gain_h2.h).
 // WIDE: the low pieces of the inputs are kept scaled (kLowPieceScale, gain_h2.h) — 16 more multiplies, a third fragment of
-// every column tile to write and to read.  Both forms are launched back to back when the call was probed (wide_cur): the one
-// the probe's word names works, the other returns at once; without a probe only the wide form is launched.
-// (the 4-wave form on paired lists with three column tiles sits at the register limit: a workgroup per tile, nothing carried)
-constexpr bool p2_persistent(int nct, int nw, bool paired) { return !(nw == 4 && nct == 3 && paired); }
-template <int NCT, int NW, bool PAIRED, bool WIDE>
+// every column tile to write and to read.  Both forms are in the kernel; the probe's word (wide_cur) picks at run time, without
+// a probe the wide form runs.
+// (the 4-wave forms with three column tiles sit at the register limit: a workgroup per tile, nothing carried)
+constexpr bool p2_persistent(int nct, int nw, bool paired) { return !(nw == 4 && nct == 3); }
+template <int NCT, int NW, bool PAIRED>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2)
 k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, const unsigned *wide_cur, unsigned *wide_next, const unsigned *gate, int ntl) {
   if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel, which did this call (k_hinge_gate)
-  if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;     // pieces whose gains one wave converts per chunk
   constexpr int NFRAG = NCT * 3;  // column tiles x {h, l, h 2^-11}
@@ -411,6 +410,10 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
   __shared__ __attribute__((aligned(16))) u32x4 ringp[RING][CH];       // ... the whole pieces (rows, p0, scale)
   constexpr int NGI = (2 * NQ * 4 * NCT + 63) / 64;                    // float4 gain-row requests per wave and chunk
   __shared__ __attribute__((aligned(16))) f32x4 stage[NW][NGI * 64];   // the wave's gain rows of a chunk: [2 NQ][16 NCT] floats
+  // Both forms of the body (WIDE or not) in ONE kernel, the probe's word picking at run time: two kernels launched back to
+  // back, one of which looks at the word and returns, cost 5 us per call for the one that returns
+  auto body = [&](auto wide_tag) __attribute__((always_inline)) {
+  constexpr bool WIDE = decltype(wide_tag)::value;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
@@ -1047,6 +1050,9 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       cur = nxt;
     }
   }
+  };  // body
+  if (!wide_cur || (*wide_cur & 1u) != 0u) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 }  // namespace earhip
