@@ -74,7 +74,8 @@ def main():
         # (exact f32 on block-aligned curves: the tile-grid kernel where the call is whole 512-sample tiles, else the slot kernel)
         forces = [None, "6", "5", "4" if fam == "dense" else "1"] + (["1"] if fam == "dense" else [])
         for force in forces:
-            env = {"EARHIP_MFMA": force, "EARHIP_HG_TILE": str(rng.choice(["256", "512"])), "EARHIP_H2_WGS": str(rng.choice(["8", "256"]))}
+            env = {"EARHIP_MFMA": force, "EARHIP_HG_TILE": str(rng.choice(["256", "512"])), "EARHIP_H2_WGS": str(rng.choice(["8", "256"])),
+                   "EARHIP_P2_WGS": str(rng.choice(["1", "3", "8", "256"]))}  # (few workgroups: every one crosses list boundaries)
             keep = {k: os.environ.get(k) for k in env}
             for k, v in env.items():
                 os.environ.pop(k, None)
@@ -99,7 +100,7 @@ def main():
             ok = e <= (1.5e-6 if force == "6" and fam in ("short", "dense", "mixed", "hold") else 1e-6)
             bad += 0 if ok else 1
             print(f"case {case:3d} {fam:7s} {layout:7s} m={m:5d} B={block:5d} nb={nblocks:3d} calls={len(calls):2d} force={force} "
-                  f"hg={env['EARHIP_HG_TILE']} wgs={env['EARHIP_H2_WGS']} -> kernel {plan['kernel']} tile {plan['tile']}: {e:.3e} {'ok' if ok else 'FAIL'}", flush=True)
+                  f"hg={env['EARHIP_HG_TILE']} wgs={env['EARHIP_H2_WGS']}/{env['EARHIP_P2_WGS']} -> kernel {plan['kernel']} tile {plan['tile']}: {e:.3e} {'ok' if ok else 'FAIL'}", flush=True)
     print("failures:", bad)
     sys.exit(1 if bad else 0)
 
