@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, float seed)
       } else if (KIND == 6) {  // 16 v_add_f32
 #pragma unroll
         for (int i = 0; i < 16; i++) asm volatile("v_add_f32 %0, %1, %2" : "=v"(s[i]) : "v"(s[(i + 1) & 15]), "v"(wt));
-      } else if (KIND >= 8) {  // 16 of one plain-encoded instruction the operand split is made of (round 5: what a split costs)
+      } else if ((KIND >= 8 && KIND < 40) || KIND >= 42) {  // 16 of one plain-encoded instruction the operand split is made of (round 5: what a split costs)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           float &d = s[i];
@@ -61,6 +61,37 @@ __global__ void __launch_bounds__(256) k_rate(float *out, int iters, float seed)
           if (KIND == 20) asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
           if (KIND == 21) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(d) : "v"(b));
           if (KIND == 22) asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 23) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 24) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 25) asm volatile("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 26) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 27) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 28) asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(b));
+          if (KIND == 29) asm volatile("v_or_b32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 30) asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(d) : "v"(b));
+          if (KIND == 31) asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 32) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(b), "v"(ws));
+          if (KIND == 33) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "s"(0x5555aaaa5555aaaaull));
+          if (KIND == 34) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(ws), "v"(wt));
+          if (KIND == 35) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(b), "v"(ws) : "vcc");
+          if (KIND == 36) asm volatile("s_mov_b64 vcc, exec\n v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d) : "v"(b), "v"(ws) : "vcc");
+          if (KIND == 37) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=&v"(d) : "v"(b), "v"(ws));
+          if (KIND == 38) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc" : "=&v"(d) : "v"(b), "v"(ws) : "vcc");
+          // a compare, N plain instructions, then the select on its vcc (3 / 6 / 10 / 18 instructions per item)
+          if (KIND == 42) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_add_f32 %0, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc" : "=&v"(d) : "v"(b), "v"(ws) : "vcc");
+          if (KIND == 43) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc" : "=&v"(d) : "v"(b), "v"(ws) : "vcc");
+          if (KIND == 44) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc" : "=&v"(d) : "v"(b), "v"(ws) : "vcc");
+          if (KIND == 45) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_add_f32 %0, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc" : "=&v"(d) : "v"(b), "v"(ws) : "vcc");
+          // the compare's result in an SGPR pair, the select on it (VOP3 forms)
+          if (KIND == 46) asm volatile("v_cmp_gt_f32_e64 s[20:21], %1, %2\n v_cndmask_b32_e64 %0, %1, %2, s[20:21]" : "=&v"(d) : "v"(b), "v"(ws) : "s20", "s21");
+          // one compare, four selects on its vcc
+          if (KIND == 47) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %0, %2, %1, vcc\n v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %0, %2, %1, vcc" : "=&v"(d) : "v"(b), "v"(ws) : "vcc");
+        }
+      } else if (KIND == 40 || KIND == 41) {  // 8 64-bit integer instructions on register pairs
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (KIND == 40) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(s[i]), "v"(s[i + 8]) : "vcc");
+          if (KIND == 41) asm volatile("v_lshl_add_u64 %0, %1, 2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
         }
       } else {  // 8 v_pk_add_f32 plain
 #pragma unroll
@@ -124,5 +155,29 @@ int main() {
   run<20>("v_med3_f32 x16", 16, out);
   run<21>("v_cvt_f32_i32 x16", 16, out);
   run<22>("v_lshl_add_u32 x16", 16, out);
+  run<23>("v_mul_lo_u32 x16", 16, out);
+  run<24>("v_mad_u32_u24 x16", 16, out);
+  run<25>("v_add_u32 x16", 16, out);
+  run<26>("v_cndmask_b32 x16", 16, out);
+  run<27>("v_add3_u32 x16", 16, out);
+  run<28>("v_mov_b32 x16", 16, out);
+  run<29>("v_or_b32 x16", 16, out);
+  run<30>("v_lshlrev_b32 x16", 16, out);
+  run<31>("v_max_f32 x16", 16, out);
+  run<32>("v_sub_f32 x16", 16, out);
+  run<33>("v_cndmask_b32_e64 (SGPR-pair mask) x16", 16, out);
+  run<34>("v_bfi_b32 x16", 16, out);
+  run<35>("v_cmp_gt_f32 -> vcc x16", 16, out);
+  run<36>("s_mov vcc + v_cndmask_b32 x16 (2 instr each)", 32, out);
+  run<37>("v_cndmask_b32 (vcc), distinct registers x16", 16, out);
+  run<38>("v_cmp + v_cndmask pairs x16 (2 instr each)", 32, out);
+  run<42>("v_cmp, 1 add, v_cndmask (3 instr per item) x16", 48, out);
+  run<43>("v_cmp, 4 adds, v_cndmask (6 per item) x16", 96, out);
+  run<44>("v_cmp, 8 adds, v_cndmask (10 per item) x16", 160, out);
+  run<45>("v_cmp, 16 adds, v_cndmask (18 per item) x16", 288, out);
+  run<46>("v_cmp_e64 -> SGPR pair, v_cndmask_e64 (2 per item) x16", 32, out);
+  run<47>("v_cmp, 4 v_cndmask on its vcc (5 per item) x16", 80, out);
+  run<40>("v_mad_u64_u32 x8", 8, out);
+  run<41>("v_lshl_add_u64 x8", 8, out);
   return 0;
 }
