@@ -239,6 +239,33 @@ def test_seed_sweep_at_1024_objects(scene):
           + f"; max {max(worst):.3e}")
 
 
+@pytest.mark.parametrize("quiet", [False, True])
+@pytest.mark.parametrize("kind", ["adm", "moving"])
+def test_both_forms_of_the_list_kernels_at_stream_length(kind, quiet):
+    """The piece-list and hinge kernels carry two forms of their body (plain / wide low pieces of the inputs) and pick on the
+    device from the level probe's word — which only calls of two rounds of workgroups and more have (512 tiles: shorter
+    calls run the wide form).  A call of 640 blocks at 320 objects, every channel against the oracle at the start, in the
+    middle and at the end: uniform audio (nothing falls 8 binades below the call's level: the plain form) and the same with
+    every fifth object 66 dB down and fading for the second half (the wide form); where every operand is a normal f16 the two
+    forms give the same bits, so the loud objects' share of both renders is the same arithmetic."""
+    layout, m, block, nblocks = "9+10+3", 320, 512, 640
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = scenes.adm_curves(m, n, total, seed=77) if kind == "adm" else scenes.adm_curves(m, n, total, period=240, ramp=240, seed=78)
+    x = device_audio(m, total, 79)
+    if quiet:
+        import torch
+        x[::5, :] *= 2.0 ** -11
+        fade = torch.linspace(0.0, -9.0, total - total // 2, device=x.device)
+        x[::5, total // 2:] *= torch.exp2(fade)[None, :]
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    if os.environ.get("EARHIP_MFMA") is None and os.environ.get("EARHIP_HINGE") is None:
+        assert plan["kernel"] == (4 if kind == "adm" else 5), plan
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks // 2 - 1, 3), (nblocks - 3, 3)])
+    print(f"both forms ({kind}, quiet objects {quiet}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
+
+
 @pytest.mark.parametrize("nblocks", [1, 2, 7, 33, 40, 63, 64])
 def test_call_lengths_between_block_and_stream_mode_off_grid_metadata(nblocks):
     """ADM-like metadata (f32 slot kernel) at 256 objects with max_blocks = 64: calls of 33..63 blocks
