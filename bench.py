@@ -638,6 +638,7 @@ def main():
     gain_kernel = plan["kernel"]
     # (a call planned for the hinge kernel is decided on the device: it, or the piece lists standing by)
     scratch_mb = round(wl.r.scratch_bytes() / 1e6, 1)
+    wide_form = wl.r.wide_form()  # (the form — plain / wide low pieces — the split-operand kernel picked on the device)
     hinge_standby = gain_kernel == 5 and wl.r.hinge_standby()
     if hinge_standby:
         GAIN_KERNELS[5] = "k_gain_mix_p2 (f16x2 MFMA over piece lists, standing by for k_gain_mix_hg: the levels of this call's inputs spread beyond its span)"
@@ -877,7 +878,8 @@ def main():
                 "strict": bool(args.strict)},
             "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"),
                          "plan": {"tile_samples": plan["tile"], "tiles": plan["ntiles"], "object_splits": plan["gsplit"],
-                                  "scratch_MB": scratch_mb},
+                                  "scratch_MB": scratch_mb,
+                                  "form": None if wide_form is None else ("wide" if wide_form else "plain")},
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,

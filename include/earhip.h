@@ -433,6 +433,12 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind);
  * (for benchmarks and tests that must name the kernel they measured).  Valid until the next process
  * call of ANY renderer or gain stage on the same context: the decision word belongs to the context. */
 int earhip_render_hinge_standby(earhip_render *r, int *standby);
+/* The split-operand kernels (3, 4, 5) have two forms of their body: plain, and wide (the low pieces of the inputs scaled so
+ * that they stay normal f16 numbers 21 binades below the call's level instead of 11).  Long calls (two rounds of workgroups
+ * and more) pick on the device, from the level probe; shorter ones run the wide form.  *wide = 1 / 0: the form the last call
+ * of this renderer ran (-1: its kernel has no split operands).  Synchronises the stream; valid until the next process call
+ * of any renderer or gain stage on the same context, like earhip_render_hinge_standby. */
+int earhip_render_wide_form(earhip_render *r, int *wide);
 /* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
  * For tests and benchmarks that must know which kernel instantiation they measured. */

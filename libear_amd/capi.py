@@ -629,6 +629,13 @@ class Renderer:
         check(load().earhip_render_hinge_standby(self.h, C.byref(flag)))
         return bool(flag.value)
 
+    def wide_form(self):
+        """True / False: the form (wide / plain low pieces of the inputs) the split-operand kernel of the last call ran — picked on
+        the device for long calls, wide for short ones; None when the kernel has no split operands; synchronises the stream"""
+        flag = C.c_int(1)
+        check(load().earhip_render_wide_form(self.h, C.byref(flag)))
+        return None if flag.value < 0 else bool(flag.value)
+
     def scratch_bytes(self):
         """device scratch (descriptors, lists) the last call needed"""
         v = C.c_size_t(0)

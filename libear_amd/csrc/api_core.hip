@@ -66,6 +66,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   unsigned *wide_cur = nullptr, *wide_next = nullptr;  // f16x2 kernel: "run this call in wide mode" (gain_h2.h)
   unsigned *gate = nullptr;                            // hinge kernel: "this call is the piece lists'" (k_hinge_gate)
   ctx->last_gate_idx = -1;
+  ctx->last_wide_idx = -1;
   if ((ml.split || ml.pieces || ml.hinge) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
     if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);  // [0..1] level words, [2..3] wide-mode words
     level_cur = ctx->level.p + ctx->level_idx;
@@ -77,6 +78,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     wide_next = ctx->level.p + 2 + (ctx->level_idx ^ 1);
     gate = ctx->level.p + 2 + ctx->level_idx;  // (the same word: bit 0 the grid kernel's wide mode, bit 1 "not the hinge kernel")
     ctx->last_gate_idx = ml.hinge ? ctx->level_idx : -1;
+    ctx->last_wide_idx = wide_cur ? ctx->level_idx : -1;
     ctx->level_idx ^= 1;
     // per-object levels (k_level_probe, gain_kernels.h): grown with the largest M this context has seen — contexts are
     // shared by gain stages of different sizes

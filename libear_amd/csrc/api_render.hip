@@ -188,6 +188,7 @@ struct earhip_render {
   size_t last_scratch_bytes = 0;  // K0 / K1 scratch the last call needed
   long scratch_regrows = 0;       // process calls that had to grow the scratch themselves (none on committed curves)
   int last_gate_idx = -1;  // the context's mode word of THIS renderer's last call when it was planned for the hinge kernel, else -1
+  int last_wide_idx = -1;  // ... when its split-operand kernel picked its form (plain / wide) on the device, else -1
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 f32 MFMA on the tile grid, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
                        // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
@@ -449,6 +450,7 @@ struct earhip_render {
     }
     if (timed) pending.push_back(pd);
     last_gate_idx = ctx->last_gate_idx;  // (set by launch_gain_mix for this call)
+    last_wide_idx = ctx->last_wide_idx;
     t += nsamples;
   }
 };
@@ -765,6 +767,21 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby) {
     EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + r->last_gate_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     *standby = (word & kGateHingeUnsafe) ? 1 : 0;
+  });
+}
+
+int earhip_render_wide_form(earhip_render *r, int *wide) {
+  return guarded([&] {
+    require(r != nullptr && wide != nullptr, "NULL argument");
+    *wide = 1;
+    earhip_ctx *ctx = r->ctx;
+    if (r->last_kind < 3) *wide = -1;  // (no split operands at all)
+    if (r->last_kind < 3 || r->last_wide_idx < 0 || !ctx->level.p) return;
+    ctx->use();
+    unsigned word = 0;
+    EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + r->last_wide_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    *wide = (word & 1u) ? 1 : 0;
   });
 }
 

@@ -152,6 +152,7 @@ struct earhip_ctx {
   earhip::DevBuf<unsigned> level;  // [2] input level words (float bits), used alternately by successive calls
   int level_idx = 0;
   int last_gate_idx = -1;  // the mode word ([2 + idx]) of the last call planned for the hinge kernel; -1: the last call was not
+  int last_wide_idx = -1;  // the mode word of the last call whose split-operand kernel picked its form on the device; -1: none (wide form)
   // [2][tile_slow_cap] words used alternately by successive calls of the f16x2 gain kernel: non-zero = some object
   // of the tile needs the kernel's exact path (set by K0: k_seg_prep, cleared for the call after next by K1)
   earhip::DevBuf<unsigned> tile_slow;

@@ -50,7 +50,7 @@ def oracle_window(curves, x_win, n_out, block, dec, delay, t_lo, two_bus=True):
 
 
 def render_device(curves, x_dev, n_out, block, dec, delay, calls, t0=0):
-    """x_dev: torch [M][total] on the GPU; returns (out_dev, plan of the last call)"""
+    """x_dev: torch [M][total] on the GPU; returns (out_dev, plan of the last call; plan["wide"]: the form its kernel ran)"""
     import torch
     from libear_amd import capi
     m, total = x_dev.shape
@@ -66,6 +66,7 @@ def render_device(curves, x_dev, n_out, block, dec, delay, calls, t0=0):
         ofs += nb * block
     ctx().synchronize()
     plan = r.last_plan()
+    plan["wide"] = r.wide_form()
     r.close()
     return out, plan
 
@@ -113,6 +114,7 @@ def test_headline_call_at_its_own_size_vs_oracle_windows():
     out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
     if os.environ.get("EARHIP_MFMA") in (None, "3") and os.environ.get("EARHIP_H2_TILE") is None:
         assert plan["kernel"] == 3 and plan["tile"] == 512 and plan["gsplit"] == 1, plan
+        assert plan["wide"] is False, plan  # (uniform audio: the plain form of the grid kernel, picked on the device)
     # (forced onto the exact-f32 slot kernel — EARHIP_MFMA=1 — the same bar holds: its waves split the slot list so that
     # no float32 chain is longer than ~256 terms)
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (511, 2), (1021, 3)])
@@ -262,6 +264,7 @@ def test_both_forms_of_the_list_kernels_at_stream_length(kind, quiet):
     out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
     if os.environ.get("EARHIP_MFMA") is None and os.environ.get("EARHIP_HINGE") is None:
         assert plan["kernel"] == (4 if kind == "adm" else 5), plan
+        assert plan["wide"] is quiet, plan  # (earhip_render_wide_form: the form the device picked)
     worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks // 2 - 1, 3), (nblocks - 3, 3)])
     print(f"both forms ({kind}, quiet objects {quiet}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
