@@ -437,7 +437,8 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby);
  * that they stay normal f16 numbers 21 binades below the call's level instead of 11).  Long calls (two rounds of workgroups
  * and more) pick on the device, from the level probe; shorter ones run the wide form.  *wide = 1 / 0: the form the last call
  * of this renderer ran (-1: its kernel has no split operands).  Synchronises the stream; valid until the next process call
- * of any renderer or gain stage on the same context, like earhip_render_hinge_standby. */
+ * of any renderer or gain stage on the same context, like earhip_render_hinge_standby.  After a call that ran as two spans
+ * (earhip_render_last_tail_blocks > 0) both queries describe the SECOND span — a short call: the wide form, no hand-over. */
 int earhip_render_wide_form(earhip_render *r, int *wide);
 /* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
