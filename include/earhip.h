@@ -393,9 +393,13 @@ int earhip_render_set_object_points(earhip_render *r, int object, int npoints,
 /* Upload pending curve changes now (otherwise done at the next process), and make everything a call on the new curves
  * can need: the scratch of the list kernels (sized from the curves) and, for curves the hinge kernel is planned for, its
  * kink rows — for calls of max_blocks, max_blocks / 2 and one block.  This is where the library allocates and
- * synchronises when curves outgrow what is there; a process call on committed curves does neither.  (One exception: a
- * process call whose launch plan no commit foresaw — an option changed in between — grows the scratch itself;
- * earhip_render_scratch_regrows counts such calls: 0 in the library's own tests and benchmarks.) */
+ * synchronises when curves outgrow what is there; a process call on committed curves does neither.  What a call keeps per
+ * CONTEXT — the level and mode words of the split-operand kernels, the per-object levels of the level probe, the grid
+ * kernel's per-tile words — is made by earhip_render_create for max_blocks and n_objects of that renderer.  (The counted
+ * exceptions: a process call whose launch plan no commit foresaw — an option changed in between — grows the scratch itself,
+ * and a call that finds one of the context's buffers smaller than it needs — none of its renderers announced that size —
+ * grows that; earhip_render_scratch_regrows counts the process calls of this renderer that did either: 0 in the
+ * library's own tests and benchmarks.) */
 int earhip_render_commit(earhip_render *r);
 int earhip_render_scratch_regrows(const earhip_render *r, long *count);
 /* Zero the DSP state (convolver tails, delay line) and set the sample clock. */
@@ -430,20 +434,28 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind);
  * call it is planned for is decided ON THE DEVICE, from the level probe of the call's inputs: the
  * hinge kernel or the piece lists launched behind it.  *standby = 1 when the last call of this
  * renderer was planned for kernel 5 and the piece lists did it, else 0.  Synchronises the stream
- * (for benchmarks and tests that must name the kernel they measured).  Valid until the next process
- * call of ANY renderer or gain stage on the same context: the decision word belongs to the context. */
+ * (for benchmarks and tests that must name the kernel they measured).  The kernel that does a call
+ * leaves a copy of the context's decision word in the renderer's own device slot: the answer stays
+ * valid until the next process call of THIS renderer, whatever other renderers or gain stages of the
+ * context do in between. */
 int earhip_render_hinge_standby(earhip_render *r, int *standby);
 /* The split-operand kernels (3, 4, 5) have two forms of their body: plain, and wide (the low pieces of the inputs scaled so
  * that they stay normal f16 numbers 21 binades below the call's level instead of 11).  Long calls (two rounds of workgroups
  * and more) pick on the device, from the level probe; shorter ones run the wide form.  *wide = 1 / 0: the form the last call
  * of this renderer ran (-1: its kernel has no split operands).  Synchronises the stream; valid until the next process call
- * of any renderer or gain stage on the same context, like earhip_render_hinge_standby.  After a call that ran as two spans
- * (earhip_render_last_tail_blocks > 0) both queries describe the SECOND span — a short call: the wide form, no hand-over. */
+ * of this renderer, like earhip_render_hinge_standby.  After a call that ran as two spans (earhip_render_last_tail_blocks
+ * > 0) both queries — like earhip_render_gain_kernel and earhip_render_last_plan — describe the MAIN span (the whole
+ * rounds of tiles: where the call's time goes); the short tail behind it runs the wide form without a hand-over. */
 int earhip_render_wide_form(earhip_render *r, int *wide);
 /* The launch plan of the last process call: [0] gain kernel (as above), [1] samples per
  * workgroup tile of the gain kernel, [2] number of such tiles, [3] grid-level object splits.
  * For tests and benchmarks that must know which kernel instantiation they measured. */
 int earhip_render_last_plan(const earhip_render *r, int out[4]);
+/* Layout of the piece lists of the last call (kernel 4, or the lists standing by behind kernel 5): *paired = 1 paired
+ * (an object's base and delta piece share one input request; curves that hold most of the time), 0 packed (every chunk
+ * sums its products among itself before it touches the running total: curves that ramp most of the time ALWAYS get this
+ * one, whatever their other statistics — the planner's rule, asserted by the tests), -1: the call built no piece lists. */
+int earhip_render_last_list_layout(const earhip_render *r, int *paired);
 /* A stream call whose tiles are whole rounds of the chip's workgroups plus a few (1025 blocks of 512 samples on 256 CUs)
  * is run as two consecutive calls — the whole rounds, then the few blocks behind them spread over the chip by object
  * splits — instead of paying a whole round for the few.  *blocks = the blocks of the last call that ran as such a tail

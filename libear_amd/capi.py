@@ -654,6 +654,12 @@ class Renderer:
         check(load().earhip_render_last_tail_blocks(self.h, C.byref(v)))
         return v.value
 
+    def last_list_layout(self):
+        """layout of the last call's piece lists: True paired, False packed, None: none built"""
+        v = C.c_int(0)
+        check(load().earhip_render_last_list_layout(self.h, C.byref(v)))
+        return None if v.value < 0 else bool(v.value)
+
     def last_plan(self):
         """launch plan of the last call: gain kernel, samples per workgroup tile, tiles, object splits"""
         out = (C.c_int * 4)()

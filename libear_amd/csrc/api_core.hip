@@ -1,6 +1,7 @@
 // api_core.hip — context, error reporting, the interpolation-policy entry
 // points (A) and the whole-curve GainInterpolator (A') of include/earhip.h.
 #include <cctype>
+#include <cerrno>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -67,8 +68,13 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   unsigned *gate = nullptr;                            // hinge kernel: "this call is the piece lists'" (k_hinge_gate)
   ctx->last_gate_idx = -1;
   ctx->last_wide_idx = -1;
+  unsigned *const record = ctx->record_slot;  // (the renderer's slot for this call's mode word; consumed here)
+  ctx->record_slot = nullptr;
   if ((ml.split || ml.pieces || ml.hinge) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
-    if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);  // [0..1] level words, [2..3] wide-mode words
+    // (the words, the per-object levels and the per-tile words below are made where a renderer is created —
+    // reserve_call_words —; a gain stage that comes here first, or a call larger than any renderer of the context announced,
+    // grows them here behind a synchronisation: counted in ctx->lazy_allocs, which a renderer reports with its regrows)
+    if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream), ctx->lazy_allocs++;  // [0..1] level words, [2..3] wide-mode words
     level_cur = ctx->level.p + ctx->level_idx;
     level_next = ctx->level.p + (ctx->level_idx ^ 1);
     // a short call (less than two rounds of workgroups: block mode) runs the wide form only: its latency does not
@@ -86,6 +92,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
       ctx->obj_level_cap = M + M / 2 + 64;
       ctx->obj_level.alloc_zero(2 * (size_t)ctx->obj_level_cap, ctx->stream);
+      ctx->lazy_allocs++;
     }
     probe.obj_level = ctx->obj_level.p;
     probe.level = level_cur;
@@ -114,6 +121,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       EARHIP_HIP(hipStreamSynchronize(ctx->stream));
       ctx->tile_slow_cap = std::max<size_t>(2 * (size_t)ml.ntiles, 1024);
       ctx->tile_slow.alloc_zero(2 * ctx->tile_slow_cap, ctx->stream);
+      ctx->lazy_allocs++;
     }
     slow_cur = ctx->tile_slow.p + (size_t)ctx->tile_slow_idx * ctx->tile_slow_cap;
     slow_next = ctx->tile_slow.p + (size_t)(ctx->tile_slow_idx ^ 1) * ctx->tile_slow_cap;
@@ -130,10 +138,12 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // with a probe: does the hinge kernel's span of levels cover this call?  (decided on the device: k_hinge_gate)
     if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate, wide_cur != nullptr);
     int tpw = 1;
-    while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= (size_t)kMaxHingeCached) tpw *= 2;
+    const size_t cached_max = std::min((size_t)kMaxHingeCached, ctx->hinge_build_lds / sizeof(HingeCached));  // (pairs a workgroup may keep)
+    if ((size_t)M > cached_max) fail_internal("hinge lists: more objects than the builder's LDS holds on this device");
+    while (tpw < 8 && ml.ntiles / (2 * tpw) >= ctx->num_cus && (size_t)M * (2 * tpw) <= cached_max) tpw *= 2;
     if (ctx->has(OPT_HBUILD_TPW)) {  // tuning knob
       const int v = ctx->get(OPT_HBUILD_TPW);
-      if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)M * v <= (size_t)kMaxHingeCached) tpw = v;
+      if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)M * v <= cached_max) tpw = v;
     }
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
     const size_t lds = sizeof(HingeCached) * (size_t)M * tpw;
@@ -195,6 +205,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
                        t_call, t_call + nsamples, fused_prep ? nullptr : desc, sl);
   if (ev) EARHIP_HIP(hipEventRecord(ev[1], ctx->stream));
   GainMixParams P;
+  P.mode_word = gate;
+  P.record = gate ? record : nullptr;
   P.sl = sl;
   P.in = in_dev;
   P.in_stride = in_stride;
@@ -278,6 +290,8 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     int wgs = std::max(8, (ctx->num_cus * per_cu / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
     if (ctx->has(OPT_H2_WGS)) wgs = std::max(1, ctx->get(OPT_H2_WGS));  // tuning knob
     wgs = std::max(wgs, ((ml.ntiles + 63) / 64 + 7) & ~7);  // (at most 64 tiles per workgroup: its redo mask)
+    // a workgroup's tiles as one contiguous run (option H2_RUNS: 1 on, 0 off; default: the single-column-tile forms — config 2)
+    P.tile_runs = ctx->has(OPT_H2_RUNS) ? (ctx->get(OPT_H2_RUNS) != 0) : 0;
     if (!h2_persistent(cp.nct, ml.tile() == 512 ? 8 : 4)) wgs = ml.ntiles;  // (a tile per workgroup)
     const dim3 bgrid(std::min(ml.ntiles, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
@@ -338,16 +352,45 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   EARHIP_HIP(hipGetLastError());
 }
 
+// What the split-operand kernels of a call of up to `max_samples` samples on M objects keep PER CONTEXT — the level and mode
+// words, the per-object levels of the probe, the per-tile "exact path" words of the grid kernel (tiles of 256 samples at the
+// smallest) — made where a renderer is created, so that no process call allocates or synchronises for them.
+void reserve_call_words(earhip_ctx *ctx, int M, size_t max_samples) {
+  if (!ctx->level.p) ctx->level.alloc_zero(4, ctx->stream);
+  const size_t ntiles = (max_samples + 255) / 256;
+  const bool grow_obj = ctx->obj_level_cap < M, grow_tiles = ctx->tile_slow_cap < ntiles;
+  if (grow_obj || grow_tiles) EARHIP_HIP(hipStreamSynchronize(ctx->stream));  // (calls of other stages may be using the old ones)
+  if (grow_obj) {
+    ctx->obj_level_cap = M + M / 2 + 64;
+    ctx->obj_level.alloc_zero(2 * (size_t)ctx->obj_level_cap, ctx->stream);
+  }
+  if (grow_tiles) {
+    ctx->tile_slow_cap = std::max<size_t>(ntiles + ntiles / 4, 1024);
+    ctx->tile_slow.alloc_zero(2 * ctx->tile_slow_cap, ctx->stream);
+    ctx->tile_slow_idx = 0;
+  }
+}
+
 // k_hinge_build keeps up to 128 KB of dynamic LDS per workgroup: the limit is an attribute of the function ON A DEVICE, so
 // every context raises it for its own device when it is created (a process-wide "done" flag left the other GPUs of a
 // multi-GPU process at the default 64 KB: launches with more failed there).
-void hinge_build_allow_lds() {
+// Returns the dynamic LDS a launch of the builder may ask for on this device: `want` (128 KB) where the device has it, else
+// what it allows (a device or runtime that refuses the attribute: the 64 KB every kernel has) — the launch picks its tiles
+// per workgroup within that (a limit, never a reason for context creation to fail).
+size_t hinge_build_allow_lds(const hipDeviceProp_t &prop) {
+  const size_t want = 128 * 1024, dflt = 64 * 1024;
+  const size_t device_max = std::max((size_t)prop.sharedMemPerBlock, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+  size_t ask = std::min(want, device_max > 4096 ? device_max - 4096 : dflt);  // (the kernel's static arrays: ~3 KB)
+  if (ask <= dflt) return dflt;
+  bool ok = true;
 #define EARHIP_HBUILD_ATTR(T_, NW_)                                                                       \
-  EARHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hinge_build<T_, NW_>),                 \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hinge_build<T_, NW_>),                 \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ask) == hipSuccess;
   EARHIP_HBUILD_ATTR(1, 4) EARHIP_HBUILD_ATTR(2, 4) EARHIP_HBUILD_ATTR(4, 4) EARHIP_HBUILD_ATTR(8, 4)
   EARHIP_HBUILD_ATTR(1, 8) EARHIP_HBUILD_ATTR(2, 8) EARHIP_HBUILD_ATTR(4, 8) EARHIP_HBUILD_ATTR(8, 8)
 #undef EARHIP_HBUILD_ATTR
+  if (!ok) (void)hipGetLastError();  // (refused: the default limit stands)
+  return ok ? ask : dflt;
 }
 
 // Device-resident M -> N gain stage with host staging; shared by the policy
@@ -419,8 +462,19 @@ using namespace earhip;
 
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
-    "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
+    "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "H2_RUNS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
     "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT"};
+
+// an option's value: a decimal integer (optional sign, surrounding blanks), nothing else — "abc" or "1x" used to read as 0 / 1
+static int parse_option_value(const std::string &key, const char *text) {
+  char *end = nullptr;
+  errno = 0;
+  const long v = std::strtol(text, &end, 10);
+  while (end && *end && std::isspace((unsigned char)*end)) end++;
+  if (end == text || (end && *end) || errno == ERANGE || v < -(1L << 30) || v > (1L << 30))
+    fail_invalid("option '" + key + "': '" + std::string(text) + "' is not an integer");
+  return (int)v;
+}
 
 void earhip_ctx::apply_options() {
   spl = 4, use_mfma = 3, x_scale_log2 = 14, x_scale_auto = true, max_waves = 4, tiles_per_wg = 4, tiles_per_wg_forced = false, nrt = 8;
@@ -587,9 +641,21 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
       throw Error{EARHIP_DEVICE_ERROR,
                   "internal error: no HIP device available (libearhip has no CPU fallback)"};
     require(device >= 0 && device < n, "device index out of range");
-    std::unique_ptr<earhip_ctx> c(new earhip_ctx);
+    // (an owned stream goes with the context whichever way this function is left)
+    struct CtxDelete {
+      void operator()(earhip_ctx *c) const {
+        if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+      }
+    };
+    std::unique_ptr<earhip_ctx, CtxDelete> c(new earhip_ctx);
     c->device = device;
     EARHIP_HIP(hipSetDevice(device));
+    // the options: once, from the environment (EARHIP_<KEY>); afterwards only earhip_ctx_set_option changes them
+    for (int o = 0; o < OPT_COUNT; o++) {
+      const std::string name = std::string("EARHIP_") + kOptNames[o];
+      if (const char *e = getenv(name.c_str())) c->opt[o].set = true, c->opt[o].v = parse_option_value(name, e);
+    }
     if (hip_stream) {
       c->stream = (hipStream_t)hip_stream;
     } else {
@@ -599,12 +665,7 @@ int earhip_ctx_create(int device, void *hip_stream, earhip_ctx **out) {
     hipDeviceProp_t prop;
     EARHIP_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    hinge_build_allow_lds();  // (this device's limit)
-    // the options: once, from the environment (EARHIP_<KEY>); afterwards only earhip_ctx_set_option changes them
-    for (int o = 0; o < OPT_COUNT; o++) {
-      const std::string name = std::string("EARHIP_") + kOptNames[o];
-      if (const char *e = getenv(name.c_str())) c->opt[o].set = true, c->opt[o].v = atoi(e);
-    }
+    c->hinge_build_lds = hinge_build_allow_lds(prop);  // (this device's limit)
     c->apply_options();
     *out = c.release();
   });
@@ -618,8 +679,10 @@ int earhip_ctx_set_option(earhip_ctx *ctx, const char *key, const char *value) {
     if (k.compare(0, 7, "EARHIP_") == 0) k = k.substr(7);
     for (int o = 0; o < OPT_COUNT; o++)
       if (k == kOptNames[o]) {
-        ctx->opt[o].set = value != nullptr && value[0] != 0;
-        ctx->opt[o].v = ctx->opt[o].set ? atoi(value) : 0;
+        const bool set = value != nullptr && value[0] != 0;
+        const int v = set ? parse_option_value(k, value) : 0;  // (refused before anything changes)
+        ctx->opt[o].set = set;
+        ctx->opt[o].v = v;
         ctx->apply_options();
         return;
       }

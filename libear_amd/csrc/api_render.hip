@@ -185,10 +185,15 @@ struct earhip_render {
   std::unique_ptr<CurveSet> curves;
   int64_t t = 0;  // sample clock: absolute time of the next block
   int last_plan[3] = {0, 0, 0};  // tile samples, tiles, grid-level object splits of the last call
+  int last_paired = -1;          // layout of its piece lists: 1 paired, 0 packed, -1 none built
   size_t last_scratch_bytes = 0;  // K0 / K1 scratch the last call needed
   long scratch_regrows = 0;       // process calls that had to grow the scratch themselves (none on committed curves)
-  int last_gate_idx = -1;  // the context's mode word of THIS renderer's last call when it was planned for the hinge kernel, else -1
-  int last_wide_idx = -1;  // ... when its split-operand kernel picked its form (plain / wide) on the device, else -1
+  // What the last call's gain kernel decided on the device: the kernel that did the call left a copy of the context's mode
+  // word in THIS renderer's own slot (rec[0]: the call, or the main span of a call cut in two; rec[1]: the tail span), so the
+  // queries below stay valid whatever other renderers of the context do afterwards.
+  DevBuf<unsigned> rec;
+  bool last_gated = false;       // the last call (its main span) was planned for the hinge kernel behind a device-side gate
+  bool last_device_form = false; // ... its split-operand kernel picked its form (plain / wide) on the device
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 f32 MFMA on the tile grid, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
                        // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
@@ -303,12 +308,16 @@ struct earhip_render {
   // second K2 launch and the boundaries (~30 us): taken when the tail is at most a quarter of a round.  Results are those
   // of two consecutive calls (every call length is a valid call: the state carries over).
   void process_device(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev, size_t out_stride) {
+    MixLaunch whole;  // the plan of the uncut call, made once (process_span takes it as it is)
+    bool have_plan = false;
     if (!ctx->strict && ctx->get(OPT_TAILCUT, 1) != 0 && nblocks >= 2) {
+      last_in_stride = in_stride;
       if (curves->dirty()) {
         curves->commit(ctx);
         reserve_for_curves();
       }
-      const MixLaunch ml = plan_call(nblocks, in_stride);
+      const MixLaunch ml = whole = plan_call(nblocks, in_stride);
+      have_plan = true;
       const int W = resident_workgroups(ml);
       if (W > 0 && ml.gsplit == 1 && ml.ntiles > W) {
         const size_t tile = (size_t)ml.tile();
@@ -321,8 +330,11 @@ struct earhip_render {
           process_span(main_blocks, in_dev, in_stride, out_dev, out_stride, false);
           const int kind = last_kind, plan3[3] = {last_plan[0], last_plan[1], last_plan[2]};
           const size_t scratch = last_scratch_bytes;
+          const bool gated = last_gated, device_form = last_device_form;
+          const int paired = last_paired;
           process_span(nblocks - main_blocks, in_dev + main_samples, in_stride, out_dev + main_samples, out_stride, true);
-          last_kind = kind;  // (what the call is reported as: its main part)
+          last_kind = kind;  // (what the call is reported as: its main part — kernel, plan and what it decided on the device)
+          last_gated = gated, last_device_form = device_form, last_paired = paired;
           for (int i = 0; i < 3; i++) last_plan[i] = plan3[i];
           last_scratch_bytes = scratch;
           last_tail_blocks = (int)(nblocks - main_blocks);
@@ -331,12 +343,12 @@ struct earhip_render {
       }
     }
     last_tail_blocks = 0;
-    process_span(nblocks, in_dev, in_stride, out_dev, out_stride, false);
+    process_span(nblocks, in_dev, in_stride, out_dev, out_stride, false, have_plan ? &whole : nullptr);
   }
   int last_tail_blocks = 0;  // blocks of the last call that ran as its tail part (0: the call was not cut)
 
   void process_span(size_t nblocks, const float *in_dev, size_t in_stride, float *out_dev,
-                    size_t out_stride, bool continues) {
+                    size_t out_stride, bool continues, const MixLaunch *planned = nullptr) {
     const int nsamples = (int)(nblocks * (size_t)B);
     last_in_stride = in_stride;
     if (curves->dirty()) {
@@ -344,7 +356,7 @@ struct earhip_render {
       reserve_for_curves();
     }
     const bool strict = ctx->strict;
-    MixLaunch ml = plan_call(nblocks, in_stride);
+    MixLaunch ml = planned ? *planned : plan_call(nblocks, in_stride);
     if (ml.hinge) curves->ensure_kinks(ctx);  // (already there unless an option changed the plan since the commit)
 
     last_kind = ml.f32grid ? 2 : ml.hinge ? 5 : ml.pieces ? 4 : ml.split ? 3 : ml.mfma ? 1 : 0;
@@ -366,6 +378,7 @@ struct earhip_render {
     // (the bus is sized for every plan plan_mix can make, earhip_render_create; should a tuning knob push a plan
     // beyond it, plan_call has taken fewer object splits, always a valid plan)
     if (part_stride * ml.gsplit > bus.n) fail_internal("bus buffer too small for this launch plan");
+    last_paired = (ml.pieces || ml.hinge) ? (ml.paired ? 1 : 0) : -1;
     last_plan[0] = ml.tile();
     last_plan[1] = ml.ntiles;
     last_plan[2] = ml.gsplit;
@@ -380,6 +393,8 @@ struct earhip_render {
       pd.continues = continues;
       evp = pd.e;
     }
+    const long lazy_before = ctx->lazy_allocs;
+    ctx->record_slot = rec.p + (continues ? 1 : 0);  // (consumed by the launch_gain_mix below)
     if (K == 1) {
       // direct bus only: K1 writes the output rows itself
       if (ml.gsplit == 1) {
@@ -449,8 +464,9 @@ struct earhip_render {
       fresh = false;
     }
     if (timed) pending.push_back(pd);
-    last_gate_idx = ctx->last_gate_idx;  // (set by launch_gain_mix for this call)
-    last_wide_idx = ctx->last_wide_idx;
+    last_gated = ctx->last_gate_idx >= 0;  // (set by launch_gain_mix for this call)
+    last_device_form = ctx->last_wide_idx >= 0;
+    if (ctx->lazy_allocs != lazy_before) scratch_regrows++;  // (a buffer of the context no renderer had announced: earhip.h)
     t += nsamples;
   }
 };
@@ -502,6 +518,8 @@ int earhip_render_create(earhip_ctx *ctx, const earhip_render_config *cfg, earhi
     }
     r->curves.reset(new CurveSet(r->M, r->K * r->N, r->K, false));
     const size_t max_samples = (size_t)r->T * r->B;
+    reserve_call_words(ctx, r->M, max_samples);  // (the context's words for calls of this size: no process call makes them)
+    r->rec.alloc_zero(2, ctx->stream);
     // smallest tile any gain kernel of this context uses (f32 MFMA: 16 * nrt samples)
     const size_t min_tile = (size_t)std::min(16 * ctx->nrt, std::min(64 * ctx->spl, 256));
     const size_t max_tiles = (max_samples + min_tile - 1) / min_tile;
@@ -759,13 +777,13 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby) {
     require(r != nullptr && standby != nullptr, "NULL argument");
     *standby = 0;
     earhip_ctx *ctx = r->ctx;
-    // (this renderer's own word index; the word itself belongs to the context and is cleared by the next probed call of
-    // ANY stage on it: the query is valid until then — include/earhip.h)
-    if (r->last_kind != 5 || r->last_gate_idx < 0 || !ctx->level.p) return;
+    // (the copy of the mode word the call's own gain kernel left in this renderer's slot: valid until this renderer's next call)
+    if (r->last_kind != 5 || !r->last_gated) return;
     ctx->use();
     unsigned word = 0;
-    EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + r->last_gate_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(&word, r->rec.p, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    if (!(word & kModeRecorded)) fail_internal("no gain kernel recorded the call's mode word");
     *standby = (word & kGateHingeUnsafe) ? 1 : 0;
   });
 }
@@ -776,11 +794,12 @@ int earhip_render_wide_form(earhip_render *r, int *wide) {
     *wide = 1;
     earhip_ctx *ctx = r->ctx;
     if (r->last_kind < 3) *wide = -1;  // (no split operands at all)
-    if (r->last_kind < 3 || r->last_wide_idx < 0 || !ctx->level.p) return;
+    if (r->last_kind < 3 || !r->last_device_form) return;
     ctx->use();
     unsigned word = 0;
-    EARHIP_HIP(hipMemcpyAsync(&word, ctx->level.p + 2 + r->last_wide_idx, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipMemcpyAsync(&word, r->rec.p, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    if (!(word & kModeRecorded)) fail_internal("no gain kernel recorded the call's mode word");
     *wide = (word & 1u) ? 1 : 0;
   });
 }
@@ -803,6 +822,13 @@ int earhip_render_last_tail_blocks(const earhip_render *r, int *blocks) {
   return guarded([&] {
     require(r != nullptr && blocks != nullptr, "NULL argument");
     *blocks = r->last_tail_blocks;
+  });
+}
+
+int earhip_render_last_list_layout(const earhip_render *r, int *paired) {
+  return guarded([&] {
+    require(r != nullptr && paired != nullptr, "NULL argument");
+    *paired = r->last_paired;
   });
 }
 

@@ -124,7 +124,7 @@ namespace earhip {
 // EARHIP_<KEY>.  Nothing on a process call's path reads the environment.  (include/earhip.h, group A, lists the keys.)
 enum Opt {
   OPT_SPL, OPT_MFMA, OPT_XSCALE, OPT_WAVES, OPT_TPW, OPT_NRT,            // gain kernels' shapes (context-wide)
-  OPT_H2_TILE, OPT_H2_WGS, OPT_P2_TILE, OPT_P2_PAIRS, OPT_P2_WGS, OPT_HINGE, OPT_HG_TILE, OPT_HBUILD_TPW, OPT_BUILD_TPW,  // launch plan of a call
+  OPT_H2_TILE, OPT_H2_WGS, OPT_H2_RUNS, OPT_P2_TILE, OPT_P2_PAIRS, OPT_P2_WGS, OPT_HINGE, OPT_HG_TILE, OPT_HBUILD_TPW, OPT_BUILD_TPW,  // launch plan of a call
   OPT_K2_WG, OPT_K2_OWN_BLOCK, OPT_RUN, OPT_GSPLIT,                      // decorrelator kernel / renderer creation
   OPT_PROBE_RUNS, OPT_BLOCK_GROUPS, OPT_DEBUG_TIMING, OPT_TAILCUT,
   OPT_COUNT
@@ -161,11 +161,14 @@ struct earhip_ctx {
   earhip::DevBuf<unsigned> obj_level;  // [2][obj_level_cap] per-object input levels of the current call (float bits): the largest and the
                                        // smallest non-zero magnitude the level probe saw (k_level_probe: plain stores, no state between calls)
   int obj_level_cap = 0;
+  long lazy_allocs = 0;  // process calls that had to make or grow one of the buffers above themselves (reserve_call_words did not cover them)
+  unsigned *record_slot = nullptr;  // where the NEXT launch_gain_mix leaves a copy of its call's mode word (a renderer's own slot; consumed by the launch)
   int max_waves = 4;  // waves per gain_mix workgroup (column groups x object splits)
   int tiles_per_wg = 4;  // MFMA kernel: adjacent tiles per workgroup (share gain rows through L1)
   bool tiles_per_wg_forced = false;  // (EARHIP_TPW: taken as given)
   int nrt = 8;  // 16-sample row tiles per wave of the MFMA kernel (4 or 8)
   int num_cus = 256;
+  size_t hinge_build_lds = 64 * 1024;  // dynamic LDS a launch of k_hinge_build may ask for on this device (earhip_ctx_create)
   // host memory the device reaches directly: earhip_host_alloc / earhip_host_register ranges (the host-pointer
   // entry points skip their staging copies for channel pointers that are evenly spaced inside one of them)
   struct HostRange {

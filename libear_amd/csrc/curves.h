@@ -721,7 +721,11 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // over the whole tile: always-ramping curves K1 0.82 vs 0.97 ms on 512).
     // EARHIP_P2_PAIRS=0|1 and EARHIP_P2_TILE=256|512 force one of them (tests, tuning).
     const double kPairWaste = 0.06;
-    L.paired = pair_waste256 < kPairWaste;
+    // Curves that ramp most of the time never get it, whatever their waste: with (nearly) every object ramping in every tile
+    // the pair chunks put ~3 M products straight onto the running totals (1.0e-6 from the CPU path at 1024 objects, measured),
+    // where the packed layout's chunks sum among themselves first (7.2e-7).
+    const double kMostlyRamping = 0.5;  // (= kHingeRamps below: the curves the hinge kernel is for)
+    L.paired = pair_waste256 < kPairWaste && ramp_share < kMostlyRamping;
     if (ctx->has(OPT_P2_PAIRS)) L.paired = ctx->get(OPT_P2_PAIRS) != 0;
     // (short calls — block mode — keep the 256-sample tiles: twice the workgroups)
     const bool long_call = nsamples / 512 >= 2 * ctx->num_cus;
@@ -734,9 +738,11 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // hold most of the time (ramp for a while, then constant) stay on the paired piece lists, which skip the position
     // factors of the objects at rest.  6 forces it, EARHIP_HINGE=0 / 1 overrides the choice.
     const double kHingeExact = 0.005, kHingeRamps = 0.5;
-    L.hinge = M <= kMaxHingeCached && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps;
-    if (ctx->has(OPT_HINGE)) L.hinge = ctx->get(OPT_HINGE) != 0 && M <= kMaxHingeCached && hinge_exact_share <= 1.0;
-    if (ctx->use_mfma == 6) L.hinge = M <= kMaxHingeCached && hinge_exact_share <= 1.0;
+    // (its list builder keeps 16 bytes per object and tile in LDS: as many objects as this device's limit holds)
+    const int hinge_max = (int)std::min((size_t)kMaxHingeCached, ctx->hinge_build_lds / 16);
+    L.hinge = M <= hinge_max && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps;
+    if (ctx->has(OPT_HINGE)) L.hinge = ctx->get(OPT_HINGE) != 0 && M <= hinge_max && hinge_exact_share <= 1.0;
+    if (ctx->use_mfma == 6) L.hinge = M <= hinge_max && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
     if (L.hinge) {
       if (ctx->has(OPT_HG_TILE)) L.hinge_tile = ctx->get(OPT_HG_TILE) == 256 ? 256 : 512;  // tuning knob
@@ -806,6 +812,7 @@ inline size_t bus_samples_bound(const earhip_ctx *ctx, size_t max_samples, int m
 }
 
 size_t mix_lds_bytes(const ColumnPlan &cp, const MixLaunch &ml);
+void reserve_call_words(earhip_ctx *ctx, int M, size_t max_samples);  // api_core.hip
 
 // 16-byte units of the scratch buffer launch_gain_mix needs for a plan: descriptors (grid kernel, VALU kernel), + slot lists
 // (f32 kernel), piece lists sized from the curves, hinge lists (+ the piece lists standing by for them)

@@ -147,7 +147,18 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   // the CU to cover it: 8 % of the kernel at 32 chunks per tile, a quarter at 4.)  vb % 8 = the XCD for every
   // tile of a workgroup when gridDim.x is a multiple of 8.
   const int ntl = P.ntiles, gx = gridDim.x;
-  if (wide_next && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *wide_next = 0u;
+  // P.tile_runs: a workgroup takes a contiguous RUN of tiles (the balanced partition of [0, ntl) over the workgroups) instead
+  // of every gx-th one: its 64 row pieces of consecutive tiles are neighbours in memory (option H2_RUNS; config 2's shape)
+  const bool runs = P.tile_runs != 0;
+  const int run_first = (int)(((int64_t)ntl * blockIdx.x) / gx), run_end = (int)(((int64_t)ntl * (blockIdx.x + 1)) / gx);
+  const int vb0 = runs ? run_first : (int)blockIdx.x, vstep = runs ? 1 : gx;
+  const int vb_last = runs ? max(run_end - 1, run_first) : ntl - 1;
+  const int my_tiles = runs ? run_end - run_first : (ntl - (int)blockIdx.x + gx - 1) / gx;
+  auto tile_at = [&](int vb) { return runs ? min(vb, ntl - 1) : xcd_tile(vb, ntl); };
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    if (wide_next) *wide_next = 0u;
+    record_mode(P, wide_cur != nullptr);
+  }
   if (level_cur) {
     // input scale of THIS call from the level K0 probed: the largest magnitude seen, in [2^E, 2^(E+1)),
     // goes to [2^7, 2^8) — peaks up to 256x the probed maximum stay inside the f16 range (beyond:
@@ -336,15 +347,14 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     struct Stage {
       int tile, c;
     };
-    const int my_tiles = (ntl - (int)blockIdx.x + gx - 1) / gx;
     int left = my_tiles * nch;
-    int vb_c = blockIdx.x;  // stage C's tile counter
+    int vb_c = vb0;  // stage C's tile counter
     auto next_stage = [&](const Stage &s) __attribute__((always_inline)) {
       Stage n;
       const bool wrap = s.c + 1 == nch;
       n.c = wrap ? 0 : s.c + 1;
-      if (wrap) vb_c = min(vb_c + gx, ntl - 1);
-      n.tile = wrap ? xcd_tile(vb_c, ntl) : s.tile;
+      if (wrap) vb_c = min(vb_c + vstep, vb_last);
+      n.tile = wrap ? tile_at(vb_c) : s.tile;
       return n;
     };
     const unsigned bcol_e = (unsigned)(col0 + min(lane, 16 * NCT - 1));  // the lane's gain column
@@ -456,7 +466,7 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     f32x4 X0[8], X1[8];
     ChunkDesc L;
     Stage sa, sb, sc;
-    sa.tile = xcd_tile(vb_c, ntl);
+    sa.tile = tile_at(vb_c);
     sa.c = 0;
     sb = next_stage(sa);
     sc = next_stage(sb);
@@ -631,9 +641,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   }
   // tiles done exactly and unscaled: every tile of unaligned rows or of fewer objects than a chunk, and the tiles
   // whose totals were not finite
-  for (int k = 0, vb = blockIdx.x; vb < ntl; k++, vb += gx) {
+  for (int k = 0; k < my_tiles; k++) {
     if (nch > 0 && !((redo_tiles[w] >> (k & 63)) & 1ull)) continue;
-    const int t = xcd_tile(vb, ntl);
+    const int t = tile_at(vb0 + k * vstep);
     if (nch == 0 && slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[t] = 0u;
     for (int m = m_lo; m < m_hi; m++) single_object(t, m, 1.0f, false);
     flush_tile(t, 1.0f, false);

@@ -45,7 +45,10 @@ k_gain_mix_h2_t1(GainMixParams P, int zero_row, float x_scale, const float *__re
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, kg = lane >> 4;
   const int wgtile = xcd_tile(blockIdx.x, gridDim.x);
-  if (wide_next && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *wide_next = 0u;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    if (wide_next) *wide_next = 0u;
+    record_mode(P, wide_cur != nullptr);
+  }
   if (level_cur) {
     // input scale of THIS call from the level K0 probed: the largest magnitude seen, in [2^E, 2^(E+1)),
     // goes to [2^7, 2^8) — peaks up to 256x the probed maximum stay inside the f16 range (beyond:

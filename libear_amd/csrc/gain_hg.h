@@ -511,6 +511,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
       *level_next = 0;
       if (wide_next) *wide_next = 0u;
+      record_mode(P, wide_cur != nullptr);
     }
   }
   const int nparts = gridDim.y, part = blockIdx.y;

@@ -519,7 +519,18 @@ struct GainMixParams {
   int tiles_per_wg;     // MFMA kernel: adjacent tiles handled by one workgroup
   int vec_ok;           // in/out rows are 16-byte aligned: vector accesses allowed
   SlotLists sl;         // f32 MFMA kernel: the tile's slot lists (k_slot_list)
+  // split-operand kernels: the context's mode word of THIS call (bit 0: wide form, bit 1: the hinge kernel handed the call
+  // to the piece lists) and where the kernel that does the call leaves a copy of it for the renderer's queries
+  // (earhip_render_wide_form / _hinge_standby): the word itself is the context's and is cleared two calls later
+  int tile_runs = 0;    // grid kernel: a workgroup's tiles are a contiguous run (else every gridDim.x-th tile)
+  const unsigned *mode_word = nullptr;
+  unsigned *record = nullptr;
 };
+constexpr unsigned kModeRecorded = 4u;  // bit 2 of a recorded mode word: "a split-operand kernel wrote this"
+// what the kernel that does a call leaves in P.record (one thread of the grid; `device_form`: the form was picked on the device)
+__device__ __forceinline__ void record_mode(const GainMixParams &P, bool device_form) {
+  if (P.record) *P.record = (P.mode_word ? *P.mode_word : 0u) | (device_form ? 0u : 1u) | kModeRecorded;
+}
 
 // accumulate one segment piece of one object into acc
 template <int NOUT, int SPL, bool STRICT>

@@ -431,6 +431,7 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
       // (the grid kernel's mode word of the NEXT call: whichever kernel runs a call clears it, or a "wide" left by an
       // earlier call would keep the grid kernel in its slower form two calls later)
       if (wide_next) *wide_next = 0u;
+      record_mode(P, wide_cur != nullptr);
     }
   }
   const int nparts = gridDim.y;
