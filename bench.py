@@ -388,7 +388,7 @@ def main():
     import scenes
     from layouts import LAYOUTS
     from libear_amd import capi
-    from libear_amd.distributed import channel_range, exchange, exchange_model, padded_channels, shard_range, time_range
+    from libear_amd.distributed import channel_range, exchange, exchange_model, lead_blocks, padded_channels, shard_range, time_range
 
     names = LAYOUTS[cfg["layout"]]
     N, B, T, K = len(names), cfg["block_size"], cfg["blocks"], cfg["buses"]
@@ -427,6 +427,24 @@ def main():
                 native_comm.close()
             native_comm = None
             native_note = "earhip_comm_create failed on a rank" + (f" ({err})" if err else "") + ": torch.distributed exchange"
+    # what RCCL itself reports (every rank's count / device, gathered on rank 0) and the link rate it gives a 50 MB
+    # ncclSend / ncclRecv pair per rank — the exchange model below uses THAT, not an assumed figure
+    rccl_info, link_measured = None, None
+    if native_comm is not None:
+        mine = native_comm.info()
+        infos = [None] * world
+        dist.all_gather_object(infos, mine)
+        rates = []
+        for shift in sorted({1, world // 2} - {0}):
+            g = torch.tensor([native_comm.link_probe(50 << 20, shift, 5)], device=dev, dtype=torch.float64)
+            dist.all_reduce(g, op=dist.ReduceOp.MIN)
+            rates.append({"shift": shift, "GBps_per_direction_slowest_rank": round(float(g.item()), 1)})
+        link_measured = min(r["GBps_per_direction_slowest_rank"] for r in rates)
+        rccl_info = {"ranks": mine["ranks"], "version": mine["version"], "devices": [i["device"] for i in infos],
+                     "all_ranks_agree": bool(all(i["ranks"] == world for i in infos) and [i["rank"] for i in infos] == list(range(world))),
+                     "link_probe": {"bytes": 50 << 20, "pairs": rates,
+                                    "note": "every rank sends 50 MB to rank + shift and receives 50 MB from rank - shift at once "
+                                            "(ncclSend / ncclRecv), 5 rounds between HIP events: the slowest rank's rate"}}
     gather_root = 0  # the rank that ends up with the whole loudspeaker bus (north_star: "the shared loudspeaker bus")
 
     class Workload:
@@ -489,7 +507,8 @@ def main():
             gen = torch.Generator(device=dev)
             gen.manual_seed(1234 + seed)
             # (time-sharded: a rank's blocks [b0, b1) of the stream and `lead` blocks in front of them)
-            self.b0, self.b1, self.lead = time_range(T, rank, world, partitions=(-(-512 // B) if K == 2 else 1)) if self.time_sharded else (0, T, 0)
+            self.b0, self.b1, self.lead = (time_range(T, rank, world, partitions=(-(-512 // B) if K == 2 else 1), delay_blocks=-(-delay // B))
+                                           if self.time_sharded else (0, T, 0))
             self.in_stride = total + args.row_pad
             rows = max(self.M, 1)
             # (the samples do not depend on the padding: the rows are drawn as a [rows][total] block)
@@ -650,15 +669,17 @@ def main():
     if world > 1 and wl.time_sharded:
         # time sharding's own check: the rank's blocks after ONE lead block equal the same blocks after THREE (the state a
         # lead block leaves is the stream's: nothing older than one block reaches a block's output)
-        if wl.b0 >= 3:
+        far = wl.lead + 2  # (the second render starts two blocks further back)
+        ncmp = max(1, min(4, wl.Tc - far))  # blocks compared (a rank with few blocks: fewer)
+        if wl.b0 >= far and wl.Tc > far:
             wl.step(0, exchange_outputs=False)
             torch.cuda.synchronize()
-            one = wl.outs[wl.last_slot][:N, wl.lead * B:(wl.lead + 4) * B].clone()
-            t_lo = (wl.b0 - 3) * B
+            one = wl.outs[wl.last_slot][:N, wl.lead * B:(wl.lead + ncmp) * B].clone()
+            t_lo = (wl.b0 - far) * B
             wl.r.reset(t_lo)
-            wl.r.process_device(min(7, wl.Tc), wl.x.data_ptr() + 4 * t_lo, wl.in_stride, wl.outs[wl.last_slot].data_ptr(), wl.clen)
+            wl.r.process_device(far + ncmp, wl.x.data_ptr() + 4 * t_lo, wl.in_stride, wl.outs[wl.last_slot].data_ptr(), wl.clen)
             torch.cuda.synchronize()
-            three = wl.outs[wl.last_slot][:N, 3 * B:7 * B]
+            three = wl.outs[wl.last_slot][:N, far * B:(far + ncmp) * B]
             err = ((one - three).abs().max() / three.abs().max().clamp_min(1e-30)).to(torch.float64).reshape(1)
         else:
             err = torch.zeros(1, device=dev, dtype=torch.float64)
@@ -715,7 +736,7 @@ def main():
     # two steps on its own stream — with the renders of the following step running beside them)
     exchange_info = None
     if world > 1 and wl.time_sharded:
-        exchange_info = {"mode": "time", "reduce_scatter_bytes_per_rank": 0, "gather_bytes_into_root": 0,
+        exchange_info = {"mode": "time", "rccl": rccl_info, "reduce_scatter_bytes_per_rank": 0, "gather_bytes_into_root": 0,
                          "blocks_of_this_rank": [wl.b0, wl.b1], "lead_blocks": wl.lead,
                          "note": "no exchange: every rank renders all objects for its blocks of the stream; the outputs of "
                                  "different time ranges live on different ranks"}
@@ -727,6 +748,7 @@ def main():
                          "root": gather_root if wl.gather else None,
                          "rows_per_rank": per, "row_floats": total, "chunks_per_step": wl.nch,
                          "overlap": "a chunk's collectives run beside the render of the step's next chunk (and the last one's beside the next step)"}
+        exchange_info["rccl"] = rccl_info
         if native_comm is not None and not wl.time_sharded:
             # (the slots hold the collectives of the last two CHUNKS: a step's are wl.nch of them)
             ms = 0.5 * (native_comm.last_exchange_ms(0) + native_comm.last_exchange_ms(1)) * wl.nch
@@ -793,10 +815,13 @@ def main():
             # exchange_model.  Objects modes: every rank renders its shard completely (K0 + K1 on M / G objects, K2 on all
             # loudspeakers), the exchange runs chunk by chunk beside the render: predicted = max(compute, exchange) + what the
             # first chunk's render and the last chunk's exchange leave uncovered.  Time mode: compute only.
-            link = float(os.environ.get("EARHIP_XGMI_GBPS", "50"))
+            link_env = os.environ.get("EARHIP_XGMI_GBPS")
+            link = float(link_env) if link_env else (link_measured if link_measured else 50.0)
             t_comp = k0_ms + k1_ms + k2_ms
             exchange_info["model"] = exchange_model(args.shard, world, n_pad, total, t_comp, link, wl.nch)
             exchange_info["model"]["measured_ms_per_step"] = round(t_step * 1e3, 4)
+            exchange_info["model"]["link_rate_source"] = ("EARHIP_XGMI_GBPS" if link_env else "measured at start-up: exchange.rccl.link_probe"
+                                                          if link_measured else "assumed (no native communicator to probe with)")
             exchange_info["model"]["note"] = "compute = this rank's kernels (HIP events); the exchange figures are a model"
         # what the fused chain itself moves: K1's bytes, plus (two buses) K2 reading the buses back and writing the outputs
         fused_b = gain_b + (4 * (K * N * B) + 4 * N * B + 2 * 4 * N * 255 / max(T, 1) if K == 2 else 0)
@@ -896,7 +921,7 @@ def main():
                          "avg_launch_ms": round(k1_ms / k1_launches, 4)},
             "roofline_mfma": mfma_roofline(gain_kernel, K * M * N * B * T_rank, k1_ms),
             "exchange_check": ({"max_rel_diff_one_lead_block_vs_three": float(f"{lead_check:.3e}"),
-                                "bit_identical": bool(lead_check == 0.0)} if lead_check is not None else
+                                "bit_identical": bool(lead_check == 0.0), "pass": bool(lead_check <= 5e-7)} if lead_check is not None else
                                None if exchange_err is None else
                                {"max_rel_err_owned_slice_vs_all_reduce": float(f"{exchange_err:.3e}"),
                                 "same_partials_exchanged_twice_bit_identical": exchange_repeat_identical}),
@@ -1015,6 +1040,57 @@ def main():
                                                        "note": "channel buffers from earhip_host_alloc: one strided H2D, "
                                                                "kernels, outputs written in place, sync"}}
 
+        # ---- libear's own calling convention in the record: earhip_render_process from HOST channel pointers, stream-length
+        # calls (src/dsp/variable_block_size_impl.cpp:44-81: `const float *const *in, float *const *out`) — PCIe-inclusive,
+        # never `value`.  The call runs as a pipeline of time chunks (H2D / kernels / D2H on three streams); the 100 % mark is
+        # what a plain hipMemcpyAsync of the same bytes from the same kind of memory takes, measured here.
+        if world == 1 and not args.stream_only and not args.brief and M >= 16:
+            hs = {"what": "earhip_render_process (host channel pointers: staging or strided DMA, H2D, K0-K2, D2H, sync) in calls of "
+                          "64 and 256 blocks; frac = input bytes per second over the measured H2D rate of a plain copy from the same memory",
+                  "never_value": True, "calls": []}
+            hb_max = min(256, T)
+            rh = wl.renderer(ctx, max_blocks=hb_max)
+            xh_all = np.ascontiguousarray(wl.x[:, :hb_max * B].cpu().numpy())
+            xp_all = ctx.pinned_array((max(M, 1), hb_max * B))
+            xp_all[...] = xh_all
+            h2d_ms_pin, d2h_ms_pin = ctx.copy_bandwidth(xp_all, reps=3)
+            h2d_ms_page, _ = ctx.copy_bandwidth(xh_all, reps=2)
+            hs["h2d_GBps_measured"] = {"pinned": round(xp_all.nbytes / h2d_ms_pin / 1e6, 1), "pageable": round(xh_all.nbytes / h2d_ms_page / 1e6, 1),
+                                       "d2h_pinned": round(xp_all.nbytes / d2h_ms_pin / 1e6, 1), "bytes": int(xp_all.nbytes)}
+            xp_all[...] = xh_all  # (the D2H leg wrote the buffer back: the same bytes, restored for clarity)
+            for hb in sorted({min(64, hb_max), hb_max}):
+                xh = np.ascontiguousarray(xh_all[:, :hb * B])
+                xp = ctx.pinned_array((max(M, 1), hb * B))
+                xp[...] = xh
+                yp = ctx.pinned_array((N, hb * B))
+                for src, (xa, ya) in (("pageable", (xh, None)), ("pinned", (xp, yp))):
+                    def call():
+                        rh.reset(0)
+                        if ya is None:
+                            return rh.process(xa)
+                        return rh.process_into(xa, ya)
+                    first = np.array(call())
+                    call()
+                    ts = []
+                    for _ in range(5):
+                        c0 = time.perf_counter()
+                        call()
+                        ts.append(time.perf_counter() - c0)
+                    hdt = sorted(ts)[len(ts) // 2]
+                    gbps = xa.nbytes / hdt / 1e9
+                    ref_rate = hs["h2d_GBps_measured"]["pinned"]
+                    hs["calls"].append({"source": src, "blocks_per_call": hb, "ms_per_call": round(hdt * 1e3, 3),
+                                        "Gsamples_per_s": round(M * hb * B / hdt / 1e9, 2), "GBps_in": round(gbps, 1),
+                                        "h2d_GBps_measured": ref_rate, "frac": round(gbps / ref_rate, 3),
+                                        "frac_of_pageable_copy": round(gbps / hs["h2d_GBps_measured"]["pageable"], 3) if src == "pageable" else None,
+                                        # (same blocks as the timed stream's first ones: held against the device-resident render)
+                                        "max_rel_diff_vs_stream_render": None, "_first": first})
+                ctx.release(xp)
+                ctx.release(yp)
+            ctx.release(xp_all)
+            rh.close()
+            result["host_stream"] = hs
+
         # ---- parity gate on the TIMED output: every step starts from reset(0), so the first blocks of
         # the buffer the last timed step wrote are the first blocks of the stream, produced by the very
         # launch plan that was timed; the CPU oracle renders the same blocks.  Per channel.
@@ -1036,9 +1112,11 @@ def main():
 
             def window(b0, count):
                 """blocks [b0, b0 + count) of the timed buffer and the CPU path's render of them (one lead block in front of
-                a window inside the stream: tail and delay line of the oracle are the stream's by then — FIRs of one partition)"""
+                a window inside the stream — as many as the FIRs and the delay reach back: tail, history and delay line of the
+                oracle are the stream's by then)"""
                 a0 = base + b0
-                lead = 1 if a0 > 0 else 0
+                # (the decorrelated bus reaches 511 samples back, the delayed direct bus 255: ceil(511 / B) lead blocks)
+                lead = min(a0, lead_blocks(B, 512 if K == 2 else 1, delay))
                 lo, hi = (a0 - lead) * B, (a0 + count) * B
                 xs_ = wl.x[:, lo:hi].cpu().numpy()
                 win_ = scenes.window_curves(wl.curves, lo, hi)
@@ -1048,6 +1126,12 @@ def main():
                     o.set_points(m, 1, t, f if K == 2 else np.zeros_like(d))
                 return buf[:N, b0 * B:(b0 + count) * B].cpu().numpy(), o.process(xs_)[:, lead * B:], xs_, win_
 
+            if result.get("host_stream") and world == 1:
+                for e in result["host_stream"]["calls"]:
+                    f_ = e.pop("_first")
+                    ref_ = buf[:N, :f_.shape[1]].cpu().numpy()
+                    e["max_rel_diff_vs_stream_render"] = float(f"{scenes.rel_rms_per_channel(f_, ref_):.3e}")
+                result["host_stream"]["pass"] = bool(all(e["max_rel_diff_vs_stream_render"] <= 5e-7 for e in result["host_stream"]["calls"]))
             # three windows of the timed buffer: its first, middle and last blocks (tests/test_gpu_render_full.py::check_windows)
             starts = [wl.lead]  # (a time-sharded rank's lead block is not output)
             if nblk >= 3 * nb + 2:
@@ -1167,10 +1251,18 @@ def main():
             # a secondary workload that errored or failed ITS parity gate is visible in the line and in the exit code (4)
             result["secondary_pass"] = bool(all("error" not in e and e.get("parity", {}).get("pass") for e in result["secondary"]))
             secondary_failed = not result["secondary_pass"]
+        for e in (result.get("host_stream") or {}).get("calls", []):
+            e.pop("_first", None)
         print(json.dumps(result), flush=True)
         if secondary_failed:
             bad = [e["workload"] for e in result["secondary"] if "error" in e or not e.get("parity", {}).get("pass")]
             print(f"bench.py: secondary workloads failed (error or parity): {bad}", file=sys.stderr, flush=True)
+        if lead_check is not None and not lead_check <= 5e-7:  # (time sharding: a rank's blocks must not depend on how far back its lead-in starts)
+            print(f"bench.py: time-sharded blocks differ with the length of the lead-in by {lead_check:.3e}", file=sys.stderr, flush=True)
+            parity_failed = True
+        if result.get("host_stream") and result["host_stream"].get("pass") is False:
+            print("bench.py: the host-pointer stream calls differ from the device-resident render beyond 5e-7", file=sys.stderr, flush=True)
+            parity_failed = True
         if result.get("parity") and not result["parity"]["pass"]:
             print("bench.py: PARITY FAILED - the timed output differs from the CPU path by "
                   f"{result['parity']['max_channel_rel_rms_vs_cpu']:.3e} (tolerance 1e-6; from a float64 render: GPU "

@@ -103,6 +103,10 @@ int earhip_debug_clock_probe(earhip_ctx *ctx, void *out_dev);
  * stride and nsamples: multiples of 256, nsamples <= stride; in_dev 16-byte aligned. */
 int earhip_debug_read_bandwidth(earhip_ctx *ctx, const float *in_dev, size_t rows, size_t stride,
                                 size_t nsamples, int reps, double ms[2]);
+/* measurement aid (bench.py's `host_stream`): what the bus gives a plain copy of `bytes` bytes between `host` (pinned or
+ * pageable, the caller's) and a device buffer of the call's own — average ms over `reps` copies of ms[0] host -> device and
+ * ms[1] device -> host, each between HIP events on the context's stream: the 100 % mark of the host-pointer entry points. */
+int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int reps, double ms[2]);
 
 /* ------------------------------------------------------------------------
  * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector
@@ -509,6 +513,13 @@ int earhip_comm_gather_device(earhip_comm *comm, int slot, const float *owned_de
                               size_t rows_per_rank, size_t row_stride, int root);
 int earhip_comm_wait(earhip_comm *comm, int slot);
 int earhip_comm_last_exchange_ms(earhip_comm *comm, int slot, double *ms);
+/* What RCCL says about the communicator: info[0] ranks (ncclCommCount), [1] this rank (ncclCommUserRank), [2] the HIP device it
+ * lives on (ncclCommCuDevice), [3] the RCCL version (ncclGetVersion) — a benchmark line shows with it that N ranks really met. */
+int earhip_comm_info(earhip_comm *comm, int info[4]);
+/* Measured rate of one link direction: every rank sends `bytes` bytes to rank + shift and receives as many from rank - shift
+ * (one ncclSend / ncclRecv pair per rank, all at once: the pattern of the exchange's point-to-point steps), `reps` times between
+ * HIP events on the communicator's stream.  *GBps = bytes a rank sent per second / 1e9 (0 with one rank).  Collective. */
+int earhip_comm_link_probe(earhip_comm *comm, size_t bytes, int shift, int reps, double *GBps);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,13 @@ class Context:
                                                  C.c_size_t(nsamples), int(reps), ms))
         return ms[0], ms[1]
 
+    def copy_bandwidth(self, host_array, reps=3):
+        """(ms host -> device, ms device -> host) of a plain copy of the array's bytes (it is overwritten with its own
+        contents by the second direction)"""
+        ms = (C.c_double * 2)()
+        check(load().earhip_debug_copy_bandwidth(self.h, C.c_void_p(host_array.ctypes.data), C.c_size_t(host_array.nbytes), int(reps), ms))
+        return ms[0], ms[1]
+
     # --- host memory the device reaches directly (earhip_host_alloc / _register / _release)
     def pinned_array(self, shape):
         """float32 array in pinned, device-reachable host memory (C-contiguous: the rows of a [channels][samples]
@@ -520,6 +527,18 @@ class Comm:
         ms = C.c_double(0.0)
         check(load().earhip_comm_last_exchange_ms(self.h, int(slot), C.byref(ms)))
         return ms.value
+
+    def info(self):
+        """what RCCL says about the communicator: ranks (ncclCommCount), this rank, its HIP device, the RCCL version"""
+        v = (C.c_int * 4)()
+        check(load().earhip_comm_info(self.h, v))
+        return {"ranks": v[0], "rank": v[1], "device": v[2], "version": v[3]}
+
+    def link_probe(self, nbytes=50 << 20, shift=1, reps=5):
+        """GB/s a rank sends to rank + shift while it receives from rank - shift (collective; 0 with one rank)"""
+        g = C.c_double(0.0)
+        check(load().earhip_comm_link_probe(self.h, C.c_size_t(nbytes), int(shift), int(reps), C.byref(g)))
+        return g.value
 
     def close(self):
         if self.h:

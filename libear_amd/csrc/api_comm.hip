@@ -179,6 +179,59 @@ int earhip_comm_last_exchange_ms(earhip_comm *c, int slot, double *ms) {
   });
 }
 
+// What RCCL itself says about this communicator — for a benchmark line that must show the exchange really ran over N ranks:
+// info[0] = ncclCommCount, [1] = ncclCommUserRank, [2] = ncclCommCuDevice (the HIP device it lives on), [3] = ncclGetVersion.
+int earhip_comm_info(earhip_comm *c, int info[4]) {
+  return guarded([&] {
+    require(c != nullptr && info != nullptr, "NULL argument");
+    EARHIP_NCCL(ncclCommCount(c->comm, &info[0]));
+    EARHIP_NCCL(ncclCommUserRank(c->comm, &info[1]));
+    EARHIP_NCCL(ncclCommCuDevice(c->comm, &info[2]));
+    EARHIP_NCCL(ncclGetVersion(&info[3]));
+  });
+}
+
+// The rate ONE link direction gives this communicator, measured: every rank sends `bytes` bytes to rank + shift and receives as
+// many from rank - shift (one ncclSend / ncclRecv pair per rank inside a group: G transfers over G different links at once, the
+// traffic pattern of the reduce-scatter's and the gather's point-to-point steps), `reps` times between HIP events on the
+// communicator's stream after one untimed round.  *GBps = bytes per second a rank SENT (1e9).  Collective: every rank calls
+// it with the same arguments.  World size 1: 0.
+int earhip_comm_link_probe(earhip_comm *c, size_t bytes, int shift, int reps, double *GBps) {
+  return guarded([&] {
+    require(c != nullptr && GBps != nullptr, "NULL argument");
+    require(bytes >= 4 && bytes <= ((size_t)1 << 32) && reps >= 1 && reps <= 100, "bytes / reps out of range");
+    *GBps = 0.0;
+    if (c->world < 2) return;
+    require(shift % c->world != 0, "shift must not be a multiple of the world size");
+    c->ctx->use();
+    const size_t count = bytes / 4;
+    DevBuf<float> src, dst;
+    src.alloc_zero(count, c->xstream);
+    dst.alloc_zero(count, c->xstream);
+    const int to = ((c->rank + shift) % c->world + c->world) % c->world, from = ((c->rank - shift) % c->world + c->world) % c->world;
+    hipEvent_t e[2];
+    for (auto &x : e) EARHIP_HIP(hipEventCreate(&x));
+    auto round = [&] {
+      EARHIP_NCCL(ncclGroupStart());
+      const ncclResult_t a = ncclSend(src.p, count, ncclFloat, to, c->comm, c->xstream);
+      const ncclResult_t b = ncclRecv(dst.p, count, ncclFloat, from, c->comm, c->xstream);
+      const ncclResult_t end = ncclGroupEnd();
+      EARHIP_NCCL(a);
+      EARHIP_NCCL(b);
+      EARHIP_NCCL(end);
+    };
+    round();
+    EARHIP_HIP(hipEventRecord(e[0], c->xstream));
+    for (int i = 0; i < reps; i++) round();
+    EARHIP_HIP(hipEventRecord(e[1], c->xstream));
+    EARHIP_HIP(hipEventSynchronize(e[1]));
+    float t = 0.0f;
+    EARHIP_HIP(hipEventElapsedTime(&t, e[0], e[1]));
+    for (auto &x : e) (void)hipEventDestroy(x);
+    if (t > 0.0f) *GBps = (double)bytes * reps / ((double)t * 1e-3) / 1e9;
+  });
+}
+
 int earhip_comm_wait(earhip_comm *c, int slot) {
   return guarded([&] {
     require(c != nullptr, "comm must not be NULL");

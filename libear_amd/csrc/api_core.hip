@@ -463,7 +463,7 @@ using namespace earhip;
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
     "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "H2_RUNS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
-    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT"};
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS"};
 
 // an option's value: a decimal integer (optional sign, surrounding blanks), nothing else — "abc" or "1x" used to read as 0 / 1
 static int parse_option_value(const std::string &key, const char *text) {
@@ -603,6 +603,34 @@ int earhip_debug_read_bandwidth(earhip_ctx *ctx, const float *in_dev, size_t row
     EARHIP_HIP(hipEventElapsedTime(&t, e[2], e[3]));
     ms[1] = (double)t / reps;
     for (auto &x : e) (void)hipEventDestroy(x);
+  });
+}
+
+int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int reps, double ms[2]) {
+  return guarded([&] {
+    require(ctx != nullptr && host != nullptr && ms != nullptr, "NULL argument");
+    require(bytes >= 4 && reps >= 1 && reps <= 1000, "bytes / reps out of range");
+    ctx->use();
+    DevBuf<char> dev;
+    dev.alloc(bytes);
+    hipEvent_t e[2];
+    for (auto &x : e) EARHIP_HIP(hipEventCreate(&x));
+    for (int dir = 0; dir < 2; dir++) {
+      auto copy = [&] {
+        if (dir == 0) EARHIP_HIP(hipMemcpyAsync(dev.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        else EARHIP_HIP(hipMemcpyAsync(host, dev.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      };
+      copy();  // (warm-up outside the interval)
+      EARHIP_HIP(hipEventRecord(e[0], ctx->stream));
+      for (int i = 0; i < reps; i++) copy();
+      EARHIP_HIP(hipEventRecord(e[1], ctx->stream));
+      EARHIP_HIP(hipEventSynchronize(e[1]));
+      float t = 0.0f;
+      EARHIP_HIP(hipEventElapsedTime(&t, e[0], e[1]));
+      ms[dir] = (double)t / reps;
+    }
+    for (auto &x : e) (void)hipEventDestroy(x);
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 

@@ -110,11 +110,12 @@ static int wave_run_len(int T, int N, int num_cus) {
 }
 
 // Staging threads of the host-pointer entry point, started at the first long call and kept: a call
-// neither creates threads nor allocates.  A job = gather the channels of kGroups channel groups into
-// the pinned buffer, thread t taking every nthreads-th channel of a group; done[g] counts the threads
-// that have finished group g (the caller starts that group's transfer then).
+// neither creates threads nor allocates.  A long call is cut into TIME chunks (a few blocks each: ~8 MB of inputs); a job =
+// gather every channel's samples of chunk g into the pinned buffer, chunk-major ([chunk][channel][samples of the chunk]: a
+// chunk is one linear transfer), thread t taking every nthreads-th channel; done[g] counts the threads that have finished
+// chunk g (the caller starts that chunk's transfer then, while the threads gather the next one).
 struct GatherPool {
-  static constexpr int kGroups = 8;
+  static constexpr int kMaxGroups = 64;
   std::vector<std::thread> threads;
   std::mutex mu;
   std::condition_variable go, finished_cv;
@@ -124,11 +125,11 @@ struct GatherPool {
   // the job
   const float *const *in = nullptr;
   float *dst = nullptr;
-  size_t n = 0;
-  int M = 0;
-  std::atomic<int> done[kGroups];
-  int group_lo(int g) const { return (int)((int64_t)M * g / kGroups); }
+  size_t n = 0, clen = 0;  // samples per channel in the call, samples per chunk (the last one may be shorter)
+  int M = 0, groups = 0;
+  std::atomic<int> done[kMaxGroups];
   int nthreads() const { return (int)threads.size(); }
+  size_t group_len(int g) const { return std::min(clen, n - (size_t)g * clen); }
   void start(int count) {
     for (int t = 0; t < count; t++)
       threads.emplace_back([this, t] {
@@ -141,8 +142,10 @@ struct GatherPool {
             seen = generation;
           }
           const int nt = nthreads();
-          for (int g = 0; g < kGroups; g++) {
-            for (int m = group_lo(g) + t; m < group_lo(g + 1); m += nt) std::memcpy(dst + (size_t)m * n, in[m], sizeof(float) * n);
+          for (int g = 0; g < groups; g++) {
+            const size_t len = group_len(g), at = (size_t)g * clen;
+            float *base = dst + (size_t)M * at;
+            for (int m = t; m < M; m += nt) std::memcpy(base + (size_t)m * len, in[m] + at, sizeof(float) * len);
             done[g].fetch_add(1, std::memory_order_release);
           }
           std::lock_guard<std::mutex> lk(mu);
@@ -150,9 +153,10 @@ struct GatherPool {
         }
       });
   }
-  void submit(const float *const *in_, float *dst_, size_t n_, int M_) {
+  void submit(const float *const *in_, float *dst_, size_t n_, size_t clen_, int M_) {
     std::lock_guard<std::mutex> lk(mu);
-    in = in_, dst = dst_, n = n_, M = M_;
+    in = in_, dst = dst_, n = n_, clen = clen_, M = M_;
+    groups = (int)((n + clen - 1) / clen);
     for (auto &d : done) d.store(0);
     finished = 0;
     generation++;
@@ -169,6 +173,36 @@ struct GatherPool {
     }
     go.notify_all();
     for (auto &th : threads) th.join();
+  }
+};
+
+// Copy streams and events of long host-pointer calls (made at the first such call and kept): the chunks of a call go
+// H2D on `in`, through the kernels on the context's stream, and D2H on `out`, each stage ordered behind the one
+// before it by the chunk's events — chunk c's kernels and the transfer of its outputs run beside the transfer of c + 1.
+struct StreamPipe {
+  hipStream_t in = nullptr, out = nullptr;
+  hipEvent_t ev_in[GatherPool::kMaxGroups], ev_k[GatherPool::kMaxGroups], ev_out[GatherPool::kMaxGroups];
+  bool made = false;
+  void make() {
+    if (made) return;
+    EARHIP_HIP(hipStreamCreateWithFlags(&in, hipStreamNonBlocking));
+    EARHIP_HIP(hipStreamCreateWithFlags(&out, hipStreamNonBlocking));
+    for (int i = 0; i < GatherPool::kMaxGroups; i++) {
+      EARHIP_HIP(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
+      EARHIP_HIP(hipEventCreateWithFlags(&ev_k[i], hipEventDisableTiming));
+      EARHIP_HIP(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
+    }
+    made = true;
+  }
+  ~StreamPipe() {
+    if (!made) return;
+    for (int i = 0; i < GatherPool::kMaxGroups; i++) {
+      (void)hipEventDestroy(ev_in[i]);
+      (void)hipEventDestroy(ev_k[i]);
+      (void)hipEventDestroy(ev_out[i]);
+    }
+    (void)hipStreamDestroy(in);
+    (void)hipStreamDestroy(out);
   }
 };
 
@@ -211,6 +245,8 @@ struct earhip_render {
   DevBuf<float> d_in, d_out;
   PinBuf<float> p_in, p_out;
   std::unique_ptr<GatherPool> gather;  // staging threads of long host-pointer calls
+  StreamPipe pipe;                     // ... their copy streams and events
+  int last_host_chunks = 0;            // time chunks the last host-pointer call ran as (0: one piece)
   // timing
   bool timing = false;
   bool last_timed = false;
@@ -660,12 +696,12 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     const bool dbg = ctx->get(OPT_DEBUG_TIMING) != 0;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = dbg ? now() : 0.0;
-    const bool short_call = in_bytes < ((size_t)16 << 20) || r->M < 16;
+    const bool short_call = in_bytes < ((size_t)16 << 20) || r->M < 16 || (ctx->has(OPT_HOST_CHUNK_MB) && ctx->get(OPT_HOST_CHUNK_MB) <= 0);
     // Channel pointers that are evenly spaced inside memory the device reaches (earhip_host_alloc /
-    // earhip_host_register: the columns of a pinned matrix) need no staging copy: one strided DMA in, and
+    // earhip_host_register: the columns of a pinned matrix) need no staging copy: strided DMA in, and
     // the output rows written in place.  stride in floats; 0: not that shape.
     auto direct_stride = [&](const float *const *ch, int count) -> size_t {
-      if (!short_call || ctx->host_ranges.empty() || count < 1) return 0;
+      if (ctx->host_ranges.empty() || count < 1) return 0;
       // (addresses as integers: the channel pointers need not belong to one array as far as C++ knows)
       const uintptr_t a0 = (uintptr_t)ch[0];
       const uintptr_t step = count > 1 ? (uintptr_t)ch[1] - a0 : sizeof(float) * n;
@@ -675,11 +711,103 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       return ctx->host_reachable(ch[0], step * (count - 1) + sizeof(float) * n) ? (size_t)(step / sizeof(float)) : 0;
     };
     const size_t in_st = direct_stride(in, r->M);
-    const size_t out_st = r->NP <= 1 ? direct_stride(out, r->N) : 0;
+    const size_t out_st = r->NP <= 1 || !short_call ? direct_stride(out, r->N) : 0;
+    r->last_host_chunks = 0;
+    if (!short_call) {
+      // Long calls (libear's calling convention for offline renders: host channel pointers, any length): the call is cut
+      // into TIME chunks of a few blocks (option HOST_CHUNK_MB: ~8 MB of inputs each, at most 64 chunks) and the chunks run
+      // through a three-stage pipeline on three streams: H2D of chunk c + 1 (its own copy stream) beside the kernels of
+      // chunk c (the context's stream: each chunk is an ordinary process call of its blocks, the DSP state carries over)
+      // beside the D2H of chunk c - 1 (a second copy stream).  The kernels are ~100 x faster than the bus, so the call
+      // takes what its inputs take over PCIe plus one chunk's kernels and output transfer.  From ordinary (pageable)
+      // pointers the staging threads gather chunk c + 1 into the pinned buffer (chunk-major: one linear transfer per
+      // chunk) while chunk c is on the bus, and the outputs of finished chunks are handed back to the caller's rows while
+      // later chunks are still in flight; from device-reachable rows (earhip_host_alloc / _register) neither copy exists.
+      const size_t block_bytes = sizeof(float) * (size_t)r->B * r->M;
+      // (rows in device-reachable memory go by strided DMA, which wants long row pieces: 32 MB chunks = 32 KB pieces at 1024
+      // objects; staged rows: 16 MB — the pieces the staging threads copy are then 16 KB, and the first chunk's gather, which
+      // nothing overlaps, stays short)
+      const size_t want_bytes = (size_t)std::max(1, ctx->get(OPT_HOST_CHUNK_MB, in_st ? 32 : 16)) << 20;
+      size_t cb = std::max<size_t>(1, want_bytes / block_bytes);
+      cb = std::max(cb, (nblocks + GatherPool::kMaxGroups - 1) / GatherPool::kMaxGroups);
+      while ((cb * (size_t)r->B) % 4 != 0) cb++;  // (chunks start on 16-byte boundaries of the staging rows: vector loads)
+      const size_t clen = cb * r->B;
+      const int nch = (int)((nblocks + cb - 1) / cb);
+      r->pipe.make();
+      if (!in_st) {
+        if (!r->gather) {
+          r->gather.reset(new GatherPool);
+          const unsigned hc = std::thread::hardware_concurrency();
+          const int want = ctx->get(OPT_HOST_THREADS, 0);
+          r->gather->start(want >= 1 && want <= 64 ? want : (int)std::max(2u, std::min(16u, hc / 2)));
+        }
+        r->gather->submit(in, r->p_in.p, n, clen, r->M);
+      }
+      hipError_t err = hipSuccess;
+      std::string fail;
+      int scattered = 0;
+      auto scatter_chunk = [&](int c) {
+        const size_t at = (size_t)c * clen, len = std::min(clen, n - at);
+        const float *base = r->p_out.p + (size_t)r->N * at;
+        for (int ch = 0; ch < r->N; ch++) std::memcpy(out[ch] + at, base + (size_t)ch * len, sizeof(float) * len);
+      };
+      for (int c = 0; c < nch; c++) {
+        const size_t at = (size_t)c * clen, len = std::min(clen, n - at);
+        float *din = r->d_in.p + (size_t)r->M * at, *dout = r->d_out.p + (size_t)r->N * at;
+        if (!in_st) {
+          GatherPool &gp = *r->gather;
+          while (gp.done[c].load(std::memory_order_acquire) < gp.nthreads()) {
+            // (meanwhile: outputs of chunks whose transfer has landed go back to the caller's rows)
+            if (!out_st && scattered < c && err == hipSuccess && hipEventQuery(r->pipe.ev_out[scattered]) == hipSuccess) scatter_chunk(scattered++);
+            else std::this_thread::yield();
+          }
+        }
+        if (err != hipSuccess || !fail.empty()) continue;  // (the staging threads still finish their job)
+        if (in_st)
+          err = hipMemcpy2DAsync(din, sizeof(float) * len, in[0] + at, sizeof(float) * in_st, sizeof(float) * len, r->M,
+                                 hipMemcpyHostToDevice, r->pipe.in);
+        else
+          err = hipMemcpyAsync(din, r->p_in.p + (size_t)r->M * at, sizeof(float) * len * r->M, hipMemcpyHostToDevice, r->pipe.in);
+        if (err == hipSuccess) err = hipEventRecord(r->pipe.ev_in[c], r->pipe.in);
+        if (err == hipSuccess) err = hipStreamWaitEvent(ctx->stream, r->pipe.ev_in[c], 0);
+        if (err != hipSuccess) continue;
+        try {
+          r->process_device(len / r->B, din, len, dout, len);
+        } catch (const Error &e) {
+          fail = e.msg;
+          continue;
+        }
+        err = hipEventRecord(r->pipe.ev_k[c], ctx->stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(r->pipe.out, r->pipe.ev_k[c], 0);
+        if (err != hipSuccess) continue;
+        if (out_st)
+          err = hipMemcpy2DAsync(out[0] + at, sizeof(float) * out_st, dout, sizeof(float) * len, sizeof(float) * len, r->N,
+                                 hipMemcpyDeviceToHost, r->pipe.out);
+        else
+          err = hipMemcpyAsync(r->p_out.p + (size_t)r->N * at, dout, sizeof(float) * len * r->N, hipMemcpyDeviceToHost, r->pipe.out);
+        if (err == hipSuccess) err = hipEventRecord(r->pipe.ev_out[c], r->pipe.out);
+      }
+      if (!in_st) r->gather->wait_all();
+      const double t_c = dbg ? now() : 0.0;
+      // (everything queued is waited for whatever happened above: nothing of this call is in flight when it returns)
+      (void)hipStreamSynchronize(r->pipe.in);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipStreamSynchronize(r->pipe.out);
+      EARHIP_HIP(err);
+      if (!fail.empty()) throw Error{EARHIP_INTERNAL_ERROR, fail};
+      const double t_d = dbg ? now() : 0.0;
+      if (!out_st)
+        for (; scattered < nch; scattered++) scatter_chunk(scattered);
+      r->last_host_chunks = nch;
+      if (dbg)
+        fprintf(stderr, "render_process: %d chunks of %zu blocks%s: enqueue incl. gather %.1f us, drain %.1f us, scatter of the rest %.1f us\n", nch,
+                cb, in_st ? " (device-reachable rows)" : "", t_c - t_a, t_d - t_c, now() - t_d);
+      return;
+    }
     if (in_st) {
       EARHIP_HIP(hipMemcpy2DAsync(r->d_in.p, sizeof(float) * n, in[0], sizeof(float) * in_st, sizeof(float) * n, r->M,
                                   hipMemcpyHostToDevice, ctx->stream));
-    } else if (short_call) {
+    } else {
       // short calls (block mode): one gather, one transfer.  Splitting a 2 MB block into groups whose
       // transfers overlap the gather was measured twice and loses (132 -> 150 us per call at the headline
       // shape: four DMA start-ups cost more than the 30 us of gather they hide).
@@ -698,26 +826,6 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
           EARHIP_HIP(hipMemcpyAsync(r->d_in.p + (size_t)m0 * n, r->p_in.p + (size_t)m0 * n, sizeof(float) * n * (m1 - m0),
                                     hipMemcpyHostToDevice, ctx->stream));
       }
-    } else {
-      // Long calls: the staging copy is what bounds the host-pointer path, so several (persistent)
-      // threads gather the channels into the pinned buffer, group of channels by group, and each
-      // group's H2D transfer starts while the next group is being gathered.
-      if (!r->gather) {
-        r->gather.reset(new GatherPool);
-        r->gather->start((int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
-      }
-      GatherPool &gp = *r->gather;
-      gp.submit(in, r->p_in.p, n, r->M);
-      hipError_t err = hipSuccess;
-      for (int g = 0; g < GatherPool::kGroups; g++) {
-        while (gp.done[g].load(std::memory_order_acquire) < gp.nthreads()) std::this_thread::yield();
-        const size_t lo = (size_t)gp.group_lo(g) * n, hi = (size_t)gp.group_lo(g + 1) * n;
-        if (err == hipSuccess && hi > lo)
-          err = hipMemcpyAsync(r->d_in.p + lo, r->p_in.p + lo, sizeof(float) * (hi - lo),
-                               hipMemcpyHostToDevice, ctx->stream);
-      }
-      gp.wait_all();
-      EARHIP_HIP(err);
     }
     const double t_b = dbg ? now() : 0.0;
     // Short calls: K2 writes the few output rows straight into host memory (the caller's own rows when they
@@ -726,7 +834,7 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
     // of inputs over PCIe themselves are slower than the copy engine plus kernels (129 us) — and neither does
     // spinning on a completion word behind one more launch.
     // (FIRs of several partitions accumulate into the output: that stays in device memory)
-    const bool direct_out = short_call && r->NP <= 1;
+    const bool direct_out = r->NP <= 1;
     float *dst = out_st ? out[0] : direct_out ? r->p_out.p : r->d_out.p;
     r->process_device(nblocks, r->d_in.p, n, dst, out_st ? out_st : n);
     if (!direct_out)

@@ -538,11 +538,185 @@ __device__ __forceinline__ void wave_dft16(v2f (&v)[16]) {
 #undef EARHIP_SW
 }
 
+// ---- Round 6: the same transforms in fewer instructions (the kernel is VALU-bound at three waves per SIMD: 3100 of the 3459
+// SIMD cycles a pair of transforms takes are its packed-f32 instructions, profiles/r05_k2_transform_cycles.txt).  Three
+// moves, all algebra on the butterflies — the spectral multiply, the overlap-add and their order stay libear's
+// (block_convolver_impl.cpp:194-226):
+//   * a twiddle multiply that feeds a butterfly's sum is folded into it: a + w c is two fused multiply-adds on a (cmul_acc)
+//     instead of a complex multiply (two instructions) and an addition, and the matching difference a - w c = 2 a - (a + w c)
+//     is ONE more instead of another subtraction of a product that no longer exists on its own;
+//   * the constant rotations of the 16-point kernel are not multiplied out: x (-+i) is a pair of operand modifiers on the
+//     butterfly that takes it, x r2 (1 -+ i) one packed addition (x -+ i x) and the factor r2 inside the butterfly's fma;
+//   * the forward transform's inputs are zero padded to twice the block (Filter / BlockConvolver: 2 B points for B samples): the
+//     first radix-4 stage of its first 16-point kernel sees c = d = 0 and is four additions instead of eight.
+// 562 -> 490 packed instructions in the kernel (static count), K2 0.0531 -> 0.0508 ms on the headline, 0.1615 -> 0.152 on config 3
+// (same box, two runs each).  NOT THE DEFAULT: built this way, tests/test_gpu_render.py::test_contexts_on_concurrent_threads —
+// four contexts rendering at once on four threads — gave one wrong block of one loudspeaker (2-4 % off) in 5 of 110 fresh
+// processes, the round-5 form built from the same tree in 0 of 78; every other test (fixed inputs, one stream) passes, the
+// instruction stream shows no unhandled hazard (every dependent pair of packed instructions has its s_nop), and a deterministic
+// kernel that is wrong once in twenty runs is not shipped for 4 % of K2.  -DEARHIP_K2_FOLDED=1 builds it (NOTES.md, round 6).
+#ifndef EARHIP_K2_FOLDED
+#define EARHIP_K2_FOLDED 0
+#endif
+// acc + a w (DIR < 0) or acc + a conj(w) (DIR > 0): t = acc + (-+ a.y w.y, a.y w.x); r = t + (a.x w.x, +- a.x w.y)
+template <int DIR>
+__device__ __forceinline__ v2f wave_cmul_acc(v2f a, v2f w, v2f acc) {
+  v2f t, r;
+  if (DIR < 0) {
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  } else {
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  }
+  return r;
+}
+template <int DIR>
+__device__ __forceinline__ v2f wave_cmul_acc_k(v2f a, v2f w, v2f acc) {  // the same with a wave-uniform w in an SGPR pair
+  v2f t, r;
+  if (DIR < 0) {
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(a), "s"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  } else {
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "s"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  }
+  return r;
+}
+__device__ __forceinline__ v2f wave_twice_minus(v2f a, v2f b) {  // 2 a - b
+  const v2f two = {2.0f, 2.0f};
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "s"(two), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f wave_fma_k(v2f u, v2f k, v2f a) {  // a + k u (k: the same constant in both halves, SGPR pair)
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "s"(k), "v"(a));
+  return r;
+}
+__device__ __forceinline__ v2f wave_fnma_k(v2f u, v2f k, v2f a) {  // a - k u
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(u), "s"(k), "v"(a));
+  return r;
+}
+__device__ __forceinline__ v2f wave_fma_k_subi(v2f q, v2f k, v2f a) {  // a - i k q = (a.x + k q.y, a.y - k q.x)
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(q), "s"(k), "v"(a));
+  return r;
+}
+__device__ __forceinline__ v2f wave_fma_k_addi(v2f q, v2f k, v2f a) {  // a + i k q = (a.x - k q.y, a.y + k q.x)
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(q), "s"(k), "v"(a));
+  return r;
+}
+// the outputs of a radix-4 butterfly from its sums: a0 = a + c, a1 = a - c, a2 = b + d, t = b - d
+template <int DIR>
+__device__ __forceinline__ void wave_r4_out(v2f a0, v2f a1, v2f a2, v2f t, v2f &a, v2f &b, v2f &c, v2f &d) {
+  a = a0 + a2;
+  c = a0 - a2;
+  b = DIR < 0 ? wave_sub_i(a1, t) : wave_add_i(a1, t);
+  d = DIR < 0 ? wave_add_i(a1, t) : wave_sub_i(a1, t);
+}
+// radix-4 butterfly of w_a a, w_b b, w_c c, w_d d (TA: a carries a twiddle too): 14 (12) instructions instead of 16 (14)
+template <int DIR, bool TA>
+__device__ __forceinline__ void wave_r4_tw(v2f &a, v2f &b, v2f &c, v2f &d, v2f wa, v2f wb, v2f wc, v2f wd) {
+  const v2f pa = TA ? wave_cmul<DIR>(a, wa) : a;
+  const v2f a0 = wave_cmul_acc<DIR>(c, wc, pa), a1 = wave_twice_minus(pa, a0);
+  const v2f pb = wave_cmul<DIR>(b, wb);
+  const v2f a2 = wave_cmul_acc<DIR>(d, wd, pb), t = wave_twice_minus(pb, a2);
+  wave_r4_out<DIR>(a0, a1, a2, t, a, b, c, d);
+}
+// 16-point DFT in registers, natural order in and out, as wave_dft16 with the constant rotations folded into the second
+// stage's butterflies.  HALF: v[8..15] are zero on entry (the forward transform's padding).  STAGE1: the first stage is done
+// here (false: the caller did it, with its own twiddles folded in)
+template <int DIR, bool HALF, bool STAGE1>
+__device__ __forceinline__ void wave_dft16_f(v2f (&v)[16]) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r2 = 0.70710678118654752f;
+  if (STAGE1) {
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+      if (HALF) {  // c = d = 0: a0 = a1 = a, a2 = t = b
+        const v2f a = v[n2], b = v[n2 + 4];
+        v[n2] = a + b;
+        v[n2 + 8] = a - b;
+        v[n2 + 4] = DIR < 0 ? wave_sub_i(a, b) : wave_add_i(a, b);
+        v[n2 + 12] = DIR < 0 ? wave_add_i(a, b) : wave_sub_i(a, b);
+      } else {
+        wave_r4<DIR>(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12]);
+      }
+    }
+  }
+  const v2f W1 = {c1, -s1}, W3 = {s1, -c1}, W9 = {-c1, s1}, R2 = {r2, r2};
+  // k1 = 0: no twiddles
+  wave_r4<DIR>(v[0], v[1], v[2], v[3]);
+  {  // k1 = 1: b = W1 v5, c = W2 v6 = r2 (1 -+ i) v6, d = W3 v7
+    const v2f u = DIR < 0 ? wave_sub_i(v[6], v[6]) : wave_add_i(v[6], v[6]);
+    const v2f a0 = wave_fma_k(u, R2, v[4]), a1 = wave_fnma_k(u, R2, v[4]);
+    const v2f pb = wave_cmul_k<DIR>(v[5], W1);
+    const v2f a2 = wave_cmul_acc_k<DIR>(v[7], W3, pb), t = wave_twice_minus(pb, a2);
+    wave_r4_out<DIR>(a0, a1, a2, t, v[4], v[5], v[6], v[7]);
+  }
+  {  // k1 = 2: b = W2 v9 = r2 (1 -+ i) v9, c = W4 v10 = -+i v10, d = W6 v11 = -r2 (1 +- i) v11
+    const v2f u9 = DIR < 0 ? wave_sub_i(v[9], v[9]) : wave_add_i(v[9], v[9]);
+    const v2f u11 = DIR < 0 ? wave_add_i(v[11], v[11]) : wave_sub_i(v[11], v[11]);
+    const v2f a0 = DIR < 0 ? wave_sub_i(v[8], v[10]) : wave_add_i(v[8], v[10]);
+    const v2f a1 = DIR < 0 ? wave_add_i(v[8], v[10]) : wave_sub_i(v[8], v[10]);
+    const v2f sm = u9 - u11, q = u9 + u11;  // a2 = r2 sm, t = r2 q
+    v[8] = wave_fma_k(sm, R2, a0);
+    v[10] = wave_fnma_k(sm, R2, a0);
+    v[9] = DIR < 0 ? wave_fma_k_subi(q, R2, a1) : wave_fma_k_addi(q, R2, a1);
+    v[11] = DIR < 0 ? wave_fma_k_addi(q, R2, a1) : wave_fma_k_subi(q, R2, a1);
+  }
+  {  // k1 = 3: b = W3 v13, c = W6 v14 = -r2 (1 +- i) v14, d = W9 v15
+    const v2f u = DIR < 0 ? wave_add_i(v[14], v[14]) : wave_sub_i(v[14], v[14]);
+    const v2f a0 = wave_fnma_k(u, R2, v[12]), a1 = wave_fma_k(u, R2, v[12]);
+    const v2f pb = wave_cmul_k<DIR>(v[13], W3);
+    const v2f a2 = wave_cmul_acc_k<DIR>(v[15], W9, pb), t = wave_twice_minus(pb, a2);
+    wave_r4_out<DIR>(a0, a1, a2, t, v[12], v[13], v[14], v[15]);
+  }
+  v2f t;
+#define EARHIP_SW(a, b) t = v[a], v[a] = v[b], v[b] = t;
+  EARHIP_SW(1, 4) EARHIP_SW(2, 8) EARHIP_SW(3, 12) EARHIP_SW(6, 9) EARHIP_SW(7, 13) EARHIP_SW(11, 14)
+#undef EARHIP_SW
+}
+
 __device__ __forceinline__ int wave_pad(int i) { return i + (i >> 4); }  // 17-word rows: conflict-free exchanges
 
 // v[m] <-> index lane + 64 m.  t1[r-1] = W256^{r (lane & 15)}, t2[256 (r-1) + j] = W1024^{r j} (both in LDS).
-template <int DIR>
+template <int DIR, bool HALF = false>
 __device__ __forceinline__ void wave_fft1024(v2f (&v)[16], v2f *lds, const v2f *t1, const v2f *t2, int lane) {
+#if EARHIP_K2_FOLDED
+  wave_dft16_f<DIR, HALF, true>(v);  // radix 16, Ns = 1: out[16 lane + r]
+#pragma unroll
+  for (int r = 0; r < 16; r++) lds[wave_pad(16 * lane + r)] = v[r];
+#pragma unroll
+  for (int r = 0; r < 16; r++) v[r] = lds[wave_pad(lane + 64 * r)];  // radix 16, Ns = 16
+  __builtin_amdgcn_sched_barrier(0);  // (keeps the twiddle reads from being hoisted: register pressure)
+  // the twiddles W256^{r (lane & 15)} folded into the first stage of the second 16-point kernel (v[0] has none)
+  wave_r4_tw<DIR, false>(v[0], v[4], v[8], v[12], v[0], t1[3], t1[7], t1[11]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n2 = 1; n2 < 4; n2++) {
+    wave_r4_tw<DIR, true>(v[n2], v[n2 + 4], v[n2 + 8], v[n2 + 12], t1[n2 - 1], t1[n2 + 3], t1[n2 + 7], t1[n2 + 11]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_dft16_f<DIR, false, false>(v);
+  __builtin_amdgcn_sched_barrier(0);
+  const int ob = (lane >> 4) * 256 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 16; r++) lds[wave_pad(ob + 16 * r)] = v[r];
+#pragma unroll
+  for (int q = 0; q < 4; q++)  // radix 4, Ns = 256: butterfly lane + 64 q
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[q + 4 * r] = lds[wave_pad(lane + 64 * q + 256 * r)];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int j = lane + 64 * q;
+    wave_r4_tw<DIR, false>(v[q], v[q + 4], v[q + 8], v[q + 12], v[q], t2[j], t2[256 + j], t2[512 + j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
   wave_dft16<DIR>(v);  // radix 16, Ns = 1: out[16 lane + r]
 #pragma unroll
   for (int r = 0; r < 16; r++) lds[wave_pad(16 * lane + r)] = v[r];
@@ -571,6 +745,7 @@ __device__ __forceinline__ void wave_fft1024(v2f (&v)[16], v2f *lds, const v2f *
     wave_r4<DIR>(v[q], v[q + 4], v[q + 8], v[q + 12]);
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
 }
 
 constexpr int kDecorWaves = 4;  // waves (= runs) per workgroup of k_decorrelate_wave
@@ -669,7 +844,7 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
     float dre[8], dim[8];
     if (have_re && tb >= first) delayed8(tb, dre);
     if (have_im) delayed8(tb + 1, dim);
-    wave_fft1024<-1>(v, lds, t1, t2, lane);
+    wave_fft1024<-1, true>(v, lds, t1, t2, lane);  // (v[8..15] = 0: the padding)
 #pragma unroll
     for (int m = 0; m < 16; m++) {
       v[m] = wave_cmul<-1>(v[m], h_lds[wave_pad(lane + 64 * m)]);

@@ -63,16 +63,24 @@ def exchange(partial, owned=None, group=None, async_op=False):
 SHARD_MODES = ("objects", "objects-nogather", "time")
 
 
-def time_range(n_blocks, rank, world, partitions=1):
+def lead_blocks(block, n_taps=512, delay=255):
+    """blocks of lead-in that bring the DSP state to where the stream has it: the decorrelated bus reaches n_taps - 1 samples
+    back, the delayed direct bus `delay` samples — ceil(max(n_taps - 1, delay) / block), at least one"""
+    reach = max(int(n_taps) - 1, int(delay), 1)
+    return max(1, -(-reach // int(block)))
+
+
+def time_range(n_blocks, rank, world, partitions=1, delay_blocks=1):
     """`time` sharding: rank r renders blocks [b0, b1) of the stream for ALL objects, after `lead` blocks rendered only to
     bring the DSP state to where the stream has it (the overlap-add tail of a one-partition decorrelator depends on
     the previous block only, the 255-sample delay line on less than one: one lead block reproduces both exactly — the
     decorrelator kernel recomputes a run's first tail the same way).  No exchange at all; the outputs of different time
     ranges live on different ranks.  A decorrelator FIR of P partitions (blocks shorter than its 512 taps) reaches P blocks
-    back: `partitions` lead blocks.  Returns (b0, b1, lead)."""
+    back: `partitions` lead blocks; a delay longer than that (`delay_blocks` = ceil(delay / block)) asks for its own
+    (lead_blocks() gives both).  Returns (b0, b1, lead)."""
     b0 = (n_blocks * rank) // world
     b1 = (n_blocks * (rank + 1)) // world
-    return b0, b1, min(b0, max(1, partitions))
+    return b0, b1, min(b0, max(1, partitions, delay_blocks))
 
 
 def exchange_model(mode, world, n_pad, samples, compute_ms, link_gbps, chunks=1):
@@ -86,7 +94,7 @@ def exchange_model(mode, world, n_pad, samples, compute_ms, link_gbps, chunks=1)
     slice_ms = (n_pad // world) * samples * 4 / (link_gbps * 1e9) * 1e3
     t_ex = {"objects": 2.0 * slice_ms, "objects-nogather": slice_ms, "time": 0.0}[mode]
     pred = max(compute_ms, t_ex) + (min(compute_ms, t_ex) / max(chunks, 1) if t_ex > 0 else 0.0)
-    return {"mode": mode, "link_GBps_per_direction_assumed": link_gbps, "compute_ms_per_step": round(compute_ms, 4),
+    return {"mode": mode, "link_GBps_per_direction": link_gbps, "compute_ms_per_step": round(compute_ms, 4),
             "exchange_ms_per_step": round(t_ex, 4), "predicted_ms_per_step": round(pred, 4),
             "exchange_equals_compute_at_link_GBps": (round(t_ex / slice_ms * (n_pad // world) * samples * 4 / (compute_ms * 1e-3) / 1e9, 1)
                                                      if t_ex > 0 and compute_ms > 0 else None),

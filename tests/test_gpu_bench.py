@@ -82,6 +82,32 @@ def test_every_baseline_config_gives_a_complete_parity_checked_line(config):
     assert line["step_ms"]["median"] > 0 and line["block_mode"]["ms_per_block"] > 0
 
 
+def test_one_gpu_line_is_the_same_measurement_with_or_without_a_shard_mode():
+    """`--gpus 1 --shard objects` is the plain one-GPU line: the same workload, launch plan and parity gate, no exchange object,
+    and the same figure up to run-to-run noise (a first multi-GPU contact reads its N = 1 point against the headline)."""
+    common = ["--blocks", "256", "--steps", "8", "--warmup", "2", "--cpu-blocks", "0", "--brief"]
+    plain = run_bench(common)
+    sharded = run_bench(["--shard", "objects"] + common)
+    for line in (plain, sharded):
+        assert line["n_gpus"] == 1 and line["exchange"] is None and line["config"]["shard"] is None
+        assert line["parity"]["pass"]
+    assert plain["config"]["workload"] == sharded["config"]["workload"]
+    assert plain["roofline"]["plan"] == sharded["roofline"]["plan"] and plain["roofline"]["kernel"] == sharded["roofline"]["kernel"]
+    assert 0.8 <= sharded["value"] / plain["value"] <= 1.25, (plain["value"], sharded["value"])
+
+
+def test_default_invocation_measures_libears_own_calling_convention():
+    """the host-pointer stream calls (earhip_render_process from pageable and from device-reachable rows, 64 blocks per call here)
+    are part of the line: rate, the measured H2D rate beside it, and their outputs held against the device-resident render"""
+    line = run_bench(["--blocks", "64", "--steps", "4", "--warmup", "1", "--cpu-blocks", "4", "--no-secondary"])
+    hs = line["host_stream"]
+    assert hs["pass"] and hs["h2d_GBps_measured"]["pinned"] > 1.0
+    srcs = {(c["source"], c["blocks_per_call"]) for c in hs["calls"]}
+    assert srcs == {("pageable", 64), ("pinned", 64)}, srcs
+    for c in hs["calls"]:
+        assert c["Gsamples_per_s"] > 0 and 0 < c["frac"] < 1.2 and c["max_rel_diff_vs_stream_render"] <= 5e-7, c
+
+
 @pytest.mark.parametrize("scene,kernel,tile", [("adm", "k_gain_mix_p2", 512), ("moving", "k_gain_mix_hg", 512),
                                                ("mixed", "k_gain_mix_h2", 512), ("panned-adm", "k_gain_mix_p2", 512)])
 def test_scenes_at_the_headline_size_pass_the_parity_gate_of_their_own_launch_plan(scene, kernel, tile):

@@ -48,6 +48,10 @@ def test_single_rank_exchange_orders_behind_the_render_and_overlaps():
     assert torch.equal(owned[0], owned[1]) and float(owned[0].abs().max()) > 0
     assert torch.equal(full[0], part[0]) and torch.equal(full[1], part[1])
     assert comm.last_exchange_ms(0) > 0.0 and comm.last_exchange_ms(1) > 0.0
+    # what RCCL says about the communicator (a multi-GPU bench line carries this: exchange.rccl), and the link probe
+    info = comm.info()
+    assert info["ranks"] == 1 and info["rank"] == 0 and info["device"] == torch.cuda.current_device() and info["version"] > 20000, info
+    assert comm.link_probe(1 << 20, 1, 2) == 0.0  # (one rank: nobody to send to)
     with pytest.raises(capi.InvalidArgument):
         comm.gather_device(0, owned[0].data_ptr(), None, pad, total, root=0)  # the root must have a buffer
     with pytest.raises(capi.InvalidArgument):

@@ -999,7 +999,12 @@ def test_contexts_on_concurrent_threads():
     assert not errors, errors
     for s in range(4):
         for k, o in enumerate(results[s]):
-            assert np.array_equal(o, serial[s][k % 2]), (s, k)
+            ref = serial[s][k % 2]
+            if not np.array_equal(o, ref):  # (say where: which thread, which call, which channels and samples, by how much)
+                d = np.abs(o - ref)
+                ch, sm = np.nonzero(d.max(axis=1))[0], np.nonzero(d.max(axis=0))[0]
+                raise AssertionError(f"thread {s} output {k} ({'renderer' if k % 2 == 0 else 'policy'}): max |diff| {d.max():.3e} of {np.abs(ref).max():.2f}, "
+                                     f"channels {ch.tolist()}, samples {sm.min()}..{sm.max()} ({len(sm)} differ), nan {int(np.isnan(o).sum())}")
 
 
 def test_one_context_shared_by_renderers_of_growing_size():

@@ -379,6 +379,58 @@ def test_call_lengths_between_block_and_stream_mode_off_grid_metadata(nblocks):
     print(plan)
 
 
+@pytest.mark.parametrize("source,kind,m", [("pageable", "dense", 1024), ("pinned", "dense", 1024), ("pageable", "adm", 256),
+                                            ("pinned-in", "moving", 256)])
+def test_long_calls_from_host_pointers_run_as_a_pipeline_of_time_chunks(source, kind, m):
+    """libear's own calling convention — host channel pointers (src/dsp/variable_block_size_impl.cpp:44-81: `const float
+    *const *in, float *const *out`) — for a long call: earhip_render_process cuts it into time chunks of ~8 MB of inputs and
+    runs them H2D / kernels / D2H on three streams.  70 blocks (17 chunks of 4 blocks and one of 2 at 1024 objects), from
+    pageable numpy arrays and from rows in device-reachable memory (earhip_host_alloc), inputs only or both directions:
+    every channel against the oracle at the start, across chunk boundaries and at the ragged end; against ONE device call
+    of the same blocks (another launch plan: within the kernels' tolerance); the DSP state carried into a second call."""
+    import torch
+    from libear_amd import capi
+    layout, block, nblocks = "9+10+3", 512, 70
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = (scenes.dense_curves(m, n, block, 2 * nblocks) if kind == "dense" else scenes.adm_curves(m, n, 2 * total, seed=3) if kind == "adm"
+              else scenes.adm_curves(m, n, 2 * total, period=240, ramp=240, seed=4))
+    x = scenes.audio(m, 2 * total, seed=17)
+    c = ctx()
+    r = capi.Renderer(c, m, n, block, dec, 255, max_blocks=nblocks)
+    for i, (t, d, f) in enumerate(curves):
+        r.set_object_points(i, t, d, f)
+    outs = []
+    keep = []
+    for call in range(2):
+        xc = np.ascontiguousarray(x[:, call * total:(call + 1) * total])
+        if source == "pageable":
+            outs.append(r.process(xc))
+        else:
+            xp = c.pinned_array((m, total))
+            xp[...] = xc
+            yp = c.pinned_array((n, total)) if source == "pinned" else np.zeros((n, total), np.float32)
+            r.process_into(xp, yp)
+            outs.append(np.array(yp))
+            keep += [xp] + ([yp] if source == "pinned" else [])
+    regrows = r.scratch_regrows()
+    r.close()
+    for a in keep:
+        c.release(a)
+    got = np.concatenate(outs, axis=1)
+    assert np.isfinite(got).all() and regrows == 0
+    xt, gt = torch.from_numpy(x), torch.from_numpy(got)
+    wins = [(0, 3), (3, 3), (7, 2), (nblocks - 3, 6), (2 * nblocks - 3, 3)]  # (chunks of 4 blocks; the second call starts at block 70)
+    worst = check_windows(curves, xt, gt, n, block, dec, 255, wins)
+    # one device call per host call
+    xd = torch.from_numpy(x).cuda()
+    ref, plan = render_device(curves, xd, n, block, dec, 255, [nblocks, nblocks])
+    diff = scenes.rel_rms_per_channel(got, ref.cpu().numpy())
+    assert diff <= 5e-7, diff
+    print(f"host pipeline ({source}, {kind}, {m} objects): worst channel vs oracle {worst:.3e}, vs one device call {diff:.3e}")
+
+
 def test_native_decorrelators_equal_the_oracles():
     """the FIRs every GPU render test uses come from the native design (libearhip group G); they are the
     oracle's (both restate src/decorrelate.cpp:31-97 in double and cast to float; the doubles agree to
