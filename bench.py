@@ -63,7 +63,8 @@ GAIN_KERNELS = {0: "k_gain_mix (VALU, strict)", 1: "k_gain_mix_mfma (f32 MFMA)",
                 3: "k_gain_mix_h2 (f16x2 MFMA)",
                 4: "k_gain_mix_p2 (f16x2 MFMA over piece lists)", 5: "k_gain_mix_hg (f16x2 MFMA, hinges)"}
 GAIN_DTYPES = {0: "f32 (VALU, libear's exact arithmetic)", 1: "f32 (f32 MFMA, f32 accumulate)", 2: "f32 (f32 MFMA, f32 accumulate)",
-               3: "f32 io / f16x2-split MFMA, f32 accumulate", 4: "f32 io / f16x2-split MFMA, f32 accumulate"}
+               3: "f32 io / f16x2-split MFMA, f32 accumulate", 4: "f32 io / f16x2-split MFMA, f32 accumulate",
+               5: "f32 io / f16x2-split MFMA, f32 accumulate"}
 
 
 def mfma_roofline(kind, macs_per_term, k1_ms):
@@ -658,6 +659,9 @@ def main():
     # (a call planned for the hinge kernel is decided on the device: it, or the piece lists standing by)
     scratch_mb = round(wl.r.scratch_bytes() / 1e6, 1)
     wide_form = wl.r.wide_form()  # (the form — plain / wide low pieces — the split-operand kernel picked on the device)
+    hinge_robust = gain_kernel == 5 and wl.r.hinge_robust()
+    if hinge_robust:
+        GAIN_KERNELS[5] = "k_gain_mix_hg (f16x2 MFMA, hinges; kink products in f32: the levels of this call's inputs spread beyond the packed-f16 products' span)"
     hinge_standby = gain_kernel == 5 and wl.r.hinge_standby()
     if hinge_standby:
         GAIN_KERNELS[5] = "k_gain_mix_p2 (f16x2 MFMA over piece lists, standing by for k_gain_mix_hg: the levels of this call's inputs spread beyond its span)"
@@ -904,7 +908,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": GAIN_KERNELS.get(gain_kernel, "?"),
                          "plan": {"tile_samples": plan["tile"], "tiles": plan["ntiles"], "object_splits": plan["gsplit"],
                                   "scratch_MB": scratch_mb,
-                                  "form": None if wide_form is None else ("wide" if wide_form else "plain")},
+                                  "form": None if wide_form is None else ("wide, f32 kink products" if hinge_robust else "wide" if wide_form else "plain"),
+                                  "handed_to_standby_lists": bool(hinge_standby)},
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,

@@ -443,6 +443,12 @@ int earhip_render_gain_kernel(const earhip_render *r, int *kind);
  * valid until the next process call of THIS renderer, whatever other renderers or gain stages of the
  * context do in between. */
 int earhip_render_hinge_standby(earhip_render *r, int *standby);
+/* Round 6: by default such a call is no longer handed over — kernel 5 has a third form of its body whose kink products are made
+ * in f32 (7 instructions per value instead of 3; inputs 21 binades below the call's level keep ~17 bits of their products),
+ * picked by the same device-side word; earhip_render_hinge_standby then answers 0 and *robust = 1 tells that the last call
+ * of this renderer ran that form (0: the packed-f16 products sufficed, or the call was not kernel 5's).  Option HG_ROBUST = 0
+ * restores the hand-over to the piece lists.  Synchronises the stream; valid until this renderer's next process call. */
+int earhip_render_hinge_robust(earhip_render *r, int *robust);
 /* The split-operand kernels (3, 4, 5) have two forms of their body: plain, and wide (the low pieces of the inputs scaled so
  * that they stay normal f16 numbers 21 binades below the call's level instead of 11).  Long calls (two rounds of workgroups
  * and more) pick on the device, from the level probe; shorter ones run the wide form.  *wide = 1 / 0: the form the last call

@@ -648,6 +648,13 @@ class Renderer:
         check(load().earhip_render_hinge_standby(self.h, C.byref(flag)))
         return bool(flag.value)
 
+    def hinge_robust(self):
+        """True when the last call was the hinge kernel's (5) and ran its robust form: kink products in f32, because the levels of
+        the call's inputs spread beyond the span of the packed-f16 products (earhip_render_hinge_robust); synchronises the stream"""
+        flag = C.c_int(0)
+        check(load().earhip_render_hinge_robust(self.h, C.byref(flag)))
+        return bool(flag.value)
+
     def wide_form(self):
         """True / False: the form (wide / plain low pieces of the inputs) the split-operand kernel of the last call ran — picked on
         the device for long calls, wide for short ones; None when the kernel has no split operands; synchronises the stream"""

@@ -70,6 +70,9 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   ctx->last_wide_idx = -1;
   unsigned *const record = ctx->record_slot;  // (the renderer's slot for this call's mode word; consumed here)
   ctx->record_slot = nullptr;
+  // hinge kernel: what a call whose levels spread beyond the packed-f16 kink products' span gets — the kernel's robust form
+  // (default) or, option HG_ROBUST = 0, the piece lists standing by behind it (rounds 4-5)
+  const bool hg_robust = ml.hinge && ctx->get(OPT_HG_ROBUST, 1) != 0;
   if ((ml.split || ml.pieces || ml.hinge) && ctx->x_scale_auto && in_stride % 4 == 0 && ((uintptr_t)in_dev & 15) == 0) {
     // (the words, the per-object levels and the per-tile words below are made where a renderer is created —
     // reserve_call_words —; a gain stage that comes here first, or a call larger than any renderer of the context announced,
@@ -84,6 +87,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     wide_next = ctx->level.p + 2 + (ctx->level_idx ^ 1);
     gate = ctx->level.p + 2 + ctx->level_idx;  // (the same word: bit 0 the grid kernel's wide mode, bit 1 "not the hinge kernel")
     ctx->last_gate_idx = ml.hinge ? ctx->level_idx : -1;
+    ctx->last_hinge_robust = hg_robust;
     ctx->last_wide_idx = wide_cur ? ctx->level_idx : -1;
     ctx->level_idx ^= 1;
     // per-object levels (k_level_probe, gain_kernels.h): grown with the largest M this context has seen — contexts are
@@ -150,7 +154,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // (more than 64 KB of dynamic LDS has to be asked for, per device and instantiation: earhip_ctx_create does, hinge_build_allow_lds)
 #define EARHIP_HBUILD_ONE(T_, NW_)                                                                                    \
   hipLaunchKernelGGL((k_hinge_build<T_, NW_>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                     t_call + nsamples, hl, obj_lv, level_cur, gate);
+                     t_call + nsamples, hl, obj_lv, level_cur, hg_robust ? nullptr : gate);
 #define EARHIP_HBUILD_CASE(T_)                                                                                        \
   if (tpw == T_) {                                                                                                    \
     if (ml.tile() == 256) EARHIP_HBUILD_ONE(T_, 4)                                                                    \
@@ -162,7 +166,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   }
   // piece-list kernel: ONE pass builds the lists (k_piece_build, gain_p2.h) behind a small probe launch
   const bool one_pass = ml.pieces || ml.hinge;
-  if (ml.pieces || (ml.hinge && gate)) {  // (behind the hinge kernel's builder: the lists of the call it may not take)
+  if (ml.pieces || (ml.hinge && gate && !hg_robust)) {  // (behind the hinge kernel's builder: the lists of the call it may not take)
     if (M > kMaxPieceObjects || ptile > kPieceMaxTile) fail_internal("piece lists: object index or tile out of range");
     unsigned *obj_lv = probe.obj_level;
     // tiles per workgroup: as many as leave one workgroup per CU (eight tiles = eight lanes per object reading
@@ -239,7 +243,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const float *gs = cs.column_scales();
 #define EARHIP_HG_LAUNCH(NCT_, NW_)                                                                                  \
   hipLaunchKernelGGL((k_gain_mix_hg<NCT_, NW_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, hl, xs, gs, level_cur,     \
-                     level_next, wide_cur, wide_next, gate);
+                     level_next, wide_cur, wide_next, hg_robust ? nullptr : gate, hg_robust ? gate : nullptr);
 #define EARHIP_HG_CASE(NCT_)                                                                                          \
   if (cp.nct == NCT_) {                                                                                               \
     if (ml.tile() == 256) EARHIP_HG_LAUNCH(NCT_, 4)                                                                   \
@@ -250,7 +254,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #undef EARHIP_HG_LAUNCH
     launched = true;
   }
-  if (ml.pieces || (ml.hinge && gate)) {
+  if (ml.pieces || (ml.hinge && gate && !hg_robust)) {
     // as many workgroups as are resident at once (a multiple of 8: a workgroup's tiles stay on its XCD), each carrying its
     // pipeline from one tile's list into the next (gain_p2.h); option P2_WGS: that number (0: a workgroup per tile)
     int wgs = std::max(8, (ctx->num_cus * (ml.pw == 4 ? 2 : 1) / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
@@ -463,7 +467,7 @@ using namespace earhip;
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
     "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "H2_RUNS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
-    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS"};
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST"};
 
 // an option's value: a decimal integer (optional sign, surrounding blanks), nothing else — "abc" or "1x" used to read as 0 / 1
 static int parse_option_value(const std::string &key, const char *text) {

@@ -228,6 +228,7 @@ struct earhip_render {
   DevBuf<unsigned> rec;
   bool last_gated = false;       // the last call (its main span) was planned for the hinge kernel behind a device-side gate
   bool last_device_form = false; // ... its split-operand kernel picked its form (plain / wide) on the device
+  bool last_hg_robust = false;   // ... a gated call beyond the packed kink products' span runs the hinge kernel's robust form (no stand-by lists)
   int last_kind = -1;  // gain kernel of the last call: 0 VALU (strict), 1 f32 MFMA, 2 f32 MFMA on the tile grid, 3 f16x2 MFMA, 4 f16x2 MFMA over piece lists,
                        // 5 f16x2 MFMA with hinges (gain_hg.h)
   int run_len = 11;       // blocks per decorrelator run of the workgroup kernel
@@ -366,11 +367,11 @@ struct earhip_render {
           process_span(main_blocks, in_dev, in_stride, out_dev, out_stride, false);
           const int kind = last_kind, plan3[3] = {last_plan[0], last_plan[1], last_plan[2]};
           const size_t scratch = last_scratch_bytes;
-          const bool gated = last_gated, device_form = last_device_form;
+          const bool gated = last_gated, device_form = last_device_form, hg_robust = last_hg_robust;
           const int paired = last_paired;
           process_span(nblocks - main_blocks, in_dev + main_samples, in_stride, out_dev + main_samples, out_stride, true);
           last_kind = kind;  // (what the call is reported as: its main part — kernel, plan and what it decided on the device)
-          last_gated = gated, last_device_form = device_form, last_paired = paired;
+          last_gated = gated, last_device_form = device_form, last_paired = paired, last_hg_robust = hg_robust;
           for (int i = 0; i < 3; i++) last_plan[i] = plan3[i];
           last_scratch_bytes = scratch;
           last_tail_blocks = (int)(nblocks - main_blocks);
@@ -502,6 +503,7 @@ struct earhip_render {
     if (timed) pending.push_back(pd);
     last_gated = ctx->last_gate_idx >= 0;  // (set by launch_gain_mix for this call)
     last_device_form = ctx->last_wide_idx >= 0;
+    last_hg_robust = last_gated && ctx->last_hinge_robust;
     if (ctx->lazy_allocs != lazy_before) scratch_regrows++;  // (a buffer of the context no renderer had announced: earhip.h)
     t += nsamples;
   }
@@ -886,13 +888,28 @@ int earhip_render_hinge_standby(earhip_render *r, int *standby) {
     *standby = 0;
     earhip_ctx *ctx = r->ctx;
     // (the copy of the mode word the call's own gain kernel left in this renderer's slot: valid until this renderer's next call)
-    if (r->last_kind != 5 || !r->last_gated) return;
+    if (r->last_kind != 5 || !r->last_gated || r->last_hg_robust) return;  // (robust form allowed: nobody stands by)
     ctx->use();
     unsigned word = 0;
     EARHIP_HIP(hipMemcpyAsync(&word, r->rec.p, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     if (!(word & kModeRecorded)) fail_internal("no gain kernel recorded the call's mode word");
     *standby = (word & kGateHingeUnsafe) ? 1 : 0;
+  });
+}
+
+int earhip_render_hinge_robust(earhip_render *r, int *robust) {
+  return guarded([&] {
+    require(r != nullptr && robust != nullptr, "NULL argument");
+    *robust = 0;
+    earhip_ctx *ctx = r->ctx;
+    if (r->last_kind != 5 || !r->last_hg_robust) return;
+    ctx->use();
+    unsigned word = 0;
+    EARHIP_HIP(hipMemcpyAsync(&word, r->rec.p, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    if (!(word & kModeRecorded)) fail_internal("no gain kernel recorded the call's mode word");
+    *robust = (word & kGateHingeUnsafe) ? 1 : 0;
   });
 }
 

@@ -126,7 +126,7 @@ enum Opt {
   OPT_SPL, OPT_MFMA, OPT_XSCALE, OPT_WAVES, OPT_TPW, OPT_NRT,            // gain kernels' shapes (context-wide)
   OPT_H2_TILE, OPT_H2_WGS, OPT_H2_RUNS, OPT_P2_TILE, OPT_P2_PAIRS, OPT_P2_WGS, OPT_HINGE, OPT_HG_TILE, OPT_HBUILD_TPW, OPT_BUILD_TPW,  // launch plan of a call
   OPT_K2_WG, OPT_K2_OWN_BLOCK, OPT_RUN, OPT_GSPLIT,                      // decorrelator kernel / renderer creation
-  OPT_PROBE_RUNS, OPT_BLOCK_GROUPS, OPT_DEBUG_TIMING, OPT_TAILCUT, OPT_HOST_CHUNK_MB, OPT_HOST_THREADS,
+  OPT_PROBE_RUNS, OPT_BLOCK_GROUPS, OPT_DEBUG_TIMING, OPT_TAILCUT, OPT_HOST_CHUNK_MB, OPT_HOST_THREADS, OPT_HG_ROBUST,
   OPT_COUNT
 };
 struct OptVal {
@@ -152,6 +152,7 @@ struct earhip_ctx {
   earhip::DevBuf<unsigned> level;  // [2] input level words (float bits), used alternately by successive calls
   int level_idx = 0;
   int last_gate_idx = -1;  // the mode word ([2 + idx]) of the last call planned for the hinge kernel; -1: the last call was not
+  bool last_hinge_robust = false;  // ... and a call beyond the packed kink products' span runs the kernel's robust form (else: the piece lists standing by)
   int last_wide_idx = -1;  // the mode word of the last call whose split-operand kernel picked its form on the device; -1: none (wide form)
   // [2][tile_slow_cap] words used alternately by successive calls of the f16x2 gain kernel: non-zero = some object
   // of the tile needs the kernel's exact path (set by K0: k_seg_prep, cleared for the call after next by K1)

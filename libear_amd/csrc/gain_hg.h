@@ -284,7 +284,7 @@ template <int TPW, int NW>
 __global__ void __launch_bounds__(kHingeBuildThreads)
 k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
               const unsigned *level_cur, const unsigned *gate) {
-  if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate)
+  if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate; gate == NULL: nobody stands by)
   constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
   constexpr int NWV = kHingeBuildThreads / 64;
   constexpr int T = 64 * NW, NC = HgClasses<NW>::N, kHgExact = HgClasses<NW>::kExact;
@@ -457,8 +457,11 @@ __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast
 template <int NCT, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
-              unsigned *level_next, const unsigned *wide_cur, unsigned *wide_next, const unsigned *gate) {
+              unsigned *level_next, const unsigned *wide_cur, unsigned *wide_next, const unsigned *gate, const unsigned *span) {
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate); they clear the words of the next
+  // `span` (round 6; the same word as `gate`, given INSTEAD of it): bit 1 = some object of this call falls further below the call's
+  // level than the packed-f16 kink products hold (kHingeSpreadBinades) — the call then runs the ROBUST form of the kinks (their
+  // products made in f32, below) instead of being handed to the piece lists
 
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk, T = 64 * NW;
   constexpr int NQ = CH / NW;        // list slots whose gains one wave converts per chunk
@@ -482,8 +485,9 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
   __shared__ __attribute__((aligned(16))) float stage[NW][NQ * NR * 16 * NCT];  // a wave's rows: [slot][NR rows][16 NCT columns]
   // Both forms of the body (WIDE or not) in ONE kernel, the probe's word picking at run time: two kernels launched back to
   // back, one of which looks at the word and returns, cost 5 us per call for the one that returns
-  auto body = [&](auto wide_tag) __attribute__((always_inline)) {
+  auto body = [&](auto wide_tag, auto robust_tag) __attribute__((always_inline)) {
   constexpr bool WIDE = decltype(wide_tag)::value;
+  constexpr bool ROBUST = decltype(robust_tag)::value;  // (with WIDE only)
   constexpr float LOW = WIDE ? kLowPieceScale : 1.0f;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -939,11 +943,31 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
                 const hg_h2 k2048 = {(_Float16)LOW, (_Float16)LOW};
                 const hg_h2 F = __builtin_elementwise_max(__builtin_elementwise_fma(as_h2(SS[r]), as_h2(SC[qp]), as_h2(P0[qp])), zero);
                 const hg_h2 xh = as_h2(ah[r][qp]), xl = as_h2(al[r][qp]);
-                const hg_h2 Ah = F * xh;                                         // rn(F xh)
-                const hg_h2 res = __builtin_elementwise_fma(F, xh, -Ah);         // ... its residual: exact
-                const hg_h2 Al = __builtin_elementwise_fma(res, k2048, F * xl);  // low piece, in the scaled units of xl
-                Fh[r2][qp] = h2_bits(Ah);
-                Fl[r2][qp] = h2_bits(Al);
+                if constexpr (ROBUST) {
+                  // The robust form: F x in f32 — Q = (F 2^11) xh + F xl = 2^11 F x exactly (F 2^11 <= 65408 is an f16, the products
+                  // of f16 pairs are exact in f32), split like an input: Ah = rn16(Q 2^-11), Al = rn16(Q - 2^11 Ah).  An input
+                  // 21 binades below the call's level still gets ~17 bits of its product (the packed form above: 2^-25 ABSOLUTE, which
+                  // is what keeps it to calls whose objects stay within 16 binades); 7 instructions per value instead of 3.
+                  const uint32_t fb = h2_bits(F), flb = h2_bits(F * k2048), xhb = ah[r][qp], xlb = al[r][qp];
+                  float q0, q1, t0, t1;
+                  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(t0) : "v"(fb), "v"(xlb));
+                  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(t1) : "v"(fb), "v"(xlb));
+                  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(q0) : "v"(flb), "v"(xhb), "v"(t0));
+                  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(q1) : "v"(flb), "v"(xhb), "v"(t1));
+                  const uint32_t A = pack_f16(q0 * (1.0f / kLowPieceScale), q1 * (1.0f / kLowPieceScale));
+                  float r0, r1;
+                  const float mlow = -kLowPieceScale;
+                  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(A), "s"(mlow), "v"(q0));
+                  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(A), "s"(mlow), "v"(q1));
+                  Fh[r2][qp] = A;
+                  Fl[r2][qp] = pack_f16(r0, r1);
+                } else {
+                  const hg_h2 Ah = F * xh;                                         // rn(F xh)
+                  const hg_h2 res = __builtin_elementwise_fma(F, xh, -Ah);         // ... its residual: exact
+                  const hg_h2 Al = __builtin_elementwise_fma(res, k2048, F * xl);  // low piece, in the scaled units of xl
+                  Fh[r2][qp] = h2_bits(Ah);
+                  Fl[r2][qp] = h2_bits(Al);
+                }
               }
 #pragma unroll
             for (int ct = 0; ct < NCT; ct++) {
@@ -1050,8 +1074,10 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
     }
   }
   };  // body
-  if (!wide_cur || (*wide_cur & 1u) != 0u) body(std::true_type{});
-  else body(std::false_type{});
+  // (three forms of the body in one kernel; the words are wave-uniform: scalar branches)
+  if (span && (*span & kGateHingeUnsafe)) body(std::true_type{}, std::true_type{});
+  else if (!wide_cur || (*wide_cur & 1u) != 0u) body(std::true_type{}, std::false_type{});
+  else body(std::false_type{}, std::false_type{});
 }
 
 }  // namespace earhip

@@ -68,6 +68,7 @@ def render_device(curves, x_dev, n_out, block, dec, delay, calls, t0=0):
     plan = r.last_plan()
     plan["wide"] = r.wide_form()
     plan["standby"] = r.hinge_standby()
+    plan["robust"] = r.hinge_robust()
     plan["paired"] = r.last_list_layout()
     r.close()
     return out, plan
@@ -212,7 +213,7 @@ def test_levels_scene_at_the_headline_size(kind):
     print(f"levels scene ({kind}): worst per-channel rel RMS {worst:.3e}, plan {plan}")
 
 
-@pytest.mark.parametrize("scene", ["dense", "adm", "adm-512", "moving", "moving-standby", "moving-standby-bursty"])
+@pytest.mark.parametrize("scene", ["dense", "adm", "adm-512", "moving", "moving-standby", "moving-standby-bursty", "moving-robust-bursty"])
 def test_seed_sweep_at_1024_objects(scene):
     """Eight seeds (curves and audio) x {block-aligned ramps, ADM-like metadata, always-ramping metadata} at 1024
     objects: the worst channel of every run against the CPU path.  The CPU path's own sequential float32 sum sits
@@ -222,9 +223,11 @@ def test_seed_sweep_at_1024_objects(scene):
     moving-standby: the always-ramping curves on the path that STANDS BY behind the hinge kernel — packed piece lists on
     256-sample tiles — with uniform loud audio (option HINGE = 0 puts the call there; every object contributes at full
     level to every running total: the case with the least headroom); moving-standby-bursty: the same curves with
-    non-stationary audio (scenes.bursty_levels, a different programme per seed) and NO option set: the planner picks
-    the hinge kernel, the device-side gate hands the call to the lists that stand by (asserted), which is how such
-    content reaches them in production.  Both are held to 9.5e-7, not 1e-6."""
+    non-stationary audio (scenes.bursty_levels, a different programme per seed) and the hand-over of rounds 4-5 (option
+    HG_ROBUST = 0): the planner picks the hinge kernel, the device-side gate hands the call to the lists that stand by
+    (asserted).  moving-robust-bursty: the same content with NO option set — since round 6 the gate's word makes the hinge
+    kernel run its robust form (kink products in f32) instead of standing down (asserted: kernel 5, no hand-over, robust).
+    All three are held to 9.5e-7, not 1e-6."""
     layout, m, block, nblocks = "9+10+3", 1024, 512, 256  # (long enough for the launch plan of a stream: no object splits)
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
@@ -239,7 +242,7 @@ def test_seed_sweep_at_1024_objects(scene):
             curves = scenes.adm_curves(m, n, total, period=240, ramp=240, seed=300 + seed)
         x = device_audio(m, total, 400 + seed)
         unforced = all(os.environ.get(k) is None for k in ("EARHIP_MFMA", "EARHIP_HINGE", "EARHIP_P2_PAIRS", "EARHIP_P2_TILE"))
-        if scene == "moving-standby-bursty":
+        if scene in ("moving-standby-bursty", "moving-robust-bursty"):
             import torch
             lv = scenes.bursty_levels(m, nblocks, solo=0, seed=500 + seed)
             x.view(m, nblocks, block).mul_(torch.as_tensor(lv, device="cuda")[:, :, None])
@@ -247,6 +250,8 @@ def test_seed_sweep_at_1024_objects(scene):
             out, plan = with_options({"EARHIP_P2_TILE": "512"}, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
         elif scene == "moving-standby":
             out, plan = with_options({"EARHIP_HINGE": "0"}, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
+        elif scene == "moving-standby-bursty":
+            out, plan = with_options({"EARHIP_HG_ROBUST": "0"}, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
         else:
             out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
         if scene == "adm-512" and os.environ.get("EARHIP_MFMA") in (None, "3", "5"):
@@ -254,12 +259,14 @@ def test_seed_sweep_at_1024_objects(scene):
         if scene == "moving-standby" and os.environ.get("EARHIP_MFMA") in (None, "3", "5") and os.environ.get("EARHIP_P2_PAIRS") is None:
             assert plan["kernel"] == 4 and plan["paired"] is False, plan  # (packed lists: the layout the stand-by path runs)
         if scene == "moving-standby-bursty" and unforced:
-            assert plan["kernel"] == 5 and plan["standby"] and plan["paired"] is False, plan
-        wins = [(0, 3), (nblocks - 3, 3)] if scene != "moving-standby-bursty" else [(0, 3), (nblocks // 2, 3), (nblocks - 3, 3)]
+            assert plan["kernel"] == 5 and plan["standby"] and not plan["robust"] and plan["paired"] is False, plan
+        if scene == "moving-robust-bursty" and unforced and os.environ.get("EARHIP_HG_ROBUST") is None:
+            assert plan["kernel"] == 5 and plan["robust"] and not plan["standby"], plan
+        wins = [(0, 3), (nblocks - 3, 3)] if not scene.endswith("-bursty") else [(0, 3), (nblocks // 2, 3), (nblocks - 3, 3)]
         worst.append(check_windows(curves, x, out, n, block, dec, 255, wins))
     print(f"seed sweep ({scene}, plan {plan}): worst channel per seed " + " ".join(f"{w:.2e}" for w in worst)
           + f"; max {max(worst):.3e}")
-    if scene.startswith("moving-standby"):
+    if scene.startswith("moving-standby") or scene == "moving-robust-bursty":
         assert max(worst) <= 9.5e-7, worst
 
 
@@ -289,8 +296,9 @@ def test_device_decisions_stay_readable_with_two_renderers_on_one_context():
     """The form a split-operand kernel picked and the hinge kernel's hand-over are decided on the device, in words of the
     CONTEXT; the kernel that does a call leaves a copy in the renderer's own slot, so a renderer's answers survive the
     calls of other renderers on the same context (they used to be valid only until ANY renderer's next call).
-    A: always-ramping curves, uniform audio -> hinge kernel, plain form, no hand-over.  B: the same curves with bursty
-    audio -> handed to the piece lists, wide form.  Rendered A, B, then asked A; then B, A, asked B."""
+    A: always-ramping curves, uniform audio -> hinge kernel, plain form, packed kink products.  B: the same curves with bursty
+    audio -> wide form, and the hinge kernel's robust form (or, option HG_ROBUST = 0, the hand-over to the piece lists).
+    Rendered A, B, then asked A; then B, A, asked B."""
     import torch
     from libear_amd import capi
     if any(os.environ.get(k) is not None for k in ("EARHIP_MFMA", "EARHIP_HINGE", "EARHIP_P2_PAIRS", "EARHIP_P2_TILE")):
@@ -315,13 +323,15 @@ def test_device_decisions_stay_readable_with_two_renderers_on_one_context():
         r.reset(0)
         r.process_device(nblocks, x.data_ptr(), total, out.data_ptr(), total)
 
+    handover = ctx().get_option("HG_ROBUST") == 0  # (the tools run the suite with it as well)
+    beyond = lambda r: (r.hinge_standby() if handover else r.hinge_robust(), r.hinge_robust() if handover else r.hinge_standby(), r.wide_form())
     call(ra, xa); call(rb, xb)
     assert ra.gain_kernel() == 5 and rb.gain_kernel() == 5
-    assert (ra.hinge_standby(), ra.wide_form()) == (False, False), "A's answers after B's call"
-    assert (rb.hinge_standby(), rb.wide_form()) == (True, True)
+    assert beyond(ra) == (False, False, False), "A's answers after B's call"
+    assert beyond(rb) == (True, False, True)
     call(rb, xb); call(ra, xa); call(ra, xa)
-    assert (rb.hinge_standby(), rb.wide_form()) == (True, True), "B's answers after two calls of A"
-    assert (ra.hinge_standby(), ra.wide_form()) == (False, False)
+    assert beyond(rb) == (True, False, True), "B's answers after two calls of A"
+    assert beyond(ra) == (False, False, False)
     assert ra.scratch_regrows() == 0 and rb.scratch_regrows() == 0
     ra.close(); rb.close()
 
