@@ -107,6 +107,9 @@ int earhip_debug_read_bandwidth(earhip_ctx *ctx, const float *in_dev, size_t row
  * pageable, the caller's) and a device buffer of the call's own — average ms over `reps` copies of ms[0] host -> device and
  * ms[1] device -> host, each between HIP events on the context's stream: the 100 % mark of the host-pointer entry points. */
 int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int reps, double ms[2]);
+/* tuning aid, diagnostic builds (-DEARHIP_K2_PROF) only: the shader-clock stamps wave 0 of two workgroups of the last decorrelator
+ * launch left at its phase boundaries, out64[2][32] (tools/k2_phases.py); an ordinary build answers EARHIP_INVALID_ARGUMENT */
+int earhip_debug_k2_prof(earhip_ctx *ctx, unsigned long long *out64);
 
 /* ------------------------------------------------------------------------
  * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector

@@ -852,6 +852,21 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
   });
 }
 
+/* diagnostic builds (-DEARHIP_K2_PROF) only: the s_memtime stamps wave 0 of two workgroups of the last k_decorrelate_wave launch
+ * left at its phase boundaries, out[2][32]; an ordinary build reports "not built in" */
+int earhip_debug_k2_prof(earhip_ctx *ctx, unsigned long long *out64) {
+  return guarded([&] {
+    require(ctx != nullptr && out64 != nullptr, "NULL argument");
+#ifdef EARHIP_K2_PROF
+    ctx->use();
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    EARHIP_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_k2_prof), sizeof(unsigned long long) * 64));
+#else
+    fail_invalid("this build has no K2 phase stamps (-DEARHIP_K2_PROF)");
+#endif
+  });
+}
+
 int earhip_render_enable_timing(earhip_render *r, int enable) {
   return guarded([&] {
     require(r != nullptr, "render must not be NULL");

@@ -555,6 +555,9 @@ __device__ __forceinline__ void wave_dft16(v2f (&v)[16]) {
 // processes, the round-5 form built from the same tree in 0 of 78; every other test (fixed inputs, one stream) passes, the
 // instruction stream shows no unhandled hazard (every dependent pair of packed instructions has its s_nop), and a deterministic
 // kernel that is wrong once in twenty runs is not shipped for 4 % of K2.  -DEARHIP_K2_FOLDED=1 builds it (NOTES.md, round 6).
+#ifndef EARHIP_K2_ABL
+#define EARHIP_K2_ABL 0  // (timing-only ablations of k_decorrelate_wave, NOTES round 6: 1 no output stores, 2 no bus loads, 3 neither)
+#endif
 #ifndef EARHIP_K2_FOLDED
 #define EARHIP_K2_FOLDED 0
 #endif
@@ -750,6 +753,18 @@ __device__ __forceinline__ void wave_fft1024(v2f (&v)[16], v2f *lds, const v2f *
 
 constexpr int kDecorWaves = 4;  // waves (= runs) per workgroup of k_decorrelate_wave
 
+// -DEARHIP_K2_PROF: wave 0 of two workgroups (the first and one from the middle of the grid) leaves s_memtime stamps at the
+// kernel's phase boundaries (earhip_debug_k2_prof reads them): a diagnostic build, the marks cost the kernel a few per cent
+#ifdef EARHIP_K2_PROF
+static __device__ unsigned long long g_k2_prof[2][32];
+#define EARHIP_K2_MARK(i)                                                                        \
+  do {                                                                                           \
+    if (prof_slot >= 0 && lane == 0 && (i) < 32) g_k2_prof[prof_slot][(i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define EARHIP_K2_MARK(i) do {} while (0)
+#endif
+
 // grid = (ceil(runs / kDecorWaves), N); same parameters and semantics as k_decorrelate_delay_mix<1024>
 __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) k_decorrelate_wave(DecorParams P) {
   constexpr int L = 1024, B = 512;
@@ -757,10 +772,20 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
   __shared__ v2f h_lds[L + L / 16];   // the loudspeaker's spectrum (all runs of a workgroup share it)
   __shared__ v2f t1_lds[16][17];    // W256^{r k}: row k = lane & 15, column r - 1 (r = 1..15)
   __shared__ v2f t2_lds[3 * 256];    // W1024^{r j}: [256 (r - 1) + j], r = 1..3, j < 256
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // (the wave index as a SCALAR: the run's blocks, its bus and output rows and every branch on them are then wave-uniform values
+  // in SGPRs.  Round 6's phase stamps — tools/k2_phases.py — showed half of a pair's time BETWEEN its transforms: with `w` a lane
+  // value the compiler kept 64-bit per-lane row pointers, spilled the output pointer, and the reload in front of a block's stores —
+  // a vector-memory operation on the in-order counter — made every block's stores wait for the block before them to be
+  // acknowledged by memory: `s_waitcnt vmcnt(0)` behind a scratch_load, twice per pair)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   v2f *lds = lds_all[w];
   auto to_v2f = [](cf c) { return v2f{c.x, c.y}; };
   const int n = blockIdx.y;
+#ifdef EARHIP_K2_PROF
+  const int prof_slot = w != 0 ? -1 : (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2) ? 1 : -1;
+  int prof_i = 2;
+#endif
+  EARHIP_K2_MARK(0);
   for (int i = threadIdx.x; i < L; i += 64 * kDecorWaves) h_lds[wave_pad(i)] = to_v2f(P.H[(size_t)n * L + i]);
   if (threadIdx.x < 240) {
     const int k = threadIdx.x / 15, r = threadIdx.x % 15 + 1;
@@ -768,6 +793,7 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
   }
   for (int i = threadIdx.x; i < 3 * 256; i += 64 * kDecorWaves) t2_lds[i] = to_v2f(P.tw[((i >> 8) + 1) * (i & 255)]);
   __syncthreads();
+  EARHIP_K2_MARK(1);
   const int first = (blockIdx.x * kDecorWaves + w) * P.R;
   if (first >= P.T) return;  // (no workgroup barriers below)
   const int last = min(first + P.R, P.T);
@@ -788,6 +814,11 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
   // acc[m] = bus sample s0 + lane + 64 m summed over the object splits (8 loads in flight per split)
   auto bus_at8 = [&](const float *row, int s0, float (&acc)[8]) {
     const float *q = row + s0 + lane;
+#if EARHIP_K2_ABL >= 2
+#pragma unroll
+    for (int m = 0; m < 8; m++) acc[m] = (float)(lane - m) * 1e-3f;
+    return;
+#endif
 #pragma unroll
     for (int m = 0; m < 8; m++) acc[m] = __builtin_nontemporal_load(q + 64 * m);  // (read once)
     for (int p = 1; p < P.nparts; p++) {
@@ -823,50 +854,124 @@ __global__ void __launch_bounds__(64 * kDecorWaves) __attribute__((amdgpu_waves_
   for (int m = 0; m < 8; m++) tl[m] = first == 0 ? P.tail_in[(size_t)n * B + lane + 64 * m] : 0.0f;
 
   // real part = diffuse block tb, imaginary part = block tb+1
-  auto load_pair = [&](int tb, float (&re)[8], float (&im)[8]) {
-#pragma unroll
-    for (int m = 0; m < 8; m++) re[m] = im[m] = 0.0f;
-    if (tb >= 0 && tb < last) bus_at8(diffuse, tb * B, re);
-    if (tb + 1 < last) bus_at8(diffuse, (tb + 1) * B, im);
-  };
-  float zre[8], zim[8];
-  load_pair(first - 1, zre, zim);
-  for (int tb = first - 1; tb < last; tb += 2) {
-    const bool have_re = tb >= 0, have_im = tb + 1 < last;
-    v2f v[16];
+  // (straight into the register pairs the transform takes them in — real part block tb, imaginary part block tb + 1 —: loaded into
+  // two float arrays, the compiler interleaved them with moves right behind the requests, i.e. waited for them at once)
+  auto load_half = [&](int tb, v2f (&z)[8], auto im_tag) {
+    constexpr bool IM = decltype(im_tag)::value;
+    const float *q = diffuse + tb * B + lane;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      v[m] = v2f{zre[m], zim[m]};
-      v[m + 8] = v2f{0.0f, 0.0f};  // zero padding to 2 B
+#if EARHIP_K2_ABL >= 2
+      const float x = (float)(lane + m) * 1e-3f;  // (timing only: no bus loads)
+#else
+      const float x = __builtin_nontemporal_load(q + 64 * m);  // (read once)
+#endif
+      if (IM) z[m].y = x;
+      else z[m].x = x;
     }
+    for (int p = 1; p < P.nparts; p++) {
+      q += P.part_stride;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const float x = __builtin_nontemporal_load(q + 64 * m);
+        if (IM) z[m].y += x;
+        else z[m].x += x;
+      }
+    }
+  };
+  auto load_pair = [&](int tb, v2f (&z)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) z[m] = v2f{0.0f, 0.0f};
+    if (tb >= 0 && tb < last) load_half(tb, z, std::false_type{});
+    if (tb + 1 < last) load_half(tb + 1, z, std::true_type{});
+  };
+  // The vector-memory counter is IN ORDER and counts stores: whatever is waited for behind a block's stores waits for those
+  // stores to be acknowledged by memory.  So a pair's iteration is laid out as: requests (the next pair's inputs, this pair's
+  // delayed direct samples) -> transforms -> everything that consumes a loaded value (the outputs, made in the registers of the
+  // delayed samples; the next pair's inputs moved into the transform registers) -> the stores, last.  (Round 5's order — stores,
+  // then the next iteration picking up its prefetched inputs — waited for every pair's stores: `s_waitcnt vmcnt(0)` at the loop's
+  // back edge, 5-10 k cycles of a pair's ~16 k: tools/k2_phases.py.)
+  v2f v[16];
+  {
+    v2f z[8];
+    load_pair(first - 1, z);
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = z[m];
+  }
+  for (int tb = first - 1; tb < last; tb += 2) {
+    const bool have_re = tb >= 0, have_im = tb + 1 < last;
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m + 8] = v2f{0.0f, 0.0f};  // zero padding to 2 B
     // loads issued ahead of the transforms: the next pair, and this pair's delayed direct samples
-    load_pair(tb + 2, zre, zim);
+    v2f z[8];
+    load_pair(tb + 2, z);
     float dre[8], dim[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) dre[m] = dim[m] = 0.0f;
     if (have_re && tb >= first) delayed8(tb, dre);
     if (have_im) delayed8(tb + 1, dim);
+#ifdef EARHIP_K2_PROF
+    EARHIP_K2_MARK(prof_i);  // pair start: registers set, next pair's loads issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EARHIP_K2_MARK(prof_i + 1);  // ... and arrived (a diagnostic wait: the kernel itself does not wait here)
+#endif
     wave_fft1024<-1, true>(v, lds, t1, t2, lane);  // (v[8..15] = 0: the padding)
+#ifdef EARHIP_K2_PROF
+    asm volatile("" : "+v"(v[0]));
+    EARHIP_K2_MARK(prof_i + 2);
+#endif
 #pragma unroll
     for (int m = 0; m < 16; m++) {
       v[m] = wave_cmul<-1>(v[m], h_lds[wave_pad(lane + 64 * m)]);
       if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef EARHIP_K2_PROF
+    asm volatile("" : "+v"(v[0]));
+    EARHIP_K2_MARK(prof_i + 3);
+#endif
     wave_fft1024<+1>(v, lds, t1, t2, lane);
-    if (have_re) {  // :223-226
-      if (tb >= first) {
+#ifdef EARHIP_K2_PROF
+    asm volatile("" : "+v"(v[0]));
+    EARHIP_K2_MARK(prof_i + 4);
+    prof_i += 5;
+#endif
+    // (the outputs are made whether the block exists or not — a block that does not is not stored —: a register that a load MAY
+    // have been issued for has then been read on every path before the stores, and the compiler's wait-count pass, which merges
+    // the paths conservatively, puts no wait in front of them)
 #pragma unroll
-        for (int m = 0; m < 8; m++) __builtin_nontemporal_store((v[m].x + tl[m]) * norm + dre[m], out + tb * B + lane + 64 * m);
-      }
+    for (int m = 0; m < 8; m++) {  // :223-226
+      dre[m] = (v[m].x + tl[m]) * norm + dre[m];
+      asm volatile("" : "+v"(dre[m]) : : "memory");  // (made HERE, not sunk into the store's branch behind other stores)
+      tl[m] = have_re ? v[m + 8].x : tl[m];  // :224
+    }
 #pragma unroll
-      for (int m = 0; m < 8; m++) tl[m] = v[m + 8].x;  // :224
+    for (int m = 0; m < 8; m++) {
+      dim[m] = (v[m].y + tl[m]) * norm + dim[m];
+      asm volatile("" : "+v"(dim[m]) : : "memory");
+      tl[m] = have_im ? v[m + 8].y : tl[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {  // the next pair's inputs (every load of this iteration has been waited for by now)
+      v[m] = z[m];
+      // (an opaque use, ordered against memory operations: left to itself the compiler coalesces v with the load's destination
+      // and the first real use — hence the wait — lands in the NEXT iteration, behind the stores)
+      asm volatile("" : "+v"(v[m]) : : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);  // nothing that reads a loaded value sinks below the stores
+#if EARHIP_K2_ABL == 1 || EARHIP_K2_ABL == 3  // (timing-only ablation: no output stores — one store per wave and pair keeps the work alive)
+    if (have_im && dre[0] + dim[0] + dre[7] + dim[7] == 123.456f) out[tb * B + lane] = dre[1] + dim[1];
+#else
+    if (have_re && tb >= first) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) __builtin_nontemporal_store(dre[m], out + tb * B + lane + 64 * m);
     }
     if (have_im) {
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        __builtin_nontemporal_store((v[m].y + tl[m]) * norm + dim[m], out + (tb + 1) * B + lane + 64 * m);
-        tl[m] = v[m + 8].y;
-      }
+      for (int m = 0; m < 8; m++) __builtin_nontemporal_store(dim[m], out + (tb + 1) * B + lane + 64 * m);
     }
+#endif
   }
+  EARHIP_K2_MARK(prof_i < 31 ? prof_i : 31);  // the run's last store issued
   if (last == P.T) {  // this wave owns the end of the call: publish the state
 #pragma unroll
     for (int m = 0; m < 8; m++) P.tail_out[(size_t)n * B + lane + 64 * m] = tl[m];
