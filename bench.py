@@ -1088,8 +1088,8 @@ def main():
                                         "Gsamples_per_s": round(M * hb * B / hdt / 1e9, 2), "GBps_in": round(gbps, 1),
                                         "h2d_GBps_measured": ref_rate, "frac": round(gbps / ref_rate, 3),
                                         "frac_of_pageable_copy": round(gbps / hs["h2d_GBps_measured"]["pageable"], 3) if src == "pageable" else None,
-                                        # (same blocks as the timed stream's first ones: held against the device-resident render)
-                                        "max_rel_diff_vs_stream_render": None, "_first": first})
+                                        # (the same blocks as the timed stream's first ones: held against the CPU path and the device-resident render)
+                                        "max_channel_rel_rms_vs_cpu": None, "max_rel_diff_vs_stream_render": None, "_first": first})
                 ctx.release(xp)
                 ctx.release(yp)
             ctx.release(xp_all)
@@ -1131,17 +1131,22 @@ def main():
                     o.set_points(m, 1, t, f if K == 2 else np.zeros_like(d))
                 return buf[:N, b0 * B:(b0 + count) * B].cpu().numpy(), o.process(xs_)[:, lead * B:], xs_, win_
 
-            if result.get("host_stream") and world == 1:
-                for e in result["host_stream"]["calls"]:
-                    f_ = e.pop("_first")
-                    ref_ = buf[:N, :f_.shape[1]].cpu().numpy()
-                    e["max_rel_diff_vs_stream_render"] = float(f"{scenes.rel_rms_per_channel(f_, ref_):.3e}")
-                result["host_stream"]["pass"] = bool(all(e["max_rel_diff_vs_stream_render"] <= 5e-7 for e in result["host_stream"]["calls"]))
             # three windows of the timed buffer: its first, middle and last blocks (tests/test_gpu_render_full.py::check_windows)
             starts = [wl.lead]  # (a time-sharded rank's lead block is not output)
             if nblk >= 3 * nb + 2:
                 starts += [nblk // 2 - nb // 2, nblk - nb]
             got, want, xs, win = window(starts[0], nb)
+            if result.get("host_stream") and world == 1:
+                # the host-pointer calls' own outputs: their first blocks against the CPU path (the gate: per channel, 1e-6 — a call
+                # from host pointers runs as chunks of a few blocks, i.e. on the launch plans of short calls), and all of them
+                # against the device-resident render of the same blocks (information: two plans of the same arithmetic)
+                for e in result["host_stream"]["calls"]:
+                    f_ = e.pop("_first")
+                    ref_ = buf[:N, :f_.shape[1]].cpu().numpy()
+                    e["max_rel_diff_vs_stream_render"] = float(f"{scenes.rel_rms_per_channel(f_, ref_):.3e}")
+                    e["max_channel_rel_rms_vs_cpu"] = float(f"{scenes.rel_rms_per_channel(f_[:, :nb * B], want):.3e}")
+                result["host_stream"]["pass"] = bool(all(e["max_channel_rel_rms_vs_cpu"] <= 1e-6 and e["max_rel_diff_vs_stream_render"] <= 2e-6
+                                                         for e in result["host_stream"]["calls"]))
             truth = scenes.render_f64([(t, d, f if K == 2 else None) for t, d, f in win], xs, N, dec, delay)
             windows = [{"first_block": base + starts[0], "blocks": nb, "rel_rms_vs_cpu": float(f"{scenes.rel_rms(got, want):.3e}"),
                         "max_channel_rel_rms_vs_cpu": float(f"{scenes.rel_rms_per_channel(got, want):.3e}")}]
@@ -1266,7 +1271,7 @@ def main():
             print(f"bench.py: time-sharded blocks differ with the length of the lead-in by {lead_check:.3e}", file=sys.stderr, flush=True)
             parity_failed = True
         if result.get("host_stream") and result["host_stream"].get("pass") is False:
-            print("bench.py: the host-pointer stream calls differ from the device-resident render beyond 5e-7", file=sys.stderr, flush=True)
+            print("bench.py: the host-pointer stream calls are beyond 1e-6 from the CPU path (or 2e-6 from the device-resident render)", file=sys.stderr, flush=True)
             parity_failed = True
         if result.get("parity") and not result["parity"]["pass"]:
             print("bench.py: PARITY FAILED - the timed output differs from the CPU path by "

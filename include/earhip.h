@@ -71,15 +71,23 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  * accepted), value = a decimal integer as text, or NULL / "" to return the option to its default ("the library decides").
  * At earhip_ctx_create every option is taken ONCE from the environment variable EARHIP_<KEY>; after that only this call
  * changes it — no process call reads the environment.  An option takes effect for calls / objects made after it is
- * set.  Unknown key: EARHIP_INVALID_ARGUMENT.
+ * set.  Unknown key, or a value that is not an integer ("abc", "1x"): EARHIP_INVALID_ARGUMENT, nothing changed (a context
+ * is not created from an environment that holds such a value).
  *   gain stage:   MFMA (0 VALU | 1 exact-f32 MFMA | 3 default | 4 grid kernel | 5 piece lists | 6 hinge kernel),
  *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, P2_WGS (workgroups of the launch;
- *                 P2_WGS 0: one per tile), BUILD_TPW, HBUILD_TPW (1 2 4 8),
+ *                 P2_WGS 0: one per tile), H2_RUNS (1: a workgroup of the grid kernel takes a contiguous run of tiles instead of
+ *                 every n-th: measured slower, kept as a knob), HG_ROBUST (default 1: a call whose levels spread beyond the hinge
+ *                 kernel's packed-f16 kink products runs that kernel's f32 form; 0: it is handed to the piece lists standing by,
+ *                 rounds 4-5), BUILD_TPW, HBUILD_TPW (1 2 4 8),
  *                 SPL (2 | 4), WAVES (1..8), TPW (1..8), NRT (4 | 8), XSCALE (log2 of a fixed input prescale), PROBE_RUNS
  *   renderer:     K2_WG, K2_OWN_BLOCK (0 | 1), RUN (odd blocks per decorrelator run), GSPLIT (1..32) — read by
  *                 earhip_render_create; TAILCUT (v = 0..7, default 2: a stream call of k rounds of tiles plus at most v / 8
  *                 of a round runs as two consecutive calls, earhip_render_last_tail_blocks; longer tails measured slower cut)
- *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING */
+ *   host pointers: HOST_CHUNK_MB (MB of inputs per time chunk of a long earhip_render_process call: default 32 from device-reachable
+ *                 rows, 16 from ordinary ones; <= 0: no pipeline, one transfer), HOST_THREADS (staging threads: default min(16, cores / 2))
+ *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING
+ * (K2_WG, K2_OWN_BLOCK, DEBUG_TIMING are "on" for any value other than 0 — rounds 1-4 read the mere presence of the environment
+ * variable as "on": EARHIP_K2_WG=0 now means off.) */
 int earhip_ctx_set_option(earhip_ctx *ctx, const char *key, const char *value);
 int earhip_ctx_get_option(const earhip_ctx *ctx, const char *key, int *is_set, int *value);
 /* Host memory the device reaches directly (pinned and mapped).  libear's interfaces take `float **` channel
@@ -88,8 +96,10 @@ int earhip_ctx_get_option(const earhip_ctx *ctx, const char *key, int *is_set, i
  * (hipHostRegister: the range must stay allocated until released), AND the channel pointers of a call are
  * evenly spaced — a column-major matrix — the short-call path of earhip_render_process copies them with
  * one strided DMA instead of gathering them into a staging buffer first, and writes the outputs in place
- * (block mode: 0.12 -> 0.09 ms per 512-sample call at the headline shape).  Any other pointers work as
- * before.  earhip_host_release frees / unregisters a range (by its start); earhip_ctx_destroy the rest. */
+ * (block mode: 0.12 -> 0.09 ms per 512-sample call at the headline shape); long calls (16 MB of inputs and more) move
+ * their time chunks by strided DMA in both directions (0.91-0.95 of the bus's own rate, against 0.83-0.88 through the staging
+ * threads).  Any other pointers work as before.  earhip_host_release frees / unregisters a range (by its start);
+ * earhip_ctx_destroy the rest. */
 int earhip_host_alloc(earhip_ctx *ctx, size_t bytes, void **out);
 int earhip_host_register(earhip_ctx *ctx, void *ptr, size_t bytes);
 int earhip_host_release(earhip_ctx *ctx, void *ptr);
@@ -417,7 +427,12 @@ int earhip_render_reset(earhip_render *r, int64_t sample_time);
 int earhip_render_process_device(earhip_render *r, size_t nblocks,
                                  const float *in_dev, size_t in_stride,
                                  float *out_dev, size_t out_stride);
-/* Same from host channel pointers (H2D, kernels, D2H, synchronise). */
+/* Same from host channel pointers — libear's own calling convention (src/dsp/variable_block_size_impl.cpp:44-81) —: H2D,
+ * kernels, D2H, synchronise.  Calls of 16 MB of inputs and more run as a PIPELINE of time chunks (a few blocks each) on three
+ * streams: chunk c + 1 on its way to the device while chunk c's kernels run and chunk c - 1's outputs come back; from ordinary
+ * pointers persistent staging threads (started at the first such call) gather the next chunk meanwhile.  Each chunk is an
+ * ordinary process call of its blocks (the DSP state carries over): the results are those of consecutive calls, and the
+ * last-call queries describe the last chunk. */
 int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *in,
                           float *const *out);
 /* Kernel timing (HIP events on the context's stream around each launch).

@@ -290,7 +290,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
   if (ml.split) {
     // as many workgroups as are resident at once (a multiple of 8: a workgroup's tiles stay on its XCD), each working
     // through its share of the tiles in one software pipeline (gain_h2.h)
-    const int per_cu = ml.tile() == 512 ? (cp.nct == 1 ? 2 : 1) : (cp.nct == 1 ? 3 : 2);
+    const int per_cu = ml.tile() == 512 ? 1 : (cp.nct == 1 ? 3 : 2);  // (the 8-wave forms: 154-243 registers, one workgroup per CU)
     int wgs = std::max(8, (ctx->num_cus * per_cu / std::max(1, ml.gsplit * cp.mnz * cp.mgroups)) & ~7);
     if (ctx->has(OPT_H2_WGS)) wgs = std::max(1, ctx->get(OPT_H2_WGS));  // tuning knob
     wgs = std::max(wgs, ((ml.ntiles + 63) / 64 + 7) & ~7);  // (at most 64 tiles per workgroup: its redo mask)

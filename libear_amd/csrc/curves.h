@@ -750,10 +750,11 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
       L.pieces = false, L.paired = false, L.pw = 4;
     }
   }
-  // (one column tile — up to 16 output columns, BASELINE config 2 — stays on the 4-wave kernel: its 8-wave form has to
-  // fit 128 registers for two workgroups per CU and has spilled inside the chunk loop since the operand fragments
-  // grew a third piece: 0.296 ms against 0.261 for the 4-wave form at three workgroups per CU, same box)
-  L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || (nsamples / 512 >= 2 * ctx->num_cus && cp.nct > 1));
+  // (rounds 3-5 kept one column tile — up to 16 output columns, BASELINE config 2 — on the 4-wave kernel: its 8-wave form was held to
+  // 128 registers for two workgroups per CU and spilled inside the chunk loop: 0.296 ms against 0.261)
+  // (round 6: the single-column-tile form too — its 8-wave kernel no longer spills (154 registers, one workgroup per CU): config 2
+  // 0.2257 ms against 0.2283 / 0.2487 (the two buffer modes) over six fresh processes each, and never in the slow mode)
+  L.wide = L.split && aligned_tile >= 512 && forced != 256 && (forced == 512 || nsamples / 512 >= 2 * ctx->num_cus);
   // Exact f32 asked for (MFMA = 1) and EVERY curve point on the 512-sample tile grid of a call of whole tiles: the line form
   // of the ramp on the f32 matrix pipe, no per-sample arithmetic in front of it (gain_f32g.h).  Finite gains only (a
   // constant segment's row is used as it is, but a ramp through a non-finite gain is libear's own arithmetic's business).
