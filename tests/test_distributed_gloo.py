@@ -170,6 +170,18 @@ def test_exchange_model_per_mode():
     assert cover == list(range(10))
 
 
+def test_lead_in_follows_the_reach_of_the_firs_and_the_delay():
+    """a time-sharded rank (and a parity window inside a stream) starts as many blocks early as the DSP state reaches back: the
+    512-tap decorrelators 511 samples, the compensation delay 255 — one block from 512 samples per block, two at 256, eight at
+    64; a longer delay asks for its own"""
+    sys.path.insert(0, ROOT)
+    from libear_amd.distributed import lead_blocks, time_range
+    assert [lead_blocks(b) for b in (1024, 512, 511, 256, 128, 64)] == [1, 1, 1, 2, 4, 8]
+    assert lead_blocks(512, n_taps=1, delay=0) == 1 and lead_blocks(512, n_taps=512, delay=2000) == 4
+    assert time_range(64, 2, 4, partitions=2, delay_blocks=1)[2] == 2 and time_range(64, 2, 4, partitions=1, delay_blocks=4)[2] == 4
+    assert time_range(64, 0, 4, partitions=2, delay_blocks=4) == (0, 16, 0)  # (the stream's first rank has nothing in front of it)
+
+
 def test_shard_ranges_cover_everything():
     sys.path.insert(0, ROOT)
     from libear_amd.distributed import channel_range, shard_range

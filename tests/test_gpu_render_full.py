@@ -721,19 +721,26 @@ def test_exact_f32_on_the_tile_grid(layout, m, nblocks, kind):
 
 def test_a_cut_call_through_the_host_pointer_entry_point():
     """earhip_render_process (host channel pointers, staged) with a call that is cut in two on the device: every sample
-    against the oracle"""
+    against the oracle.  (21 MB of inputs: since round 6 such a call runs as a pipeline of time chunks — option HOST_CHUNK_MB = 0
+    keeps it one transfer and one device call, which is then cut —; the default is checked beside it.)"""
     from libear_amd import capi
     layout, m, block, nblocks = "4+5+0", 40, 512, 258
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
     curves = scenes.dense_curves(m, n, block, nblocks, seed=12)
     x = scenes.audio(m, block * nblocks, seed=5)
-    r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
-    for i, (t, d, f) in enumerate(curves):
-        r.set_object_points(i, t, d, f)
-    got = r.process(x)
-    tail = r.last_tail_blocks()
-    r.close()
+
+    def render():
+        r = capi.Renderer(ctx(), m, n, block, dec, 255, max_blocks=nblocks)
+        for i, (t, d, f) in enumerate(curves):
+            r.set_object_points(i, t, d, f)
+        got = r.process(x)
+        tail = r.last_tail_blocks()
+        r.close()
+        return got, tail
     want = oracle_window(curves, x, n, block, dec, 255, 0)
+    got, tail = with_options({"EARHIP_HOST_CHUNK_MB": "0"}, render)
     assert tail == 2, tail
     assert scenes.rel_rms_per_channel(got, want) <= 1e-6
+    got2, _ = render()  # the pipeline of time chunks
+    assert scenes.rel_rms_per_channel(got2, want) <= 1e-6

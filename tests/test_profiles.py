@@ -52,7 +52,7 @@ def test_every_traffic_entry_cites_a_tracked_file_that_holds_its_counters():
 
 def test_bench_lines_of_the_round_are_tracked_and_parse():
     tracked = tracked_files()
-    lines = sorted(f for f in tracked if re.match(r"profiles/r05_bench_.*\.json$", f))
+    lines = sorted(f for f in tracked if re.match(r"profiles/r06_bench_.*\.json$", f))
     assert len(lines) >= 10, lines
     for f in lines:
         d = json.loads(open(os.path.join(ROOT, f)).read().strip().splitlines()[-1])
@@ -62,10 +62,10 @@ def test_bench_lines_of_the_round_are_tracked_and_parse():
 
 
 def test_default_line_of_the_round_carries_the_other_workloads():
-    """profiles/r05_bench_default.json: the default `python bench.py` line as the driver runs it — headline + the
+    """profiles/r06_bench_default.json: the default `python bench.py` line as the driver runs it — headline + the
     `secondary` array (configs 2, 3, 5, the scenes that take the other gain kernels, a rank's share at 8 GPUs), every entry
     parity-gated on its own timed buffer"""
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")).read().strip().splitlines()[-1])
     assert d["config"]["baseline_config"] == "C4" and d["parity"]["pass"]
     assert d["parity"]["gpu_rel_rms_vs_float64"] <= d["parity"]["cpu_rel_rms_vs_float64"]
     sec = {s["workload"]: s for s in d["secondary"]}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the bench lines of every configuration / scene for profiles/ (on the GPU box):
 #   bash tools/collect_round.sh <tag>     -> gpurun_out/<tag>_bench_<name>.json
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT && mkdir -p gpurun_out
 run() { # name, bench args...
