@@ -140,7 +140,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     if (!hinge_addressable(M, in_stride, nsamples, (size_t)ps.kink_row0 + ps.rows, ps.row)) fail_internal("hinge kernel: buffers beyond its 32-bit offsets");
     unsigned *obj_lv = probe.obj_level;
     // with a probe: does the hinge kernel's span of levels cover this call?  (decided on the device: k_hinge_gate)
-    if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate, wide_cur != nullptr);
+    if (gate) hipLaunchKernelGGL(k_hinge_gate, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, obj_lv, ctx->obj_level_cap, M, level_cur, gate, wide_cur != nullptr, hg_robust);
     int tpw = 1;
     const size_t cached_max = std::min((size_t)kMaxHingeCached, ctx->hinge_build_lds / sizeof(HingeCached));  // (pairs a workgroup may keep)
     if ((size_t)M > cached_max) fail_internal("hinge lists: more objects than the builder's LDS holds on this device");
@@ -154,7 +154,7 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     // (more than 64 KB of dynamic LDS has to be asked for, per device and instantiation: earhip_ctx_create does, hinge_build_allow_lds)
 #define EARHIP_HBUILD_ONE(T_, NW_)                                                                                    \
   hipLaunchKernelGGL((k_hinge_build<T_, NW_>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                     t_call + nsamples, hl, obj_lv, level_cur, hg_robust ? nullptr : gate);
+                     t_call + nsamples, hl, obj_lv, level_cur, hg_robust ? nullptr : gate, hg_robust ? gate : nullptr);
 #define EARHIP_HBUILD_CASE(T_)                                                                                        \
   if (tpw == T_) {                                                                                                    \
     if (ml.tile() == 256) EARHIP_HBUILD_ONE(T_, 4)                                                                    \

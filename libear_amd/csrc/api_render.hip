@@ -924,7 +924,7 @@ int earhip_render_hinge_robust(earhip_render *r, int *robust) {
     EARHIP_HIP(hipMemcpyAsync(&word, r->rec.p, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     EARHIP_HIP(hipStreamSynchronize(ctx->stream));
     if (!(word & kModeRecorded)) fail_internal("no gain kernel recorded the call's mode word");
-    *robust = (word & kGateHingeUnsafe) ? 1 : 0;
+    *robust = hinge_span_exceeded(word, r->M) ? 1 : 0;
   });
 }
 

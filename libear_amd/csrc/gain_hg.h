@@ -283,8 +283,11 @@ static_assert(sizeof(HingeCached) == 16, "");
 template <int TPW, int NW>
 __global__ void __launch_bounds__(kHingeBuildThreads)
 k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
-              const unsigned *level_cur, const unsigned *gate) {
+              const unsigned *level_cur, const unsigned *gate, const unsigned *span) {
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate; gate == NULL: nobody stands by)
+  // (span: the kernel's robust form does this call when the word says so — it keeps its precision as far down as the other
+  // split-operand kernels, so only objects quieter than THEIR bound take the exact path)
+  const int quiet_binades = span && hinge_span_exceeded(*span, M) ? kQuietBinades : kHingeQuietBinades;
   constexpr int OB = kHingeBuildThreads / TPW;  // objects per batch
   constexpr int NWV = kHingeBuildThreads / 64;
   constexpr int T = 64 * NW, NC = HgClasses<NW>::N, kHgExact = HgClasses<NW>::kExact;
@@ -310,7 +313,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       const HingeRecs R = hinge_load(ps, base, n, kc);
       const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
       int cls = hp.cls;
-      if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - kHingeQuietBinades)
+      if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - quiet_binades)
         cls = kHgExact;
       LinEntry e;
       HingeEntry h;
@@ -1075,7 +1078,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
   }
   };  // body
   // (three forms of the body in one kernel; the words are wave-uniform: scalar branches)
-  if (span && (*span & kGateHingeUnsafe)) body(std::true_type{}, std::true_type{});
+  if (span && hinge_span_exceeded(*span, P.M)) body(std::true_type{}, std::true_type{});
   else if (!wide_cur || (*wide_cur & 1u) != 0u) body(std::true_type{}, std::false_type{});
   else body(std::false_type{}, std::false_type{});
 }

@@ -241,16 +241,29 @@ k_level_probe(const float *in, size_t in_stride, int nsamples, int M, unsigned *
 // lists, launched behind them, do the call (each pair of launches looks at the word: the ones that do not work cost ~3 us).
 constexpr int kHingeSpreadBinades = 16;
 constexpr unsigned kGateHingeUnsafe = 2u;
+// (round 6, `count_quiet`: the objects that are quiet THROUGHOUT the call — their loudest probed instant below the span — are
+// counted into bits 8.. of the word as well: one of them is cheaper on the exact path than the robust form is for everybody,
+// a tenth of the scene — chunks of a few blocks of non-stationary audio — is not: hinge_span_exceeded)
+constexpr int kGateQuietShift = 8;
+__host__ __device__ __forceinline__ bool hinge_span_exceeded(unsigned word, int M) {
+  const int limit = M / 64 > 4 ? M / 64 : 4;
+  return (word & kGateHingeUnsafe) != 0u || (int)(word >> kGateQuietShift) > limit;
+}
 static __global__ void __launch_bounds__(256)
-k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cur, unsigned *gate, bool wide) {
+k_hinge_gate(const unsigned *obj_level, int cap, int M, const unsigned *level_cur, unsigned *gate, bool wide, bool count_quiet) {
   const int m = blockIdx.x * 256 + threadIdx.x;
-  bool unsafe = false;
+  bool unsafe = false, quiet = false;
   if (m < M) {
     const unsigned hi = obj_level[m], lo = obj_level[cap + m], call = *level_cur;
     const bool exact_anyway = hi != 0u && call != 0u && (int)(hi >> 23) < (int)(call >> 23) - kHingeSpreadBinades;
     unsafe = !exact_anyway && lo != 0u && call != 0u && (int)(lo >> 23) < (int)(call >> 23) - kHingeSpreadBinades;
+    quiet = exact_anyway;
   }
   if (__syncthreads_or(unsafe ? 1 : 0) && threadIdx.x == 0) atomicOr(gate, kGateHingeUnsafe);
+  if (count_quiet) {
+    const int nq = __syncthreads_count(quiet ? 1 : 0);
+    if (nq > 0 && threadIdx.x == 0) atomicAdd(gate, (unsigned)nq << kGateQuietShift);
+  }
   // bit 0 of the same word, when `wide` (else the split-operand kernels behind this launch run their wide form only): the form
   // they need — wide when some object falls more than kPlainBinades below the call's level at some probed instant (k_seg_prep)
   if (wide) {
