@@ -120,6 +120,8 @@ int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int r
 /* tuning aid, diagnostic builds (-DEARHIP_K2_PROF) only: the shader-clock stamps wave 0 of two workgroups of the last decorrelator
  * launch left at its phase boundaries, out64[2][32] (tools/k2_phases.py); an ordinary build answers EARHIP_INVALID_ARGUMENT */
 int earhip_debug_k2_prof(earhip_ctx *ctx, unsigned long long *out64);
+/* the same for the list builders (k_piece_build / k_hinge_build; -DEARHIP_BUILD_PROF; tools/build_phases.py) */
+int earhip_debug_build_prof(earhip_ctx *ctx, unsigned long long *out64);
 
 /* ------------------------------------------------------------------------
  * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector

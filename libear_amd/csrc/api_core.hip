@@ -638,6 +638,21 @@ int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int r
   });
 }
 
+/* diagnostic builds (-DEARHIP_BUILD_PROF) only: the s_memtime stamps thread 0 of two workgroups of the LAST list-builder launch
+ * (k_piece_build or k_hinge_build) left at its phase boundaries, out[2][32]; an ordinary build reports "not built in" */
+int earhip_debug_build_prof(earhip_ctx *ctx, unsigned long long *out64) {
+  return guarded([&] {
+    require(ctx != nullptr && out64 != nullptr, "NULL argument");
+#ifdef EARHIP_BUILD_PROF
+    ctx->use();
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    EARHIP_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_build_prof), sizeof(unsigned long long) * 64));
+#else
+    fail_invalid("this build has no list-builder phase stamps (-DEARHIP_BUILD_PROF)");
+#endif
+  });
+}
+
 // Tuning aid: enqueue a probe that samples the shader-cycle and the constant-rate
 // counters into device memory `out_dev[2]` (two probes bracket a region to get
 // the average shader clock).  wall_clock64 rate: hipDeviceAttributeWallClockRate.

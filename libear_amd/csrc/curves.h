@@ -52,6 +52,7 @@ struct ColumnPlan {
 // launch: a commit that touches 16 of 1024 objects costs the host one kernel launch, not 64 copy calls, and the device
 // what those objects' points weigh (CurveSet::commit).  grid = changed objects, block = 256 threads.
 struct CurveImage {
+  ObjHdr *hdr;
   int32_t *off, *cnt;
   int64_t *time;
   uint8_t *flat;
@@ -62,7 +63,7 @@ static __global__ void __launch_bounds__(256)
 k_curve_upload(CurveImage src, CurveImage dst, const int32_t *changed, int row) {
   const int m = changed[blockIdx.x];
   const int off = src.off[m], n = src.cnt[m];
-  if (threadIdx.x == 0) dst.off[m] = off, dst.cnt[m] = n;
+  if (threadIdx.x == 0) dst.off[m] = off, dst.cnt[m] = n, dst.hdr[m] = src.hdr[m];
   for (int i = threadIdx.x; i < n; i += 256) {
     dst.time[off + i] = src.time[off + i];
     dst.flat[off + i] = src.flat[off + i];
@@ -248,8 +249,8 @@ class CurveSet {
       full_upload = true;
     }
     if (!h_off_.p) {
-      h_off_.reserve(M_), h_cnt_.reserve(M_), h_changed_.reserve(M_), h_gcol_.reserve(row);
-      d_off_.alloc(M_), d_cnt_.alloc(M_), d_gcol_.alloc(row);
+      h_off_.reserve(M_), h_cnt_.reserve(M_), h_changed_.reserve(M_), h_gcol_.reserve(row), h_hdr_.reserve(M_);
+      d_off_.alloc(M_), d_cnt_.alloc(M_), d_gcol_.alloc(row), d_hdr_.alloc(M_);
     }
     EARHIP_LAP(1);
     // ---- the changed objects: mirror, statistics
@@ -260,6 +261,7 @@ class CurveSet {
       const int n = (int)o.t.size();
       h_off_.p[m] = o.off;
       h_cnt_.p[m] = n;
+      h_hdr_.p[m] = ObjHdr{o.off, n, o.t[0], o.t[n - 1], 0};
       std::memcpy(h_time_.p + o.off, o.t.data(), (size_t)n * sizeof(int64_t));
       std::memcpy(h_flat_.p + o.off, o.flat.data(), (size_t)n);
       std::memcpy(h_gain_.p + (size_t)o.off * row, o.g.data(), (size_t)n * row * sizeof(float));
@@ -312,14 +314,15 @@ class CurveSet {
     if (full_upload || dirty_list_.size() > (size_t)M_ / 4) {
       EARHIP_HIP(hipMemcpyAsync(d_off_.p, h_off_.p, M_ * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
       EARHIP_HIP(hipMemcpyAsync(d_cnt_.p, h_cnt_.p, M_ * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      EARHIP_HIP(hipMemcpyAsync(d_hdr_.p, h_hdr_.p, M_ * sizeof(ObjHdr), hipMemcpyHostToDevice, ctx->stream));
       EARHIP_HIP(hipMemcpyAsync(d_time_.p, h_time_.p, arena_used_ * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
       EARHIP_HIP(hipMemcpyAsync(d_flat_.p, h_flat_.p, arena_used_, hipMemcpyHostToDevice, ctx->stream));
       EARHIP_HIP(hipMemcpyAsync(d_rec_.p, h_rec_.p, arena_used_ * sizeof(PointRec), hipMemcpyHostToDevice, ctx->stream));
       EARHIP_HIP(hipMemcpyAsync(d_gain_.p, h_gain_.p, arena_used_ * row * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     } else {
       for (size_t i = 0; i < dirty_list_.size(); i++) h_changed_.p[i] = dirty_list_[i];
-      CurveImage src{h_off_.p, h_cnt_.p, h_time_.p, h_flat_.p, h_rec_.p, h_gain_.p};
-      CurveImage dst{d_off_.p, d_cnt_.p, d_time_.p, d_flat_.p, d_rec_.p, d_gain_.p};
+      CurveImage src{h_hdr_.p, h_off_.p, h_cnt_.p, h_time_.p, h_flat_.p, h_rec_.p, h_gain_.p};
+      CurveImage dst{d_hdr_.p, d_off_.p, d_cnt_.p, d_time_.p, d_flat_.p, d_rec_.p, d_gain_.p};
       hipLaunchKernelGGL(k_curve_upload, dim3((unsigned)dirty_list_.size()), dim3(256), 0, ctx->stream, src, dst, h_changed_.p,
                          (int)row);
       EARHIP_HIP(hipGetLastError());
@@ -427,6 +430,7 @@ class CurveSet {
 
   PointStore device() const {
     PointStore ps;
+    ps.hdr = d_hdr_.p;
     ps.off = d_off_.p;
     ps.cnt = d_cnt_.p;
     ps.time = d_time_.p;
@@ -655,6 +659,8 @@ class CurveSet {
   std::vector<float> cmax_;         // [row] largest |gain| per column over the set
   float gain_max_ = 0;
   DevBuf<int32_t> d_off_, d_cnt_;
+  DevBuf<ObjHdr> d_hdr_;
+  PinBuf<ObjHdr> h_hdr_;
   DevBuf<int64_t> d_time_;
   DevBuf<uint8_t> d_flat_;
   DevBuf<PointRec> d_rec_;

@@ -301,6 +301,8 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   const int tile = blockIdx.x * TPW + j;
   const unsigned call_level = level_cur ? *level_cur : 0u;
   for (int i = tid; i < TPW * NC; i += kHingeBuildThreads) (&cnt[0][0])[i] = 0, (&run[0][0])[i] = 0;
+  EARHIP_BUILD_PROF_SLOT
+  EARHIP_BUILD_MARK(0);
   const int64_t t0 = t_call + (int64_t)tile * T;
   const int64_t t1 = t0 + T > t_call_end ? t_call_end : t0 + T;
   __syncthreads();
@@ -308,8 +310,9 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   for (int mb = 0; mb < M; mb += OB) {
     const int m = mb + oi;
     if (m < M && tile < ntiles) {
-      const int base = ps.off[m], n = ps.cnt[m];
-      const int kc = upper_bound_time_window(ps.time + base, n, t0 + T / 2);
+      const ObjHdr hd = ps.hdr[m];  // (gain_p2.h, k_piece_build: one header load, the search on the records hinge_load reads next)
+      const int base = hd.off, n = hd.cnt;
+      const int kc = upper_bound_rec_window(ps.rec + base, n, hd.first, hd.last, t0 + T / 2);
       const HingeRecs R = hinge_load(ps, base, n, kc);
       const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
       int cls = hp.cls;
@@ -326,8 +329,16 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       hg_cache[(size_t)m * TPW + j] = hc;
       atomicAdd(&cnt[j][cls], 1);
     }
+#ifdef EARHIP_BUILD_PROF
+    EARHIP_BUILD_MARK(prof_i);  // pass 1, this batch
+    prof_i++;
+#endif
   }
   __syncthreads();
+#ifdef EARHIP_BUILD_PROF
+  EARHIP_BUILD_MARK(prof_i);  // everybody's pass 1
+  prof_i++;
+#endif
   if (tid < TPW) {
     int at = 0;
     for (int b = 0; b < NC; b++)
@@ -406,6 +417,10 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
       run[jj][b] += sm;
     }
     __syncthreads();
+#ifdef EARHIP_BUILD_PROF
+    EARHIP_BUILD_MARK(prof_i);  // pass 2, this batch
+    prof_i++;
+#endif
   }
   // pad the lists to whole chunks with null entries; publish counts and chunk flags
   for (int i = tid; i < TPW * 32; i += kHingeBuildThreads) {
@@ -431,6 +446,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
     const int jj = i / (hl.cap / 32), c = i % (hl.cap / 32), tl = blockIdx.x * TPW + jj;
     if (tl < ntiles && c < start[jj][NC + 1]) hl.cflags[(size_t)tl * (hl.cap / 32) + c] = chunk_flags(jj, c);
   }
+  EARHIP_BUILD_MARK(31);
 }
 
 #ifndef EARHIP_HG_RINGU

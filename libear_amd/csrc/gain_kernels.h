@@ -41,7 +41,17 @@ struct PointRec {
 static_assert(sizeof(PointRec) == 16, "PointRec is loaded as one dwordx4");
 
 // Flattened gain curves of all objects (device pointers).
+// What a search of an object's points starts from, in one 32-byte load: where its points are and the times of the first and
+// the last one (the list builders' threads used to fetch these in two dependent rounds: offset and count, then the two
+// times from the curve itself — a trip to HBM each).  Made where curves are committed (CurveSet::commit).
+struct ObjHdr {
+  int32_t off, cnt;
+  int64_t first, last;  // times of points 0 and cnt - 1
+  int64_t reserved;
+};
+static_assert(sizeof(ObjHdr) == 32, "an object's header is two dwordx4 loads");
 struct PointStore {
+  const ObjHdr *hdr;     // [M] offset, count, first and last time of each object
   const int32_t *off;    // [M] first point of each object (its region of the arena: curves.h)
   const int32_t *cnt;    // [M] its points
   const int64_t *time;   // [P]   point times, sorted per object
@@ -307,7 +317,11 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       atomicOr(qm.wide, 1u);
   }
   if (tile0 < ntiles && m < M) {
-    const int base = ps.off[m], n = ps.cnt[m];
+    // (round 6: offset, count and the curve's end points in ONE header load, the search and the walk on the packed records —
+    // the lines describe_segment_rec reads next — instead of four dependent trips: header words, end points, a window of
+    // times, the records)
+    const ObjHdr hd = ps.hdr[m];
+    const int base = hd.off, n = hd.cnt;
     int k = 0;
 #pragma unroll
     for (int j = 0; j < kPrepRun; j++) {
@@ -317,9 +331,9 @@ k_seg_prep(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, i
       int64_t t_end = t0 + tile_samples;
       if (t_end > t_call_end) t_end = t_call_end;
       if (j == 0) {
-        k = upper_bound_time_window(ps.time + base, n, t0);
+        k = upper_bound_rec_window(ps.rec + base, n, hd.first, hd.last, t0);
       } else {
-        while (k < n && ps.time[base + k] <= t0) k++;  // = upper_bound_time(.., t0), from the previous tile's
+        while (k < n && ps.rec[base + k].time <= t0) k++;  // = upper_bound_time(.., t0), from the previous tile's
       }
       SegDesc d = describe_segment_rec(ps, base, n, k, t0, t_end);
       if (quiet) d.info |= kSegQuiet;

@@ -206,6 +206,19 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
   return nd > kPieceMaxPerObject ? -1 : nd;
 }
 
+// -DEARHIP_BUILD_PROF: thread 0 of two workgroups of a list builder (the first and one from the middle of the grid) leaves
+// s_memtime stamps at the builder's phase boundaries (earhip_debug_build_prof reads them; tools/build_phases.py)
+#ifdef EARHIP_BUILD_PROF
+static __device__ unsigned long long g_build_prof[2][32];
+#define EARHIP_BUILD_MARK(i)                                                                                 \
+  do {                                                                                                       \
+    if (prof_slot >= 0 && threadIdx.x == 0 && (i) < 32) g_build_prof[prof_slot][(i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define EARHIP_BUILD_PROF_SLOT const int prof_slot = blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : -1; int prof_i = 1;
+#else
+#define EARHIP_BUILD_MARK(i) do {} while (0)
+#define EARHIP_BUILD_PROF_SLOT
+#endif
 constexpr int kBuildThreads = 1024;
 // grid = ceil(ntiles / TPW) workgroups of 1024 threads; a thread = one (object, tile) pair of a batch of 1024 / TPW
 // objects, the TILE index fastest: the TPW lanes of an object read neighbouring points of its curve (the same
@@ -256,6 +269,8 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
   const bool paired = pl.paired != 0;
   const unsigned call_level = level_cur ? *level_cur : 0u;
   if (tid < TPW) run[tid][0] = run[tid][1] = run[tid][2] = 0;
+  EARHIP_BUILD_PROF_SLOT
+  EARHIP_BUILD_MARK(0);
   const int64_t t0 = t_call + (int64_t)tile * tile_samples;
   const int64_t t1 = t0 + tile_samples > t_call_end ? t_call_end : t0 + tile_samples;
   __syncthreads();
@@ -265,14 +280,18 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
     int base = 0, n = 0, kst = 0, cnt = 0;
     Piece keep[kKeepPieces];
     if (in) {
-      base = ps.off[m];
-      n = ps.cnt[m];
-      kst = upper_bound_time_window(ps.time + base, n, t0);
+      const ObjHdr hd = ps.hdr[m];  // (offset, count and the curve's end points in one load; the search on the records themselves:
+      base = hd.off;                 // the walk below then reads lines the search has just brought in)
+      n = hd.cnt;
+      kst = ps.force_ramp ? upper_bound_time_window(ps.time + base, n, t0) : upper_bound_rec_window(ps.rec + base, n, hd.first, hd.last, t0);
       int k = kst;
       cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr, keep);
       if (paired && cnt > kPairMaxPerObject) cnt = -1;
       if (obj_level && level_is_quiet(obj_level[m], call_level)) cnt = -1;
     }
+#ifdef EARHIP_BUILD_PROF
+    EARHIP_BUILD_MARK(prof_i);  // search + counting walk of this thread done
+#endif
     // ---- ordered scan over the batch's objects, per tile: element e = tile * OB + object, a tile = WPT whole waves
     lcnt[j * OB + oi] = !in ? (u64)0 : cnt < 0 ? kExactUnit : !paired ? kOne * (u64)(1 + cnt) : cnt == 0 ? kOne : kPairUnit * (u64)cnt;
     __syncthreads();
@@ -292,6 +311,9 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
       lcnt[tid] = v + pre;  // inclusive over the tile's objects of the batch
     }
     __syncthreads();
+#ifdef EARHIP_BUILD_PROF
+    EARHIP_BUILD_MARK(prof_i + 1);  // scan done (three barriers)
+#endif
     // ---- the pieces, at the scanned offsets
     if (in) {
       const u64 incl = lcnt[j * OB + oi];
@@ -340,7 +362,14 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
         }
       }
     }
+#ifdef EARHIP_BUILD_PROF
+    EARHIP_BUILD_MARK(prof_i + 2);  // this thread's pieces stored
+#endif
     __syncthreads();  // (everybody has read run[] and lcnt[])
+#ifdef EARHIP_BUILD_PROF
+    EARHIP_BUILD_MARK(prof_i + 3);
+    prof_i += 4;
+#endif
     if (tid < TPW) {
       const u64 tot = lcnt[tid * OB + OB - 1];
       run[tid][0] += (int)(tot & kMaskA);
@@ -349,6 +378,9 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
     }
     __syncthreads();
   }
+#ifdef EARHIP_BUILD_PROF
+  EARHIP_BUILD_MARK(30);
+#endif
   // pad the lists to whole chunks with null pieces; publish the counts
   Piece null_piece;
   null_piece.m = 0u;

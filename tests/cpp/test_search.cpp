@@ -1,4 +1,4 @@
-// CPU unit test of libear_amd/csrc/search.h: the guess-started and the windowed search return exactly what the
+// CPU unit test of libear_amd/csrc/search.h: the guess-started, the windowed and the record-window search return exactly what the
 // plain upper bound returns (= libear's find_block, gain_interpolator.hpp:110-129) for sorted
 // times with duplicates, clusters, evenly spaced grids and queries before / inside / past them.
 #include <cstdint>
@@ -29,8 +29,13 @@ int main() {
       const int a = earhip::upper_bound_time(t.data(), n, v);
       const int b = earhip::upper_bound_time_guess(t.data(), n, v);
       const int c = earhip::upper_bound_time_window(t.data(), n, v);
+      // ... and the search over packed records with the end points handed in (the list builders': an object's header)
+      struct Rec { int64_t time; float scale; uint32_t flat; };
+      std::vector<Rec> rec(n);
+      for (int i = 0; i < n; i++) rec[i] = Rec{t[i], 0.0f, 0u};
+      const int d = earhip::upper_bound_rec_window(rec.data(), n, t[0], t[n - 1], v);
       tests++;
-      if (a != b || a != c) {
+      if (a != b || a != c || a != d) {
         if (bad < 5) printf("mismatch n=%d v=%lld a=%d b=%d\n", n, (long long)v, a, b);
         bad++;
       }
