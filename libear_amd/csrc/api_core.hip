@@ -178,10 +178,22 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       if (v == 1 || v == 2 || v == 4 || v == 8) tpw = v;
     }
     const dim3 bgrid((pnt + tpw - 1) / tpw);
+    // two kernels (default; option BUILD_2K = 0: the one-pass builder): classify object-major into the staging matrix behind the
+    // lists (scratch_units holds room for it), then place tile-major
+    PairRec *stage = nullptr;
+    // (default: where the lists are PAIRED — curves that hold most of the time: at most one ramp per object and tile nearly
+    // everywhere, which the staged pair carries; always-ramping curves on packed lists have several per pair, the placing kernel
+    // would walk most pairs itself: 0.097 against 0.076 ms, measured)
+    if (ctx->has(OPT_BUILD_2K) ? ctx->get(OPT_BUILD_2K) != 0 : ml.paired) {
+      stage = reinterpret_cast<PairRec *>(desc) + piece_units((size_t)M, (size_t)pnt, (size_t)pl.slots);
+      hipLaunchKernelGGL(k_piece_classify, dim3((pnt + 63) / 64, (M + kClassifyObjects - 1) / kClassifyObjects), dim3(64 * kClassifyObjects), 0,
+                         ctx->stream, ps, M, pnt, ptile, t_call, t_call + nsamples, pl.paired, stage, obj_lv, level_cur,
+                         ml.hinge ? gate : nullptr);
+    }
 #define EARHIP_BUILD_CASE(T_)                                                                                          \
   if (tpw == T_)                                                                                                       \
     hipLaunchKernelGGL(k_piece_build<T_>, bgrid, dim3(kBuildThreads), 0, ctx->stream, ps, M, pnt, ptile, t_call, \
-                       t_call + nsamples, pl, obj_lv, level_cur, ml.hinge ? gate : nullptr, ctx->obj_level_cap, wide_cur);
+                       t_call + nsamples, pl, obj_lv, level_cur, ml.hinge ? gate : nullptr, ctx->obj_level_cap, wide_cur, stage);
     EARHIP_BUILD_CASE(1) EARHIP_BUILD_CASE(2) EARHIP_BUILD_CASE(4) EARHIP_BUILD_CASE(8)
 #undef EARHIP_BUILD_CASE
   }
@@ -467,7 +479,7 @@ using namespace earhip;
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
     "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "H2_RUNS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
-    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST"};
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST", "BUILD_2K"};
 
 // an option's value: a decimal integer (optional sign, surrounding blanks), nothing else — "abc" or "1x" used to read as 0 / 1
 static int parse_option_value(const std::string &key, const char *text) {

@@ -826,11 +826,13 @@ void reserve_call_words(earhip_ctx *ctx, int M, size_t max_samples);  // api_cor
 inline size_t scratch_units(const CurveSet &cs, const MixLaunch &ml, int M) {
   const size_t nt = (size_t)ml.ntiles;
   // (the piece lists that stand by behind the hinge kernel: tiles of 64 pw samples, at most tile / (64 pw) times as many)
+  // (+ M x tiles units behind the lists: the staging matrix of the two-kernel builders, 16 bytes per (object, tile) pair)
   if (ml.hinge) {
     const size_t pnt = nt * (size_t)std::max(1, ml.tile() / (64 * ml.pw));
-    return std::max(hinge_units((size_t)M, nt), piece_units((size_t)M, pnt, (size_t)cs.piece_cap(64 * ml.pw, ml.paired)));
+    return std::max(hinge_units((size_t)M, nt) + (size_t)M * nt,
+                    piece_units((size_t)M, pnt, (size_t)cs.piece_cap(64 * ml.pw, ml.paired)) + (size_t)M * pnt);
   }
-  if (ml.pieces) return piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired));
+  if (ml.pieces) return piece_units((size_t)M, nt, (size_t)cs.piece_cap(ml.tile(), ml.paired)) + (size_t)M * nt;
   if (ml.split || ml.f32grid || !ml.mfma) return (size_t)M * nt + 1;
   return desc_units((size_t)M, nt);
 }

@@ -206,6 +206,35 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
   return nd > kPieceMaxPerObject ? -1 : nd;
 }
 
+// ---------------------------------------------------------------------------
+// Round 6: K0 of the list kernels in TWO kernels.  The one-pass builders below do a search and a walk of the curve per (object,
+// tile) pair with the lanes of a wave on 16 different objects: every load instruction of theirs asks for 16-32 different cache
+// lines, and ~3 M such line requests are what those kernels' 41-58 us are made of (the CUs' path to L2 passes ~50 requests
+// per ns, chip-wide: DESIGN 4) — searches and walks are 70 % of a workgroup's time (tools/build_phases.py).
+//   classify (object-major): a WAVE = one object x 64 consecutive tiles.  The lanes search neighbouring points of ONE curve
+//     (the header is a scalar load, the window of records and the walk behind it hit the same few lines for the whole wave),
+//     and what the placing kernel needs of the pair goes, 16 bytes, into a staging matrix [tile][object] — through LDS, so that
+//     a tile's row of 8 objects leaves as one 128-byte line;
+//   place (tile-major): the one-pass builder with the search and the walk replaced by ONE coalesced 16-byte load per pair: the
+//     scan and the stores are its own.  Pairs with two and more delta pieces (rare where piece lists are used) walk the curve
+//     there, from the segment index the classify kernel left.
+// The lists are the one-pass builder's, bit for bit (option BUILD_2K = 0 runs that one; tests compare both).
+// A workgroup barrier for data exchanged through LDS only: waits for the wave's own LDS operations, not for its global stores.
+// (__syncthreads() is a workgroup-scope fence over every address space: `s_waitcnt vmcnt(0)` in front of the barrier — in the list
+// builders' batch loops that made every batch wait for the previous batch's list stores to be acknowledged by memory.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+struct PairRec {
+  int32_t row0;     // the base piece's gain row
+  uint32_t info;    // bits 0..7: delta pieces of the object in the tile (kPairExact: it takes the exact path there); bits 8..: the
+                    // first delta piece's row - row0
+  float p0, scale;  // the first delta piece's; with two and more delta pieces p0 holds the tile's first segment index (its bits)
+};
+static_assert(sizeof(PairRec) == 16, "a pair of the staging matrix is one dwordx4");
+constexpr uint32_t kPairExact = 0xffu;
+constexpr int kClassifyObjects = 8;  // objects (= waves) of a classify workgroup: a tile's row of them is one 128-byte line
+
 // -DEARHIP_BUILD_PROF: thread 0 of two workgroups of a list builder (the first and one from the middle of the grid) leaves
 // s_memtime stamps at the builder's phase boundaries (earhip_debug_build_prof reads them; tools/build_phases.py)
 #ifdef EARHIP_BUILD_PROF
@@ -219,6 +248,57 @@ static __device__ unsigned long long g_build_prof[2][32];
 #define EARHIP_BUILD_MARK(i) do {} while (0)
 #define EARHIP_BUILD_PROF_SLOT
 #endif
+// grid = (ceil(ntiles / 64), ceil(M / kClassifyObjects)), block = 64 kClassifyObjects threads: wave w = object blockIdx.y * 8 + w,
+// lane = tile blockIdx.x * 64 + lane
+static __global__ void __launch_bounds__(64 * kClassifyObjects)
+k_piece_classify(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end, int paired, PairRec *stage,
+                 const unsigned *obj_level, const unsigned *level_cur, const unsigned *gate) {
+  if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel's builder, which does this call (k_hinge_gate)
+  __shared__ __attribute__((aligned(16))) PairRec sh[64][kClassifyObjects + 1];  // (+ 1: the lanes' rows on different banks)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = blockIdx.y * kClassifyObjects + w;  // wave-uniform
+  const int tile = blockIdx.x * 64 + lane;
+  PairRec pr;
+  pr.row0 = ps.zero_row, pr.info = 0u, pr.p0 = 1.0f, pr.scale = 0.0f;
+  if (m < M && tile < ntiles) {
+    const unsigned call_level = level_cur ? *level_cur : 0u;
+    const ObjHdr hd = ps.hdr[m];
+    const int base = hd.off, n = hd.cnt;
+    const int64_t t0 = t_call + (int64_t)tile * tile_samples;
+    const int64_t t1 = t0 + tile_samples > t_call_end ? t_call_end : t0 + tile_samples;
+    const int kst = ps.force_ramp ? upper_bound_time_window(ps.time + base, n, t0) : upper_bound_rec_window(ps.rec + base, n, hd.first, hd.last, t0);
+    int k = kst;
+    Piece keep[kKeepPieces];
+    int cnt = piece_walk(ps, base, n, k, t0, t1, m, nullptr, keep);
+    if (paired && cnt > kPairMaxPerObject) cnt = -1;
+    if (obj_level && level_is_quiet(obj_level[m], call_level)) cnt = -1;
+    // the row of the segment the tile starts in (k_piece_build's own rule)
+    int row;
+    if (ps.force_ramp) {
+      row = describe_segment(ps, base, n, kst, t0, t1).row;
+    } else {
+      const bool ramp = kst > 0 && kst < n && ((int)ps.rec[base + kst].flat & ((1 << ps.nbus) - 1)) != (1 << ps.nbus) - 1;
+      row = base + (ramp ? kst - 1 : kst == n ? kst - 1 : kst);
+    }
+    pr.row0 = row;
+    if (cnt < 0) {
+      pr.info = kPairExact;
+    } else if (cnt == 1) {
+      pr.info = 1u | (uint32_t)(keep[0].row - row) << 8;
+      pr.p0 = keep[0].p0, pr.scale = keep[0].scale;
+    } else if (cnt >= 2) {
+      pr.info = (uint32_t)cnt;
+      pr.p0 = __int_as_float(kst);
+    }
+  }
+  sh[lane][w] = pr;
+  __syncthreads();
+  // a tile's row of this workgroup's objects: 8 x 16 bytes = one line
+  const int to = threadIdx.x / kClassifyObjects, oo = threadIdx.x % kClassifyObjects;
+  const int tile_o = blockIdx.x * 64 + to, m_o = blockIdx.y * kClassifyObjects + oo;
+  if (tile_o < ntiles && m_o < M) stage[(size_t)tile_o * M + m_o] = sh[to][oo];
+}
+
 constexpr int kBuildThreads = 1024;
 // grid = ceil(ntiles / TPW) workgroups of 1024 threads; a thread = one (object, tile) pair of a batch of 1024 / TPW
 // objects, the TILE index fastest: the TPW lanes of an object read neighbouring points of its curve (the same
@@ -236,7 +316,8 @@ template <int TPW>
 __global__ void __launch_bounds__(kBuildThreads)
 k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call, int64_t t_call_end, PieceLists pl,
               const unsigned *obj_level, const unsigned *level_cur, const unsigned *gate = nullptr, int level_cap = 0,
-              unsigned *wide = nullptr) {
+              unsigned *wide = nullptr, const PairRec *stage = nullptr) {
+  // stage != nullptr: the placing kernel of the two-kernel K0 — what a pair is comes from k_piece_classify's matrix
   if (gate && !(*gate & kGateHingeUnsafe)) return;  // launched behind the hinge kernel's builder, which does this call (k_hinge_gate)
   // the form of k_gain_mix_p2 this call needs (gain_h2.h, k_seg_prep): wide when some object falls more than kPlainBinades
   // below the call's level at some probed instant
@@ -279,7 +360,16 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
     const bool in = m < M && tile < ntiles;
     int base = 0, n = 0, kst = 0, cnt = 0;
     Piece keep[kKeepPieces];
-    if (in) {
+    PairRec pr;
+    pr.row0 = 0, pr.info = 0u, pr.p0 = 0.0f, pr.scale = 0.0f;
+    if (in && stage) {
+      pr = stage[(size_t)tile * M + m];
+      const uint32_t c = pr.info & 0xffu;
+      cnt = c == kPairExact ? -1 : (int)c;
+      keep[0].m = (uint32_t)m | kPieceDelta;
+      keep[0].row = pr.row0 + (int32_t)(pr.info >> 8);
+      keep[0].p0 = pr.p0, keep[0].scale = pr.scale;
+    } else if (in) {
       const ObjHdr hd = ps.hdr[m];  // (offset, count and the curve's end points in one load; the search on the records themselves:
       base = hd.off;                 // the walk below then reads lines the search has just brought in)
       n = hd.cnt;
@@ -322,11 +412,19 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
         pl.ovf[(size_t)tile * M + run[j][2] + iC - 1] = m;
       } else {
         Piece *tl = pl.pieces + (size_t)tile * pl.cap();
+        // delta pieces at hand without another walk: the counting walk's first three, or (two kernels) the staged pair's one
+        const int have = stage ? (cnt == 1 ? 1 : 0) : (cnt < kKeepPieces ? cnt : kKeepPieces);
+        if (stage && cnt > have) {  // (rare: the walk below starts from what the classify kernel found)
+          const ObjHdr hd = ps.hdr[m];
+          base = hd.off, n = hd.cnt, kst = __float_as_int(pr.p0);
+        }
         int k = kst;
         // the row of the segment the tile starts in: a ramp's start point, else the point itself (the last one
         // beyond the end of the curve): describe_segment's rule
         int row;
-        if (ps.force_ramp) {
+        if (stage) {
+          row = pr.row0;
+        } else if (ps.force_ramp) {
           row = describe_segment(ps, base, n, k, t0, t1).row;
         } else {
           const bool ramp = k > 0 && k < n && ((int)ps.rec[base + k].flat & ((1 << ps.nbus) - 1)) != (1 << ps.nbus) - 1;
@@ -342,22 +440,22 @@ k_piece_build(PointStore ps, int M, int ntiles, int tile_samples, int64_t t_call
         if (!paired) {
           Piece *out = tl + run[j][0] + iA - (1 + cnt);
           out[0] = b;
-          if (cnt >= 1) out[1] = keep[0];
-          if (cnt >= 2) out[2] = keep[1];
-          if (cnt >= 3) out[3] = keep[2];
-          if (cnt > kKeepPieces) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
+          if (have >= 1) out[1] = keep[0];
+          if (have >= 2) out[2] = keep[1];
+          if (have >= 3) out[3] = keep[2];
+          if (cnt > have) (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1);
         } else if (cnt == 0) {
           tl[run[j][0] + iA - 1] = b;
         } else {
           Piece *out = tl + pl.pair_off() + 2 * (run[j][1] + iB - cnt);
           out[0] = b;
-          out[1] = keep[0];
+          if (have >= 1) out[1] = keep[0];
           b.row = ps.zero_row;  // the even slots of the object's further pairs: its input, no gain
-          if (cnt >= 2) out[2] = b, out[3] = keep[1];
-          if (cnt >= 3) out[4] = b, out[5] = keep[2];
-          if (cnt > kKeepPieces) {
+          if (have >= 2) out[2] = b, out[3] = keep[1];
+          if (have >= 3) out[4] = b, out[5] = keep[2];
+          if (cnt > have) {
             (void)piece_walk(ps, base, n, k, t0, t1, m, out + 1, nullptr, 2);
-            for (int i = kKeepPieces; i < cnt; i++) out[2 * i] = b;
+            for (int i = have < 1 ? 1 : have; i < cnt; i++) out[2 * i] = b;
           }
         }
       }

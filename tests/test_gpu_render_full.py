@@ -441,6 +441,36 @@ def test_long_calls_from_host_pointers_run_as_a_pipeline_of_time_chunks(source, 
     print(f"host pipeline ({source}, {kind}, {m} objects): worst channel vs oracle {worst:.3e}, vs one device call {diff:.3e}")
 
 
+@pytest.mark.parametrize("kind,m,nblocks,opts", [("adm", 320, 640, {}), ("adm", 1024, 96, {}), ("adm", 200, 33, {"EARHIP_P2_PAIRS": "0"}),
+                                                ("moving", 256, 130, {"EARHIP_HINGE": "0"}), ("moving", 96, 7, {"EARHIP_HINGE": "0", "EARHIP_P2_PAIRS": "1"}),
+                                                ("ragged", 77, 19, {})])
+def test_the_two_kernel_list_builder_builds_the_one_pass_builders_lists(kind, m, nblocks, opts):
+    """K0 of the piece lists as two kernels (classify object-major into a staging matrix, place tile-major: the default since
+    round 6) against the one-pass builder (option BUILD_2K = 0): the same lists, so the same bits out of the gain kernel — long
+    and short calls, paired and packed layouts, pairs with several ramps per tile (always-ramping curves on the piece lists: the
+    placing kernel walks those itself), ragged curves and object counts that fill no workgroup."""
+    import torch
+    if any(os.environ.get(k) is not None for k in ("EARHIP_MFMA", "EARHIP_BUILD_2K")):
+        pytest.skip("kernels forced")
+    layout, block = "9+10+3", 512
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    curves = (scenes.adm_curves(m, n, total, seed=21) if kind == "adm" else scenes.adm_curves(m, n, total, period=240, ramp=240, seed=22) if kind == "moving"
+              else scenes.ragged_curves(m, n, total, seed=23))
+    x = device_audio(m, total, 24)
+    outs = {}
+    for two in ("0", "1"):
+        o = dict(opts)
+        o["EARHIP_BUILD_2K"] = two
+        out, plan = with_options(o, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
+        outs[two] = out
+        if kind != "ragged":
+            assert plan["kernel"] == 4, plan
+    assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
+    check_windows(curves, x, outs["1"], n, block, dec, 255, [(0, min(3, nblocks)), (max(nblocks - 3, 0), min(3, nblocks))])
+
+
 def test_native_decorrelators_equal_the_oracles():
     """the FIRs every GPU render test uses come from the native design (libearhip group G); they are the
     oracle's (both restate src/decorrelate.cpp:31-97 in double and cast to float; the doubles agree to
