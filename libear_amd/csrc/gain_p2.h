@@ -219,12 +219,8 @@ __device__ __forceinline__ int piece_walk(const PointStore &ps, int base, int n,
 //     scan and the stores are its own.  Pairs with two and more delta pieces (rare where piece lists are used) walk the curve
 //     there, from the segment index the classify kernel left.
 // The lists are the one-pass builder's, bit for bit (option BUILD_2K = 0 runs that one; tests compare both).
-// A workgroup barrier for data exchanged through LDS only: waits for the wave's own LDS operations, not for its global stores.
-// (__syncthreads() is a workgroup-scope fence over every address space: `s_waitcnt vmcnt(0)` in front of the barrier — in the list
-// builders' batch loops that made every batch wait for the previous batch's list stores to be acknowledged by memory.)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// (Barriers that wait for the waves' LDS operations only — not, like __syncthreads(), for their list stores as well — were tried in
+// both builders' batch loops: level.)
 struct PairRec {
   int32_t row0;     // the base piece's gain row
   uint32_t info;    // bits 0..7: delta pieces of the object in the tile (kPairExact: it takes the exact path there); bits 8..: the
