@@ -149,12 +149,33 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
       const int v = ctx->get(OPT_HBUILD_TPW);
       if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)M * v <= cached_max) tpw = v;
     }
+    // two kernels (option BUILD_2K = 1; NOT the default here): k_hinge_classify object-major into the staging matrix behind the
+    // lists, then the builder from its counting loop on, without the LDS its first pass kept its results in.  Measured: classify
+    // 21 us + the builder's second half 42 us against 58 us in one kernel — that half (ranking by ballots over 32 classes between
+    // three barriers per batch, two scattered 16-byte stores per pair) is what the builder is made of, and it does not get faster
+    // at two workgroups per CU.  The lists are the same bit for bit (tests run both).
+    const HingeCached *stage = nullptr;
+    if (ctx->get(OPT_BUILD_2K, 0) != 0) {
+      HingeCached *st = reinterpret_cast<HingeCached *>(desc) + hinge_units((size_t)M, (size_t)ml.ntiles);
+      stage = st;
+      const dim3 cgrid((ml.ntiles + 63) / 64, (M + kClassifyObjects - 1) / kClassifyObjects);
+      if (ml.tile() == 256)
+        hipLaunchKernelGGL((k_hinge_classify<4>), cgrid, dim3(64 * kClassifyObjects), 0, ctx->stream, ps, M, ml.ntiles, t_call, t_call + nsamples, st,
+                           obj_lv, level_cur, hg_robust ? nullptr : gate, hg_robust ? gate : nullptr);
+      else
+        hipLaunchKernelGGL((k_hinge_classify<8>), cgrid, dim3(64 * kClassifyObjects), 0, ctx->stream, ps, M, ml.ntiles, t_call, t_call + nsamples, st,
+                           obj_lv, level_cur, hg_robust ? nullptr : gate, hg_robust ? gate : nullptr);
+      if (!ctx->has(OPT_HBUILD_TPW)) {
+        tpw = 1;
+        while (tpw < 8 && ml.ntiles / (2 * tpw) >= 2 * ctx->num_cus) tpw *= 2;
+      }
+    }
     const dim3 bgrid((ml.ntiles + tpw - 1) / tpw);
-    const size_t lds = sizeof(HingeCached) * (size_t)M * tpw;
+    const size_t lds = stage ? 0 : sizeof(HingeCached) * (size_t)M * tpw;
     // (more than 64 KB of dynamic LDS has to be asked for, per device and instantiation: earhip_ctx_create does, hinge_build_allow_lds)
 #define EARHIP_HBUILD_ONE(T_, NW_)                                                                                    \
   hipLaunchKernelGGL((k_hinge_build<T_, NW_>), bgrid, dim3(kHingeBuildThreads), lds, ctx->stream, ps, M, ml.ntiles, t_call, \
-                     t_call + nsamples, hl, obj_lv, level_cur, hg_robust ? nullptr : gate, hg_robust ? gate : nullptr);
+                     t_call + nsamples, hl, obj_lv, level_cur, hg_robust ? nullptr : gate, hg_robust ? gate : nullptr, stage);
 #define EARHIP_HBUILD_CASE(T_)                                                                                        \
   if (tpw == T_) {                                                                                                    \
     if (ml.tile() == 256) EARHIP_HBUILD_ONE(T_, 4)                                                                    \

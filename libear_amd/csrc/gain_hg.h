@@ -266,6 +266,18 @@ k_kink_rows(const int32_t *off, const int32_t *cnt, const PointRec *rec, const f
   }
 }
 
+struct HingeCached;
+// K0 of the hinge lists in two kernels (round 6; gain_p2.h, k_piece_classify has the reasons): the first pass of k_hinge_build —
+// a search, six records, the pair's class, kinks and line — OBJECT-major: a wave = one object x 64 consecutive tiles, so the lanes
+// of a load instruction ask for neighbouring points of one curve; what the second pass needs of a pair (16 bytes: HingeCached)
+// goes through LDS into a staging matrix [tile][object].  k_hinge_build then starts at its counting loop with one coalesced
+// load per pair and needs no LDS for what the first pass found (two 1024-thread workgroups per CU instead of one).
+// grid = (ceil(ntiles / 64), ceil(M / kClassifyObjects)), block = 64 kClassifyObjects threads.
+template <int NW>
+__global__ void __launch_bounds__(64 * kClassifyObjects)
+k_hinge_classify(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeCached *stage, const unsigned *obj_level,
+                 const unsigned *level_cur, const unsigned *gate, const unsigned *span);
+
 constexpr int kHingeBuildThreads = 1024;
 // grid = ceil(ntiles / TPW) workgroups of 1024 threads; a thread = one (object, tile) pair of a batch of 1024 / TPW
 // objects, the tile index fastest (the lanes of an object read neighbouring points: gain_p2.h, k_piece_build).  Two
@@ -280,10 +292,56 @@ struct HingeCached {
   float p0, scale; // of the LinEntry
 };
 static_assert(sizeof(HingeCached) == 16, "");
+// what the first pass keeps of a pair (k_hinge_build's and k_hinge_classify's: the same expressions)
+template <int NW>
+__device__ __forceinline__ HingeCached hinge_pair(const PointStore &ps, int m, const ObjHdr &hd, int64_t t0, int64_t t1, const unsigned *obj_level,
+                                                  unsigned call_level, int quiet_binades) {
+  constexpr int T = 64 * NW, kHgExact = HgClasses<NW>::kExact;
+  const int base = hd.off, n = hd.cnt;
+  const int kc = upper_bound_rec_window(ps.rec + base, n, hd.first, hd.last, t0 + T / 2);
+  const HingeRecs R = hinge_load(ps, base, n, kc);
+  const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
+  int cls = hp.cls;
+  if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - quiet_binades)
+    cls = kHgExact;
+  LinEntry e;
+  HingeEntry h;
+  hinge_entries(ps, R, base, n, kc, m, t0, hp, T / 2, e, h);
+  HingeCached hc;
+  auto place = [&](int g) { return (hp.kinks >> g) & 1u ? (uint32_t)hp.pos[g] & 511u : 0u; };
+  hc.code = (uint32_t)(kc << 5 | cls) | place(3) << 23;  // (classes below 32, kc below 2^18)
+  hc.kinks = hp.kinks | place(0) << 4 | place(1) << 13 | place(2) << 22;
+  hc.p0 = e.p0, hc.scale = e.scale;
+  return hc;
+}
+template <int NW>
+__global__ void __launch_bounds__(64 * kClassifyObjects)
+k_hinge_classify(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeCached *stage, const unsigned *obj_level,
+                 const unsigned *level_cur, const unsigned *gate, const unsigned *span) {
+  if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate)
+  constexpr int T = 64 * NW;
+  __shared__ __attribute__((aligned(16))) HingeCached sh[64][kClassifyObjects + 1];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = blockIdx.y * kClassifyObjects + w;  // wave-uniform
+  const int tile = blockIdx.x * 64 + lane;
+  const int quiet_binades = span && hinge_span_exceeded(*span, M) ? kQuietBinades : kHingeQuietBinades;
+  HingeCached hc = {0u, 0u, 0.0f, 0.0f};
+  if (m < M && tile < ntiles) {
+    const int64_t t0 = t_call + (int64_t)tile * T;
+    const int64_t t1 = t0 + T > t_call_end ? t_call_end : t0 + T;
+    hc = hinge_pair<NW>(ps, m, ps.hdr[m], t0, t1, obj_level, level_cur ? *level_cur : 0u, quiet_binades);
+  }
+  sh[lane][w] = hc;
+  __syncthreads();
+  const int to = threadIdx.x / kClassifyObjects, oo = threadIdx.x % kClassifyObjects;
+  const int tile_o = blockIdx.x * 64 + to, m_o = blockIdx.y * kClassifyObjects + oo;
+  if (tile_o < ntiles && m_o < M) stage[(size_t)tile_o * M + m_o] = sh[to][oo];
+}
 template <int TPW, int NW>
 __global__ void __launch_bounds__(kHingeBuildThreads)
 k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_end, HingeLists hl, const unsigned *obj_level,
-              const unsigned *level_cur, const unsigned *gate, const unsigned *span) {
+              const unsigned *level_cur, const unsigned *gate, const unsigned *span, const HingeCached *stage = nullptr) {
+  // stage != nullptr: the second kernel of the two-kernel K0 — what a pair is comes from k_hinge_classify's matrix (no dynamic LDS)
   if (gate && (*gate & kGateHingeUnsafe)) return;  // the piece lists do this call (k_hinge_gate; gate == NULL: nobody stands by)
   // (span: the kernel's robust form does this call when the word says so — it keeps its precision as far down as the other
   // split-operand kernels, so only objects quieter than THEIR bound take the exact path)
@@ -310,24 +368,14 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
   for (int mb = 0; mb < M; mb += OB) {
     const int m = mb + oi;
     if (m < M && tile < ntiles) {
-      const ObjHdr hd = ps.hdr[m];  // (gain_p2.h, k_piece_build: one header load, the search on the records hinge_load reads next)
-      const int base = hd.off, n = hd.cnt;
-      const int kc = upper_bound_rec_window(ps.rec + base, n, hd.first, hd.last, t0 + T / 2);
-      const HingeRecs R = hinge_load(ps, base, n, kc);
-      const HingePair hp = hinge_classify<NW>(ps, R, t0, t1);
-      int cls = hp.cls;
-      if (obj_level && obj_level[m] != 0u && call_level != 0u && (int)(obj_level[m] >> 23) < (int)(call_level >> 23) - quiet_binades)
-        cls = kHgExact;
-      LinEntry e;
-      HingeEntry h;
-      hinge_entries(ps, R, base, n, kc, m, t0, hp, T / 2, e, h);
-      HingeCached hc;
-      auto place = [&](int g) { return (hp.kinks >> g) & 1u ? (uint32_t)hp.pos[g] & 511u : 0u; };
-      hc.code = (uint32_t)(kc << 5 | cls) | place(3) << 23;  // (classes below 32, kc below 2^18)
-      hc.kinks = hp.kinks | place(0) << 4 | place(1) << 13 | place(2) << 22;
-      hc.p0 = e.p0, hc.scale = e.scale;
-      hg_cache[(size_t)m * TPW + j] = hc;
-      atomicAdd(&cnt[j][cls], 1);
+      if (stage) {  // (two kernels: the pair's class from the staging matrix; the second pass reads the rest from there)
+        atomicAdd(&cnt[j][(int)(stage[(size_t)tile * M + m].code & 31u)], 1);
+      } else {
+        // (gain_p2.h, k_piece_build: one header load, the search on the records hinge_load reads next)
+        const HingeCached hc = hinge_pair<NW>(ps, m, ps.hdr[m], t0, t1, obj_level, call_level, quiet_binades);
+        hg_cache[(size_t)m * TPW + j] = hc;
+        atomicAdd(&cnt[j][(int)(hc.code & 31u)], 1);
+      }
     }
 #ifdef EARHIP_BUILD_PROF
     EARHIP_BUILD_MARK(prof_i);  // pass 1, this batch
@@ -370,7 +418,7 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
     const int m = mb + oi;
     const bool in = m < M && tile < ntiles;
     HingeCached hc = {0u, 0u, 0.0f, 0.0f};
-    if (in) hc = hg_cache[(size_t)m * TPW + j];
+    if (in) hc = stage ? stage[(size_t)tile * M + m] : hg_cache[(size_t)m * TPW + j];
     const int cls = in ? (int)(hc.code & 31u) : -1, kc = (int)((hc.code >> 5) & 0x3ffffu);
     unsigned long long mine = 0;
     for (int b = 0; b < NC; b++) {

@@ -443,10 +443,11 @@ def test_long_calls_from_host_pointers_run_as_a_pipeline_of_time_chunks(source, 
 
 @pytest.mark.parametrize("kind,m,nblocks,opts", [("adm", 320, 640, {}), ("adm", 1024, 96, {}), ("adm", 200, 33, {"EARHIP_P2_PAIRS": "0"}),
                                                 ("moving", 256, 130, {"EARHIP_HINGE": "0"}), ("moving", 96, 7, {"EARHIP_HINGE": "0", "EARHIP_P2_PAIRS": "1"}),
-                                                ("ragged", 77, 19, {})])
+                                                ("ragged", 77, 19, {}),
+                                                ("moving", 1024, 64, {}), ("moving", 320, 640, {}), ("moving", 100, 9, {}), ("moving", 200, 70, {"EARHIP_HG_TILE": "256"})])
 def test_the_two_kernel_list_builder_builds_the_one_pass_builders_lists(kind, m, nblocks, opts):
-    """K0 of the piece lists as two kernels (classify object-major into a staging matrix, place tile-major: the default since
-    round 6) against the one-pass builder (option BUILD_2K = 0): the same lists, so the same bits out of the gain kernel — long
+    """K0 of the piece lists and of the hinge lists as two kernels (classify object-major into a staging matrix, place tile-major:
+    round 6) against the one-pass builders (option BUILD_2K = 0): the same lists, so the same bits out of the gain kernel — long
     and short calls, paired and packed layouts, pairs with several ramps per tile (always-ramping curves on the piece lists: the
     placing kernel walks those itself), ragged curves and object counts that fill no workgroup."""
     import torch
@@ -466,7 +467,7 @@ def test_the_two_kernel_list_builder_builds_the_one_pass_builders_lists(kind, m,
         out, plan = with_options(o, lambda: render_device(curves, x, n, block, dec, 255, [nblocks]))
         outs[two] = out
         if kind != "ragged":
-            assert plan["kernel"] == 4, plan
+            assert plan["kernel"] == (5 if kind == "moving" and "EARHIP_HINGE" not in opts else 4), plan
     assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
     check_windows(curves, x, outs["1"], n, block, dec, 255, [(0, min(3, nblocks)), (max(nblocks - 3, 0), min(3, nblocks))])
 
