@@ -396,13 +396,19 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
     start[tid][NC + 1] = (at + 31) >> 5;
   }
   __syncthreads();
-  // flags of the chunk a slot lies in: the waves each kink set reaches, over the classes that share the chunk
-  auto chunk_flags = [&](int jj, int c) -> uint32_t {
+  // flags of the chunk a slot lies in: the waves each kink set reaches, over the classes that share the chunk — made ONCE per
+  // (tile, chunk) into LDS (round 6: every thread of the second pass used to run this loop over the classes for its own slot —
+  // ~640 instructions of a thread's ~800 per batch, half of the whole builder: tools/build_phases.py)
+  __shared__ uint32_t cfl[TPW][kMaxHingeCached / 32];
+  for (int i = tid; i < TPW * (hl.cap / 32); i += kHingeBuildThreads) {
+    const int jj = i / (hl.cap / 32), c = i % (hl.cap / 32);
     uint32_t f = 0;
     for (int b = 0; b < NC; b++)
       if (b != kHgExact && cnt[jj][b] > 0 && start[jj][b] < 32 * c + 32 && start[jj][b] + cnt[jj][b] > 32 * c) f |= hinge_class_masks<NW>(b);
-    return f;
-  };
+    cfl[jj][c] = f;
+  }
+  __syncthreads();
+  auto chunk_flags = [&](int jj, int c) -> uint32_t { return cfl[jj][c]; };
   // ---- pass 2
   const unsigned long long samej = [&] {  // the lanes of this wave with the same tile
     unsigned long long v = 0;
