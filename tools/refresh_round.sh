@@ -7,4 +7,4 @@ bash tools/profile_passes.sh r06_bursty_moving --scene bursty-moving > gpurun_ou
 bash tools/traffic_passes.sh r06_C2 --config C2 > gpurun_out/r06_tp_C2.log 2>&1
 bash tools/traffic_passes.sh r06_C3 --config C3 > gpurun_out/r06_tp_C3.log 2>&1
 bash tools/traffic_passes.sh r06_C5 --config C5 > gpurun_out/r06_tp_C5.log 2>&1
-timeout 600 python bench.py 2> gpurun_out/r06_bench_default.err | tail -1 > gpurun_out/r06_bench_default.json
+( time timeout 600 python bench.py ) 2> gpurun_out/r06_bench_default.err | tail -1 > gpurun_out/r06_bench_default.json
