@@ -122,6 +122,9 @@ int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int r
 int earhip_debug_k2_prof(earhip_ctx *ctx, unsigned long long *out64);
 /* the same for the list builders (k_piece_build / k_hinge_build; -DEARHIP_BUILD_PROF; tools/build_phases.py) */
 int earhip_debug_build_prof(earhip_ctx *ctx, unsigned long long *out64);
+/* the same for the hinge kernel (k_gain_mix_hg; -DEARHIP_HG_PROF; tools/hg_phases.py): per wave of two workgroups the cycles summed
+ * over its chunk loop's phases, out128[2][8][8] */
+int earhip_debug_hg_prof(earhip_ctx *ctx, unsigned long long *out128);
 
 /* ------------------------------------------------------------------------
  * (A) Interpolation policies — replaces LinearInterpSingle / LinearInterpVector

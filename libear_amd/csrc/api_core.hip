@@ -671,6 +671,21 @@ int earhip_debug_copy_bandwidth(earhip_ctx *ctx, void *host, size_t bytes, int r
   });
 }
 
+/* diagnostic builds (-DEARHIP_HG_PROF) only: the phase sums every wave of two workgroups of the LAST hinge-kernel launch left
+ * (gain_hg.h), out[2][8][8]; an ordinary build reports "not built in" */
+int earhip_debug_hg_prof(earhip_ctx *ctx, unsigned long long *out128) {
+  return guarded([&] {
+    require(ctx != nullptr && out128 != nullptr, "NULL argument");
+#ifdef EARHIP_HG_PROF
+    ctx->use();
+    EARHIP_HIP(hipStreamSynchronize(ctx->stream));
+    EARHIP_HIP(hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_hg_prof), sizeof(unsigned long long) * 128));
+#else
+    fail_invalid("this build has no hinge-kernel phase sums (-DEARHIP_HG_PROF)");
+#endif
+  });
+}
+
 /* diagnostic builds (-DEARHIP_BUILD_PROF) only: the s_memtime stamps thread 0 of two workgroups of the LAST list-builder launch
  * (k_piece_build or k_hinge_build) left at its phase boundaries, out[2][32]; an ordinary build reports "not built in" */
 int earhip_debug_build_prof(earhip_ctx *ctx, unsigned long long *out64) {

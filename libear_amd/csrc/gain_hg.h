@@ -506,6 +506,21 @@ k_hinge_build(PointStore ps, int M, int ntiles, int64_t t_call, int64_t t_call_e
 #ifndef EARHIP_HG_RINGU
 #define EARHIP_HG_RINGU 1
 #endif
+// -DEARHIP_HG_PROF: every wave of two workgroups of the hinge kernel (the grid's first and a middle one, part 0) sums the s_memtime
+// cycles of its chunk loop's phases — 0: at the chunk barrier, 1: row requests + operand split (the wait for the chunk's inputs),
+// 2: the line's MFMA blocks with the requests and conversions woven in, 3: staging the rows that arrived + ring, 4: kink sets,
+// 5: chunks, 6: kink sets run, 7: the whole kernel — (earhip_debug_hg_prof reads them; tools/hg_phases.py)
+#ifdef EARHIP_HG_PROF
+static __device__ unsigned long long g_hg_prof[2][8][8];
+#define EARHIP_HG_MARK(i)                                            \
+  do {                                                               \
+    const unsigned long long t_now_ = __builtin_readcyclecounter();  \
+    hgp_acc[(i)] += t_now_ - hgp_last;                               \
+    hgp_last = t_now_;                                               \
+  } while (0)
+#else
+#define EARHIP_HG_MARK(i) do {} while (0)
+#endif
 typedef _Float16 hg_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ hg_h2 as_h2(uint32_t u) { return __builtin_bit_cast(hg_h2, u); }
 __device__ __forceinline__ uint32_t h2_bits(hg_h2 h) { return __builtin_bit_cast(uint32_t, h); }
@@ -610,6 +625,11 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
       for (int c = 0; c < NCT; c++) tot0[r][c] = tot1[r][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   };
   clear_totals();
+#ifdef EARHIP_HG_PROF
+  unsigned long long hgp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long hgp_start = __builtin_readcyclecounter();
+  unsigned long long hgp_last = hgp_start;
+#endif
 
   // ---- exact path: one object, all its pieces inside this wave's 64 samples, f32 MFMA with k = {a, b} of ONE
   // object, accumulated into tot0 in units of 1 / (sx sg) (gain_p2.h)
@@ -876,6 +896,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
 
       auto chunk_body = [&](int c, f32x4 (&X)[8]) __attribute__((always_inline)) {
         __syncthreads();  // the fragments of chunk c are in place; ring slots up to c + RD - 1 are visible
+        EARHIP_HG_MARK(0);
         const LaneCtx L = lane_ctx(false);
         const uint32_t cf = ringc[c & (RING - 1)];
         f32x3 G[NREQ];
@@ -900,6 +921,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             al[rp + 1][qp] = pack_f16(r0[1], r1[1]);
           }
         __builtin_amdgcn_sched_barrier(0);  // the splitting above stays above
+        EARHIP_HG_MARK(1);
         // ======== the line: 2 NCT blocks of 12 MFMAs (operand B0 / B1 of a column tile: the three partial products, small
         // ones first).  Between them, in this order: the requests of the next chunk's inputs (into the registers the
         // split has just freed), then the next chunk's operands from the rows staged a step ago — MFMA and VALU
@@ -976,6 +998,7 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
           block(std::integral_constant<int, 5>{});
         }
         __builtin_amdgcn_sched_barrier(0);
+        EARHIP_HG_MARK(2);
         stage_gains(L, G);  // the rows of the chunk after next replace the next chunk's (same wave: in order)
         if (w == 0) ring_store(L, c + RD);
 #if EARHIP_HG_RINGU
@@ -985,9 +1008,13 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
         if (w == 0) ring_load(L, c + 1 + RD);
 #endif
         // ======== its kinks: forward, then backward
+        EARHIP_HG_MARK(3);
 #pragma unroll 1
         for (int g = 0; g < KS; g++) {
-          if (!((cf >> (8 * g + w)) & 1u)) continue;  // (wave-uniform) no such kinks, or none that reach this wave's samples
+          if (!((cf >> (8 * g + w)) & 1u)) continue;
+#ifdef EARHIP_HG_PROF
+          hgp_acc[6]++;
+#endif  // (wave-uniform) no such kinks, or none that reach this wave's samples
           // the lane's 8 factor words -> (slope, slope) and (offset, offset) pairs of its slot pairs
           const u32x4 fa = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][L.kg * 8]);
           const u32x4 fb = *reinterpret_cast<const u32x4 *>(&ringf[c & (RING - 1)][g][L.kg * 8 + 4]);
@@ -1059,7 +1086,15 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
             }
           }
         }
+#ifdef EARHIP_HG_PROF
+        __builtin_amdgcn_sched_barrier(0);
+        EARHIP_HG_MARK(4);
+        hgp_acc[5]++;
+#endif
       };
+#ifdef EARHIP_HG_PROF
+      hgp_last = __builtin_readcyclecounter();  // (the prologue is not a phase)
+#endif
 #pragma unroll 1
       for (int c = c_lo; c < c_hi; c++) chunk_body(c, X0);
     }
@@ -1098,6 +1133,14 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
     for (int m = m_lo; m < m_hi; m++) single_object(m, 1.0f, false);  // unaligned rows
   }
 
+#ifdef EARHIP_HG_PROF
+  {
+    const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 1 : -1;
+    hgp_acc[7] = __builtin_readcyclecounter() - hgp_start;
+    if (slot >= 0 && part == 0 && blockIdx.z == 0 && lane == 0 && w < 8)
+      for (int i = 0; i < 8; i++) g_hg_prof[slot][w][i] = hgp_acc[i];
+  }
+#endif
   if (tile_len <= 0) return;
   // D fragment of row tile r: rows 4 kg + e = samples 16 kg + 4 e + r; (s - c) counts from the WORKGROUP tile's centre
   // (where the line is anchored: LinEntry::p0)
