@@ -78,7 +78,9 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  *                 P2_WGS 0: one per tile), H2_RUNS (1: a workgroup of the grid kernel takes a contiguous run of tiles instead of
  *                 every n-th: measured slower, kept as a knob), HG_ROBUST (default 1: a call whose levels spread beyond the hinge
  *                 kernel's packed-f16 kink products runs that kernel's f32 form; 0: it is handed to the piece lists standing by,
- *                 rounds 4-5), BUILD_TPW, HBUILD_TPW (1 2 4 8),
+ *                 rounds 4-5), BUILD_TPW, HBUILD_TPW (1 2 4 8), BUILD_2K (1: the list builders as two kernels — classify every (object,
+ *                 tile) pair object-major into a staging matrix, place tile-major: the same lists bit for bit; 0: one pass; default:
+ *                 two kernels for the paired piece lists only, where they are faster),
  *                 SPL (2 | 4), WAVES (1..8), TPW (1..8), NRT (4 | 8), XSCALE (log2 of a fixed input prescale), PROBE_RUNS
  *   renderer:     K2_WG, K2_OWN_BLOCK (0 | 1), RUN (odd blocks per decorrelator run), GSPLIT (1..32) — read by
  *                 earhip_render_create; TAILCUT (v = 0..7, default 2: a stream call of k rounds of tiles plus at most v / 8
