@@ -267,10 +267,19 @@ def launch_ranks(n):
     not replace itself: the child is an ordinary subprocess."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import random
+    port = 29500
+    for _ in range(64):  # (below the kernel's ephemeral range: a port from there can be taken again before the rendezvous binds it)
+        cand = random.randint(15000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", cand))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        port = cand
+        break
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only does dmabuf IPC (RCCL needs it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",

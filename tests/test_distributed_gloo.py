@@ -19,11 +19,20 @@ ROOT = os.path.dirname(HERE)
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """a port nobody listens on, taken BELOW the kernel's ephemeral range (32768-60999): a port from that range (bind to 0) can be
+    handed to somebody's outgoing connection between this check and the rendezvous' own bind (seen once: EADDRINUSE)"""
+    import random
+    for _ in range(64):
+        port = random.randint(15000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return port
+    raise RuntimeError("no free port found")
 
 
 def _worker(rank, world, port, tmp):

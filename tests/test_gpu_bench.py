@@ -16,11 +16,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """a port nobody listens on, taken BELOW the kernel's ephemeral range (32768-60999): a port from that range (bind to 0) can be
+    handed to somebody's outgoing connection between this check and the rendezvous' own bind (seen once: EADDRINUSE)"""
+    import random
+    for _ in range(64):
+        port = random.randint(15000, 30000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return port
+    raise RuntimeError("no free port found")
 
 
 def _run_with_one_retry(cmd, env, timeout):
@@ -34,6 +43,10 @@ def _run_with_one_retry(cmd, env, timeout):
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
         try:
             out, err = proc.communicate(timeout=timeout)
+            if attempt == 0 and proc.returncode != 0 and "EADDRINUSE" in err and "--master-port" in cmd:
+                cmd = list(cmd)  # somebody took the rendezvous port between the check and the bind: once more on another one
+                cmd[cmd.index("--master-port") + 1] = str(_free_port())
+                continue
             return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
         except subprocess.TimeoutExpired:
             try:
