@@ -638,11 +638,13 @@ k_gain_mix_hg(GainMixParams P, HingeLists hl, float x_scale, const float *__rest
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? 0.5f * gcol[col0 + c * 16 + li] : 1.0f;
-    const int base = P.ps.off[m], n = P.ps.cnt[m];
+    // (header + a window of records around the guess: two dependent rounds of loads instead of a bisection's ~12 — gain_p2.h)
+    const ObjHdr hd = P.ps.hdr[m];
+    const int base = hd.off, n = hd.cnt;
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;
-    int k = upper_bound_time(P.ps.time + base, n, tile_t0);
+    int k = upper_bound_rec_window(P.ps.rec + base, n, hd.first, hd.last, tile_t0);
     int cur = 0;
     while (cur < tile_len) {
       const SegDesc dk = describe_segment(P.ps, base, n, k, tile_t0, tile_t1);

@@ -602,11 +602,14 @@ k_gain_mix_p2(GainMixParams P, PieceLists pl, float x_scale, const float *__rest
     float gsc[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; c++) gsc[c] = sg ? gcol[col0 + c * 16 + li] : 1.0f;
-    const int base = P.ps.off[m], n = P.ps.cnt[m];
+    // (offset, count and the curve's end points in one load, then a window of eight records around the evenly-spaced guess: two
+    // dependent rounds of loads per object instead of the ~12 of a bisection — gain_kernels.h, ObjHdr; search.h)
+    const ObjHdr hd = P.ps.hdr[m];
+    const int base = hd.off, n = hd.cnt;
     const float *row = P.in + (size_t)m * P.in_stride + tile_s0;
     const bool is_b = kg & 1;
     const bool slot0 = kg < 2;
-    int k = upper_bound_time(P.ps.time + base, n, tile_t0);
+    int k = P.ps.force_ramp ? upper_bound_time(P.ps.time + base, n, tile_t0) : upper_bound_rec_window(P.ps.rec + base, n, hd.first, hd.last, tile_t0);
     int cur = 0;
     while (cur < tile_len) {
       const SegDesc dk = describe_segment(P.ps, base, n, k, tile_t0, tile_t1);
