@@ -86,7 +86,10 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  *                 earhip_render_create; TAILCUT (v = 0..7, default 2: a stream call of k rounds of tiles plus at most v / 8
  *                 of a round runs as two consecutive calls, earhip_render_last_tail_blocks; longer tails measured slower cut)
  *   host pointers: HOST_CHUNK_MB (MB of inputs per time chunk of a long earhip_render_process call: default 32 from device-reachable
- *                 rows, 16 from ordinary ones; <= 0: no pipeline, one transfer), HOST_THREADS (staging threads: default min(16, cores / 2))
+ *                 rows, 16 from ordinary ones; <= 0: no pipeline, one transfer), HOST_THREADS (staging threads: default min(16, cores / 2)),
+ *                 HOST_BIND (default 1: the staging threads run on the NUMA node that holds the caller's rows — found with move_pages(2),
+ *                 the node's CPUs from /sys —; 0: wherever the scheduler puts them.  A thread remote to both the rows and the pinned
+ *                 staging buffer gathers at 38 GB/s where any other placement reaches 46-48: tools/host_stream_numa.py)
  *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING
  * (K2_WG, K2_OWN_BLOCK, DEBUG_TIMING are "on" for any value other than 0 — rounds 1-4 read the mere presence of the environment
  * variable as "on": EARHIP_K2_WG=0 now means off.) */
@@ -496,6 +499,10 @@ int earhip_render_last_list_layout(const earhip_render *r, int *paired);
  * splits — instead of paying a whole round for the few.  *blocks = the blocks of the last call that ran as such a tail
  * (0: the call was not cut).  Results are those of the two calls made by the caller. */
 int earhip_render_last_tail_blocks(const earhip_render *r, int *blocks);
+/* earhip_render_process from host channel pointers (libear's calling convention, variable_block_size_impl.cpp:44-81) runs a long
+ * call — 16 MB of inputs and more — as a pipeline of time chunks on three streams (transfer in / kernels / transfer out; options
+ * HOST_CHUNK_MB, HOST_THREADS, HOST_BIND).  *chunks = the chunks the last such call of this renderer ran as (0: one piece). */
+int earhip_render_last_host_chunks(const earhip_render *r, int *chunks);
 /* Bytes of device scratch (segment descriptors, slot / piece / hinge lists) the last process call needed: sized per call
  * from its launch plan and the curves (the piece lists from the most ramps any window of a tile's length overlaps, per
  * object), not for the worst case. */

@@ -680,6 +680,12 @@ class Renderer:
         check(load().earhip_render_last_tail_blocks(self.h, C.byref(v)))
         return v.value
 
+    def last_host_chunks(self):
+        """time chunks the last call from host channel pointers ran as (0: one piece)"""
+        v = C.c_int(0)
+        check(load().earhip_render_last_host_chunks(self.h, C.byref(v)))
+        return v.value
+
     def last_list_layout(self):
         """layout of the last call's piece lists: True paired, False packed, None: none built"""
         v = C.c_int(0)

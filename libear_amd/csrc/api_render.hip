@@ -11,6 +11,11 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <cstdio>
+
 #include "common.h"
 #include "curves.h"
 #include "fft_kernels.h"
@@ -114,8 +119,66 @@ static int wave_run_len(int T, int N, int num_cus) {
 // gather every channel's samples of chunk g into the pinned buffer, chunk-major ([chunk][channel][samples of the chunk]: a
 // chunk is one linear transfer), thread t taking every nthreads-th channel; done[g] counts the threads that have finished
 // chunk g (the caller starts that chunk's transfer then, while the threads gather the next one).
+// Where a range of the caller's memory lives (NUMA node; -1: unknown, or its pages sit on several nodes) and which CPUs are that
+// node's: the staging threads of long host-pointer calls run on the node of the rows they read (option HOST_BIND, default on).
+// A staging thread that runs on a node remote to BOTH the caller's pages and the pinned staging buffer moves 38 GB/s where any
+// other placement moves 46-48 (two-socket host, `tools/host_stream_numa.py`) — and where the scheduler puts free threads is a
+// lottery between processes.  Plain Linux interfaces: move_pages(2) with no target nodes only reports, /sys lists a node's CPUs.
+struct NumaMap {
+  cpu_set_t allowed;                 // the CPUs this process may use at all (cpusets, taskset)
+  std::vector<cpu_set_t> node_cpus;  // per node: its CPUs among the allowed ones (empty set: unknown / none)
+  std::vector<char> known;
+  bool ok = false;
+  NumaMap() {
+    CPU_ZERO(&allowed);
+    ok = sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
+    known.reserve(64), node_cpus.reserve(64);  // (the staging threads hold pointers to a node's set while a job runs)
+  }
+  static int page_node(const void *p) {
+    void *pg = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095);
+    int status = -1;
+    const long rc = syscall(SYS_move_pages, 0, 1ul, &pg, nullptr, &status, 0);
+    return rc == 0 && status >= 0 ? status : -1;
+  }
+  // the node of the first, a middle and the last row of a call's inputs when they agree
+  static int rows_node(const float *const *in, int M, size_t n) {
+    const int a = page_node(in[0]), b = page_node(in[M / 2] + n / 2), c = page_node(in[M - 1] + (n ? n - 1 : 0));
+    return a >= 0 && a == b && b == c ? a : -1;
+  }
+  const cpu_set_t *cpus_of(int node) {
+    if (!ok || node < 0 || node >= 1024) return nullptr;
+    if ((size_t)node >= known.size()) known.resize(node + 1, 0), node_cpus.resize(node + 1);
+    if (!known[node]) {
+      known[node] = 1;
+      CPU_ZERO(&node_cpus[node]);
+      char path[96];
+      snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+      if (FILE *f = fopen(path, "r")) {
+        int a = 0, b = 0;
+        for (;;) {  // "0-63,128-191"
+          if (fscanf(f, "%d", &a) != 1) break;
+          b = a;
+          int ch = fgetc(f);
+          if (ch == '-') {
+            if (fscanf(f, "%d", &b) != 1) break;
+            ch = fgetc(f);
+          }
+          for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) CPU_SET(c, &node_cpus[node]);
+          if (ch != ',') break;
+        }
+        fclose(f);
+      }
+    }
+    return CPU_COUNT(&node_cpus[node]) > 0 ? &node_cpus[node] : nullptr;
+  }
+};
+
 struct GatherPool {
   static constexpr int kMaxGroups = 64;
+  NumaMap numa;
+  int job_node = -1;                  // the node this job's rows live on (-1: run anywhere)
+  const cpu_set_t *job_cpus = nullptr;
   std::vector<std::thread> threads;
   std::mutex mu;
   std::condition_variable go, finished_cv;
@@ -134,12 +197,23 @@ struct GatherPool {
     for (int t = 0; t < count; t++)
       threads.emplace_back([this, t] {
         uint64_t seen = 0;
+        int my_node = -1;  // the node this thread is bound to (-1: not bound)
         for (;;) {
+          int want_node;
+          const cpu_set_t *want_cpus;
           {
             std::unique_lock<std::mutex> lk(mu);
             go.wait(lk, [&] { return quit || generation != seen; });
             if (quit) return;
             seen = generation;
+            want_node = job_node, want_cpus = job_cpus;
+          }
+          if (want_node != my_node) {  // (a failure leaves the thread where it is: placement is an optimisation)
+            if (want_node >= 0 && want_cpus) {
+              if (sched_setaffinity(0, sizeof(cpu_set_t), want_cpus) == 0) my_node = want_node;
+            } else if (numa.ok && sched_setaffinity(0, sizeof(cpu_set_t), &numa.allowed) == 0) {
+              my_node = -1;
+            }
           }
           const int nt = nthreads();
           for (int g = 0; g < groups; g++) {
@@ -153,9 +227,12 @@ struct GatherPool {
         }
       });
   }
-  void submit(const float *const *in_, float *dst_, size_t n_, size_t clen_, int M_) {
+  void submit(const float *const *in_, float *dst_, size_t n_, size_t clen_, int M_, bool bind) {
+    const int node = bind && numa.ok ? NumaMap::rows_node(in_, M_, n_) : -1;
     std::lock_guard<std::mutex> lk(mu);
     in = in_, dst = dst_, n = n_, clen = clen_, M = M_;
+    job_cpus = numa.cpus_of(node);
+    job_node = job_cpus ? node : -1;
     groups = (int)((n + clen - 1) / clen);
     for (auto &d : done) d.store(0);
     finished = 0;
@@ -743,7 +820,7 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
           const int want = ctx->get(OPT_HOST_THREADS, 0);
           r->gather->start(want >= 1 && want <= 64 ? want : (int)std::max(2u, std::min(16u, hc / 2)));
         }
-        r->gather->submit(in, r->p_in.p, n, clen, r->M);
+        r->gather->submit(in, r->p_in.p, n, clen, r->M, ctx->get(OPT_HOST_BIND, 1) != 0);
       }
       hipError_t err = hipSuccess;
       std::string fail;
@@ -962,6 +1039,13 @@ int earhip_render_last_tail_blocks(const earhip_render *r, int *blocks) {
   return guarded([&] {
     require(r != nullptr && blocks != nullptr, "NULL argument");
     *blocks = r->last_tail_blocks;
+  });
+}
+
+int earhip_render_last_host_chunks(const earhip_render *r, int *chunks) {
+  return guarded([&] {
+    require(r != nullptr && chunks != nullptr, "NULL argument");
+    *chunks = r->last_host_chunks;
   });
 }
 

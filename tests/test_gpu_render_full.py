@@ -441,6 +441,74 @@ def test_long_calls_from_host_pointers_run_as_a_pipeline_of_time_chunks(source, 
     print(f"host pipeline ({source}, {kind}, {m} objects): worst channel vs oracle {worst:.3e}, vs one device call {diff:.3e}")
 
 
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out |= set(range(int(a), int(b or a) + 1))
+    return out
+
+
+def test_staging_threads_of_long_host_calls_run_on_the_node_of_the_callers_rows():
+    """Long calls from pageable channel pointers gather their time chunks with staging threads; option HOST_BIND (default on)
+    puts those threads on the NUMA node that holds the caller's rows (a thread remote to both the rows and the pinned staging
+    buffer moves 38 GB/s where any other placement moves 46-48: tools/host_stream_numa.py).  The mechanism, on any Linux host:
+    after such a call as many threads of this process as the pool has are confined to the CPUs of the rows' node; with
+    HOST_BIND = 0 none is; the outputs are the same bits either way (placement is not arithmetic)."""
+    import glob
+    from libear_amd import capi
+    allowed = os.sched_getaffinity(0)
+    nodes = {}
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        cpus = _cpulist(open(d + "/cpulist").read()) & allowed
+        if cpus:
+            nodes[int(d.rsplit("node", 1)[1])] = cpus
+    if not nodes:
+        pytest.skip("no NUMA topology in /sys")
+    layout, block, nblocks, m = "9+10+3", 512, 40, 1024
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    curves = scenes.dense_curves(m, n, block, nblocks)
+    node = sorted(nodes)[-1]
+    os.sched_setaffinity(0, nodes[node])  # first touch on this node
+    try:
+        x = np.array(scenes.audio(m, block * nblocks, seed=23), dtype=np.float32, copy=True)
+    finally:
+        os.sched_setaffinity(0, allowed)
+
+    def confined():
+        """threads of this process whose allowed CPUs lie inside ONE node that is smaller than the process's own set"""
+        k = 0
+        for st in glob.glob("/proc/self/task/*/status"):
+            try:
+                line = [ln for ln in open(st).read().splitlines() if ln.startswith("Cpus_allowed_list:")][0]
+            except (OSError, IndexError):
+                continue
+            cpus = _cpulist(line.split(":", 1)[1])
+            if cpus != allowed and any(cpus <= nodes[nd] for nd in nodes):
+                k += 1
+        return k
+
+    outs = {}
+    for bind in (0, 1):
+        c = capi.Context(0, None)
+        c.set_option("HOST_BIND", str(bind))
+        c.set_option("HOST_THREADS", "6")
+        r = capi.Renderer(c, m, n, block, dec, 255, max_blocks=nblocks)
+        for i, (t, d, f) in enumerate(curves):
+            r.set_object_points(i, t, d, f)
+        before = confined()
+        outs[bind] = r.process(x)
+        assert r.last_host_chunks() > 1
+        after = confined()
+        if len(nodes) > 1 or len(nodes[node]) < len(allowed):
+            assert after - before == (6 if bind else 0), (bind, before, after)
+        r.close()
+        c.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("kind,m,nblocks,opts", [("adm", 320, 640, {}), ("adm", 1024, 96, {}), ("adm", 200, 33, {"EARHIP_P2_PAIRS": "0"}),
                                                 ("moving", 256, 130, {"EARHIP_HINGE": "0"}), ("moving", 96, 7, {"EARHIP_HINGE": "0", "EARHIP_P2_PAIRS": "1"}),
                                                 ("ragged", 77, 19, {}),
