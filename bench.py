@@ -1091,9 +1091,14 @@ def main():
                         capi.check(capi.load().earhip_render_process(rh.h, ctypes.c_size_t(hb), ipp_, opp_))
                         return ya
                     first = np.array(call())
-                    call()
+                    # (untimed calls for 0.2 s first: the staging threads have just been woken or made — the first ~100 ms of calls
+                    # run at 0.6 of the steady rate while the scheduler spreads them and their cores leave their idle states;
+                    # an offline render makes such calls back to back for minutes)
+                    w0 = time.perf_counter()
+                    while time.perf_counter() - w0 < 0.2:
+                        call()
                     ts = []
-                    for _ in range(5):
+                    for _ in range(7):
                         c0 = time.perf_counter()
                         call()
                         ts.append(time.perf_counter() - c0)
@@ -1103,6 +1108,7 @@ def main():
                     hs["calls"].append({"source": src, "blocks_per_call": hb, "ms_per_call": round(hdt * 1e3, 3),
                                         "Gsamples_per_s": round(M * hb * B / hdt / 1e9, 2), "GBps_in": round(gbps, 1),
                                         "h2d_GBps_measured": ref_rate, "frac": round(gbps / ref_rate, 3),
+                                        "ms_per_call_min_max": [round(min(ts) * 1e3, 3), round(max(ts) * 1e3, 3)],
                                         "frac_of_pageable_copy": round(gbps / hs["h2d_GBps_measured"]["pageable"], 3) if src == "pageable" else None,
                                         # (the same blocks as the timed stream's first ones: held against the CPU path and the device-resident render)
                                         "max_channel_rel_rms_vs_cpu": None, "max_rel_diff_vs_stream_render": None, "_first": first})

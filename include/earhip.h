@@ -86,10 +86,11 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  *                 earhip_render_create; TAILCUT (v = 0..7, default 2: a stream call of k rounds of tiles plus at most v / 8
  *                 of a round runs as two consecutive calls, earhip_render_last_tail_blocks; longer tails measured slower cut)
  *   host pointers: HOST_CHUNK_MB (MB of inputs per time chunk of a long earhip_render_process call: default 32 from device-reachable
- *                 rows, 16 from ordinary ones; <= 0: no pipeline, one transfer), HOST_THREADS (staging threads: default min(16, cores / 2)),
- *                 HOST_BIND (default 1: the staging threads run on the NUMA node that holds the caller's rows — found with move_pages(2),
- *                 the node's CPUs from /sys —; 0: wherever the scheduler puts them.  A thread remote to both the rows and the pinned
- *                 staging buffer gathers at 38 GB/s where any other placement reaches 46-48: tools/host_stream_numa.py)
+ *                 rows, 16 from ordinary ones; <= 0: no pipeline, one transfer), HOST_THREADS (staging threads: default min(8, the CPUs the process may use — affinity mask, cgroup quota — less 2)),
+ *                 HOST_BIND (1: the staging threads run on the NUMA node that holds the caller's rows — found with move_pages(2), the
+ *                 node's CPUs from /sys; a thread remote to both the rows and the pinned staging buffer gathers at 38 GB/s where any
+ *                 other placement reaches 46-48: tools/host_stream_numa.py; default 0: the scheduler's placement, 1.4 % faster
+ *                 where it is good), HOST_NT (default 1: the gather writes the staging buffer with streaming stores; 0: memcpy)
  *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING
  * (K2_WG, K2_OWN_BLOCK, DEBUG_TIMING are "on" for any value other than 0 — rounds 1-4 read the mere presence of the environment
  * variable as "on": EARHIP_K2_WG=0 now means off.) */

@@ -11,6 +11,9 @@
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -120,10 +123,10 @@ static int wave_run_len(int T, int N, int num_cus) {
 // chunk is one linear transfer), thread t taking every nthreads-th channel; done[g] counts the threads that have finished
 // chunk g (the caller starts that chunk's transfer then, while the threads gather the next one).
 // Where a range of the caller's memory lives (NUMA node; -1: unknown, or its pages sit on several nodes) and which CPUs are that
-// node's: the staging threads of long host-pointer calls run on the node of the rows they read (option HOST_BIND, default on).
+// node's: option HOST_BIND = 1 runs the staging threads of long host-pointer calls on the node of the rows they read.
 // A staging thread that runs on a node remote to BOTH the caller's pages and the pinned staging buffer moves 38 GB/s where any
-// other placement moves 46-48 (two-socket host, `tools/host_stream_numa.py`) — and where the scheduler puts free threads is a
-// lottery between processes.  Plain Linux interfaces: move_pages(2) with no target nodes only reports, /sys lists a node's CPUs.
+// other placement moves 46-48 (two-socket host, `tools/host_stream_numa.py`).  Not the default: where the scheduler had the threads
+// well placed already, binding them to the rows' node measured 1.4 % slower (`tools/host_stream_ab.py`).  Plain Linux interfaces: move_pages(2) with no target nodes only reports, /sys lists a node's CPUs.
 struct NumaMap {
   cpu_set_t allowed;                 // the CPUs this process may use at all (cpusets, taskset)
   std::vector<cpu_set_t> node_cpus;  // per node: its CPUs among the allowed ones (empty set: unknown / none)
@@ -174,9 +177,66 @@ struct NumaMap {
   }
 };
 
+// A row piece into the pinned staging buffer with NON-TEMPORAL stores: the buffer is written once and read by the copy engine,
+// never by a CPU — ordinary stores first READ every destination line into the cache (16 KB pieces are far below the size at which
+// memcpy switches to streaming stores itself), a third of the gather's memory traffic and the whole of its cache footprint.
+// (SSE2: baseline x86-64.  The caller fences before it publishes the chunk.)
+static inline void stream_copy(float *dst, const float *src, size_t nfloats) {
+#if defined(__x86_64__)
+  const size_t head = std::min(nfloats, (size_t)(((64 - (reinterpret_cast<uintptr_t>(dst) & 63)) & 63) / sizeof(float)));
+  if (head) std::memcpy(dst, src, head * sizeof(float));
+  dst += head, src += head, nfloats -= head;
+  const size_t lines = nfloats / 16;
+  const __m128i *s = reinterpret_cast<const __m128i *>(src);
+  __m128i *d = reinterpret_cast<__m128i *>(dst);
+  for (size_t i = 0; i < lines; i++) {
+    const __m128i a = _mm_loadu_si128(s + 4 * i), b = _mm_loadu_si128(s + 4 * i + 1), c = _mm_loadu_si128(s + 4 * i + 2), e = _mm_loadu_si128(s + 4 * i + 3);
+    _mm_stream_si128(d + 4 * i, a);
+    _mm_stream_si128(d + 4 * i + 1, b);
+    _mm_stream_si128(d + 4 * i + 2, c);
+    _mm_stream_si128(d + 4 * i + 3, e);
+  }
+  const size_t done = lines * 16;
+  if (nfloats > done) std::memcpy(dst + done, src + done, (nfloats - done) * sizeof(float));
+#else
+  std::memcpy(dst, src, nfloats * sizeof(float));
+#endif
+}
+
+// How many staging threads a long host-pointer call gets by default: 8 — the gather is bound by its memory accesses' latency, not by
+// cores: 8, 16 and 32 threads move the same bytes per second (tools/host_stream_ab.py: 0.895 / 0.885 / 0.866 of the bus) — but never
+// more than the CPUs this process may actually USE less two (the calling thread polls while it waits, the HIP runtime has
+// threads of its own): a container sees all of the host's cores (hardware_concurrency: 256) while its cgroup grants it 16 CPUs'
+// worth of time, and threads beyond the grant get the whole group throttled in the middle of a call (32 threads: 0.62).
+static int default_staging_threads() {
+  double cpus = (double)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) cpus = std::min(cpus, (double)CPU_COUNT(&set));
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota us | max> <period us>"
+    char q[32] = {0};
+    long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && q[0] != 'm') cpus = std::min(cpus, (double)atol(q) / (double)period);
+    fclose(f);
+  } else {  // cgroup v1
+    long quota = -1, period = 0;
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+      fclose(g);
+    }
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(g, "%ld", &period) != 1) period = 0;
+      fclose(g);
+    }
+    if (quota > 0 && period > 0) cpus = std::min(cpus, (double)quota / (double)period);
+  }
+  return (int)std::max(2.0, std::min(8.0, cpus - 2.0));
+}
+
 struct GatherPool {
   static constexpr int kMaxGroups = 64;
   NumaMap numa;
+  bool streaming = true;              // (option HOST_NT, read when a job is submitted)
   int job_node = -1;                  // the node this job's rows live on (-1: run anywhere)
   const cpu_set_t *job_cpus = nullptr;
   std::vector<std::thread> threads;
@@ -219,7 +279,14 @@ struct GatherPool {
           for (int g = 0; g < groups; g++) {
             const size_t len = group_len(g), at = (size_t)g * clen;
             float *base = dst + (size_t)M * at;
-            for (int m = t; m < M; m += nt) std::memcpy(base + (size_t)m * len, in[m] + at, sizeof(float) * len);
+            if (streaming) {
+              for (int m = t; m < M; m += nt) stream_copy(base + (size_t)m * len, in[m] + at, len);
+#if defined(__x86_64__)
+              _mm_sfence();  // (streaming stores are weakly ordered: globally visible before the chunk counts as gathered)
+#endif
+            } else {
+              for (int m = t; m < M; m += nt) std::memcpy(base + (size_t)m * len, in[m] + at, sizeof(float) * len);
+            }
             done[g].fetch_add(1, std::memory_order_release);
           }
           std::lock_guard<std::mutex> lk(mu);
@@ -227,10 +294,11 @@ struct GatherPool {
         }
       });
   }
-  void submit(const float *const *in_, float *dst_, size_t n_, size_t clen_, int M_, bool bind) {
+  void submit(const float *const *in_, float *dst_, size_t n_, size_t clen_, int M_, bool bind, bool nt) {
     const int node = bind && numa.ok ? NumaMap::rows_node(in_, M_, n_) : -1;
     std::lock_guard<std::mutex> lk(mu);
     in = in_, dst = dst_, n = n_, clen = clen_, M = M_;
+    streaming = nt;
     job_cpus = numa.cpus_of(node);
     job_node = job_cpus ? node : -1;
     groups = (int)((n + clen - 1) / clen);
@@ -816,11 +884,10 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       if (!in_st) {
         if (!r->gather) {
           r->gather.reset(new GatherPool);
-          const unsigned hc = std::thread::hardware_concurrency();
           const int want = ctx->get(OPT_HOST_THREADS, 0);
-          r->gather->start(want >= 1 && want <= 64 ? want : (int)std::max(2u, std::min(16u, hc / 2)));
+          r->gather->start(want >= 1 && want <= 64 ? want : default_staging_threads());
         }
-        r->gather->submit(in, r->p_in.p, n, clen, r->M, ctx->get(OPT_HOST_BIND, 1) != 0);
+        r->gather->submit(in, r->p_in.p, n, clen, r->M, ctx->get(OPT_HOST_BIND, 0) != 0, ctx->get(OPT_HOST_NT, 1) != 0);
       }
       hipError_t err = hipSuccess;
       std::string fail;

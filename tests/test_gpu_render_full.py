@@ -451,7 +451,7 @@ def _cpulist(text):
 
 
 def test_staging_threads_of_long_host_calls_run_on_the_node_of_the_callers_rows():
-    """Long calls from pageable channel pointers gather their time chunks with staging threads; option HOST_BIND (default on)
+    """Long calls from pageable channel pointers gather their time chunks with staging threads; option HOST_BIND = 1
     puts those threads on the NUMA node that holds the caller's rows (a thread remote to both the rows and the pinned staging
     buffer moves 38 GB/s where any other placement moves 46-48: tools/host_stream_numa.py).  The mechanism, on any Linux host:
     after such a call as many threads of this process as the pool has are confined to the CPUs of the rows' node; with
