@@ -90,7 +90,8 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  *                 HOST_BIND (1: the staging threads run on the NUMA node that holds the caller's rows — found with move_pages(2), the
  *                 node's CPUs from /sys; a thread remote to both the rows and the pinned staging buffer gathers at 38 GB/s where any
  *                 other placement reaches 46-48: tools/host_stream_numa.py; default 0: the scheduler's placement, 1.4 % faster
- *                 where it is good), HOST_NT (default 1: the gather writes the staging buffer with streaming stores; 0: memcpy)
+ *                 where it is good), HOST_NT (default 1: the gather writes the staging buffer with streaming stores; 0: memcpy),
+ *                 HOST_FIRST (1: the first chunk of staged rows a quarter of the others; measured level, default 0)
  *   diagnostics:  BLOCK_GROUPS, DEBUG_TIMING
  * (K2_WG, K2_OWN_BLOCK, DEBUG_TIMING are "on" for any value other than 0 — rounds 1-4 read the mere presence of the environment
  * variable as "on": EARHIP_K2_WG=0 now means off.) */

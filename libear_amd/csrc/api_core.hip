@@ -500,7 +500,7 @@ using namespace earhip;
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
     "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "H2_RUNS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
-    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST", "BUILD_2K", "HOST_BIND", "HOST_NT"};
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST", "BUILD_2K", "HOST_BIND", "HOST_NT", "HOST_FIRST"};
 
 // an option's value: a decimal integer (optional sign, surrounding blanks), nothing else — "abc" or "1x" used to read as 0 / 1
 static int parse_option_value(const std::string &key, const char *text) {

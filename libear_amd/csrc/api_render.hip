@@ -248,11 +248,12 @@ struct GatherPool {
   // the job
   const float *const *in = nullptr;
   float *dst = nullptr;
-  size_t n = 0, clen = 0;  // samples per channel in the call, samples per chunk (the last one may be shorter)
+  size_t n = 0;                      // samples per channel in the call
+  size_t cstart[kMaxGroups + 1] = {0};  // chunk g = samples [cstart[g], cstart[g + 1]) of every channel
   int M = 0, groups = 0;
   std::atomic<int> done[kMaxGroups];
   int nthreads() const { return (int)threads.size(); }
-  size_t group_len(int g) const { return std::min(clen, n - (size_t)g * clen); }
+  size_t group_len(int g) const { return cstart[g + 1] - cstart[g]; }
   void start(int count) {
     for (int t = 0; t < count; t++)
       threads.emplace_back([this, t] {
@@ -277,7 +278,7 @@ struct GatherPool {
           }
           const int nt = nthreads();
           for (int g = 0; g < groups; g++) {
-            const size_t len = group_len(g), at = (size_t)g * clen;
+            const size_t len = group_len(g), at = cstart[g];
             float *base = dst + (size_t)M * at;
             if (streaming) {
               for (int m = t; m < M; m += nt) stream_copy(base + (size_t)m * len, in[m] + at, len);
@@ -294,14 +295,15 @@ struct GatherPool {
         }
       });
   }
-  void submit(const float *const *in_, float *dst_, size_t n_, size_t clen_, int M_, bool bind, bool nt) {
+  void submit(const float *const *in_, float *dst_, size_t n_, const size_t *starts, int nchunks, int M_, bool bind, bool nt) {
     const int node = bind && numa.ok ? NumaMap::rows_node(in_, M_, n_) : -1;
     std::lock_guard<std::mutex> lk(mu);
-    in = in_, dst = dst_, n = n_, clen = clen_, M = M_;
+    in = in_, dst = dst_, n = n_, M = M_;
+    for (int g = 0; g <= nchunks; g++) cstart[g] = starts[g];
     streaming = nt;
     job_cpus = numa.cpus_of(node);
     job_node = job_cpus ? node : -1;
-    groups = (int)((n + clen - 1) / clen);
+    groups = nchunks;
     for (auto &d : done) d.store(0);
     finished = 0;
     generation++;
@@ -876,10 +878,20 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
       // nothing overlaps, stays short)
       const size_t want_bytes = (size_t)std::max(1, ctx->get(OPT_HOST_CHUNK_MB, in_st ? 32 : 16)) << 20;
       size_t cb = std::max<size_t>(1, want_bytes / block_bytes);
-      cb = std::max(cb, (nblocks + GatherPool::kMaxGroups - 1) / GatherPool::kMaxGroups);
-      while ((cb * (size_t)r->B) % 4 != 0) cb++;  // (chunks start on 16-byte boundaries of the staging rows: vector loads)
-      const size_t clen = cb * r->B;
-      const int nch = (int)((nblocks + cb - 1) / cb);
+      cb = std::max(cb, (nblocks + GatherPool::kMaxGroups - 2) / (GatherPool::kMaxGroups - 1));
+      size_t gran = 1;  // (chunks start on 16-byte boundaries of the staging rows: vector loads)
+      while ((gran * (size_t)r->B) % 4 != 0) gran++;
+      cb = (cb + gran - 1) / gran * gran;
+      // (option HOST_FIRST = 1: from staged rows the first chunk a quarter of the others — its gather is the one nothing overlaps —;
+      // measured level with whole chunks (2.906 vs 2.905 ms per 64-block call): the staging threads are through ALL chunks of such a
+      // call after 0.66 ms, the call's time is the bus's plus ~19 us per chunk — 11 between two copies on a stream, 8 for the event
+      // and the kernels' stream behind it, tools/experiments/h2d_chunks.hip — so the default keeps whole chunks)
+      size_t cb0 = in_st || ctx->get(OPT_HOST_FIRST, 0) == 0 ? cb : std::max(gran, cb / 4 / gran * gran);
+      if (cb0 >= nblocks) cb0 = cb;
+      size_t cstart[GatherPool::kMaxGroups + 1];
+      int nch = 0;
+      for (size_t b = 0; b < nblocks; b += nch == 1 ? cb0 : cb) cstart[nch++] = b * r->B;  // (nch counts the chunk being opened)
+      cstart[nch] = n;
       r->pipe.make();
       if (!in_st) {
         if (!r->gather) {
@@ -887,18 +899,18 @@ int earhip_render_process(earhip_render *r, size_t nblocks, const float *const *
           const int want = ctx->get(OPT_HOST_THREADS, 0);
           r->gather->start(want >= 1 && want <= 64 ? want : default_staging_threads());
         }
-        r->gather->submit(in, r->p_in.p, n, clen, r->M, ctx->get(OPT_HOST_BIND, 0) != 0, ctx->get(OPT_HOST_NT, 1) != 0);
+        r->gather->submit(in, r->p_in.p, n, cstart, nch, r->M, ctx->get(OPT_HOST_BIND, 0) != 0, ctx->get(OPT_HOST_NT, 1) != 0);
       }
       hipError_t err = hipSuccess;
       std::string fail;
       int scattered = 0;
       auto scatter_chunk = [&](int c) {
-        const size_t at = (size_t)c * clen, len = std::min(clen, n - at);
+        const size_t at = cstart[c], len = cstart[c + 1] - at;
         const float *base = r->p_out.p + (size_t)r->N * at;
         for (int ch = 0; ch < r->N; ch++) std::memcpy(out[ch] + at, base + (size_t)ch * len, sizeof(float) * len);
       };
       for (int c = 0; c < nch; c++) {
-        const size_t at = (size_t)c * clen, len = std::min(clen, n - at);
+        const size_t at = cstart[c], len = cstart[c + 1] - at;
         float *din = r->d_in.p + (size_t)r->M * at, *dout = r->d_out.p + (size_t)r->N * at;
         if (!in_st) {
           GatherPool &gp = *r->gather;

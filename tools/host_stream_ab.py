@@ -17,8 +17,8 @@ try:
     print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip(), " affinity:", len(os.sched_getaffinity(0)), " loadavg:", open("/proc/loadavg").read().strip())
 except OSError:
     pass
-variants = [("nt0 bind0", {"HOST_NT": "0", "HOST_BIND": "0"}), ("nt1 bind0", {"HOST_NT": "1", "HOST_BIND": "0"}), ("nt1 bind1", {"HOST_NT": "1", "HOST_BIND": "1"}),
-            ("nt1 bind1 th8", {"HOST_NT": "1", "HOST_BIND": "1", "HOST_THREADS": "8"}), ("nt1 bind1 th32", {"HOST_NT": "1", "HOST_BIND": "1", "HOST_THREADS": "32"})]
+variants = [("defaults", {}), ("first chunk whole", {"HOST_FIRST": "0"}), ("nt0", {"HOST_NT": "0"}), ("bind1", {"HOST_BIND": "1"}),
+            ("th16", {"HOST_THREADS": "16"}), ("th4", {"HOST_THREADS": "4"}), ("chunk 8 MB", {"HOST_CHUNK_MB": "8"}), ("chunk 32 MB", {"HOST_CHUNK_MB": "32"})]
 rs = []
 ctxs = []
 for name, opts in variants:
