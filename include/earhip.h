@@ -75,7 +75,8 @@ int earhip_ctx_set_strict(earhip_ctx *ctx, int strict);
  * is not created from an environment that holds such a value).
  *   gain stage:   MFMA (0 VALU | 1 exact-f32 MFMA | 3 default | 4 grid kernel | 5 piece lists | 6 hinge kernel),
  *                 H2_TILE, P2_TILE, HG_TILE (256 | 512), P2_PAIRS, HINGE (0 | 1), H2_WGS, P2_WGS (workgroups of the launch;
- *                 P2_WGS 0: one per tile), H2_RUNS (1: a workgroup of the grid kernel takes a contiguous run of tiles instead of
+ *                 P2_WGS 0: one per tile), H2_PAIR (1: the 8-wave grid kernel's plain and wide forms as a pair of launches instead of one kernel that
+ *                 branches on the device's mode word: rounds 1-5), H2_RUNS (1: a workgroup of the grid kernel takes a contiguous run of tiles instead of
  *                 every n-th: measured slower, kept as a knob), HG_ROBUST (default 1: a call whose levels spread beyond the hinge
  *                 kernel's packed-f16 kink products runs that kernel's f32 form; 0: it is handed to the piece lists standing by,
  *                 rounds 4-5), BUILD_TPW, HBUILD_TPW (1 2 4 8), BUILD_2K (1: the list builders as two kernels — classify every (object,

@@ -333,10 +333,12 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
     const dim3 bgrid(std::min(ml.ntiles, wgs), ml.gsplit, cp.mnz * cp.mgroups);
     const float xs = std::ldexp(1.0f, ctx->x_scale_log2);
     const float *gs = cs.column_scales();
-    // two forms of the kernel, back to back: the one the device-side mode word names runs, the other returns at once
+    // two forms of the kernel: the 8-wave kernel carries both and branches on the device-side mode word (round 6); the 4-wave
+    // kernels are launched as a pair, back to back: the form the word names runs, the other returns at once
     // (gain_h2.h; the piece-list and hinge kernels carry both forms in one kernel — for this one the merged kernel measured
     // slower: config 2 0.224 -> 0.259 ms, its 4-wave form loses a wave per SIMD to the larger of the two register counts);
     // without a probe only the wide form
+    const bool two_launches = ctx->get(OPT_H2_PAIR, 0) != 0;  // (tuning knob: the 8-wave kernel as a pair of launches, as until round 6)
 #define EARHIP_H2_LAUNCH(NCT_, NW_, WIDE_)                                                                          \
   hipLaunchKernelGGL((k_gain_mix_h2<NCT_, NW_, WIDE_>), bgrid, dim3(64 * NW_), 0, ctx->stream, P, ps.zero_row, xs,  \
                      gs, level_cur, level_next, slow_cur, slow_next, wide_cur, wide_next);
@@ -346,11 +348,14 @@ void launch_gain_mix(earhip_ctx *ctx, const CurveSet &cs, const MixLaunch &ml, b
 #define EARHIP_H2_CASE(NCT_)                                                                                        \
   if (cp.nct == NCT_) {                                                                                             \
     if (ml.tile() == 512) {                                                                                         \
-      if (wide_cur) EARHIP_H2_LAUNCH(NCT_, 8, false)                                                                \
-      EARHIP_H2_LAUNCH(NCT_, 8, true)                                                                               \
+      if (wide_cur && !two_launches) EARHIP_H2_LAUNCH(NCT_, 8, 2)                                                   \
+      else {                                                                                                        \
+        if (wide_cur) EARHIP_H2_LAUNCH(NCT_, 8, 0)                                                                  \
+        EARHIP_H2_LAUNCH(NCT_, 8, 1)                                                                                \
+      }                                                                                                             \
     } else if (NCT_ == 1) {                                                                                         \
-      if (wide_cur) EARHIP_H2_LAUNCH(1, 4, false)                                                                   \
-      EARHIP_H2_LAUNCH(1, 4, true)                                                                                  \
+      if (wide_cur) EARHIP_H2_LAUNCH(1, 4, 0)                                                                       \
+      EARHIP_H2_LAUNCH(1, 4, 1)                                                                                     \
     } else {                                                                                                        \
       if (wide_cur) EARHIP_H2T1_LAUNCH(NCT_, 4, false)                                                              \
       EARHIP_H2T1_LAUNCH(NCT_, 4, true)                                                                             \
@@ -500,7 +505,7 @@ using namespace earhip;
 // keys of earhip_ctx_set_option (and, prefixed with EARHIP_, the environment variables read at earhip_ctx_create)
 static const char *const kOptNames[OPT_COUNT] = {
     "SPL", "MFMA", "XSCALE", "WAVES", "TPW", "NRT", "H2_TILE", "H2_WGS", "H2_RUNS", "P2_TILE", "P2_PAIRS", "P2_WGS", "HINGE", "HG_TILE", "HBUILD_TPW",
-    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST", "BUILD_2K", "HOST_BIND", "HOST_NT", "HOST_FIRST"};
+    "BUILD_TPW", "K2_WG", "K2_OWN_BLOCK", "RUN", "GSPLIT", "PROBE_RUNS", "BLOCK_GROUPS", "DEBUG_TIMING", "TAILCUT", "HOST_CHUNK_MB", "HOST_THREADS", "HG_ROBUST", "BUILD_2K", "HOST_BIND", "HOST_NT", "HOST_FIRST", "H2_PAIR"};
 
 // an option's value: a decimal integer (optional sign, surrounding blanks), nothing else — "abc" or "1x" used to read as 0 / 1
 static int parse_option_value(const std::string &key, const char *text) {

@@ -127,7 +127,7 @@ enum Opt {
   OPT_H2_TILE, OPT_H2_WGS, OPT_H2_RUNS, OPT_P2_TILE, OPT_P2_PAIRS, OPT_P2_WGS, OPT_HINGE, OPT_HG_TILE, OPT_HBUILD_TPW, OPT_BUILD_TPW,  // launch plan of a call
   OPT_K2_WG, OPT_K2_OWN_BLOCK, OPT_RUN, OPT_GSPLIT,                      // decorrelator kernel / renderer creation
   OPT_PROBE_RUNS, OPT_BLOCK_GROUPS, OPT_DEBUG_TIMING, OPT_TAILCUT, OPT_HOST_CHUNK_MB, OPT_HOST_THREADS, OPT_HG_ROBUST, OPT_BUILD_2K,
-  OPT_HOST_BIND, OPT_HOST_NT, OPT_HOST_FIRST, OPT_COUNT
+  OPT_HOST_BIND, OPT_HOST_NT, OPT_HOST_FIRST, OPT_H2_PAIR, OPT_COUNT
 };
 struct OptVal {
   bool set = false;

@@ -111,20 +111,24 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // WIDE: the low pieces of the inputs are kept scaled (kLowPieceScale) — 16 more multiplies and 6 more LDS reads per
 // chunk: 4 % of this kernel on the headline scene (measured by bisection; neither reading the third piece a block
 // ahead, nor making it from h in registers, nor v_fma_mix forms of the split bring that down).  So both forms
-// exist, as two instantiations launched back to back: the level probe decides on the device which one works
-// (k_seg_prep sets *wide_cur when some object lies more than kPlainBinades below the loudest) and the other
-// returns at once (an empty grid: ~3 us).  Without a probe (wide_cur == NULL) only the wide form is launched.  The
-// mode words alternate between calls like the level words.
+// exist and the level probe decides on the device which one works (k_seg_prep sets *wide_cur when some object lies
+// more than kPlainBinades below the loudest): the 8-wave kernel carries both bodies and branches on the word (FORM 2,
+// round 6), the 4-wave kernel is two instantiations launched back to back, of which the one not named returns at once
+// (an empty grid: ~3-5 us).  Without a probe (wide_cur == NULL) only the wide form runs.  The mode words alternate
+// between calls like the level words.
 // NW waves per workgroup (4 or 8), each on 64 samples of the workgroup's tile of 64 NW samples: the
 // conversion of a chunk's gains is shared by the whole workgroup, so the 512-sample tile halves that
 // work (and the gain rows' L2 traffic) when no curve point falls inside 512-sample tiles.
 // (the 4-wave forms with two or three column tiles: gain_h2_t1.h, a tile per workgroup)
 constexpr bool h2_persistent(int nct, int nw) { return nw == 8 || nct == 1; }
-template <int NCT, int NW, bool WIDE>
+// FORM: 0 the plain form, 1 the wide form (each returns at once when the probe's word names the other: the 4-wave kernel is launched
+// as such a pair), 2: both forms in ONE kernel, the word picking with a wave-uniform branch (the 8-wave kernel: one workgroup per CU
+// at either form's register count, and no launch whose only job is to return — ~5 us per call)
+template <int NCT, int NW, int FORM>
 __global__ void __launch_bounds__(64 * NW, NCT == 1 && NW == 8 ? 2 : (NW == 4 ? 2 : 1))
 k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restrict__ gcol, const unsigned *level_cur,
               unsigned *level_next, const unsigned *slow_cur, unsigned *slow_next, const unsigned *wide_cur, unsigned *wide_next) {
-  if (wide_cur && ((*wide_cur & 1u) != 0u) != WIDE) return;  // the other form of this kernel works on this call
+  if (FORM != 2 && wide_cur && ((*wide_cur & 1u) != 0u) != (FORM == 1)) return;  // the other form of this kernel works on this call
   constexpr int NRT = 4, TS = 16 * NRT, CH = kSplitChunk;
   constexpr int NQ = CH / NW;         // objects whose gains one wave converts per chunk
   constexpr int NFRAG = 2 * NCT * 3;  // {B0,B1} x column tiles x {h, l, h 2^-11 (wide mode)}
@@ -135,6 +139,11 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
   __shared__ __attribute__((aligned(16))) float otile[NW][16 * OP];
   __shared__ float inv_gcol[16 * NCT];  // 1 / the gain scale of the workgroup's columns: read at the END of a tile, where a
                                         // round trip to memory would stand in the open
+  // the workgroup's tiles that a wave has to redo exactly (bit k: its k-th tile; at most 64: the host's grid), kept in
+  // LDS: set once in a blue moon, read once
+  __shared__ unsigned long long redo_tiles[NW];
+  auto body = [&](auto wide_tag) __attribute__((always_inline)) {
+  constexpr bool WIDE = decltype(wide_tag)::value;
   if (threadIdx.x < 16 * NCT) inv_gcol[threadIdx.x] = 1.0f / gcol[blockIdx.z * 16 * NCT + threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -326,9 +335,6 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     clear_totals();
   };
 
-  // the workgroup's tiles that a wave has to redo exactly (bit k: its k-th tile; at most 64: the host's grid), kept in
-  // LDS: set once in a blue moon, read once
-  __shared__ unsigned long long redo_tiles[NW];
   if (lane == 0) redo_tiles[w] = 0ull;
   if (nch > 0) {
     // lane-constant part of the input address: byte offset of this lane's float4 (lanes past the
@@ -647,6 +653,13 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
     if (nch == 0 && slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[t] = 0u;
     for (int m = m_lo; m < m_hi; m++) single_object(t, m, 1.0f, false);
     flush_tile(t, 1.0f, false);
+  }
+  };  // body
+  if constexpr (FORM == 2) {
+    if (!wide_cur || (*wide_cur & 1u) != 0u) body(std::true_type{});
+    else body(std::false_type{});
+  } else {
+    body(std::integral_constant<bool, FORM == 1>{});
   }
 }
 

@@ -14,13 +14,13 @@ NEEDED = ("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_
 OPTIONAL = ("TCP_TCC_READ_REQ_sum",)
 # (summary file, kernel, shape: objects, blocks, block size, channels, buses, scene, gain kernel id, tile)
 ENTRIES = [
-    ("r06_final_rocprofv3_summary.txt", "k_gain_mix_h2<3, 8, false>", 1024, 1024, 512, 24, 2, "dense", 3, 512),
+    ("r06_final_rocprofv3_summary.txt", "k_gain_mix_h2<3, 8, 2>", 1024, 1024, 512, 24, 2, "dense", 3, 512),
     ("r06_adm_scene_rocprofv3_summary.txt", "k_gain_mix_p2<3, 8, true>", 1024, 1024, 512, 24, 2, "adm", 4, 512),
     ("r06_moving_scene_rocprofv3_summary.txt", "k_gain_mix_hg<3, 8>", 1024, 1024, 512, 24, 2, "moving", 5, 512),
     ("r06_bursty_moving_scene_rocprofv3_summary.txt", "k_gain_mix_hg<3, 8>", 1024, 1024, 512, 24, 2, "bursty-moving", 5, 512),
-    ("r06_traffic_C2_summary.txt", "k_gain_mix_h2<1, 8, false>", 64, 8192, 512, 10, 1, "dense", 3, 512),
-    ("r06_traffic_C3_summary.txt", "k_gain_mix_h2<3, 8, false>", 256, 4096, 512, 24, 2, "dense", 3, 512),
-    ("r06_traffic_C5_summary.txt", "k_gain_mix_h2<3, 8, false>", 528, 512, 1024, 24, 2, "dense", 3, 512),
+    ("r06_traffic_C2_summary.txt", "k_gain_mix_h2<1, 8, 2>", 64, 8192, 512, 10, 1, "dense", 3, 512),
+    ("r06_traffic_C3_summary.txt", "k_gain_mix_h2<3, 8, 2>", 256, 4096, 512, 24, 2, "dense", 3, 512),
+    ("r06_traffic_C5_summary.txt", "k_gain_mix_h2<3, 8, 2>", 528, 512, 1024, 24, 2, "dense", 3, 512),
 ]
 
 
