@@ -600,6 +600,9 @@ k_gain_mix_h2(GainMixParams P, int zero_row, float x_scale, const float *__restr
         const bool any_slow = !slow_cur || ((ConstWord)slow_cur)[t] != 0u;
         if (slow_next && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) slow_next[t] = 0u;
         // objects with curve points inside this workgroup tile (zero rows above)
+        // (looking through the descriptors eight groups of 64 at a time — eight independent loads, then their ballots — instead of a
+        // dependent trip to memory per group: built in round 6, 1-2 % on the scene with 8 of 1024 objects off the grid, and 1.7 %
+        // SLOWER on the headline, whose chunk loop the extra scalar state re-allocated: not kept)
         for (int b0 = 0; any_slow && b0 < nobj; b0 += 64) {
           const int ol = opaque_lane();
           const SegDesc db = (P.desc + (size_t)t * P.M)[min(m_lo + b0 + ol, m_hi - 1)];
