@@ -494,6 +494,7 @@ def test_staging_threads_of_long_host_calls_run_on_the_node_of_the_callers_rows(
     for bind in (0, 1):
         c = capi.Context(0, None)
         c.set_option("HOST_BIND", str(bind))
+        c.set_option("HOST_NT", str(bind))  # (and the gather by memcpy against streaming stores: the same bytes staged)
         c.set_option("HOST_THREADS", "6")
         r = capi.Renderer(c, m, n, block, dec, 255, max_blocks=nblocks)
         for i, (t, d, f) in enumerate(curves):
