@@ -107,6 +107,19 @@ def test_segment_search_on_cpu(tmp_path):
     assert res.returncode == 0, res.stdout
 
 
+def test_staging_path_helpers_on_cpu(tmp_path):
+    """libear_amd/csrc/host_gather.h (the host side of long host-pointer calls): the streaming-store copy == memcpy for every size
+    and misalignment, the staging threads' default count within its bounds, the NUMA helpers answer or decline — under ASan + UBSan"""
+    exe = tmp_path / "test_host_gather"
+    src = os.path.join(ROOT, "tests", "cpp", "test_host_gather.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "libear_amd", "csrc"), src, "-o", str(exe), "-lpthread"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    res = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    assert res.returncode == 0, res.stdout
+
+
 def test_launch_plans_fit_the_bus_buffer_on_cpu(tmp_path):
     """libear_amd/csrc/curves.h: every plan plan_mix makes fits bus_samples_bound() (host code, hipcc)"""
     exe = tmp_path / "test_plan_bounds"
