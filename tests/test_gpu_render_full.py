@@ -390,8 +390,14 @@ def test_call_lengths_between_block_and_stream_mode_off_grid_metadata(nblocks):
 
 
 @pytest.mark.parametrize("source,kind,m", [("pageable", "dense", 1024), ("pinned", "dense", 1024), ("pageable", "adm", 256),
-                                            ("pinned-in", "moving", 256)])
+                                            ("pinned-in", "moving", 256), ("pageable-short-first", "dense", 1024)])
 def test_long_calls_from_host_pointers_run_as_a_pipeline_of_time_chunks(source, kind, m):
+    if source == "pageable-short-first":  # (option HOST_FIRST: the first chunk a quarter of the others — the chunk table's other shape)
+        return with_options({"EARHIP_HOST_FIRST": "1"}, lambda: _long_host_calls("pageable", kind, m))
+    return _long_host_calls(source, kind, m)
+
+
+def _long_host_calls(source, kind, m):
     """libear's own calling convention — host channel pointers (src/dsp/variable_block_size_impl.cpp:44-81: `const float
     *const *in, float *const *out`) — for a long call: earhip_render_process cuts it into time chunks of ~8 MB of inputs and
     runs them H2D / kernels / D2H on three streams.  70 blocks (17 chunks of 4 blocks and one of 2 at 1024 objects), from
