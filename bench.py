@@ -487,9 +487,10 @@ def main():
                 curves = scenes.constant_curves(m, N, seed=8 + seed)
             elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
                 curves = scenes.dense_curves(m, N, B, T, seed=7 + seed)
-                odd = scenes.adm_curves(max(m // 128, 1), N, total, seed=11 + seed)
+                every = max(2, int(os.environ.get("EARHIP_BENCH_MIXED_EVERY", "128")))  # (tuning: one such object in every `every`)
+                odd = scenes.adm_curves(max(m // every, 1), N, total, seed=11 + seed)
                 for i, c in enumerate(odd):
-                    curves[(128 * i + 7) % m] = c
+                    curves[(every * i + 7) % m] = c
             elif args.scene in ("panned", "panned-adm"):
                 # moving point sources: positions -> gain vectors by the device batch panner (earhip group I)
                 if args.scene == "panned":  # a new position at every block boundary, reached over the whole block

@@ -370,15 +370,17 @@ class CurveSet {
   }
 
   // largest tile of the split-operand kernels (512, 256) with no curve point strictly inside; 0: none
-  // A few objects off the grid (at most M / 32) are tolerated: the split-operand kernels send an object
-  // with a point inside a tile through their exact slow path for that tile only (1.2 % of K1 per such
-  // object on the headline scene: break-even with moving the whole scene to the slot kernel at ~80).
+  // A few objects off the grid (at most M / 64) are tolerated: the split-operand kernels send an object
+  // with a point inside a tile through their exact slow path for that tile only — 10.7 us per such object and
+  // 1024-block call on the headline scene (2.7 % of K1; 8 objects: step 0.546 ms against 0.460), break-even with
+  // moving the whole scene to the hinge kernel (0.61) at ~14 objects, to the piece lists (0.67) at ~20
+  // (tools/r6_mixed.sh; until round 6 the bound was M / 32, set against the f32 slot kernel's 1.08 ms).
   int aligned_tile(int64_t t_call) const {
     const int grids[2] = {512, 256};
     for (int gi = 0; gi < 2; gi++) {
       const int64_t G = grids[gi];
       if (tiles_aligned((int)G, t_call)) return (int)G;
-      if (grid_off_[gi] <= M_ / 32 && (((t_call - grid_phase_[gi]) % G) + G) % G == 0) return (int)G;
+      if (grid_off_[gi] <= M_ / 64 && (((t_call - grid_phase_[gi]) % G) + G) % G == 0) return (int)G;
     }
     return 0;
   }

@@ -673,7 +673,7 @@ def test_grid_kernel_several_tiles_per_workgroup(layout, tile, wgs):
 
 @pytest.mark.parametrize("tile", [None, "256", "512"])
 def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
-    """A few objects whose metadata ignores the block grid (2 of 128 here; up to M / 32) do not move the
+    """A few objects whose metadata ignores the block grid (2 of 128 here; up to M / 64) do not move the
     scene to the slot kernel: they take the exact slow path in the tiles where their points fall."""
     from libear_amd import capi
     if os.environ.get("EARHIP_MFMA") not in (None, "3"):
@@ -699,7 +699,7 @@ def test_mostly_aligned_scene_keeps_the_split_operand_kernel(tile):
     got, kind = _with_env({"EARHIP_H2_TILE": tile}, render)
     assert kind == 3
     assert scenes.rel_rms(got, want) <= 1e-6
-    # five such objects are more than M / 32: the piece-list kernel takes over (cost proportional to the
+    # five such objects are more than M / 64: the piece-list kernel takes over (cost proportional to the
     # curve points, whatever their times)
     more = scenes.adm_curves(3, n, total, period=500, ramp=100, seed=4)
     curves[5], curves[40], curves[77] = more[0], more[1], more[2]
