@@ -486,7 +486,8 @@ def main():
             elif args.scene == "static":  # one gain vector per object and bus, never changing
                 curves = scenes.constant_curves(m, N, seed=8 + seed)
             elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
-                curves = scenes.dense_curves(m, N, B, T, seed=7 + seed)
+                curves = (scenes.constant_curves(m, N, seed=8 + seed) if os.environ.get("EARHIP_BENCH_MIXED_BASE") == "static"
+                          else scenes.dense_curves(m, N, B, T, seed=7 + seed))  # (tuning: the other objects' curves)
                 every = max(2, int(os.environ.get("EARHIP_BENCH_MIXED_EVERY", "128")))  # (tuning: one such object in every `every`)
                 odd = scenes.adm_curves(max(m // every, 1), N, total, seed=11 + seed)
                 for i, c in enumerate(odd):

@@ -370,7 +370,7 @@ class CurveSet {
   }
 
   // largest tile of the split-operand kernels (512, 256) with no curve point strictly inside; 0: none
-  // A few objects off the grid (at most M / 64) are tolerated: the split-operand kernels send an object
+  // A few objects off the grid (at most M / 64; fewer, down to none, when the curves hold most of the time: below) are tolerated: the split-operand kernels send an object
   // with a point inside a tile through their exact slow path for that tile only — 10.7 us per such object and
   // 1024-block call on the headline scene (2.7 % of K1; 8 objects: step 0.546 ms against 0.460), break-even with
   // moving the whole scene to the hinge kernel (0.61) at ~14 objects, to the piece lists (0.67) at ~20
@@ -379,8 +379,19 @@ class CurveSet {
     const int grids[2] = {512, 256};
     for (int gi = 0; gi < 2; gi++) {
       const int64_t G = grids[gi];
+      // Curves that hold most of the time have the cheaper alternative: the paired piece lists cost the grid kernel's time plus
+      // what their ramps' delta pieces add — static gains with a few moving objects: 0.43 ms per step on the lists whatever the
+      // number of movers, against 0.46 / 0.47 / 0.49 on the grid kernel with 2 / 4 / 6 of them on its exact path; ADM-style curves
+      // (0.8 delta pieces per object and tile): 0.53 on the lists, worth ~4 objects.  So their bound follows the delta pieces per
+      // (object, tile) pair of the WHOLE set (tools/r6_mixed2.sh).  (stats index: [0] 256-sample tiles, [1] 512)
+      const int si = 1 - gi;
+      int off_grid_limit = M_ / 64;
+      if (ramp_share() < 0.5) {
+        const double deltas = tot_.tiles[si] > 0 && tot_.moving > 0 ? tot_.incid[si] / tot_.tiles[si] * ((double)tot_.moving / M_) : 0.0;
+        off_grid_limit = (int)(M_ * std::min(1.0 / 64, deltas / 200.0));
+      }
       if (tiles_aligned((int)G, t_call)) return (int)G;
-      if (grid_off_[gi] <= M_ / 64 && (((t_call - grid_phase_[gi]) % G) + G) % G == 0) return (int)G;
+      if (grid_off_[gi] <= off_grid_limit && (((t_call - grid_phase_[gi]) % G) + G) % G == 0) return (int)G;
     }
     return 0;
   }
@@ -560,6 +571,7 @@ class CurveSet {
   // take an object's old contribution out of the totals; true when one of its column maxima was the set's
   bool retire(const ObjStats &s, const float *cm) {
     tot_.span -= s.span, tot_.ramp -= s.ramp, tot_.npts -= s.npts, tot_.bad -= s.bad, tot_.points -= s.points;
+    tot_.moving -= s.npts > 0 ? 1 : 0;
     for (int gi = 0; gi < 2; gi++) {
       tot_.incid[gi] -= s.incid[gi], tot_.touched[gi] -= s.touched[gi], tot_.tiles[gi] -= s.tiles[gi];
       tot_.sum_r15[gi] -= std::min(s.maxr[gi], kPieceMaxPerObject), tot_.sum_r7[gi] -= std::min(s.maxr[gi], kPairMaxPerObject);
@@ -576,6 +588,7 @@ class CurveSet {
   }
   void admit(const ObjStats &s, const float *cm) {
     tot_.span += s.span, tot_.ramp += s.ramp, tot_.npts += s.npts, tot_.bad += s.bad, tot_.points += s.points;
+    tot_.moving += s.npts > 0 ? 1 : 0;
     for (int gi = 0; gi < 2; gi++) {
       tot_.incid[gi] += s.incid[gi], tot_.touched[gi] += s.touched[gi], tot_.tiles[gi] += s.tiles[gi];
       tot_.sum_r15[gi] += std::min(s.maxr[gi], kPieceMaxPerObject), tot_.sum_r7[gi] += std::min(s.maxr[gi], kPairMaxPerObject);
@@ -633,6 +646,7 @@ class CurveSet {
   // statistics of the set
   struct Totals {
     double span = 0, ramp = 0, npts = 0, bad = 0, points = 0;
+    long moving = 0;  // objects with more than one point
     double incid[2] = {0, 0}, touched[2] = {0, 0}, tiles[2] = {0, 0};
     long sum_r15[2] = {0, 0}, sum_r7[2] = {0, 0};  // sums of the objects' maxr, clipped to what a list takes per object (packed / paired)
   } tot_;
