@@ -482,7 +482,8 @@ def main():
             if args.scene in ("adm", "levels-adm", "bursty-adm"):
                 curves = scenes.adm_curves(m, N, total, seed=11 + seed)
             elif args.scene in ("moving", "bursty-moving"):  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
-                curves = scenes.adm_curves(m, N, total, period=240, ramp=240, seed=12 + seed)
+                mp = max(64, int(os.environ.get("EARHIP_BENCH_MOVING_PERIOD", "240")))  # (tuning: the update period, samples)
+                curves = scenes.adm_curves(m, N, total, period=mp, ramp=mp, seed=12 + seed)
             elif args.scene == "static":  # one gain vector per object and bus, never changing
                 curves = scenes.constant_curves(m, N, seed=8 + seed)
             elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
