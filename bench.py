@@ -480,7 +480,8 @@ def main():
             self.M = self.M_obj + self.M_hoa
             m, seed = max(self.M_obj, 1), seed_base + (0 if self.time_sharded else rank)
             if args.scene in ("adm", "levels-adm", "bursty-adm"):
-                curves = scenes.adm_curves(m, N, total, seed=11 + seed)
+                ap_, ar_ = (int(v) for v in os.environ.get("EARHIP_BENCH_ADM", "960,240").split(","))  # (tuning: period, ramp in samples)
+                curves = scenes.adm_curves(m, N, total, period=ap_, ramp=ar_, seed=11 + seed)
             elif args.scene in ("moving", "bursty-moving"):  # always ramping: a new target every 240 samples (5 ms) at a per-object phase
                 mp = max(64, int(os.environ.get("EARHIP_BENCH_MOVING_PERIOD", "240")))  # (tuning: the update period, samples)
                 curves = scenes.adm_curves(m, N, total, period=mp, ramp=mp, seed=12 + seed)

@@ -456,7 +456,8 @@ struct GainStage {
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
                             curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
-                            curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share(in_stride, (size_t)nsamples));
+                            curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share(in_stride, (size_t)nsamples), false,
+                            curves.deltas_per_pair(256));
     if (ml.hinge) curves.ensure_kinks(ctx);
     desc.reserve(scratch_units(curves, ml, n_in));
     if (ml.gsplit == 1) {

@@ -396,6 +396,11 @@ class CurveSet {
     return 0;
   }
 
+  // ramp pieces (ramp x tile incidences) per (object, tile) pair of the objects that move at all; tile = 256 or 512
+  double deltas_per_pair(int tile) const {
+    const int gi = tile >= 512 ? 1 : 0;
+    return tot_.tiles[gi] > 0 ? tot_.incid[gi] / tot_.tiles[gi] : 0.0;
+  }
   // fraction of the curves' time in ramps; 0 for static gains
   double ramp_share() const { return tot_.span > 0 ? tot_.ramp / tot_.span : 0.0; }
   // curve points per sample and object (0 for static gains)
@@ -713,7 +718,8 @@ struct MixLaunch {
 inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, int nsamples,
                           bool strict, int max_gsplit, int aligned_tile = 0, double ramp_share = 1.0,
                           float gain_scale = 0.0f, double point_density = 0.0, double pair_waste256 = 1.0,
-                          double pair_waste512 = 1.0, double hinge_exact_share = 2.0, bool grid512_strict = false) {
+                          double pair_waste512 = 1.0, double hinge_exact_share = 2.0, bool grid512_strict = false,
+                          double deltas256 = 0.0) {
   const bool aligned = aligned_tile >= 256;  // no curve point inside 256- (512-) sample tiles of the call
   MixLaunch L;
   L.mfma = !strict && ctx->use_mfma;
@@ -752,7 +758,6 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // (short calls — block mode — keep the 256-sample tiles: twice the workgroups)
     const bool long_call = nsamples / 512 >= 2 * ctx->num_cus;
     L.pw = ptile == 512 ? 8 : ptile == 256 ? 4 : (L.paired && long_call && pair_waste512 < kPairWaste) ? 8 : 4;
-    (void)point_density;
     // Hinge kernel (gain_hg.h): curves that ramp most of the time in ramps of half a tile or more — every object always on
     // its way to its next target, the points at arbitrary times.  There the piece lists cost an operand split per ramp
     // and tile; the hinge kernel one per object and tile.  Every (object, tile) pair it cannot take (short ramps, steps,
@@ -766,6 +771,17 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     if (ctx->has(OPT_HINGE)) L.hinge = ctx->get(OPT_HINGE) != 0 && M <= hinge_max && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 6) L.hinge = M <= hinge_max && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
+    // Curves that ramp most of the time AND hold in between (ADM blocks whose interpolationLength is 50-80 % of their duration):
+    // both kernels take them, and which is faster follows the curves — the hinge kernel pays per curve point, the packed lists per
+    // ramp piece.  Fitted on 1024 objects x 24 channels over update periods of 240-1920 samples and ramp shares of 0.5-1
+    // (tools/r6_period.sh, r6_rampshare.sh; ms per 1024-block call, K0 + K1): hinge 0.56 + 0.077 x (points per object and 512-sample
+    // tile), lists 0.15 + 0.238 x (1 + ramp pieces per object and 256-sample tile).  Always-ramping curves stay on the hinge kernel
+    // at every period (0.72 vs 0.88 at 5 ms, 0.58 vs 0.66 at 40 ms); ramp 500 of 960: lists 0.59 vs 0.63 (measured 0.636 / 0.675 per
+    // step), ramp 260 of 480: 0.65 vs 0.72 (0.710 / 0.766).  Within 3 %: the hinge kernel.  Only where nothing forces a kernel.
+    if (L.hinge && !ctx->has(OPT_HINGE) && ctx->use_mfma == 3 && deltas256 > 0.0 && point_density > 0.0) {
+      const double hinge_est = 0.56 + 0.077 * (point_density * 512.0), lists_est = 0.151 + 0.238 * (1.0 + deltas256);
+      if (lists_est < 0.97 * hinge_est) L.hinge = false;
+    }
     if (L.hinge) {
       if (ctx->has(OPT_HG_TILE)) L.hinge_tile = ctx->get(OPT_HG_TILE) == 256 ? 256 : 512;  // tuning knob
       // (the piece lists stand by on 256-sample tiles of their own, packed: k_hinge_gate)
