@@ -491,7 +491,8 @@ def main():
                 curves = (scenes.constant_curves(m, N, seed=8 + seed) if os.environ.get("EARHIP_BENCH_MIXED_BASE") == "static"
                           else scenes.dense_curves(m, N, B, T, seed=7 + seed))  # (tuning: the other objects' curves)
                 every = max(2, int(os.environ.get("EARHIP_BENCH_MIXED_EVERY", "128")))  # (tuning: one such object in every `every`)
-                odd = scenes.adm_curves(max(m // every, 1), N, total, seed=11 + seed)
+                op_, or_ = (int(v) for v in os.environ.get("EARHIP_BENCH_MIXED_ODD", "960,240").split(","))  # (tuning: their period, ramp)
+                odd = scenes.adm_curves(max(m // every, 1), N, total, period=op_, ramp=or_, seed=11 + seed)
                 for i, c in enumerate(odd):
                     curves[(every * i + 7) % m] = c
             elif args.scene in ("panned", "panned-adm"):

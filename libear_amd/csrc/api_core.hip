@@ -455,7 +455,7 @@ struct GainStage {
     // 1 -> N policies have no accumulation: always use libear's exact arithmetic
     const bool strict = ctx->strict || n_in == 1;
     MixLaunch ml = plan_mix(ctx, curves.plan(), n_in, nsamples, strict, 32,
-                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density(),
+                            curves.aligned_tile(t_call), curves.ramp_share(), curves.gain_scale(), curves.point_density_all(),
                             curves.pair_waste(256), curves.pair_waste(512), curves.hinge_exact_share(in_stride, (size_t)nsamples), false,
                             curves.deltas_per_pair(256));
     if (ml.hinge) curves.ensure_kinks(ctx);

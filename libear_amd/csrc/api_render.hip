@@ -332,7 +332,7 @@ struct earhip_render {
   MixLaunch plan_call(size_t nblocks, size_t in_stride) {
     const int nsamples = (int)(nblocks * (size_t)B);
     MixLaunch ml = plan_mix(ctx, curves->plan(), M, nsamples, ctx->strict, max_gsplit, curves->aligned_tile(t),
-                            curves->ramp_share(), curves->gain_scale(), curves->point_density(), curves->pair_waste(256), curves->pair_waste(512),
+                            curves->ramp_share(), curves->gain_scale(), curves->point_density_all(), curves->pair_waste(256), curves->pair_waste(512),
                             curves->hinge_exact_share(in_stride, (size_t)nsamples), curves->tiles_aligned(kF32GridTile, t),
                             curves->deltas_per_pair(256));
     const size_t bus_stride = ((size_t)nsamples + 3) & ~(size_t)3;

@@ -387,7 +387,7 @@ class CurveSet {
       const int si = 1 - gi;
       int off_grid_limit = M_ / 64;
       if (ramp_share() < 0.5) {
-        const double deltas = tot_.tiles[si] > 0 && tot_.moving > 0 ? tot_.incid[si] / tot_.tiles[si] * ((double)tot_.moving / M_) : 0.0;
+        const double deltas = deltas_per_pair(si ? 512 : 256);
         off_grid_limit = (int)(M_ * std::min(1.0 / 64, deltas / 200.0));
       }
       if (tiles_aligned((int)G, t_call)) return (int)G;
@@ -396,11 +396,15 @@ class CurveSet {
     return 0;
   }
 
-  // ramp pieces (ramp x tile incidences) per (object, tile) pair of the objects that move at all; tile = 256 or 512
+  // ramp pieces (ramp x tile incidences) per (object, tile) pair of the WHOLE set (objects with one point have none); tile = 256 or 512
   double deltas_per_pair(int tile) const {
     const int gi = tile >= 512 ? 1 : 0;
-    return tot_.tiles[gi] > 0 ? tot_.incid[gi] / tot_.tiles[gi] : 0.0;
+    return tot_.tiles[gi] > 0 ? tot_.incid[gi] / tot_.tiles[gi] * moving_share() : 0.0;
   }
+  // share of the objects that have more than one point (a bed of static gains has none)
+  double moving_share() const { return M_ > 0 ? (double)tot_.moving / M_ : 0.0; }
+  // curve points per sample and object of the whole set
+  double point_density_all() const { return point_density() * moving_share(); }
   // fraction of the curves' time in ramps; 0 for static gains
   double ramp_share() const { return tot_.span > 0 ? tot_.ramp / tot_.span : 0.0; }
   // curve points per sample and object (0 for static gains)
@@ -777,7 +781,9 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // (tools/r6_period.sh, r6_rampshare.sh; ms per 1024-block call, K0 + K1): hinge 0.56 + 0.077 x (points per object and 512-sample
     // tile), lists 0.15 + 0.238 x (1 + ramp pieces per object and 256-sample tile).  Always-ramping curves stay on the hinge kernel
     // at every period (0.72 vs 0.88 at 5 ms, 0.58 vs 0.66 at 40 ms); ramp 500 of 960: lists 0.59 vs 0.63 (measured 0.636 / 0.675 per
-    // step), ramp 260 of 480: 0.65 vs 0.72 (0.710 / 0.766).  Within 3 %: the hinge kernel.  Only where nothing forces a kernel.
+    // step), ramp 260 of 480: 0.65 vs 0.72 (0.710 / 0.766).  Both counts are per pair of the WHOLE set: a bed of static gains with
+    // always-ramping objects among it (one in 4 / 8 / 16: lists 0.579 / 0.532 / 0.514 ms per step, hinge 0.631 / 0.612 / 0.603;
+    // one in 2: 0.694 / 0.679).  Within 3 %: the hinge kernel.  Only where nothing forces a kernel.
     if (L.hinge && !ctx->has(OPT_HINGE) && ctx->use_mfma == 3 && deltas256 > 0.0 && point_density > 0.0) {
       const double hinge_est = 0.56 + 0.077 * (point_density * 512.0), lists_est = 0.151 + 0.238 * (1.0 + deltas256);
       if (lists_est < 0.97 * hinge_est) L.hinge = false;
