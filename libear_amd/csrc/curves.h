@@ -753,11 +753,15 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // over the whole tile: always-ramping curves K1 0.82 vs 0.97 ms on 512).
     // EARHIP_P2_PAIRS=0|1 and EARHIP_P2_TILE=256|512 force one of them (tests, tuning).
     const double kPairWaste = 0.06;
-    // Curves that ramp most of the time never get it, whatever their waste: with (nearly) every object ramping in every tile
-    // the pair chunks put ~3 M products straight onto the running totals (1.0e-6 from the CPU path at 1024 objects, measured),
-    // where the packed layout's chunks sum among themselves first (7.2e-7).
-    const double kMostlyRamping = 0.5;  // (= kHingeRamps below: the curves the hinge kernel is for)
-    L.paired = pair_waste256 < kPairWaste && ramp_share < kMostlyRamping;
+    // Curves that ramp (nearly) all the time never get it, whatever their waste: with every object ramping in every tile the pair
+    // chunks put ~3 M products straight onto the running totals (1.0e-6 from the CPU path at 1024 objects, measured), where the
+    // packed layout's chunks sum among themselves first (7.2e-7).  The bound was one half until round 6; ramp-then-hold curves
+    // between it and 0.7 (tools/r6_pairs.sh, period 960: ramp 500 / 600 — 8.65e-7 / 8.67e-7 worst channel against the ADM scene's
+    // 8.45e-7 at a share of 0.25 and 8.74e-7 at 0.83) run 10 % faster paired than packed (0.567 / 0.578 ms per step against
+    // 0.633 / 0.659) and 15 % faster than on the hinge kernel (0.675 / 0.682).
+    const double kMostlyRamping = 0.7;
+    const bool paired_by_rule = pair_waste256 < kPairWaste && ramp_share < kMostlyRamping;
+    L.paired = paired_by_rule;
     if (ctx->has(OPT_P2_PAIRS)) L.paired = ctx->get(OPT_P2_PAIRS) != 0;
     // (short calls — block mode — keep the 256-sample tiles: twice the workgroups)
     const bool long_call = nsamples / 512 >= 2 * ctx->num_cus;
@@ -771,7 +775,8 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     const double kHingeExact = 0.005, kHingeRamps = 0.5;
     // (its list builder keeps 16 bytes per object and tile in LDS: as many objects as this device's limit holds)
     const int hinge_max = (int)std::min((size_t)kMaxHingeCached, ctx->hinge_build_lds / 16);
-    L.hinge = M <= hinge_max && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps;
+    // (curves the paired lists take are theirs: faster there than here in every measured case)
+    L.hinge = M <= hinge_max && hinge_exact_share <= kHingeExact && ramp_share >= kHingeRamps && !(paired_by_rule && L.paired);
     if (ctx->has(OPT_HINGE)) L.hinge = ctx->get(OPT_HINGE) != 0 && M <= hinge_max && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 6) L.hinge = M <= hinge_max && hinge_exact_share <= 1.0;
     if (ctx->use_mfma == 5) L.hinge = false;  // (5 forces the piece lists)
