@@ -759,7 +759,9 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // between it and 0.7 (tools/r6_pairs.sh, period 960: ramp 500 / 600 — 8.65e-7 / 8.67e-7 worst channel against the ADM scene's
     // 8.45e-7 at a share of 0.25 and 8.74e-7 at 0.83) run 10 % faster paired than packed (0.567 / 0.578 ms per step against
     // 0.633 / 0.659) and 15 % faster than on the hinge kernel (0.675 / 0.682).
-    const double kMostlyRamping = 0.7;
+    // (fitted on three column tiles — 24 channels x 2 buses; with one or two the hinge kernel is the cheaper one in that band —
+    // 5 channels: 0.457 against 0.490 ms per step — so the old bound stays there: tools/r6_layouts.sh)
+    const double kMostlyRamping = cp.nct == 3 ? 0.7 : 0.5;
     const bool paired_by_rule = pair_waste256 < kPairWaste && ramp_share < kMostlyRamping;
     L.paired = paired_by_rule;
     if (ctx->has(OPT_P2_PAIRS)) L.paired = ctx->get(OPT_P2_PAIRS) != 0;
@@ -789,7 +791,9 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // step), ramp 260 of 480: 0.65 vs 0.72 (0.710 / 0.766).  Both counts are per pair of the WHOLE set: a bed of static gains with
     // always-ramping objects among it (one in 4 / 8 / 16: lists 0.579 / 0.532 / 0.514 ms per step, hinge 0.631 / 0.612 / 0.603;
     // one in 2: 0.694 / 0.679).  Within 3 %: the hinge kernel.  Only where nothing forces a kernel.
-    if (L.hinge && !ctx->has(OPT_HINGE) && ctx->use_mfma == 3 && deltas256 > 0.0 && point_density > 0.0) {
+    // (three column tiles only: with one or two a kink set is one or two thirds of the MFMAs and the hinge kernel wins these
+    // cases too — a bed with one fast mover in 8 on 5 / 10 channels: 0.414 / 0.443 ms per step against the lists' 0.489 / 0.505)
+    if (L.hinge && !ctx->has(OPT_HINGE) && ctx->use_mfma == 3 && cp.nct == 3 && deltas256 > 0.0 && point_density > 0.0) {
       const double hinge_est = 0.56 + 0.077 * (point_density * 512.0), lists_est = 0.151 + 0.238 * (1.0 + deltas256);
       if (lists_est < 0.97 * hinge_est) L.hinge = false;
     }
