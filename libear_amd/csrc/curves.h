@@ -761,7 +761,9 @@ inline MixLaunch plan_mix(const earhip_ctx *ctx, const ColumnPlan &cp, int M, in
     // 0.633 / 0.659) and 15 % faster than on the hinge kernel (0.675 / 0.682).
     // (fitted on three column tiles — 24 channels x 2 buses; with one or two the hinge kernel is the cheaper one in that band —
     // 5 channels: 0.457 against 0.490 ms per step — so the old bound stays there: tools/r6_layouts.sh)
-    const double kMostlyRamping = cp.nct == 3 ? 0.7 : 0.5;
+    // (and up to 1024 objects, where eight seeds hold 9.1e-7: the paired layout's distance from the CPU path grows with the number
+    // of products a running total takes — 2048 objects at a share of 0.62: 1.18e-6 paired, beyond any BASELINE configuration)
+    const double kMostlyRamping = cp.nct == 3 && M <= 1024 ? 0.7 : 0.5;
     const bool paired_by_rule = pair_waste256 < kPairWaste && ramp_share < kMostlyRamping;
     L.paired = paired_by_rule;
     if (ctx->has(OPT_P2_PAIRS)) L.paired = ctx->get(OPT_P2_PAIRS) != 0;
