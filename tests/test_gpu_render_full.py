@@ -836,6 +836,8 @@ def test_a_cut_call_through_the_host_pointer_entry_point():
     against the oracle.  (21 MB of inputs: since round 6 such a call runs as a pipeline of time chunks — option HOST_CHUNK_MB = 0
     keeps it one transfer and one device call, which is then cut —; the default is checked beside it.)"""
     from libear_amd import capi
+    if os.environ.get("EARHIP_MFMA") in ("0", "1"):
+        pytest.skip("the VALU / exact-f32 slot kernels are forced: their calls are not cut")
     layout, m, block, nblocks = "4+5+0", 40, 512, 258
     n = len(LAYOUTS[layout])
     dec = decorrelators(layout)
