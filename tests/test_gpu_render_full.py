@@ -276,6 +276,52 @@ def test_seed_sweep_at_1024_objects(scene):
         assert max(worst) <= 9.5e-7, worst
 
 
+@pytest.mark.parametrize("case,layout,kernel,paired", [
+    ("bed + ADM movers", "9+10+3", 4, True),            # static gains + a few objects off the grid: the paired lists (no exact-path objects)
+    ("bed + ADM movers", "0+5+0", 4, True),
+    ("dense + M/64 off the grid", "9+10+3", 3, None),   # curves that ramp all the time: the grid kernel keeps up to M / 64 on its exact path
+    ("dense + more off the grid", "9+10+3", 5, None),   # ... beyond that the hinge kernel does the whole scene
+    ("bed + fast movers", "9+10+3", 4, False),          # always-ramping objects, one in 8, among static gains: packed lists on 24 channels
+    ("bed + fast movers", "0+5+0", 5, None),            # ... the hinge kernel on 5 (one column tile: its kink sets are cheap)
+    ("long ramps", "9+10+3", 4, True),                  # ramp 600 of 960: paired lists up to a ramp share of 0.7 (three column tiles)
+    ("long ramps", "0+5+0", 5, None),                   # ... the hinge kernel otherwise
+    ("always ramping", "9+10+3", 5, None)])             # a new target every 480 samples: the hinge kernel at every update period
+def test_the_planner_sends_mixed_content_to_the_kernel_measured_fastest_for_it(case, layout, kernel, paired):
+    """Round 6's planner rules (plan_mix, CurveSet::aligned_tile; measured over update periods, ramp shares, mover counts, layouts and
+    object counts: tools/r6_*.sh, NOTES.md): which kernel a curve set gets, asserted on small instances of the measured cases, every
+    channel of the result against the oracle."""
+    if any(os.environ.get(k) is not None for k in ("EARHIP_MFMA", "EARHIP_HINGE", "EARHIP_P2_PAIRS")):
+        pytest.skip("a kernel or a list layout is forced from the environment")
+    m, block, nblocks = 256, 512, 72
+    n = len(LAYOUTS[layout])
+    dec = decorrelators(layout)
+    total = block * nblocks
+    if case == "bed + ADM movers":
+        curves = scenes.constant_curves(m, n, seed=3)
+        for i, c in enumerate(scenes.adm_curves(3, n, total, seed=4)):
+            curves[(80 * i + 7) % m] = c
+    elif case.startswith("dense"):
+        curves = scenes.dense_curves(m, n, block, nblocks, seed=5)
+        k = m // 64 if "M/64" in case else m // 64 + 2
+        for i, c in enumerate(scenes.adm_curves(k, n, total, seed=6)):
+            curves[(37 * i + 5) % m] = c
+    elif case == "bed + fast movers":
+        curves = scenes.constant_curves(m, n, seed=7)
+        for i, c in enumerate(scenes.adm_curves(m // 8, n, total, period=240, ramp=240, seed=8)):
+            curves[8 * i + 3] = c
+    elif case == "long ramps":
+        curves = scenes.adm_curves(m, n, total, period=960, ramp=600, seed=9)
+    else:
+        curves = scenes.adm_curves(m, n, total, period=480, ramp=480, seed=10)
+    x = device_audio(m, total, 31)
+    out, plan = render_device(curves, x, n, block, dec, 255, [nblocks])
+    assert plan["kernel"] == kernel, (case, layout, plan)
+    if paired is not None:
+        assert plan["paired"] is paired, (case, layout, plan)
+    worst = check_windows(curves, x, out, n, block, dec, 255, [(0, 3), (nblocks // 2, 2), (nblocks - 2, 2)])
+    print(f"planner ({case}, {layout}): plan {plan}, worst channel {worst:.3e}")
+
+
 @pytest.mark.parametrize("period", [128, 240, 480, 960, 4096])
 def test_the_planner_never_pairs_the_lists_of_curves_that_ramp_all_the_time(period):
     """Paired piece lists put a ramping object's base and delta products straight onto the running totals; with every
