@@ -490,7 +490,8 @@ def main():
             elif args.scene == "mixed":  # the headline scene with 8 of every 1024 objects on ADM-like metadata off the block grid
                 base_ = os.environ.get("EARHIP_BENCH_MIXED_BASE")  # (tuning: the other objects' curves)
                 curves = (scenes.constant_curves(m, N, seed=8 + seed) if base_ == "static" else scenes.adm_curves(m, N, total, seed=5 + seed)
-                          if base_ == "adm" else scenes.dense_curves(m, N, B, T, seed=7 + seed))
+                          if base_ == "adm" else scenes.adm_curves(m, N, total, period=240, ramp=240, seed=12 + seed) if base_ == "moving"
+                          else scenes.dense_curves(m, N, B, T, seed=7 + seed))
                 every = max(2, int(os.environ.get("EARHIP_BENCH_MIXED_EVERY", "128")))  # (tuning: one such object in every `every`)
                 op_, or_ = (int(v) for v in os.environ.get("EARHIP_BENCH_MIXED_ODD", "960,240").split(","))  # (tuning: their period, ramp)
                 odd = scenes.adm_curves(max(m // every, 1), N, total, period=op_, ramp=or_, seed=11 + seed)
